@@ -1,0 +1,16 @@
+"""CPU oracle — TEST INFRASTRUCTURE ONLY.
+
+A torch-CPU / numpy / scipy restatement of the reference hot path
+(`/root/reference/audiodiffusion/pipeline_audio_diffusion.py:71-258`,
+`/root/reference/audiodiffusion/mel.py:58-168`) and of the pinned third-party
+arithmetic it calls (diffusers==0.24.0, librosa==0.10.2.post1 — NOT vendored in
+the reference tree and NOT installed here; see `requirements-lock.txt:25,57`).
+
+PARITY UNPINNED: the reference ships no tests, fixtures or stored notebook
+outputs for this path and neither third-party package can be imported in this
+container, so the oracle is pinned only by the analytic anchors of SURVEY.md
+§8(c) (see tests/test_oracle_anchors.py).
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg
+may import this package. The product (`audio-diffusion_amd/`) never does.
+"""
