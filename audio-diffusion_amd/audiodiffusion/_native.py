@@ -1,0 +1,132 @@
+"""ctypes binding of the C-ABI in include/adm.h (libadm_hip.so, built for gfx950 by csrc/build.sh).
+
+This is plumbing only: torch supplies device memory and streams, every arithmetic op on the hot path is a
+hand-written HIP kernel inside the library. There is NO CPU fallback: if the library is missing the import
+of any product class fails loudly. (`load(path)` with an explicit path exists so the test-suite can point the
+same binding at the CPU-emulation build of the very same kernel sources, tests/emu/libadm_emu.so.)
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libadm_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class SchedCoef(C.Structure):
+    _fields_ = [(n, C.c_float) for n in
+                ("sqrt_beta", "sqrt_alpha", "clip", "k_x0", "k_x", "k_eps", "k_noise", "timestep")]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("x1", C.c_void_p), ("C1", C.c_int),
+        ("x2", C.c_void_p), ("C2", C.c_int),
+        ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("up", C.c_int), ("stride", C.c_int), ("ks", C.c_int), ("pad_lo", C.c_int),
+        ("gn_scale", C.c_void_p), ("gn_shift", C.c_void_p), ("act", C.c_int),
+        ("wpacked", C.c_void_p), ("bias", C.c_void_p), ("Cout", C.c_int),
+        ("chan_add", C.c_void_p), ("chan_add_stride", C.c_int),
+        ("residual", C.c_void_p),
+        ("out", C.c_void_p),
+    ]
+
+
+class UNetConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int), ("out_channels", C.c_int), ("layers_per_block", C.c_int), ("n_blocks", C.c_int),
+        ("block_out_channels", C.c_int * 8), ("down_attn", C.c_int * 8), ("up_attn", C.c_int * 8),
+        ("attention_head_dim", C.c_int), ("norm_num_groups", C.c_int), ("norm_eps", C.c_float),
+        ("flip_sin_to_cos", C.c_int), ("freq_shift", C.c_float), ("sample_h", C.c_int), ("sample_w", C.c_int),
+    ]
+
+
+_SIGS = {
+    "adm_version": (C.c_int, []),
+    "adm_last_error": (C.c_char_p, []),
+    "adm_is_device_build": (C.c_int, []),
+    "adm_sched_step": (C.c_int, [C.c_void_p] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
+    "adm_add_noise": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                C.c_int, C.c_int, C.c_long, C.c_void_p]),
+    "adm_dequant_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+    "adm_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "adm_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "adm_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "adm_conv_out_dims": (None, [C.c_int] * 6 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "adm_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "adm_unet_create": (C.c_int, [C.POINTER(UNetConfig), C.POINTER(C.c_void_p)]),
+    "adm_unet_destroy": (None, [C.c_void_p]),
+    "adm_unet_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "adm_unet_missing_params": (C.c_int, [C.c_void_p]),
+    "adm_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, c_float_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "adm_unet_workspace_bytes": (C.c_size_t, [C.c_void_p]),
+    "adm_sample_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(SchedCoef), C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "adm_encode_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(SchedCoef), C.c_int, C.c_int, C.c_void_p]),
+}
+# entry points added by later translation units (k_mel.hip); bound when present in the header AND the library
+_OPTIONAL_SIGS = {}
+
+_lib = None
+_lib_path = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """Load the native library (idempotent). Raises if it is missing — there is no fallback."""
+    global _lib, _lib_path
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if _lib is not None and _lib_path == path:
+        return _lib
+    if not os.path.exists(path):
+        raise NativeError(
+            f"native library {path} not found: build it with `bash audio-diffusion_amd/csrc/build.sh` "
+            "(hipcc --offload-arch=gfx950). The hot path has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in list(_SIGS.items()) + list(_OPTIONAL_SIGS.items()):
+        if name in _OPTIONAL_SIGS and not hasattr(lib, name):
+            continue
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib, _lib_path = lib, path
+    return lib
+
+
+def lib():
+    return _lib if _lib is not None else load()
+
+
+def is_device_build():
+    return bool(lib().adm_is_device_build())
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError(lib().adm_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t):
+    """Device (or, for the emulation build, host) address of a contiguous fp32/u8/int32 tensor; None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "native ops need contiguous tensors"
+    if is_device_build():
+        assert t.is_cuda, "native ops need tensors on the GPU (cuda == HIP device on ROCm)"
+    else:
+        assert not t.is_cuda
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_for(t):
+    """The HIP stream torch is currently using for t's device (NULL on the emulation build)."""
+    if t is not None and t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None

@@ -1,0 +1,44 @@
+// adm_kernels.h — internal launcher declarations shared by the C-ABI layer and the UNet executor.
+#pragma once
+#include "../../include/adm.h"
+#include "adm_rt.h"
+
+namespace adm {
+
+// k_sched.hip
+int launch_sched_step(const float* x, const float* eps, const float* noise, float* out, uint8_t* u8,
+                      const adm_sched_coef* table, const int* step_dev, int step, const float* mask,
+                      int n_mask_steps, int mask_start, int mask_end, int B, int C, int H, int W, hipStream_t st);
+int launch_sched_step_loop(const float* x, const float* eps, const float* noise, long noise_step_stride, float* out,
+                           uint8_t* u8, int u8_step, const adm_sched_coef* table, const int* step_dev, int step,
+                           const float* mask, int n_mask_steps, int mask_start, int mask_end, int B, int C, int H,
+                           int W, hipStream_t st);
+int launch_step_advance(int* step_dev, hipStream_t st);
+int launch_encode_step(float* x, const float* eps, const adm_sched_coef* table, const int* step_dev, int step, long n,
+                       hipStream_t st);
+int launch_add_noise(const float* x0, long x0_bstride, const float* noise, const float* sa, const float* sb, int cb,
+                     int cn, float* out, int B, int N, long P, hipStream_t st);
+int launch_dequant(const float* x, uint8_t* out, long n, hipStream_t st);
+
+// k_groupnorm.hip
+int launch_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int groups, float eps,
+                           const float* gamma, const float* beta, float* scale, float* shift, hipStream_t st);
+
+// k_conv_mfma.hip / k_conv_small.hip
+int launch_conv2d(const adm_conv_args& a, hipStream_t st);
+int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, hipStream_t st);
+void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);
+
+// k_attention.hip
+int launch_attention(const float* qkv, float* out, int N, int C, int T, int head_dim, hipStream_t st);
+
+// k_temb.hip
+// emb[b][:] = linear_2(silu(linear_1(sinusoid(t_b)))); t from host-provided device array or coef table.
+int launch_time_embedding(const float* t_dev, int t_stride, const adm_sched_coef* table, const int* step_dev,
+                          const float* freqs, int half_dim, int flip, const float* w1, const float* b1, const float* w2,
+                          const float* b2, int dim_in, int dim_emb, float* emb, int B, hipStream_t st);
+// out[b][r] = bias[r] + sum_k W[r][k] * silu(emb[b][k])   for all resnets' time_emb_proj rows at once.
+int launch_temb_proj(const float* emb, const float* w, const float* bias, float* out, int B, int K, int R,
+                     hipStream_t st);
+
+}  // namespace adm

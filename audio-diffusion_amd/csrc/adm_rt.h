@@ -1,0 +1,83 @@
+// adm_rt.h — thin runtime layer shared by every kernel file.
+// Product build: hipcc --offload-arch=gfx950 (HIP runtime, real kernels).
+// -DADM_EMU (tests only): the same sources compile with g++ against tests/emu/hip_emu.h.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#if defined(ADM_EMU)
+#include "hip_emu.h"
+#define ADM_LAUNCH(kern, grid, block, shmem, stream, ...) \
+  adm_emu::launch((grid), (block), (shmem), [=]() { kern(__VA_ARGS__); })
+#define ADM_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(adm_emu::S().dyn_smem)
+#define ADM_UNROLL
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define ADM_LAUNCH(kern, grid, block, shmem, stream, ...) \
+  hipLaunchKernelGGL(kern, (grid), (block), (shmem), (stream), __VA_ARGS__)
+#define ADM_DYN_SMEM(type, name)                                              \
+  extern __shared__ __attribute__((aligned(16))) unsigned char adm_dyn_smem_[]; \
+  type* name = reinterpret_cast<type*>(adm_dyn_smem_)
+#define ADM_UNROLL _Pragma("unroll")
+#endif
+
+namespace adm {
+
+// ---- error plumbing: C-ABI functions return int (0 ok) and record a message ------------------
+void set_error(const std::string& msg);
+const char* last_error();
+
+#define ADM_FAIL(msg)                                                          \
+  do {                                                                         \
+    ::adm::set_error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " + (msg)); \
+    return -1;                                                                 \
+  } while (0)
+#define ADM_REQUIRE(cond, msg) \
+  do {                         \
+    if (!(cond)) ADM_FAIL(msg); \
+  } while (0)
+
+#if defined(ADM_EMU)
+#define ADM_HIP_OK(expr) (void)(expr)
+#define ADM_CHECK_LAUNCH() 0
+inline int dmalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : -1; }
+inline void dfree(void* p) { free(p); }
+inline int copy_h2d(void* d, const void* s, size_t n, hipStream_t) { memcpy(d, s, n); return 0; }
+inline int copy_d2h(void* d, const void* s, size_t n, hipStream_t) { memcpy(d, s, n); return 0; }
+inline int copy_d2d(void* d, const void* s, size_t n, hipStream_t) { memmove(d, s, n); return 0; }
+inline int dmemset(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+inline int stream_sync(hipStream_t) { return 0; }
+#else
+#define ADM_HIP_OK(expr)                                                              \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) ADM_FAIL(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+inline int check_launch_() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return -1; }
+  return 0;
+}
+#define ADM_CHECK_LAUNCH() ::adm::check_launch_()
+inline int dmalloc(void** p, size_t n) { ADM_HIP_OK(hipMalloc(p, n ? n : 1)); return 0; }
+inline void dfree(void* p) { (void)hipFree(p); }
+inline int copy_h2d(void* d, const void* s, size_t n, hipStream_t st) { ADM_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st)); return 0; }
+inline int copy_d2h(void* d, const void* s, size_t n, hipStream_t st) { ADM_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st)); return 0; }
+inline int copy_d2d(void* d, const void* s, size_t n, hipStream_t st) { ADM_HIP_OK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st)); return 0; }
+inline int dmemset(void* d, int v, size_t n, hipStream_t st) { ADM_HIP_OK(hipMemsetAsync(d, v, n, st)); return 0; }
+inline int stream_sync(hipStream_t st) { ADM_HIP_OK(hipStreamSynchronize(st)); return 0; }
+#endif
+
+#define ADM_TRY(expr)        \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace adm

@@ -1,0 +1,39 @@
+#!/usr/bin/env bash
+# Build the product library for gfx950 (default) or the CPU-emulation TEST library (emu).
+#   build.sh          -> audio-diffusion_amd/audiodiffusion/libadm_hip.so   (hipcc, gfx950)
+#   build.sh emu      -> tests/emu/libadm_emu.so                          (g++ -DADM_EMU; tests only)
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+root="$(cd "$here/../.." && pwd)"
+srcs=(c_api.hip k_sched.hip k_groupnorm.hip k_conv_mfma.hip k_conv_small.hip k_attention.hip k_temb.hip unet_exec.hip)
+[ -f "$here/k_mel.hip" ] && srcs+=(k_mel.hip)
+cd "$here"
+if [ "${1:-hip}" = "emu" ]; then
+  out="$root/tests/emu/libadm_emu.so"
+  objs=()
+  mkdir -p "$root/tests/emu/obj"
+  for s in "${srcs[@]}"; do
+    o="$root/tests/emu/obj/${s%.hip}.o"
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ adm_rt.h -nt "$o" ] || [ adm_kernels.h -nt "$o" ] || [ "$root/tests/emu/hip_emu.h" -nt "$o" ] || [ "$root/include/adm.h" -nt "$o" ]; then
+      g++ -O2 -g -std=c++17 -fPIC -DADM_EMU -I"$root/tests/emu" -x c++ -c "$s" -o "$o" -Wall -Wno-unknown-pragmas -Wno-unused-variable -Wno-unused-function -Wno-sign-compare -Wno-psabi &
+    fi
+    objs+=("$o")
+  done
+  wait
+  g++ -shared -o "$out" "${objs[@]}" -lpthread
+  echo "built $out"
+else
+  out="$root/audio-diffusion_amd/audiodiffusion/libadm_hip.so"
+  mkdir -p "$here/obj"
+  objs=()
+  for s in "${srcs[@]}"; do
+    o="$here/obj/${s%.hip}.o"
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ adm_rt.h -nt "$o" ] || [ adm_kernels.h -nt "$o" ] || [ "$root/include/adm.h" -nt "$o" ]; then
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" &
+    fi
+    objs+=("$o")
+  done
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+  echo "built $out"
+fi

@@ -1,0 +1,69 @@
+// c_api.hip — error state + op-level C-ABI entry points (include/adm.h). The UNet executor and the
+// sampling loop export their own entry points from unet_exec.hip.
+#include "adm_kernels.h"
+
+namespace adm {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+const char* last_error() { return g_err.c_str(); }
+}  // namespace adm
+
+using namespace adm;
+
+extern "C" {
+
+int adm_version(void) { return 100; }
+const char* adm_last_error(void) { return adm::last_error(); }
+int adm_is_device_build(void) {
+#if defined(ADM_EMU)
+  return 0;
+#else
+  return 1;
+#endif
+}
+
+int adm_sched_step(const float* x, const float* eps, const float* noise, float* out, uint8_t* u8_out,
+                   const adm_sched_coef* coef_table, const int* step_dev, int step, const float* mask,
+                   int n_mask_steps, int mask_start, int mask_end, int B, int C, int H, int W, void* stream) {
+  ADM_REQUIRE(x && eps && out && coef_table, "sched_step: null argument");
+  return launch_sched_step(x, eps, noise, out, u8_out, coef_table, step_dev, step, mask, n_mask_steps, mask_start,
+                           mask_end, B, C, H, W, (hipStream_t)stream);
+}
+
+int adm_add_noise(const float* x0, long x0_bstride, const float* noise, const float* sa, const float* sb, int cb,
+                  int cn, float* out, int B, int N, long P, void* stream) {
+  ADM_REQUIRE(x0 && noise && sa && sb && out, "add_noise: null argument");
+  return launch_add_noise(x0, x0_bstride, noise, sa, sb, cb, cn, out, B, N, P, (hipStream_t)stream);
+}
+
+int adm_dequant_u8(const float* x, uint8_t* out, long n, void* stream) {
+  ADM_REQUIRE(x && out, "dequant: null argument");
+  return launch_dequant(x, out, n, (hipStream_t)stream);
+}
+
+int adm_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int groups, float eps,
+                        const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
+  ADM_REQUIRE(x1 && gamma && beta && scale && shift, "groupnorm_stats: null argument");
+  return launch_groupnorm_stats(x1, C1, x2, C2, N, HW, groups, eps, gamma, beta, scale, shift, (hipStream_t)stream);
+}
+
+int adm_conv2d(const adm_conv_args* a, void* stream) {
+  ADM_REQUIRE(a && a->x1 && a->wpacked && a->out, "conv2d: null argument");
+  return launch_conv2d(*a, (hipStream_t)stream);
+}
+
+int adm_pack_conv_weight(const float* w, float* wpacked, int Cout, int Cin, int ks, void* stream) {
+  ADM_REQUIRE(w && wpacked, "pack_conv_weight: null argument");
+  return launch_pack_conv_weight(w, wpacked, Cout, Cin, ks, (hipStream_t)stream);
+}
+
+void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo) {
+  conv_out_dims(H, W, up, stride, ks, pad_lo, Ho, Wo);
+}
+
+int adm_attention(const float* qkv, float* out, int N, int C, int T, int head_dim, void* stream) {
+  ADM_REQUIRE(qkv && out, "attention: null argument");
+  return launch_attention(qkv, out, N, C, T, head_dim, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// k_conv_mfma.hip — fused 2-D convolution as an implicit GEMM on the exact-f32 matrix core
+// (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, 157 TF peak = the f32 vector peak; guide §3).
+//
+// Replaces every nn.Conv2d the UNet forward reaches (SURVEY.md §2.2 / §8(a) U2-U5,U7): ResnetBlock2D
+// conv1/conv2/conv_shortcut, Downsample2D (stride 2), Upsample2D (nearest x2 folded into the load),
+// attention q/k/v/out projections (1x1), with these fusions so an activation is read once and written once:
+//   load path : virtual channel concat (two base pointers), nearest x2 upsample by index, zero padding,
+//               GroupNorm affine (per-(n,c) scale/shift from k_groupnorm) + SiLU;
+//   epilogue  : + bias[co] + time-embedding bias[n][co] + residual[n][co][y][x].
+//
+// GEMM view: D[co][pixel] = sum_{c,tap} W[co][c][tap] * X[c][pixel+tap]; M = Cout, N = pixels, K = Cin*ks*ks.
+// Workgroup = 4 waves, tile BM x 128 pixels (BM = 128/64/32), K in chunks of 8 input channels staged in LDS:
+//   ldsX [8][NI][IH][IW]  the haloed (and already activated) input patch — NCHW rows, so a wave's 32 pixels are
+//                         consecutive LDS words (conflict-free ds_read_b32 up to the row seam);
+//   ldsW [8*ks*ks][BM]    weights pre-packed [Cin][tap][Cout] so a wave's 32 couts are consecutive words.
+// MFMA operands: A = weights (lane l: co = l&31, k = l>>5), B = pixels (lane l: pixel = l&31, k = l>>5); the
+// two k of one instruction are the two channels (2cp, 2cp+1) of the same tap. Output fragment: col = pixel,
+// row = cout, so each store instruction writes 2 couts x 32 consecutive pixels (64-B..128-B segments, NCHW).
+// Pixel tile = NI images x TH x TW with TW = min(Wo,16), TH = min(Ho,8): 128 pixels at every UNet level
+// (256^2 ... 1x1). Algorithmic bytes per launch: 4*(N*Cin*Hs*Ws + N*Cout*Ho*Wo [+ residual]) + 4*Cout*Cin*ks^2.
+#include "adm_kernels.h"
+
+namespace adm {
+
+constexpr int CK = 8;      // input channels per K chunk
+constexpr int MAXQ = 5;    // max ldsX elements per thread per channel plane (CS <= 1280)
+
+struct ConvParams {
+  const float* x1; const float* x2; int C1, C2;
+  int N, Hs, Ws, Hi, Wi, Ho, Wo;
+  int up, pad_lo;
+  const float* gn_scale; const float* gn_shift; int act;
+  const float* wp; const float* bias; int Cout;
+  const float* chan_add; int chan_add_stride;
+  const float* residual; float* out;
+  int lTW, lTH, tiles_x, tiles_y, n_ct, IH, IW, CS, nblk;
+};
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+template <int KS, int STRIDE, int WM, int TM>
+__global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams p) {
+  constexpr int WN = 4 / WM;
+  constexpr int TN = 4 / WN;
+  constexpr int BM = 32 * WM * TM;
+  constexpr int KS2 = KS * KS;
+  ADM_DYN_SMEM(float, smem);
+  float* ldsX = smem;                 // CK * CS
+  float* ldsW = smem + CK * p.CS;     // CK*KS2 * BM   (CS is rounded so this stays 16-B aligned)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware bijective remap: hardware places block b on XCD b%8; give each XCD a contiguous logical range so
+  // workgroups sharing an input patch / weight slab hit the same L2 (guide §5 "XCD swizzle must be bijective").
+  int lid;
+  {
+    const int b = blockIdx.x, q = p.nblk >> 3, r = p.nblk & 7, xcd = b & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int ct = lid % p.n_ct, pt = lid / p.n_ct;
+  const int tx = pt % p.tiles_x, ty = (pt / p.tiles_x) % p.tiles_y, ig = pt / (p.tiles_x * p.tiles_y);
+  const int TW = 1 << p.lTW, TH = 1 << p.lTH, NI = 128 >> (p.lTW + p.lTH);
+  const int m0 = ct * BM, n0 = ig * NI;
+  const int Ct = p.C1 + p.C2;
+  const int planeS = p.Hs * p.Ws;
+  const int IHW = p.IH * p.IW;
+
+  // ---- per-thread gather plan for the input patch (same for every channel plane) -------------------
+  int q_soff[MAXQ];   // offset inside a source channel plane, or -1 (zero padding / out of range)
+  int q_img[MAXQ];    // image index inside the tile
+  ADM_UNROLL
+  for (int qi = 0; qi < MAXQ; ++qi) {
+    const int q = tid + qi * 256;
+    q_soff[qi] = -1;
+    q_img[qi] = 0;
+    if (q < NI * IHW) {
+      const int img = q / IHW, r2 = q - img * IHW;
+      const int ly = r2 / p.IW, lx = r2 - ly * p.IW;
+      const int gy = ty * TH * STRIDE + ly - p.pad_lo, gx = tx * TW * STRIDE + lx - p.pad_lo;
+      q_img[qi] = img;
+      if (gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi && n0 + img < p.N) {
+        const int sy = p.up ? (gy >> 1) : gy, sx = p.up ? (gx >> 1) : gx;
+        q_soff[qi] = sy * p.Ws + sx;
+      }
+    }
+  }
+  // ---- per-lane B (pixel) offsets into ldsX, and output coordinates ---------------------------------
+  int poff[TN];
+  ADM_UNROLL
+  for (int tn = 0; tn < TN; ++tn) {
+    const int pp = (wn * TN + tn) * 32 + l31;
+    const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
+    poff[tn] = img * IHW + py * STRIDE * p.IW + px * STRIDE;
+  }
+
+  f32x16 acc[TM][TN];
+  ADM_UNROLL
+  for (int a = 0; a < TM; ++a)
+    ADM_UNROLL
+    for (int b = 0; b < TN; ++b)
+      ADM_UNROLL
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int a_lane = wm * TM * 32 + l31;
+
+  for (int c0 = 0; c0 < Ct; c0 += CK) {
+    // ---- stage the activated input patch ----------------------------------------------------------
+    const bool from1 = c0 < p.C1;
+    const float* xb = from1 ? p.x1 : p.x2;
+    const int Cb = from1 ? p.C1 : p.C2;
+    const int cb0 = from1 ? c0 : c0 - p.C1;
+    ADM_UNROLL
+    for (int qi = 0; qi < MAXQ; ++qi) {
+      const int q = tid + qi * 256;
+      if (q < NI * IHW) {
+        const int soff = q_soff[qi];
+        const int n = n0 + q_img[qi];
+        float v[CK];
+        ADM_UNROLL
+        for (int c = 0; c < CK; ++c) {
+          v[c] = 0.f;
+          if (soff >= 0) v[c] = xb[((long)n * Cb + cb0 + c) * planeS + soff];
+        }
+        if (p.gn_scale != nullptr && soff >= 0) {
+          ADM_UNROLL
+          for (int c = 0; c < CK; ++c) {
+            const float sc = p.gn_scale[(long)n * Ct + c0 + c], sh = p.gn_shift[(long)n * Ct + c0 + c];
+            float y = v[c] * sc + sh;
+            if (p.act) y = silu_f(y);
+            v[c] = y;
+          }
+        } else if (p.act && soff >= 0) {
+          ADM_UNROLL
+          for (int c = 0; c < CK; ++c) v[c] = silu_f(v[c]);
+        }
+        ADM_UNROLL
+        for (int c = 0; c < CK; ++c) ldsX[c * p.CS + q] = v[c];
+      }
+    }
+    // ---- stage the weight slab: rows (c, tap), BM consecutive couts each --------------------------
+    {
+      constexpr int ROW4 = BM / 4;
+      constexpr int TOT4 = CK * KS2 * ROW4;
+      const float* wsrc = p.wp + (long)c0 * KS2 * p.Cout + m0;
+      for (int idx = tid; idx < TOT4; idx += 256) {
+        const int row = idx / ROW4, c4 = idx - row * ROW4;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + c4 * 4 < p.Cout) w = *reinterpret_cast<const float4*>(wsrc + (long)row * p.Cout + c4 * 4);
+        *reinterpret_cast<float4*>(ldsW + row * BM + c4 * 4) = w;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over this chunk: 9 taps x 4 channel pairs ------------------------------------------
+    ADM_UNROLL
+    for (int tap = 0; tap < KS2; ++tap) {
+      const int toff = (tap / KS) * p.IW + (tap % KS);
+      ADM_UNROLL
+      for (int cp = 0; cp < CK / 2; ++cp) {
+        const int ch = 2 * cp + h;
+        float av[TM], bv[TN];
+        ADM_UNROLL
+        for (int a = 0; a < TM; ++a) av[a] = ldsW[(ch * KS2 + tap) * BM + a_lane + a * 32];
+        ADM_UNROLL
+        for (int b = 0; b < TN; ++b) bv[b] = ldsX[ch * p.CS + poff[b] + toff];
+        ADM_UNROLL
+        for (int a = 0; a < TM; ++a)
+          ADM_UNROLL
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + temb bias + residual, NCHW store ---------------------------------------------
+  const long planeO = (long)p.Ho * p.Wo;
+  ADM_UNROLL
+  for (int tn = 0; tn < TN; ++tn) {
+    const int pp = (wn * TN + tn) * 32 + l31;
+    const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
+    const int oy = ty * TH + py, ox = tx * TW + px, n = n0 + img;
+    if (n >= p.N || oy >= p.Ho || ox >= p.Wo) continue;
+    ADM_UNROLL
+    for (int tm = 0; tm < TM; ++tm) {
+      ADM_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co >= p.Cout) continue;
+        float v = acc[tm][tn][r];
+        if (p.bias != nullptr) v += p.bias[co];
+        if (p.chan_add != nullptr) v += p.chan_add[(long)n * p.chan_add_stride + co];
+        const long o = ((long)n * p.Cout + co) * planeO + (long)oy * p.Wo + ox;
+        if (p.residual != nullptr) v += p.residual[o];
+        p.out[o] = v;
+      }
+    }
+  }
+}
+
+void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo) {
+  const int Hi = up ? 2 * H : H, Wi = up ? 2 * W : W;
+  if (stride == 1) {
+    *Ho = Hi; *Wo = Wi;  // "same" (ks=3,pad 1) or 1x1
+  } else {
+    // symmetric pad 1: floor((Hi+2-3)/2)+1 ; asymmetric (0,1): floor((Hi+1-3)/2)+1
+    *Ho = (Hi + (pad_lo ? 2 : 1) - ks) / stride + 1;
+    *Wo = (Wi + (pad_lo ? 2 : 1) - ks) / stride + 1;
+  }
+}
+
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+int launch_conv_small(const adm_conv_args& a, hipStream_t st);  // k_conv_small.hip
+
+template <int KS, int STRIDE>
+static int dispatch_bm(const ConvParams& p, int bm, size_t smem, hipStream_t st) {
+  dim3 grid(p.nblk), block(256);
+  if (bm == 128) {
+    ADM_LAUNCH((conv_mfma_kernel<KS, STRIDE, 2, 2>), grid, block, smem, st, p);
+  } else if (bm == 64) {
+    ADM_LAUNCH((conv_mfma_kernel<KS, STRIDE, 2, 1>), grid, block, smem, st, p);
+  } else {
+    ADM_LAUNCH((conv_mfma_kernel<KS, STRIDE, 1, 1>), grid, block, smem, st, p);
+  }
+  return ADM_CHECK_LAUNCH();
+}
+
+int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
+  const int C2 = a.x2 ? a.C2 : 0;
+  const int Ct = a.C1 + C2;
+  ADM_REQUIRE(a.ks == 3 || a.ks == 1, "conv2d: ks must be 1 or 3");
+  ADM_REQUIRE(a.stride == 1 || a.stride == 2, "conv2d: stride must be 1 or 2");
+  if (Ct % CK != 0 || a.C1 % CK != 0 || a.Cout % 4 != 0 || a.Cout < 32)
+    return launch_conv_small(a, st);  // conv_in / conv_out class (tiny Cin or Cout): direct kernel
+  ADM_REQUIRE(!(a.ks == 1 && (a.stride != 1 || a.up)), "conv2d: 1x1 supports stride 1, no upsample");
+  ConvParams p;
+  p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2;
+  p.N = a.N; p.Hs = a.H; p.Ws = a.W;
+  p.Hi = a.up ? 2 * a.H : a.H; p.Wi = a.up ? 2 * a.W : a.W;
+  conv_out_dims(a.H, a.W, a.up, a.stride, a.ks, a.pad_lo, &p.Ho, &p.Wo);
+  p.up = a.up; p.pad_lo = a.ks == 1 ? 0 : a.pad_lo;
+  p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.act = a.act;
+  p.wp = a.wpacked; p.bias = a.bias; p.Cout = a.Cout;
+  p.chan_add = a.chan_add; p.chan_add_stride = a.chan_add_stride;
+  p.residual = a.residual; p.out = a.out;
+  const int TW = p.Wo >= 16 ? 16 : p.Wo, TH = p.Ho >= 8 ? 8 : p.Ho;
+  ADM_REQUIRE((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "conv2d: output dims below 16x8 must be powers of two");
+  p.lTW = ilog2(TW); p.lTH = ilog2(TH);
+  const int NI = 128 / (TW * TH);
+  p.tiles_x = ceil_div(p.Wo, TW); p.tiles_y = ceil_div(p.Ho, TH);
+  const int img_groups = ceil_div(a.N, NI);
+  p.IH = (TH - 1) * a.stride + a.ks; p.IW = (TW - 1) * a.stride + a.ks;
+  p.CS = (NI * p.IH * p.IW + 3) & ~3;
+  ADM_REQUIRE(p.CS <= MAXQ * 256, "conv2d: input patch too large for the gather plan");
+  const int n_pt = p.tiles_x * p.tiles_y * img_groups;
+  // cout tile: largest of 128/64/32 that still gives >= 1 workgroup per CU (256 CUs), else the smallest.
+  int bm = 32;
+  if (a.Cout % 128 == 0 && (long)n_pt * (a.Cout / 128) >= 256) bm = 128;
+  else if (a.Cout % 64 == 0 && (long)n_pt * (a.Cout / 64) >= 256) bm = 64;
+  p.n_ct = ceil_div(a.Cout, bm);
+  p.nblk = n_pt * p.n_ct;
+  const size_t smem = sizeof(float) * ((size_t)CK * p.CS + (size_t)CK * a.ks * a.ks * bm);
+  if (a.ks == 3 && a.stride == 1) return dispatch_bm<3, 1>(p, bm, smem, st);
+  if (a.ks == 3 && a.stride == 2) return dispatch_bm<3, 2>(p, bm, smem, st);
+  return dispatch_bm<1, 1>(p, bm, smem, st);
+}
+
+// (Cout,Cin,ks,ks) -> [Cin][tap][Cout]
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KS2) {
+  const long total = (long)Cout * Cin * KS2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    const long r = i / Cout;
+    const int tap = (int)(r % KS2), c = (int)(r / KS2);
+    wp[i] = w[((long)co * Cin + c) * KS2 + tap];
+  }
+}
+
+int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, hipStream_t st) {
+  const long total = (long)Cout * Cin * ks * ks;
+  long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  ADM_LAUNCH(pack_weight_kernel, dim3((unsigned)g), dim3(256), 0, st, w, wp, Cout, Cin, ks * ks);
+  return ADM_CHECK_LAUNCH();
+}
+
+}  // namespace adm

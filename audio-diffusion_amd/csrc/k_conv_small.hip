@@ -1,0 +1,125 @@
+// k_conv_small.hip — direct 3x3 convolutions for the two degenerate GEMM shapes of the UNet/VAE:
+//   conv_in  class (Cin <= 4, e.g. 1 -> 128 @256^2): K = 9 — write-bound, one thread per output pixel;
+//   conv_out class (Cout <= 4, e.g. GN+SiLU -> 128 -> 1 @256^2): read-bound, LDS-staged 18x18 halo tiles
+//   with the GroupNorm affine + SiLU applied once per staged element.
+// Both are HBM-bound: algorithmic bytes = 4*(N*Cin*H*W + N*Cout*H*W).
+// Stride 1, ks = 3 (pad 1) or ks = 1 only; anything else is routed to the MFMA kernel by launch_conv2d.
+#include "adm_kernels.h"
+
+namespace adm {
+
+__device__ __forceinline__ float silu_s(float v) { return v / (1.0f + __expf(-v)); }
+
+// ---- Cin <= 4: each thread one output pixel, loops over all couts -------------------------------------
+template <int CIN, int KS>
+__global__ void __launch_bounds__(256) conv_small_cin_kernel(const float* __restrict__ x, int N, int H, int W,
+                                                             const float* __restrict__ wp,  // [Cin][tap][Cout]
+                                                             const float* __restrict__ bias, int Cout,
+                                                             const float* __restrict__ residual,
+                                                             float* __restrict__ out) {
+  constexpr int KS2 = KS * KS, PAD = KS / 2, K = CIN * KS2;
+  const long HW = (long)H * W;
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (pix >= HW) return;
+  const int y = (int)(pix / W), xx = (int)(pix % W);
+  float v[K];
+  ADM_UNROLL
+  for (int c = 0; c < CIN; ++c)
+    ADM_UNROLL
+    for (int t = 0; t < KS2; ++t) {
+      const int gy = y + t / KS - PAD, gx = xx + t % KS - PAD;
+      v[c * KS2 + t] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((long)n * CIN + c) * HW + (long)gy * W + gx] : 0.f;
+    }
+  for (int co = 0; co < Cout; ++co) {
+    float acc = bias ? bias[co] : 0.f;
+    ADM_UNROLL
+    for (int k = 0; k < K; ++k) acc = fmaf(wp[(long)k * Cout + co], v[k], acc);
+    const long o = ((long)n * Cout + co) * HW + pix;
+    if (residual) acc += residual[o];
+    out[o] = acc;
+  }
+}
+
+// ---- Cout <= 4: 16x16 output tile per workgroup, channels staged 8 at a time through LDS ----------------
+constexpr int SC = 8;
+__global__ void __launch_bounds__(256) conv_small_cout_kernel(const float* __restrict__ x, int Cin, int N, int H,
+                                                              int W, const float* __restrict__ gn_scale,
+                                                              const float* __restrict__ gn_shift, int act,
+                                                              const float* __restrict__ wp,  // [Cin][tap][Cout]
+                                                              const float* __restrict__ bias, int Cout,
+                                                              const float* __restrict__ residual,
+                                                              float* __restrict__ out, int tiles_x) {
+  __shared__ float tile[SC][18][18 + 1];
+  __shared__ float wl[4][SC][9];
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, n = blockIdx.y;
+  const int lx = tid & 15, ly = tid >> 4;
+  const int ox = tx * 16 + lx, oy = ty * 16 + ly;
+  const long HW = (long)H * W;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < Cin; c0 += SC) {
+    for (int e = tid; e < SC * 18 * 18; e += 256) {
+      const int c = e / 324, r = e - c * 324, yy = r / 18, xx = r - yy * 18;
+      const int gy = ty * 16 + yy - 1, gx = tx * 16 + xx - 1;
+      float v = 0.f;
+      if (c0 + c < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        v = x[((long)n * Cin + c0 + c) * HW + (long)gy * W + gx];
+        if (gn_scale) v = v * gn_scale[(long)n * Cin + c0 + c] + gn_shift[(long)n * Cin + c0 + c];
+        if (act) v = silu_s(v);
+      }
+      tile[c][yy][xx] = v;
+    }
+    for (int e = tid; e < 4 * SC * 9; e += 256) {
+      const int co = e / (SC * 9), r = e - co * SC * 9, c = r / 9, t = r - c * 9;
+      wl[co][c][t] = (co < Cout && c0 + c < Cin) ? wp[((long)(c0 + c) * 9 + t) * Cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int c = 0; c < SC; ++c) {
+      ADM_UNROLL
+      for (int t = 0; t < 9; ++t) {
+        const float v = tile[c][ly + t / 3][lx + t % 3];
+        ADM_UNROLL
+        for (int co = 0; co < 4; ++co) acc[co] = fmaf(wl[co][c][t], v, acc[co]);
+      }
+    }
+    __syncthreads();
+  }
+  if (ox < W && oy < H) {
+    for (int co = 0; co < Cout; ++co) {
+      const long o = ((long)n * Cout + co) * HW + (long)oy * W + ox;
+      float v = acc[co] + (bias ? bias[co] : 0.f);
+      if (residual) v += residual[o];
+      out[o] = v;
+    }
+  }
+}
+
+int launch_conv_small(const adm_conv_args& a, hipStream_t st) {
+  ADM_REQUIRE(a.x2 == nullptr || a.C2 == 0, "conv_small: virtual concat not supported");
+  ADM_REQUIRE(a.stride == 1 && !a.up, "conv_small: stride 1, no upsample only");
+  ADM_REQUIRE(a.chan_add == nullptr, "conv_small: chan_add not supported");
+  if (a.C1 <= 4) {
+    ADM_REQUIRE(a.gn_scale == nullptr && !a.act, "conv_small(cin): no fused norm/activation");
+    ADM_REQUIRE(a.ks == 3 || a.ks == 1, "conv_small: ks");
+    const long HW = (long)a.H * a.W;
+    dim3 grid((unsigned)((HW + 255) / 256), a.N), block(256);
+#define ADM_CIN_CASE(CI, KK)                                                                                       \
+  if (a.C1 == CI && a.ks == KK) {                                                                                  \
+    ADM_LAUNCH((conv_small_cin_kernel<CI, KK>), grid, block, 0, st, a.x1, a.N, a.H, a.W, a.wpacked, a.bias, a.Cout, \
+               a.residual, a.out);                                                                                 \
+    return ADM_CHECK_LAUNCH();                                                                                     \
+  }
+    ADM_CIN_CASE(1, 3) ADM_CIN_CASE(2, 3) ADM_CIN_CASE(3, 3) ADM_CIN_CASE(4, 3)
+    ADM_CIN_CASE(1, 1) ADM_CIN_CASE(2, 1) ADM_CIN_CASE(3, 1) ADM_CIN_CASE(4, 1)
+#undef ADM_CIN_CASE
+    ADM_FAIL("conv_small(cin): unsupported (Cin, ks)");
+  }
+  ADM_REQUIRE(a.Cout <= 4 && a.ks == 3 && a.pad_lo == 1, "conv_small: unsupported shape (need Cin<=4 or Cout<=4, 3x3)");
+  const int tiles_x = ceil_div(a.W, 16), tiles_y = ceil_div(a.H, 16);
+  ADM_LAUNCH(conv_small_cout_kernel, dim3(tiles_x * tiles_y, a.N), dim3(256), 0, st, a.x1, a.C1, a.N, a.H, a.W,
+             a.gn_scale, a.gn_shift, a.act, a.wpacked, a.bias, a.Cout, a.residual, a.out, tiles_x);
+  return ADM_CHECK_LAUNCH();
+}
+
+}  // namespace adm

@@ -1,0 +1,84 @@
+// k_groupnorm.hip — GroupNorm statistics -> per-(n,c) scale/shift (HBM-bound read-only pass).
+// torch.nn.GroupNorm as used by ResnetBlock2D.norm1/norm2, conv_norm_out and the attention group_norm
+// (SURVEY.md §2.2 "GroupNorm(32)+SiLU", §8(a) U3/U6/U8). The normalisation itself (x*scale+shift, SiLU) is
+// applied in the consumer convolution's LDS-fill path, so the activation is read once here and once there,
+// never written. Input may be a virtual channel concat (x1|x2) — a group can straddle the seam.
+// One workgroup per (n, group); fp64 accumulation; wavefront shuffles (64 lanes) then LDS across the 4 waves.
+// Algorithmic bytes: 4 B per input element.
+#include "adm_kernels.h"
+
+namespace adm {
+
+__device__ __forceinline__ double wave_sum(double v) {
+  ADM_UNROLL
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x1, int C1,
+                                                       const float* __restrict__ x2, int C2, int HW, int groups,
+                                                       float eps, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ scale,
+                                                       float* __restrict__ shift) {
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int C = C1 + C2, cg = C / groups;
+  const int tid = threadIdx.x;
+  const long total = (long)cg * HW;
+  double s = 0.0, ss = 0.0;
+  if ((HW & 3) == 0) {
+    for (long e = (long)tid * 4; e < total; e += 256 * 4) {
+      const int cl = (int)(e / HW);
+      const int p = (int)(e - (long)cl * HW);
+      const int c = g * cg + cl;
+      const float* src = c < C1 ? x1 + ((long)n * C1 + c) * HW : x2 + ((long)n * C2 + (c - C1)) * HW;
+      const float4 v = *reinterpret_cast<const float4*>(src + p);
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    for (long e = tid; e < total; e += 256) {
+      const int cl = (int)(e / HW);
+      const int p = (int)(e - (long)cl * HW);
+      const int c = g * cg + cl;
+      const float* src = c < C1 ? x1 + ((long)n * C1 + c) * HW : x2 + ((long)n * C2 + (c - C1)) * HW;
+      const double v = src[p];
+      s += v;
+      ss += v * v;
+    }
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  __shared__ double red[2][4];
+  __shared__ float stat[2];
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+  __syncthreads();
+  if (tid == 0) {
+    const double S = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double SS = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double mean = S / (double)total;
+    double var = SS / (double)total - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[0] = (float)mean;
+    stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+  for (int cl = tid; cl < cg; cl += 256) {
+    const int c = g * cg + cl;
+    const float sc = rstd * gamma[c];  // same form as ATen's CPU kernel: y = x*scale + (beta - scale*mean)
+    scale[(long)n * C + c] = sc;
+    shift[(long)n * C + c] = -sc * mean + beta[c];
+  }
+}
+
+int launch_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int groups, float eps,
+                           const float* gamma, const float* beta, float* scale, float* shift, hipStream_t st) {
+  if (x2 == nullptr) C2 = 0;
+  ADM_REQUIRE((C1 + C2) % groups == 0, "groupnorm: channels not divisible by groups");
+  ADM_LAUNCH(gn_stats_kernel, dim3(groups, N), dim3(256), 0, st, x1, C1, x2, C2, HW, groups, eps, gamma, beta, scale,
+             shift);
+  return ADM_CHECK_LAUNCH();
+}
+
+}  // namespace adm

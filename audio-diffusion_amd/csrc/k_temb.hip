@@ -1,0 +1,93 @@
+// k_temb.hip — timestep embedding path (SURVEY.md §8(a) U1 and the per-resnet time_emb_proj of U3).
+//   time_embedding: sinusoid(t) [cos|sin after flip_sin_to_cos] -> Linear(128->512) -> SiLU -> Linear(512->512)
+//   temb_proj     : for ALL resnets at once, out[b][r] = bias[r] + W[r][:] . silu(emb[b][:]) with the 32
+//                   time_emb_proj matrices stacked row-wise (9984 x 512 for the 256x256 model); the conv1
+//                   epilogue then adds its slice as a per-(n,cout) bias.
+// Tiny, launch-latency class work: two launches per UNet forward instead of ~70 eager ops.
+// The timestep comes either from a device array (training / direct forward) or from the scheduler coefficient
+// table indexed by the device-side step counter (hipGraph replay).
+#include "adm_kernels.h"
+
+namespace adm {
+
+__device__ __forceinline__ float silu_t(float v) { return v / (1.0f + __expf(-v)); }
+
+__global__ void __launch_bounds__(256) time_embedding_kernel(const float* __restrict__ t_dev, int t_stride,
+                                                             const adm_sched_coef* __restrict__ table,
+                                                             const int* __restrict__ step_dev,
+                                                             const float* __restrict__ freqs, int half_dim, int flip,
+                                                             const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             int dim_in, int dim_emb, float* __restrict__ emb) {
+  ADM_DYN_SMEM(float, smem);
+  float* sinus = smem;          // dim_in
+  float* hid = smem + dim_in;   // dim_emb
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float t = t_dev ? t_dev[b * t_stride] : table[*step_dev].timestep;
+  for (int i = tid; i < half_dim; i += blockDim.x) {
+    const float arg = t * freqs[i];  // fp32 product as in diffusers; sin/cos evaluated in fp64 then rounded
+    const float s = (float)sin((double)arg), c = (float)cos((double)arg);
+    if (flip) { sinus[i] = c; sinus[half_dim + i] = s; }
+    else { sinus[i] = s; sinus[half_dim + i] = c; }
+  }
+  __syncthreads();
+  for (int j = tid; j < dim_emb; j += blockDim.x) {
+    float acc = b1[j];
+    const float* wr = w1 + (long)j * dim_in;
+    for (int k = 0; k < dim_in; ++k) acc = fmaf(wr[k], sinus[k], acc);
+    hid[j] = silu_t(acc);
+  }
+  __syncthreads();
+  for (int j = tid; j < dim_emb; j += blockDim.x) {
+    float acc = b2[j];
+    const float* wr = w2 + (long)j * dim_emb;
+    for (int k = 0; k < dim_emb; ++k) acc = fmaf(wr[k], hid[k], acc);
+    emb[(long)b * dim_emb + j] = acc;
+  }
+}
+
+// one wave per output row r; lanes split K; up to 8 batch rows per pass.
+__global__ void __launch_bounds__(256) temb_proj_kernel(const float* __restrict__ emb, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                        int K, int R) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* wr = w + (long)r * K;
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    float acc[8];
+    ADM_UNROLL
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float wv = wr[k];
+      ADM_UNROLL
+      for (int i = 0; i < 8; ++i)
+        if (b0 + i < B) acc[i] = fmaf(wv, silu_t(emb[(long)(b0 + i) * K + k]), acc[i]);
+    }
+    ADM_UNROLL
+    for (int i = 0; i < 8; ++i) {
+      float v = acc[i];
+      ADM_UNROLL
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      if (lane == 0 && b0 + i < B) out[(long)(b0 + i) * R + r] = v + bias[r];
+    }
+  }
+}
+
+int launch_time_embedding(const float* t_dev, int t_stride, const adm_sched_coef* table, const int* step_dev,
+                          const float* freqs, int half_dim, int flip, const float* w1, const float* b1, const float* w2,
+                          const float* b2, int dim_in, int dim_emb, float* emb, int B, hipStream_t st) {
+  ADM_REQUIRE(t_dev != nullptr || (table != nullptr && step_dev != nullptr), "time_embedding: no timestep source");
+  const size_t smem = sizeof(float) * (size_t)(dim_in + dim_emb);
+  ADM_LAUNCH(time_embedding_kernel, dim3(B), dim3(256), smem, st, t_dev, t_stride, table, step_dev, freqs, half_dim,
+             flip, w1, b1, w2, b2, dim_in, dim_emb, emb);
+  return ADM_CHECK_LAUNCH();
+}
+
+int launch_temb_proj(const float* emb, const float* w, const float* bias, float* out, int B, int K, int R,
+                     hipStream_t st) {
+  ADM_LAUNCH(temb_proj_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, st, emb, w, bias, out, B, K, R);
+  return ADM_CHECK_LAUNCH();
+}
+
+}  // namespace adm

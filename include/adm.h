@@ -1,0 +1,134 @@
+/* adm.h — C-ABI of the MI355X-native audio-diffusion hot path (libadm_hip.so).
+ *
+ * The reference (teticio/audio-diffusion) is pure Python: its hot path sits behind a duck-typed
+ * component API (`AudioDiffusionPipeline(vqvae, unet, mel, scheduler)`,
+ * audiodiffusion/pipeline_audio_diffusion.py:53-61), not behind an FFI. This header is the boundary a
+ * maintainer binds with ctypes to replace the calls cited per function.
+ *
+ * Conventions: every function returns 0 on success, non-zero on error (message via
+ * adm_last_error()); nothing throws across the ABI; the CALLER owns every I/O buffer (device
+ * pointers, fp32 NCHW contiguous unless stated); the library owns only opaque handles;
+ * `stream` is a hipStream_t passed as void* (NULL = default stream). One handle = one device = one stream
+ * at a time (the reference pipeline is not re-entrant either).
+ */
+#ifndef ADM_H
+#define ADM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int adm_version(void);
+const char* adm_last_error(void);
+/* 1 if built for the device (hipcc, gfx950), 0 for the CPU-emulation test build. */
+int adm_is_device_build(void);
+
+/* ---------------------------------------------------------------- scheduler epilogue (rows S2,S3,P4,P5)
+ * One fused elementwise kernel replacing DDIMScheduler.step / DDPMScheduler.step
+ * (pipeline_audio_diffusion.py:165-179), the mask overwrite (:181-185) and, on the last step, the
+ * dequantisation (images/2+0.5).clamp(0,1)*255 -> round-half-even -> uint8 (:192-194).
+ *   x0   = clamp((x - sqrt_beta*eps) / sqrt_alpha, -clip, clip)        (clip < 0: no clamp)
+ *   prev = k_x0*x0 + k_x*x + k_eps*eps + k_noise*noise
+ * DDIM: k_x0=sqrt(a_prev), k_x=0, k_eps=sqrt(1-a_prev-std^2), k_noise=std (eta>0).
+ * DDPM: k_x0=sqrt(a_prev)*cur_beta/beta_t, k_x=sqrt(cur_alpha)*beta_prev/beta_t, k_eps=0, k_noise=sqrt(var) (t>0).
+ * The host computes the scalars in the same fp32 arithmetic diffusers uses. */
+typedef struct adm_sched_coef {
+  float sqrt_beta, sqrt_alpha, clip, k_x0, k_x, k_eps, k_noise, timestep;
+} adm_sched_coef;
+
+/* coef_table: device array of adm_sched_coef; entry used = step_dev ? *step_dev : step.
+ * noise: NULL or (B,C,H,W). mask: NULL or (B,n_steps,H,W) (requires C==1); columns [0,mask_start) and
+ * [W-mask_end,W) of `out` are overwritten with mask[:,step]. u8_out: NULL or (B,H*W*C) uint8 image of `out`.
+ * out may alias x. */
+int adm_sched_step(const float* x, const float* eps, const float* noise, float* out, uint8_t* u8_out,
+                   const adm_sched_coef* coef_table, const int* step_dev, int step,
+                   const float* mask, int n_mask_steps, int mask_start, int mask_end,
+                   int B, int C, int H, int W, void* stream);
+
+/* scheduler.add_noise (rows S4,P3,T3): out[b][n][p] = sa[b*cb+n*cn]*x0[b*x0_bstride+p] + sb[..]*noise[b*P+p];
+ * sa/sb are device arrays (sqrt(acp[t]), sqrt(1-acp[t])). */
+int adm_add_noise(const float* x0, long x0_bstride, const float* noise, const float* sa, const float* sb,
+                  int cb, int cn, float* out, int B, int N, long P, void* stream);
+
+/* (x/2+0.5).clamp(0,1)*255 round-half-even -> u8 (pipeline_audio_diffusion.py:192-194). */
+int adm_dequant_u8(const float* x, uint8_t* out, long n, void* stream);
+
+/* ---------------------------------------------------------------- op-level entry points (parity tests)
+ * GroupNorm statistics over a (virtually concatenated) NCHW input: writes per-(n,c) scale/shift with
+ *   scale = rstd*gamma[c], shift = beta[c] - mean*scale   (torch.nn.GroupNorm, biased variance). */
+int adm_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int groups, float eps,
+                        const float* gamma, const float* beta, float* scale, float* shift, void* stream);
+
+/* Fused 2-D convolution (rows U2-U5,U7,U8): implicit GEMM on v_mfma_f32_32x32x2_f32.
+ *   in  = concat(x1[C1], x2[C2]) (x2 may be NULL), optional nearest x2 upsample (up=1) of the input,
+ *   optional per-(n,c) affine (gn_scale/gn_shift from adm_groupnorm_stats) and SiLU (act=1) applied on load,
+ *   out = conv(in, w, stride, pad) + bias[co] + chan_add[n][co] (NULL ok) + residual[n][co][y][x] (NULL ok).
+ * wpacked: weights repacked by adm_pack_conv_weight to [Cin][ks*ks][Cout]. H,W are the *source* dims of x1/x2.
+ * pad_lo is the top/left zero padding (1 for ks=3 "same"; 0 with stride 2 gives diffusers' (0,1,0,1) pad). */
+typedef struct adm_conv_args {
+  const float* x1; int C1;
+  const float* x2; int C2;
+  int N, H, W;
+  int up, stride, ks, pad_lo;
+  const float* gn_scale; const float* gn_shift; int act;
+  const float* wpacked; const float* bias; int Cout;
+  const float* chan_add; int chan_add_stride;
+  const float* residual;
+  float* out;
+} adm_conv_args;
+int adm_conv2d(const adm_conv_args* a, void* stream);
+/* (Cout,Cin,ks,ks) -> [Cin][ks*ks][Cout]; both device pointers. */
+int adm_pack_conv_weight(const float* w, float* wpacked, int Cout, int Cin, int ks, void* stream);
+void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);
+
+/* Self-attention core (row U6): qkv is (N, 3*C, T) with channels [q | k | v], head h = channels
+ * [h*d, (h+1)*d); out (N, C, T) = softmax(q^T k * d^-0.5) v per head, fp32 softmax. */
+int adm_attention(const float* qkv, float* out, int N, int C, int T, int head_dim, void* stream);
+
+/* ---------------------------------------------------------------- UNet2DModel executor (rows U1-U8)
+ * Replaces `self.unet(images, t)["sample"]` (pipeline_audio_diffusion.py:163,237; train_unet.py:257). */
+typedef struct adm_unet adm_unet_t;
+typedef struct adm_unet_config {
+  int in_channels, out_channels, layers_per_block, n_blocks;
+  int block_out_channels[8];
+  int down_attn[8]; /* 1 = AttnDownBlock2D */
+  int up_attn[8];   /* 1 = AttnUpBlock2D */
+  int attention_head_dim, norm_num_groups;
+  float norm_eps;
+  int flip_sin_to_cos;
+  float freq_shift;
+  int sample_h, sample_w;
+} adm_unet_config;
+
+int adm_unet_create(const adm_unet_config* cfg, adm_unet_t** out);
+void adm_unet_destroy(adm_unet_t* h);
+/* Upload one parameter by its diffusers state-dict key (host pointer, fp32, `numel` elements).
+ * Deprecated attention names (query/key/value/proj_attn, audiodiffusion/utils.py:41-54) are accepted. */
+int adm_unet_set_param(adm_unet_t* h, const char* key, const float* host_data, size_t numel);
+/* Number of parameters still missing after the set_param calls (0 = ready); names via adm_last_error(). */
+int adm_unet_missing_params(adm_unet_t* h);
+/* eps = unet(x, t): x,out (B,Cin,H,W)/(B,Cout,H,W) device; timesteps: B floats on the HOST (or 1 broadcast). */
+int adm_unet_forward(adm_unet_t* h, const float* x, const float* timesteps_host, int n_timesteps, float* out,
+                     int B, void* stream);
+/* Debug/testing: copy an intermediate activation by name after a forward ("conv_in", "down.0.res.0", ...). */
+size_t adm_unet_workspace_bytes(adm_unet_t* h);
+
+/* ---------------------------------------------------------------- whole denoising loop (row P4; hipGraph)
+ * Runs n_steps x {UNet forward, scheduler epilogue, mask} on `x` in place and (optionally) the final u8 image.
+ * coef_host: n_steps adm_sched_coef (host) including .timestep; step_noise: NULL or device
+ * (n_steps,B,C,H,W) noise consumed where k_noise != 0. With use_graph=1 one step is captured into a hipGraph
+ * and replayed n_steps times (step-dependent scalars come from a device table indexed by a device counter). */
+int adm_sample_loop(adm_unet_t* h, float* x, int B, const adm_sched_coef* coef_host, int n_steps,
+                    const float* step_noise, const float* mask, int mask_start, int mask_end,
+                    uint8_t* u8_out, int use_graph, void* stream);
+/* DDIM inversion loop (row P6, pipeline_audio_diffusion.py:228-240): per step
+ *   x = (x - c_dir*eps) * c_inv * c_fwd + c_eps*eps  with coef {sqrt_beta=c_dir, sqrt_alpha=c_inv, k_x0=c_fwd, k_eps=c_eps}. */
+int adm_encode_loop(adm_unet_t* h, float* x, int B, const adm_sched_coef* coef_host, int n_steps, int use_graph,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADM_H */

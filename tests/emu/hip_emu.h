@@ -1,0 +1,278 @@
+// hip_emu.h — TEST INFRASTRUCTURE ONLY. A lock-step fiber emulator of the HIP execution model
+// (workgroups, 64-lane waves, __syncthreads, wave shuffles, f32 MFMA fragment semantics) so that
+// the *same* kernel sources under audio-diffusion_amd/csrc compile with g++ (-DADM_EMU) and can be
+// checked against the oracle inside this GPU-less container. The product never builds or loads
+// this; the shipped library is compiled by hipcc for gfx950 only (see __graft_entry__.build()).
+//
+// Model: each workgroup's threads are ucontext fibers on one OS thread, scheduled round-robin and
+// switched only at collectives, so a missing barrier shows up deterministically (thread 0 runs
+// ahead). Workgroups are distributed over OS threads; `__shared__` becomes `static thread_local`.
+// MFMA lane->element maps follow /opt/skills/guides/cdna_hip_programming.md §3.
+#pragma once
+#include <ucontext.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) double2 { double x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+#define hipSuccess 0
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+namespace adm_emu {
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = true;
+  dim3 tid;
+};
+struct Wave {
+  int nlive = 0, arrived = 0;
+  unsigned gen = 0;
+  uint64_t xch[64];
+  float a[64], b[64];
+};
+struct State {
+  dim3 grid, block, bid;
+  std::vector<Fiber> fibers;
+  std::vector<Wave> waves;
+  int cur = 0, live = 0, bar_arrived = 0;
+  unsigned bar_gen = 0;
+  ucontext_t sched;
+  unsigned char* dyn_smem = nullptr;
+  void (*entry)(void*) = nullptr;
+  void* entry_arg = nullptr;
+};
+inline State& S() {
+  static thread_local State s;
+  return s;
+}
+static constexpr size_t kStack = 96 * 1024;
+
+inline void yield() {
+  State& s = S();
+  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+inline int flat_tid() {
+  State& s = S();
+  const dim3& t = s.fibers[s.cur].tid;
+  return t.x + s.block.x * (t.y + s.block.y * t.z);
+}
+inline void block_sync() {
+  State& s = S();
+  unsigned g = s.bar_gen;
+  if (++s.bar_arrived >= s.live) {
+    s.bar_arrived = 0;
+    s.bar_gen++;
+  } else {
+    while (s.bar_gen == g) yield();
+  }
+}
+inline void wave_sync() {
+  State& s = S();
+  Wave& w = s.waves[flat_tid() >> 6];
+  unsigned g = w.gen;
+  if (++w.arrived >= w.nlive) {
+    w.arrived = 0;
+    w.gen++;
+  } else {
+    unsigned spins = 0;
+    while (w.gen == g) {
+      yield();
+      if (++spins > 1000000u) {
+        fprintf(stderr, "adm_emu: divergent wave collective (deadlock) in block (%u,%u,%u)\n", s.bid.x, s.bid.y, s.bid.z);
+        abort();
+      }
+    }
+  }
+}
+inline void fiber_main(int) {
+  State& s = S();
+  s.entry(s.entry_arg);
+  Fiber& f = s.fibers[s.cur];
+  f.done = true;
+  s.live--;
+  Wave& w = s.waves[flat_tid() >> 6];
+  w.nlive--;
+  if (w.nlive > 0 && w.arrived >= w.nlive) { w.arrived = 0; w.gen++; }
+  if (s.live > 0 && s.bar_arrived >= s.live) { s.bar_arrived = 0; s.bar_gen++; }
+  swapcontext(&f.ctx, &s.sched);
+}
+inline void run_block(dim3 grid, dim3 block, dim3 bid, size_t shmem, void (*entry)(void*), void* arg) {
+  State& s = S();
+  s.grid = grid; s.block = block; s.bid = bid;
+  s.entry = entry; s.entry_arg = arg;
+  int n = block.x * block.y * block.z;
+  if ((int)s.fibers.size() < n) s.fibers.resize(n);
+  s.waves.assign((n + 63) / 64, Wave());
+  std::vector<unsigned char> smem(shmem + 64);
+  s.dyn_smem = (unsigned char*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63);
+  s.live = n; s.bar_arrived = 0; s.bar_gen = 0;
+  for (int i = 0; i < n; ++i) {
+    Fiber& f = s.fibers[i];
+    if (!f.stack) f.stack = (char*)malloc(kStack);
+    f.done = false;
+    f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
+    s.waves[i >> 6].nlive++;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = &s.sched;
+    makecontext(&f.ctx, (void (*)())fiber_main, 1, 0);
+  }
+  while (s.live > 0) {
+    for (int i = 0; i < n; ++i) {
+      if (s.fibers[i].done) continue;
+      s.cur = i;
+      swapcontext(&s.sched, &s.fibers[i].ctx);
+    }
+  }
+}
+template <class F>
+void launch(dim3 grid, dim3 block, size_t shmem, F body) {
+  struct Tramp { static void call(void* p) { (*(F*)p)(); } };
+  size_t nblk = (size_t)grid.x * grid.y * grid.z;
+  static int nthr_env = getenv("ADM_EMU_THREADS") ? atoi(getenv("ADM_EMU_THREADS")) : 0;
+  unsigned nthr = nthr_env > 0 ? nthr_env : std::thread::hardware_concurrency();
+  if (nthr > nblk) nthr = (unsigned)nblk;
+  if (nthr < 1) nthr = 1;
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    for (;;) {
+      size_t b = next.fetch_add(1);
+      if (b >= nblk) break;
+      dim3 bid(b % grid.x, (b / grid.x) % grid.y, b / ((size_t)grid.x * grid.y));
+      F local = body;
+      run_block(grid, block, bid, shmem, &Tramp::call, &local);
+    }
+  };
+  if (nthr == 1) { worker(); return; }
+  std::vector<std::thread> th;
+  for (unsigned i = 0; i < nthr; ++i) th.emplace_back(worker);
+  for (auto& t : th) t.join();
+}
+
+template <class T>
+inline T shfl_idx(T v, int src) {
+  static_assert(sizeof(T) <= 8, "shfl payload");
+  State& s = S();
+  int lane = flat_tid() & 63;
+  Wave& w = s.waves[flat_tid() >> 6];
+  uint64_t raw = 0;
+  memcpy(&raw, &v, sizeof(T));
+  w.xch[lane] = raw;
+  wave_sync();
+  T r;
+  memcpy(&r, &w.xch[src & 63], sizeof(T));
+  wave_sync();
+  return r;
+}
+}  // namespace adm_emu
+
+#define threadIdx (adm_emu::S().fibers[adm_emu::S().cur].tid)
+#define blockIdx (adm_emu::S().bid)
+#define blockDim (adm_emu::S().block)
+#define gridDim (adm_emu::S().grid)
+
+static inline void __syncthreads() { adm_emu::block_sync(); }
+template <class T> static inline T __shfl_xor(T v, int m, int = 64) { return adm_emu::shfl_idx(v, (adm_emu::flat_tid() & 63) ^ m); }
+template <class T> static inline T __shfl_down(T v, int d, int = 64) {
+  int l = adm_emu::flat_tid() & 63;
+  return adm_emu::shfl_idx(v, l + d < 64 ? l + d : l);
+}
+template <class T> static inline T __shfl(T v, int src, int = 64) { return adm_emu::shfl_idx(v, src); }
+
+typedef float f32x16 __attribute__((vector_size(64)));
+typedef float f32x4 __attribute__((vector_size(16)));
+
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D col=l&31,row=(r&3)+8*(r>>2)+4*(l>>5);
+// k-ordered fmaf chain (bitwise-equal to the hardware per the guide §3).
+static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) {
+  using namespace adm_emu;
+  int lane = flat_tid() & 63;
+  Wave& w = S().waves[flat_tid() >> 6];
+  w.a[lane] = a; w.b[lane] = b;
+  wave_sync();
+  f32x16 d;
+  int j = lane & 31;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    d[r] = fmaf(w.a[i + 32], w.b[j + 32], fmaf(w.a[i], w.b[j], c[r]));
+  }
+  wave_sync();
+  return d;
+}
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D col=l&15,row=4*(l>>4)+r.
+static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
+  using namespace adm_emu;
+  int lane = flat_tid() & 63;
+  Wave& w = S().waves[flat_tid() >> 6];
+  w.a[lane] = a; w.b[lane] = b;
+  wave_sync();
+  f32x4 d;
+  int j = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    int i = 4 * (lane >> 4) + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = fmaf(w.a[i + 16 * k], w.b[j + 16 * k], acc);
+    d[r] = acc;
+  }
+  wave_sync();
+  return d;
+}
+
+static inline float adm_emu_expf(float x) { return expf(x); }
+#define __expf adm_emu_expf
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline double rsqrt(double x) { return 1.0 / sqrt(x); }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
+
+template <class T> static inline T atomicAdd(T* p, T v) {
+  if constexpr (std::is_integral<T>::value) {
+    return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+  } else {
+    using U = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
+    U* up = (U*)p;
+    U old = __atomic_load_n(up, __ATOMIC_RELAXED), nw;
+    T o;
+    do {
+      memcpy(&o, &old, sizeof(T));
+      T n = o + v;
+      memcpy(&nw, &n, sizeof(T));
+    } while (!__atomic_compare_exchange_n(up, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return o;
+  }
+}
+static inline unsigned atomicMax(unsigned* p, unsigned v) {
+  unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
