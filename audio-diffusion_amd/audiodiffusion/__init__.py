@@ -11,3 +11,103 @@ from . import _native
 # _native.load(<emulation build>) — the product default is libadm_hip.so and there is no CPU fallback.
 
 VERSION = "1.5.7"
+
+from typing import Iterable, Tuple  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from PIL import Image  # noqa: E402
+
+from .mel import Mel  # noqa: E402,F401
+from .pipeline_audio_diffusion import AudioDiffusionPipeline  # noqa: E402
+from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: E402,F401
+from .unet import UNet2DModel  # noqa: E402,F401
+
+try:  # progress bars are optional plumbing
+    from tqdm.auto import tqdm  # noqa: E402
+except Exception:  # pragma: no cover
+    tqdm = None
+
+
+class AudioDiffusion:
+    def __init__(
+        self,
+        model_id: str = "teticio/audio-diffusion-256",
+        cuda: bool = torch.cuda.is_available(),
+        progress_bar: Iterable = tqdm,
+    ):
+        """Class for generating audio using De-noising Diffusion Probabilistic Models
+        (`audiodiffusion/__init__.py:15-33`).
+
+        Args:
+            model_id (String): name of model (local directory in the diffusers layout; no hub access here)
+            cuda (bool): use CUDA? (the MI355X is torch's "cuda" device on ROCm; this path has no CPU mode)
+            progress_bar (iterable): iterable callback for progress updates or None
+        """
+        self.model_id = model_id
+        self.pipe = AudioDiffusionPipeline.from_pretrained(self.model_id)
+        if cuda:
+            self.pipe.to("cuda")
+        self.progress_bar = progress_bar or (lambda _: _)
+
+    def generate_spectrogram_and_audio(
+        self,
+        steps: int = None,
+        generator: torch.Generator = None,
+        step_generator: torch.Generator = None,
+        eta: float = 0,
+        noise: torch.Tensor = None,
+        encoding: torch.Tensor = None,
+    ) -> Tuple[Image.Image, Tuple[int, np.ndarray]]:
+        """Generate random mel spectrogram and convert to audio (`__init__.py:35-68`)."""
+        images, (sample_rate, audios) = self.pipe(
+            batch_size=1,
+            steps=steps,
+            generator=generator,
+            step_generator=step_generator,
+            eta=eta,
+            noise=noise,
+            encoding=encoding,
+            return_dict=False,
+        )
+        return images[0], (sample_rate, audios[0])
+
+    def generate_spectrogram_and_audio_from_audio(
+        self,
+        audio_file: str = None,
+        raw_audio: np.ndarray = None,
+        slice: int = 0,
+        start_step: int = 0,
+        steps: int = None,
+        generator: torch.Generator = None,
+        mask_start_secs: float = 0,
+        mask_end_secs: float = 0,
+        step_generator: torch.Generator = None,
+        eta: float = 0,
+        encoding: torch.Tensor = None,
+        noise: torch.Tensor = None,
+    ) -> Tuple[Image.Image, Tuple[int, np.ndarray]]:
+        """Generate random mel spectrogram from audio input and convert to audio (`__init__.py:70-122`)."""
+        images, (sample_rate, audios) = self.pipe(
+            batch_size=1,
+            audio_file=audio_file,
+            raw_audio=raw_audio,
+            slice=slice,
+            start_step=start_step,
+            steps=steps,
+            generator=generator,
+            mask_start_secs=mask_start_secs,
+            mask_end_secs=mask_end_secs,
+            step_generator=step_generator,
+            eta=eta,
+            noise=noise,
+            encoding=encoding,
+            return_dict=False,
+        )
+        return images[0], (sample_rate, audios[0])
+
+    @staticmethod
+    def loop_it(audio: np.ndarray, sample_rate: int, loops: int = 12) -> np.ndarray:
+        """Loop audio on bar boundaries (`__init__.py:124-140`). The reference delegates to librosa's beat
+        tracker, a post-hoc CPU nicety that SURVEY.md §2.1 #3 places outside the hot path."""
+        raise NotImplementedError("loop_it needs librosa.beat.beat_track, which is outside the MI355X hot path")

@@ -69,7 +69,13 @@ _SIGS = {
     "adm_encode_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(SchedCoef), C.c_int, C.c_int, C.c_void_p]),
 }
 # entry points added by later translation units (k_mel.hip); bound when present in the header AND the library
-_OPTIONAL_SIGS = {}
+_OPTIONAL_SIGS = {
+    "adm_mel_create": (C.c_int, [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.POINTER(C.c_void_p)]),
+    "adm_mel_destroy": (None, [C.c_void_p]),
+    "adm_mel_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
+    "adm_mel_inverse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.POINTER(C.c_float), C.c_void_p]),
+}
 
 _lib = None
 _lib_path = None

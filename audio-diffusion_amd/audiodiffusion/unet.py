@@ -1,0 +1,285 @@
+"""UNet2DModel drop-in backed by the native executor (csrc/unet_exec.hip).
+
+Duck-types what the reference touches on `pipeline.unet`:
+`unet(images, t)["sample"]` (`pipeline_audio_diffusion.py:163,237`, `train_unet.py:257`), `.sample_size`
+(assigned to at `:119`), `.in_channels` (`:124`), `.config`, and the diffusers on-disk layout
+(`unet/config.json` + `diffusion_pytorch_model.{safetensors,bin}`, state-dict keys of diffusers==0.24.0,
+including the 2022-era attention names `query/key/value/proj_attn`, `audiodiffusion/utils.py:41-54`).
+The constructor arguments / defaults are those of `scripts/train_unet.py:115-137`.
+"""
+import ctypes as C
+import json
+import math
+import os
+
+import torch
+
+from . import _native as N
+from .schedulers import FrozenConfig
+
+_DEFAULTS = dict(
+    sample_size=None, in_channels=3, out_channels=3, center_input_sample=False, time_embedding_type="positional",
+    freq_shift=0, flip_sin_to_cos=True,
+    down_block_types=("DownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D"),
+    up_block_types=("AttnUpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D", "UpBlock2D"),
+    block_out_channels=(224, 448, 672, 896), layers_per_block=2, mid_block_scale_factor=1, downsample_padding=1,
+    downsample_type="conv", upsample_type="conv", dropout=0.0, act_fn="silu", attention_head_dim=8,
+    norm_num_groups=32, attn_norm_num_groups=None, norm_eps=1e-5, resnet_time_scale_shift="default",
+    add_attention=True, class_embed_type=None, num_class_embeds=None, num_train_timesteps=None,
+)
+
+
+class UNetOutput(dict):
+    __getattr__ = dict.__getitem__
+
+
+def param_specs(cfg):
+    """(key, shape, fan_in) for every parameter, in diffusers' module order (mirrors csrc/unet_exec.hip declare_all)."""
+    boc = list(cfg["block_out_channels"])
+    nb, L = len(boc), cfg["layers_per_block"]
+    temb = boc[0] * 4
+    out = []
+
+    def conv(p, co, ci, ks):
+        out.append((p + ".weight", (co, ci, ks, ks), ci * ks * ks))
+        out.append((p + ".bias", (co,), ci * ks * ks))
+
+    def lin(p, co, ci):
+        out.append((p + ".weight", (co, ci), ci))
+        out.append((p + ".bias", (co,), ci))
+
+    def gn(p, c):
+        out.append((p + ".weight", (c,), 0))
+        out.append((p + ".bias", (c,), -1))
+
+    def resnet(p, ci, co):
+        gn(p + ".norm1", ci), conv(p + ".conv1", co, ci, 3), lin(p + ".time_emb_proj", co, temb)
+        gn(p + ".norm2", co), conv(p + ".conv2", co, co, 3)
+        if ci != co:
+            conv(p + ".conv_shortcut", co, ci, 1)
+
+    def attn(p, c):
+        gn(p + ".group_norm", c)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            lin(p + "." + n, c, c)
+
+    conv("conv_in", boc[0], cfg["in_channels"], 3)
+    lin("time_embedding.linear_1", temb, boc[0]), lin("time_embedding.linear_2", temb, temb)
+    o = boc[0]
+    for i, t in enumerate(cfg["down_block_types"]):
+        ci, o = o, boc[i]
+        for j in range(L):
+            resnet(f"down_blocks.{i}.resnets.{j}", ci if j == 0 else o, o)
+        if t.startswith("Attn"):
+            for j in range(L):
+                attn(f"down_blocks.{i}.attentions.{j}", o)
+        if i != nb - 1:
+            conv(f"down_blocks.{i}.downsamplers.0.conv", o, o, 3)
+    resnet("mid_block.resnets.0", boc[-1], boc[-1]), attn("mid_block.attentions.0", boc[-1])
+    resnet("mid_block.resnets.1", boc[-1], boc[-1])
+    rev = boc[::-1]
+    o = rev[0]
+    for i, t in enumerate(cfg["up_block_types"]):
+        prev, o = o, rev[i]
+        ci = rev[min(i + 1, nb - 1)]
+        for j in range(L + 1):
+            resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else o) + (ci if j == L else o), o)
+        if t.startswith("Attn"):
+            for j in range(L + 1):
+                attn(f"up_blocks.{i}.attentions.{j}", o)
+        if i != nb - 1:
+            conv(f"up_blocks.{i}.upsamplers.0.conv", o, o, 3)
+    gn("conv_norm_out", boc[0]), conv("conv_out", cfg["out_channels"], boc[0], 3)
+    return out
+
+
+_OLD_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def _canon_key(k):
+    parts = k.split(".")
+    if "attentions" in parts and parts[-2] in _OLD_ATTN:
+        parts[-2] = _OLD_ATTN[parts[-2]]
+    return ".".join(parts)
+
+
+class UNet2DModel:
+    config_name = "config.json"
+
+    def __init__(self, **kwargs):
+        cfg = dict(_DEFAULTS)
+        cfg.update({k: v for k, v in kwargs.items() if not k.startswith("_")})
+        for k in ("down_block_types", "up_block_types", "block_out_channels"):
+            cfg[k] = tuple(cfg[k])
+        self._validate(cfg)
+        self.config = FrozenConfig(cfg)
+        self.sample_size = cfg["sample_size"]
+        self.in_channels = cfg["in_channels"]
+        self.dtype = torch.float32
+        self._handle = None
+        self._handle_hw = None
+        self._sd = {}
+        self.device = torch.device("cuda:0") if N.is_device_build() else torch.device("cpu")
+
+    @staticmethod
+    def _validate(cfg):
+        ok_down, ok_up = {"DownBlock2D", "AttnDownBlock2D"}, {"UpBlock2D", "AttnUpBlock2D"}
+        bad = [t for t in cfg["down_block_types"] if t not in ok_down] + [t for t in cfg["up_block_types"] if t not in ok_up]
+        if bad:
+            raise NotImplementedError(f"block types {bad} are not implemented (hot path covers Down/AttnDown/Up/AttnUp)")
+        for k, want in (("time_embedding_type", "positional"), ("act_fn", "silu"), ("resnet_time_scale_shift", "default"),
+                        ("downsample_type", "conv"), ("upsample_type", "conv"), ("add_attention", True),
+                        ("center_input_sample", False), ("class_embed_type", None), ("downsample_padding", 1),
+                        ("mid_block_scale_factor", 1), ("attn_norm_num_groups", None)):
+            if cfg.get(k, want) != want:
+                raise NotImplementedError(f"UNet2DModel config {k}={cfg[k]!r} is not implemented (expected {want!r})")
+        if len(cfg["block_out_channels"]) > 8:
+            raise NotImplementedError("more than 8 blocks")
+
+    # ---- native handle ---------------------------------------------------------------------------------
+    def _hw(self):
+        ss = self.sample_size
+        return (ss, ss) if isinstance(ss, int) else tuple(ss)
+
+    def _ensure_handle(self):
+        hw = self._hw()
+        if self._handle is not None and self._handle_hw == hw:
+            return self._handle
+        self._free()
+        c = self.config
+        nc = N.UNetConfig()
+        nc.in_channels, nc.out_channels = c.in_channels, c.out_channels
+        nc.layers_per_block, nc.n_blocks = c.layers_per_block, len(c.block_out_channels)
+        for i, v in enumerate(c.block_out_channels):
+            nc.block_out_channels[i] = v
+            nc.down_attn[i] = int(c.down_block_types[i].startswith("Attn"))
+            nc.up_attn[i] = int(c.up_block_types[i].startswith("Attn"))
+        nc.attention_head_dim = c.attention_head_dim if c.attention_head_dim is not None else 0
+        nc.norm_num_groups, nc.norm_eps = c.norm_num_groups, c.norm_eps
+        nc.flip_sin_to_cos, nc.freq_shift = int(c.flip_sin_to_cos), float(c.freq_shift)
+        nc.sample_h, nc.sample_w = hw
+        h = C.c_void_p()
+        N.check(N.lib().adm_unet_create(C.byref(nc), C.byref(h)))
+        self._handle, self._handle_hw = h, hw
+        for k, v in self._sd.items():
+            self._upload(k, v)
+        return h
+
+    def _upload(self, key, t):
+        t = t.detach().to(torch.float32).cpu().contiguous()
+        N.check(N.lib().adm_unet_set_param(self._handle, key.encode(), C.c_void_p(t.data_ptr()), t.numel()))
+
+    def _free(self):
+        if self._handle is not None:
+            N.lib().adm_unet_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+    # ---- weights ---------------------------------------------------------------------------------------
+    def load_state_dict(self, sd, strict=True):
+        specs = {k: s for k, s, _ in param_specs(self.config)}
+        new = {}
+        for k, v in sd.items():
+            ck = _canon_key(k)
+            if ck not in specs:
+                if strict:
+                    raise KeyError(f"unexpected key {k}")
+                continue
+            v = v.reshape(specs[ck]) if tuple(v.shape) != tuple(specs[ck]) and v.numel() == math.prod(specs[ck]) else v
+            if tuple(v.shape) != tuple(specs[ck]):
+                raise ValueError(f"shape mismatch for {k}: {tuple(v.shape)} vs {specs[ck]}")
+            new[ck] = v.detach().to(torch.float32).cpu().contiguous()
+        missing = [k for k in specs if k not in new]
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:8]}{'...' if len(missing) > 8 else ''}")
+        self._sd.update(new)
+        self._free()  # re-created (and re-uploaded) lazily at the next forward
+        return self
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def init_random(self, seed=0):
+        """torch's default nn.Conv2d / nn.Linear / nn.GroupNorm initialisation (kaiming_uniform(a=sqrt(5)) ==
+        U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias), seeded — for benchmarks and parity tests."""
+        g = torch.Generator().manual_seed(seed)
+        sd = {}
+        for k, shape, fan_in in param_specs(self.config):
+            if fan_in == 0:
+                sd[k] = torch.ones(shape)
+            elif fan_in == -1:
+                sd[k] = torch.zeros(shape)
+            else:
+                b = 1.0 / math.sqrt(fan_in)
+                sd[k] = (torch.rand(shape, generator=g) * 2 - 1) * b
+        return self.load_state_dict(sd)
+
+    def num_parameters(self):
+        return sum(math.prod(s) for _, s, _ in param_specs(self.config))
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    # ---- forward ---------------------------------------------------------------------------------------
+    def _timesteps(self, timestep, B):
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t])
+        t = t.detach().to("cpu", torch.float32).reshape(-1)
+        if t.numel() not in (1, B):
+            raise ValueError("timestep must be a scalar or have one entry per sample")
+        return t.contiguous()
+
+    def forward(self, sample, timestep, return_dict=True):
+        assert sample.dim() == 4 and sample.dtype == torch.float32
+        if tuple(sample.shape[2:]) != self._hw():
+            self.sample_size = tuple(sample.shape[2:])
+        h = self._ensure_handle()
+        x = sample.contiguous()
+        B = x.shape[0]
+        t = self._timesteps(timestep, B)
+        out = torch.empty((B, self.config.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        N.check(N.lib().adm_unet_forward(h, N.ptr(x), C.cast(t.data_ptr(), N.c_float_p), t.numel(),
+                                         N.ptr(out), B, N.stream_for(x)))
+        return UNetOutput(sample=out)
+
+    __call__ = forward
+
+    # ---- diffusers on-disk layout ------------------------------------------------------------------------
+    @classmethod
+    def from_config(cls, cfg):
+        return cls(**{k: v for k, v in dict(cfg).items() if not k.startswith("_")})
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None):
+        p = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(p, cls.config_name)) as f:
+            m = cls.from_config(json.load(f))
+        st = os.path.join(p, "diffusion_pytorch_model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(p, "diffusion_pytorch_model.bin"), map_location="cpu", weights_only=True)
+        return m.load_state_dict(sd)
+
+    def save_pretrained(self, path, safe_serialization=True):
+        os.makedirs(path, exist_ok=True)
+        d = {"_class_name": "UNet2DModel", "_diffusers_version": "0.24.0"}
+        d.update({k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()})
+        d["sample_size"] = list(self.sample_size) if isinstance(self.sample_size, tuple) else self.sample_size
+        with open(os.path.join(path, self.config_name), "w") as f:
+            json.dump(d, f, indent=2, sort_keys=True)
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(self._sd, os.path.join(path, "diffusion_pytorch_model.safetensors"))
+        else:
+            torch.save(self._sd, os.path.join(path, "diffusion_pytorch_model.bin"))

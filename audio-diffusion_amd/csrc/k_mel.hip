@@ -1,0 +1,504 @@
+// k_mel.hip — the audio <-> 8-bit log-mel-spectrogram codec as HIP kernels.
+//
+// Replaces, for whole batches of slices/images at once (the reference does them one by one on a host core,
+// pipeline_audio_diffusion.py:201):
+//   Mel.audio_slice_to_image (audiodiffusion/mel.py:135-151): librosa melspectrogram (Hann-2048 STFT, |.|^2,
+//     Slaney filterbank) -> power_to_db(ref=max, top_db) -> u8 quantise;
+//   Mel.image_to_audio (mel.py:153-168): u8 -> dB -> power -> mel_to_stft (NNLS) -> Griffin-Lim (n_iter, momentum .99).
+// Numerics follow librosa/numpy dtype-by-dtype: FFTs run in fp64 (the Hann window is fp64, so numpy's rfft runs
+// in double) and are rounded to complex64 exactly where librosa stores into a complex64 array; the mel
+// projection, log10 and quantisation run in the input precision (fp32 for fp32 audio, fp64 for fp64 audio).
+// NNLS: librosa's L-BFGS-B starts from clip(pinv(A) S, 0) and — because the objective is scaled by 1/size —
+// its projected gradient is already below pgtol=1e-5 there for any dB image, so it returns that point after
+// zero iterations (oracle/mel.py records nit == 0). We compute exactly that point (fp64 GEMM) and verify the
+// projected-gradient criterion on the device with the sparse filterbank; `status` reports its max.
+// FFT: radix-2 in LDS (2048 complex fp64 = 32 KiB), one frame per workgroup, twiddles from an L2-resident table.
+// All spectral arrays are laid out [b][frame][bin] so a workgroup's bins are contiguous (coalesced).
+// Algorithmic bytes: forward 4 B/sample in + 1 B/pixel out; inverse 1 B/pixel in + 4 B/sample out.
+#include <vector>
+
+#include "adm_kernels.h"
+
+extern "C" {
+typedef struct adm_mel adm_mel_t;
+typedef struct adm_mel_config {
+  int x_res, y_res, sample_rate, n_fft, hop_length, top_db, n_iter;
+} adm_mel_config;
+}
+
+struct adm_mel {
+  adm_mel_config cfg;
+  int n_bins = 0, n_mels = 0, log2n = 0, nnz = 0, nnz_t = 0, nnls_cols = 0;
+  double *window = nullptr, *twiddle = nullptr, *fb_w64 = nullptr, *pinv = nullptr, *fbt_w64 = nullptr;
+  float *fb_w32 = nullptr, *wss = nullptr;
+  int *fb_start = nullptr, *fb_count = nullptr, *fb_off = nullptr, *fbt_off = nullptr, *fbt_idx = nullptr;
+  std::vector<void*> owned;
+  // scratch (grown on demand)
+  size_t cap_fwd = 0, cap_inv = 0;
+  void* melspec = nullptr;
+  double *angles = nullptr, *mag = nullptr, *ytmp = nullptr, *Smel = nullptr, *Xpow = nullptr, *diff = nullptr;
+  float *reb0 = nullptr, *reb1 = nullptr, *y = nullptr;
+  float* pgmax = nullptr;
+};
+
+namespace adm {
+
+// ---------------------------------------------------------------------------------------------------------
+// In-LDS radix-2 FFT over n = 2^log2n complex fp64 points held in x (bit-reversed order on entry).
+// tw[q] = exp(-2*pi*i*q/n), q < n/2. inverse: conjugate twiddles (no scaling).
+__device__ __forceinline__ void fft_lds(double2* x, int n, int log2n, const double2* __restrict__ tw, bool inverse) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int s = 1; s <= log2n; ++s) {
+    const int half = 1 << (s - 1);
+    const int tstride = n >> s;
+    for (int j = tid; j < (n >> 1); j += nt) {
+      const int k = j >> (s - 1), i = j & (half - 1);
+      const int i0 = (k << s) + i, i1 = i0 + half;
+      double2 w = tw[i * tstride];
+      if (inverse) w.y = -w.y;
+      const double2 a = x[i0], b = x[i1];
+      const double tr = w.x * b.x - w.y * b.y, ti = w.x * b.y + w.y * b.x;
+      x[i0] = make_double2(a.x + tr, a.y + ti);
+      x[i1] = make_double2(a.x - tr, a.y - ti);
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ int bitrev(int v, int log2n) {
+  unsigned r = 0, u = (unsigned)v;
+  for (int i = 0; i < log2n; ++i) { r = (r << 1) | (u & 1u); u >>= 1; }
+  return (int)r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Forward: one workgroup per (frame, slice): centred Hann STFT frame -> |D|^2 -> sparse mel projection.
+template <typename T>
+__global__ void __launch_bounds__(256) mel_stft_power_kernel(const T* __restrict__ audio, long slice_stride,
+                                                             int n_samples, int n_fft, int log2n, int hop,
+                                                             const double* __restrict__ window,
+                                                             const double2* __restrict__ tw,
+                                                             const int* __restrict__ fb_start,
+                                                             const int* __restrict__ fb_count,
+                                                             const int* __restrict__ fb_off,
+                                                             const float* __restrict__ fb_w32,
+                                                             const double* __restrict__ fb_w64, int n_mels,
+                                                             int n_frames, T* __restrict__ melspec) {
+  ADM_DYN_SMEM(double2, x);                             // n_fft complex
+  T* pw = reinterpret_cast<T*>(x + n_fft);               // n_fft/2+1 powers
+  const int frame = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const T* y = audio + (long)b * slice_stride;
+  for (int n = tid; n < n_fft; n += blockDim.x) {
+    const long src = (long)frame * hop + n - n_fft / 2;  // center=True, pad_mode="constant"
+    const double v = (src >= 0 && src < n_samples) ? (double)y[src] : 0.0;
+    x[bitrev(n, log2n)] = make_double2(window[n] * v, 0.0);
+  }
+  __syncthreads();
+  fft_lds(x, n_fft, log2n, tw, false);
+  const int n_bins = n_fft / 2 + 1;
+  for (int k = tid; k < n_bins; k += blockDim.x) {
+    if (sizeof(T) == 4) {
+      const float re = (float)x[k].x, im = (float)x[k].y;  // stored into a complex64 array by librosa.stft
+      const float a = hypotf(re, im);                      // np.abs(complex64) -> float32
+      pw[k] = (T)(a * a);
+    } else {
+      const double a = hypot(x[k].x, x[k].y);
+      pw[k] = (T)(a * a);
+    }
+  }
+  __syncthreads();
+  for (int m = tid; m < n_mels; m += blockDim.x) {
+    const int s = fb_start[m], c = fb_count[m], o = fb_off[m];
+    double acc = 0.0;
+    for (int i = 0; i < c; ++i)
+      acc += (sizeof(T) == 4 ? (double)fb_w32[o + i] : fb_w64[o + i]) * (double)pw[s + i];
+    melspec[((long)b * n_mels + m) * n_frames + frame] = (T)acc;
+  }
+}
+
+// power_to_db(ref=np.max, amin=1e-10, top_db) + u8 quantise (mel.py:148-150): one workgroup per spectrogram.
+template <typename T>
+__global__ void __launch_bounds__(256) mel_db_u8_kernel(const T* __restrict__ melspec, int n, float top_db,
+                                                         unsigned char* __restrict__ img) {
+  __shared__ double red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const T* s = melspec + (long)b * n;
+  double mx = 0.0;
+  for (int i = tid; i < n; i += blockDim.x) mx = fmax(mx, (double)s[i]);
+  for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) mx = fmax(mx, red[i]);
+  const T amin = (T)1e-10;
+  const T ref_db = (T)10.0 * (T)log10((double)(((T)mx > amin) ? (T)mx : amin));
+  const T peak = (T)10.0 * (T)log10((double)(((T)mx > amin) ? (T)mx : amin)) - ref_db;  // log_spec.max()
+  const T floor_db = peak - (T)top_db;
+  for (int i = tid; i < n; i += blockDim.x) {
+    const T v = s[i] > amin ? s[i] : amin;
+    T db = (T)10.0 * (T)log10((double)v);
+    db = db - ref_db;
+    db = db > floor_db ? db : floor_db;
+    T q = (db + (T)top_db) * (T)255 / (T)top_db;
+    q = q < (T)0 ? (T)0 : (q > (T)255 ? (T)255 : q);
+    img[(long)b * n + i] = (unsigned char)(q + (T)0.5);  // astype(uint8) truncation
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Inverse step 1: u8 -> dB -> power (mel.py:162-164), fp64:  S = 10^(0.1*(u8*top_db/255 - top_db)).
+__global__ void __launch_bounds__(256) mel_u8_to_power_kernel(const unsigned char* __restrict__ img, long n,
+                                                              double top_db, double* __restrict__ S) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const double db = (double)img[i] * top_db / 255.0 - top_db;
+    S[i] = pow(10.0, 0.1 * db);
+  }
+}
+
+// Inverse step 2: X[b][t][f] = max(0, sum_m pinv[f][m] * S[b][m][t])  (fp64 GEMM, 64x64 tiles, K chunks of 16);
+// also writes mag = sqrt(X) (mel_to_stft power=2).
+__global__ void __launch_bounds__(256) mel_pinv_gemm_kernel(const double* __restrict__ pinv, const double* __restrict__ S,
+                                                            int n_bins, int n_mels, int n_frames,
+                                                            double* __restrict__ Xpow, double* __restrict__ mag) {
+  __shared__ double As[16][64 + 1];  // [k][f]
+  __shared__ double Bs[16][64 + 1];  // [k][t]
+  const int b = blockIdx.z, f0 = blockIdx.x * 64, t0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int tf = (tid & 15) * 4, tt = (tid >> 4) * 4;
+  double acc[4][4] = {{0}};
+  const double* Sb = S + (long)b * n_mels * n_frames;
+  for (int k0 = 0; k0 < n_mels; k0 += 16) {
+    for (int e = tid; e < 16 * 64; e += 256) {
+      const int kk = e & 15, ff = e >> 4;
+      As[kk][ff] = (f0 + ff < n_bins && k0 + kk < n_mels) ? pinv[(long)(f0 + ff) * n_mels + k0 + kk] : 0.0;
+      const int tt2 = e & 63, kk2 = e >> 6;
+      Bs[kk2][tt2] = (t0 + tt2 < n_frames && k0 + kk2 < n_mels) ? Sb[(long)(k0 + kk2) * n_frames + t0 + tt2] : 0.0;
+    }
+    __syncthreads();
+    for (int kk = 0; kk < 16; ++kk) {
+      double a[4], c[4];
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][tf + i]; c[i] = Bs[kk][tt + i]; }
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], c[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i) {
+      const int f = f0 + tf + i, t = t0 + tt + j;
+      if (f < n_bins && t < n_frames) {
+        const double v = acc[i][j] > 0.0 ? acc[i][j] : 0.0;
+        const long o = ((long)b * n_frames + t) * n_bins + f;
+        Xpow[o] = v;
+        mag[o] = sqrt(v);
+      }
+    }
+}
+
+// NNLS check a: diff[b][m][t] = sum_k A[m][k] X[b][t][k] - S[b][m][t]
+__global__ void __launch_bounds__(256) mel_nnls_diff_kernel(const double* __restrict__ X, const double* __restrict__ S,
+                                                            const int* __restrict__ fb_start,
+                                                            const int* __restrict__ fb_count,
+                                                            const int* __restrict__ fb_off,
+                                                            const double* __restrict__ fb_w64, int n_bins, int n_mels,
+                                                            int n_frames, double* __restrict__ diff) {
+  const int b = blockIdx.y;
+  const long n = (long)n_mels * n_frames;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(e / n_frames), t = (int)(e - (long)m * n_frames);
+    const int s = fb_start[m], c = fb_count[m], o = fb_off[m];
+    const double* xr = X + ((long)b * n_frames + t) * n_bins;
+    double acc = 0.0;
+    for (int i = 0; i < c; ++i) acc += fb_w64[o + i] * xr[s + i];
+    diff[(long)b * n + e] = acc - S[(long)b * n + e];
+  }
+}
+// NNLS check b: projected gradient of 0.5*||AX-S||^2/size at X (bounds [0,inf)), max-abs over everything.
+__global__ void __launch_bounds__(256) mel_nnls_pg_kernel(const double* __restrict__ X, const double* __restrict__ diff,
+                                                          const int* __restrict__ fbt_off,
+                                                          const int* __restrict__ fbt_idx,
+                                                          const double* __restrict__ fbt_w64, int n_bins, int n_mels,
+                                                          int n_frames, int nnls_cols, float* __restrict__ pgmax) {
+  const int b = blockIdx.y;
+  const long n = (long)n_bins * n_frames;
+  float local = 0.f;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(e / n_bins), f = (int)(e - (long)t * n_bins);
+    const int blk0 = (t / nnls_cols) * nnls_cols;
+    const int cols = (blk0 + nnls_cols <= n_frames) ? nnls_cols : n_frames - blk0;
+    const double inv_size = 1.0 / ((double)n_mels * cols);
+    double g = 0.0;
+    for (int i = fbt_off[f]; i < fbt_off[f + 1]; ++i)
+      g += fbt_w64[i] * diff[((long)b * n_mels + fbt_idx[i]) * n_frames + t];
+    g *= inv_size;
+    const double x = X[((long)b * n_frames + t) * n_bins + f];
+    const double pg = x > 0.0 ? g : (g < 0.0 ? g : 0.0);
+    local = fmaxf(local, (float)fabs(pg));
+  }
+  for (int m = 32; m >= 1; m >>= 1) local = fmaxf(local, __shfl_xor(local, m, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(pgmax), __float_as_uint(local));
+}
+
+// Griffin-Lim init: angles = (cos(2*pi*u) + i sin(2*pi*u)) * mag   (librosa.griffinlim init="random")
+__global__ void __launch_bounds__(256) gl_init_kernel(const double* __restrict__ phase, const double* __restrict__ mag,
+                                                      int n_bins, int n_frames, double2* __restrict__ angles) {
+  const int b = blockIdx.y;
+  const long n = (long)n_bins * n_frames;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(e / n_bins), f = (int)(e - (long)t * n_bins);
+    const double ph = 2.0 * 3.141592653589793 * phase[((long)b * n_bins + f) * n_frames + t];  // caller layout (B,bins,frames)
+    const double m = mag[(long)b * n + e];
+    angles[(long)b * n + e] = make_double2(cos(ph) * m, sin(ph) * m);
+  }
+}
+
+// iSTFT part 1: per frame irfft (Hermitian, imag of DC/Nyquist ignored) * window -> ytmp[b][frame][n] fp64.
+__global__ void __launch_bounds__(256) gl_istft_frames_kernel(const double2* __restrict__ angles, int n_fft, int log2n,
+                                                              const double* __restrict__ window,
+                                                              const double2* __restrict__ tw, int n_frames,
+                                                              double* __restrict__ ytmp) {
+  ADM_DYN_SMEM(double2, x);
+  const int frame = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int n_bins = n_fft / 2 + 1;
+  const double2* src = angles + ((long)b * n_frames + frame) * n_bins;
+  for (int k = tid; k < n_fft; k += blockDim.x) {
+    double2 v;
+    if (k <= n_fft / 2) {
+      v = src[k];
+      if (k == 0 || k == n_fft / 2) v.y = 0.0;
+    } else {
+      v = src[n_fft - k];
+      v.y = -v.y;
+    }
+    x[bitrev(k, log2n)] = v;
+  }
+  __syncthreads();
+  fft_lds(x, n_fft, log2n, tw, true);
+  const double fct = 1.0 / (double)n_fft;
+  double* dst = ytmp + ((long)b * n_frames + frame) * n_fft;
+  for (int n = tid; n < n_fft; n += blockDim.x) dst[n] = window[n] * (x[n].x * fct);
+}
+
+// iSTFT part 2: overlap-add in frame order with numpy's float32 in-place `+=` rounding, trim n_fft/2, divide by
+// the window sum-square where it exceeds float32 tiny.
+__global__ void __launch_bounds__(256) gl_overlap_add_kernel(const double* __restrict__ ytmp, int n_fft, int hop,
+                                                             int n_frames, const float* __restrict__ wss, int out_len,
+                                                             float* __restrict__ y) {
+  const int b = blockIdx.y;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < out_len; j += gridDim.x * blockDim.x) {
+    const int i = j + n_fft / 2;
+    int f_lo = (i - n_fft + hop) / hop;  // ceil((i - n_fft + 1)/hop) for i - n_fft + 1 > 0
+    if (i - n_fft + 1 <= 0) f_lo = 0;
+    int f_hi = i / hop;
+    if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+    float acc = 0.f;
+    for (int f = f_lo; f <= f_hi; ++f)
+      acc = (float)((double)acc + ytmp[((long)b * n_frames + f) * n_fft + (i - f * hop)]);
+    const float w = wss[j];
+    if (w > 1.17549435e-38f) acc = acc / w;
+    y[(long)b * out_len + j] = acc;
+  }
+}
+
+// STFT of y (float32) -> rebuilt (complex64) and the momentum / projection update of `angles`:
+//   angles = rebuilt - (momentum/(1+momentum)) * tprev ; angles /= |angles| + tiny ; angles *= mag
+__global__ void __launch_bounds__(256) gl_stft_update_kernel(const float* __restrict__ y, int out_len, int n_fft,
+                                                             int log2n, int hop, const double* __restrict__ window,
+                                                             const double2* __restrict__ tw, int n_frames,
+                                                             float2* __restrict__ rebuilt,
+                                                             const float2* __restrict__ tprev, float mom,
+                                                             const double* __restrict__ mag,
+                                                             double2* __restrict__ angles) {
+  ADM_DYN_SMEM(double2, x);
+  const int frame = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* yb = y + (long)b * out_len;
+  for (int n = tid; n < n_fft; n += blockDim.x) {
+    const long src = (long)frame * hop + n - n_fft / 2;
+    const double v = (src >= 0 && src < out_len) ? (double)yb[src] : 0.0;
+    x[bitrev(n, log2n)] = make_double2(window[n] * v, 0.0);
+  }
+  __syncthreads();
+  fft_lds(x, n_fft, log2n, tw, false);
+  const int n_bins = n_fft / 2 + 1;
+  const long base = ((long)b * n_frames + frame) * n_bins;
+  for (int k = tid; k < n_bins; k += blockDim.x) {
+    const float2 r = make_float2((float)x[k].x, (float)x[k].y);
+    rebuilt[base + k] = r;
+    double ar = (double)r.x, ai = (double)r.y;
+    if (tprev != nullptr) {
+      const float2 tp = tprev[base + k];
+      ar -= (double)(mom * tp.x);  // python float * complex64 array stays complex64 (fp32 products)
+      ai -= (double)(mom * tp.y);
+    }
+    const double den = hypot(ar, ai) + 2.2250738585072014e-308;
+    const double scl = 1.0 / den;  // numpy complex/real division multiplies by the reciprocal
+    const double m = mag[base + k];
+    angles[base + k] = make_double2(ar * scl * m, ai * scl * m);
+  }
+}
+
+static int grow(adm_mel* h, void** p, size_t bytes) {
+  if (*p) dfree(*p);
+  *p = nullptr;
+  return dmalloc(p, bytes);
+}
+
+template <typename T>
+static int upload(adm_mel* h, T** dst, const T* src, size_t n) {
+  ADM_TRY(dmalloc((void**)dst, sizeof(T) * (n ? n : 1)));
+  h->owned.push_back(*dst);
+  ADM_TRY(copy_h2d(*dst, src, sizeof(T) * n, nullptr));
+  return 0;
+}
+
+static size_t fft_smem(const adm_mel* h) { return sizeof(double) * 2 * (size_t)h->cfg.n_fft + sizeof(double) * (h->n_bins + 3); }
+
+}  // namespace adm
+
+using namespace adm;
+
+extern "C" {
+
+int adm_mel_create(const adm_mel_config* cfg, const double* window, const double* twiddle, const int* fb_start,
+                   const int* fb_count, const float* fb_w32, const double* fb_w64, int nnz, const int* fbt_off,
+                   const int* fbt_idx, const double* fbt_w64, const double* pinv, const float* wss, int nnls_cols,
+                   adm_mel_t** out) {
+  ADM_REQUIRE(cfg && window && twiddle && fb_start && fb_count && fb_w32 && fb_w64 && pinv && wss && out,
+              "mel_create: null argument");
+  ADM_REQUIRE(cfg->n_fft >= 64 && cfg->n_fft <= 4096 && (cfg->n_fft & (cfg->n_fft - 1)) == 0,
+              "mel_create: n_fft must be a power of two in [64, 4096]");
+  adm_mel* h = new adm_mel();
+  h->cfg = *cfg;
+  h->n_bins = cfg->n_fft / 2 + 1;
+  h->n_mels = cfg->y_res;
+  h->nnz = nnz;
+  h->nnls_cols = nnls_cols;
+  while ((1 << h->log2n) < cfg->n_fft) ++h->log2n;
+  std::vector<int> off(h->n_mels + 1, 0);
+  for (int m = 0; m < h->n_mels; ++m) off[m + 1] = off[m] + fb_count[m];
+  ADM_REQUIRE(off[h->n_mels] == nnz, "mel_create: filterbank tap count mismatch");
+  int rc = 0;
+  rc |= upload(h, &h->window, window, cfg->n_fft);
+  rc |= upload(h, &h->twiddle, twiddle, cfg->n_fft);
+  rc |= upload(h, &h->fb_start, fb_start, h->n_mels);
+  rc |= upload(h, &h->fb_count, fb_count, h->n_mels);
+  rc |= upload(h, &h->fb_off, off.data(), h->n_mels + 1);
+  rc |= upload(h, &h->fb_w32, fb_w32, nnz);
+  rc |= upload(h, &h->fb_w64, fb_w64, nnz);
+  rc |= upload(h, &h->fbt_off, fbt_off, h->n_bins + 1);
+  rc |= upload(h, &h->fbt_idx, fbt_idx, nnz);
+  rc |= upload(h, &h->fbt_w64, fbt_w64, nnz);
+  rc |= upload(h, &h->pinv, pinv, (size_t)h->n_bins * h->n_mels);
+  rc |= upload(h, &h->wss, wss, (size_t)cfg->hop_length * (cfg->x_res - 1));
+  rc |= dmalloc((void**)&h->pgmax, sizeof(float));
+  rc |= stream_sync(nullptr);
+  if (rc) { delete h; return -1; }
+  h->owned.push_back(h->pgmax);
+  *out = h;
+  return 0;
+}
+
+void adm_mel_destroy(adm_mel_t* h) {
+  if (!h) return;
+  for (void* p : h->owned) dfree(p);
+  for (void* p : {(void*)h->melspec, (void*)h->angles, (void*)h->mag, (void*)h->ytmp, (void*)h->Smel, (void*)h->Xpow,
+                  (void*)h->diff, (void*)h->reb0, (void*)h->reb1, (void*)h->y})
+    if (p) dfree(p);
+  delete h;
+}
+
+// audio: device, B slices of n_samples (fp32 or fp64), consecutive slices `slice_stride` elements apart.
+// image_out: device (B, n_mels, n_frames) uint8 with n_frames = 1 + n_samples / hop.
+int adm_mel_forward(adm_mel_t* h, const void* audio, int is_f64, int B, long slice_stride, int n_samples,
+                    uint8_t* image_out, void* stream) {
+  ADM_REQUIRE(h && audio && image_out && B > 0, "mel_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const adm_mel_config& c = h->cfg;
+  const int n_frames = 1 + n_samples / c.hop_length;
+  const size_t need = (size_t)B * h->n_mels * n_frames * 8;
+  if (h->cap_fwd < need) { ADM_TRY(stream_sync(st)); ADM_TRY(grow(h, &h->melspec, need)); h->cap_fwd = need; }
+  dim3 grid(n_frames, B);
+  const size_t smem = fft_smem(h);
+  if (is_f64) {
+    ADM_LAUNCH((mel_stft_power_kernel<double>), grid, dim3(256), smem, st, (const double*)audio, slice_stride, n_samples,
+               c.n_fft, h->log2n, c.hop_length, h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count,
+               h->fb_off, h->fb_w32, h->fb_w64, h->n_mels, n_frames, (double*)h->melspec);
+    ADM_LAUNCH((mel_db_u8_kernel<double>), dim3(B), dim3(256), 0, st, (const double*)h->melspec, h->n_mels * n_frames,
+               (float)c.top_db, image_out);
+  } else {
+    ADM_LAUNCH((mel_stft_power_kernel<float>), grid, dim3(256), smem, st, (const float*)audio, slice_stride, n_samples,
+               c.n_fft, h->log2n, c.hop_length, h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count,
+               h->fb_off, h->fb_w32, h->fb_w64, h->n_mels, n_frames, (float*)h->melspec);
+    ADM_LAUNCH((mel_db_u8_kernel<float>), dim3(B), dim3(256), 0, st, (const float*)h->melspec, h->n_mels * n_frames,
+               (float)c.top_db, image_out);
+  }
+  return ADM_CHECK_LAUNCH();
+}
+
+// images: device (B, n_mels, n_frames) uint8; init_phase: device (B, n_bins, n_frames) fp64 in [0,1);
+// audio_out: device (B, hop*(n_frames-1)) fp32; stft_mag_out: optional device (B, n_bins, n_frames) fp64 copy of the
+// NNLS magnitude (tests); pg_max_host: optional, receives max |projected gradient| of the NNLS start point
+// (librosa's L-BFGS-B returns the start point iff this is <= 1e-5).
+int adm_mel_inverse(adm_mel_t* h, const uint8_t* images, const double* init_phase, int B, int n_frames,
+                    float* audio_out, double* stft_mag_out, float* pg_max_host, void* stream) {
+  ADM_REQUIRE(h && images && init_phase && audio_out && B > 0, "mel_inverse: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const adm_mel_config& c = h->cfg;
+  const int nb = h->n_bins, nm = h->n_mels, nfft = c.n_fft, hop = c.hop_length;
+  const int out_len = hop * (n_frames - 1);
+  ADM_REQUIRE(n_frames == c.x_res, "mel_inverse: image width must equal x_res (window-sum table is built for it)");
+  const size_t spec = (size_t)B * n_frames * nb;
+  const size_t need = spec * 16;
+  if (h->cap_inv < need) {
+    ADM_TRY(stream_sync(st));
+    ADM_TRY(grow(h, (void**)&h->angles, spec * 16));
+    ADM_TRY(grow(h, (void**)&h->mag, spec * 8));
+    ADM_TRY(grow(h, (void**)&h->Xpow, spec * 8));
+    ADM_TRY(grow(h, (void**)&h->reb0, spec * 8));
+    ADM_TRY(grow(h, (void**)&h->reb1, spec * 8));
+    ADM_TRY(grow(h, (void**)&h->ytmp, (size_t)B * n_frames * nfft * 8));
+    ADM_TRY(grow(h, (void**)&h->Smel, (size_t)B * nm * n_frames * 8));
+    ADM_TRY(grow(h, (void**)&h->diff, (size_t)B * nm * n_frames * 8));
+    ADM_TRY(grow(h, (void**)&h->y, (size_t)B * out_len * 4));
+    h->cap_inv = need;
+  }
+  const long npix = (long)B * nm * n_frames;
+  ADM_LAUNCH(mel_u8_to_power_kernel, dim3((unsigned)((npix + 255) / 256 > 2048 ? 2048 : (npix + 255) / 256)), dim3(256), 0,
+             st, images, npix, (double)c.top_db, h->Smel);
+  ADM_LAUNCH(mel_pinv_gemm_kernel, dim3(ceil_div(nb, 64), ceil_div(n_frames, 64), B), dim3(256), 0, st, h->pinv, h->Smel,
+             nb, nm, n_frames, h->Xpow, h->mag);
+  ADM_TRY(dmemset(h->pgmax, 0, sizeof(float), st));
+  ADM_LAUNCH(mel_nnls_diff_kernel, dim3(256, B), dim3(256), 0, st, h->Xpow, h->Smel, h->fb_start, h->fb_count, h->fb_off,
+             h->fb_w64, nb, nm, n_frames, h->diff);
+  ADM_LAUNCH(mel_nnls_pg_kernel, dim3(256, B), dim3(256), 0, st, h->Xpow, h->diff, h->fbt_off, h->fbt_idx, h->fbt_w64, nb,
+             nm, n_frames, h->nnls_cols, h->pgmax);
+  ADM_LAUNCH(gl_init_kernel, dim3(256, B), dim3(256), 0, st, init_phase, h->mag, nb, n_frames, (double2*)h->angles);
+  const size_t smem = fft_smem(h);
+  const float mom = (float)(0.99 / (1.0 + 0.99));
+  float2* reb = (float2*)h->reb0;
+  float2* tprev = nullptr;
+  float2* spare = (float2*)h->reb1;
+  dim3 fgrid(n_frames, B), ogrid(ceil_div(out_len, 256) > 1024 ? 1024 : ceil_div(out_len, 256), B);
+  for (int it = 0; it < c.n_iter; ++it) {
+    ADM_LAUNCH(gl_istft_frames_kernel, fgrid, dim3(256), smem, st, (const double2*)h->angles, nfft, h->log2n, h->window,
+               (const double2*)h->twiddle, n_frames, h->ytmp);
+    ADM_LAUNCH(gl_overlap_add_kernel, ogrid, dim3(256), 0, st, h->ytmp, nfft, hop, n_frames, h->wss, out_len, h->y);
+    ADM_LAUNCH(gl_stft_update_kernel, fgrid, dim3(256), smem, st, h->y, out_len, nfft, h->log2n, hop, h->window,
+               (const double2*)h->twiddle, n_frames, reb, (const float2*)tprev, mom, h->mag, (double2*)h->angles);
+    // rebuilt, tprev = tprev, rebuilt
+    float2* old = tprev;
+    tprev = reb;
+    reb = old ? old : spare;
+  }
+  ADM_LAUNCH(gl_istft_frames_kernel, fgrid, dim3(256), smem, st, (const double2*)h->angles, nfft, h->log2n, h->window,
+             (const double2*)h->twiddle, n_frames, h->ytmp);
+  ADM_LAUNCH(gl_overlap_add_kernel, ogrid, dim3(256), 0, st, h->ytmp, nfft, hop, n_frames, h->wss, out_len, audio_out);
+  ADM_TRY(ADM_CHECK_LAUNCH());
+  if (stft_mag_out) ADM_TRY(copy_d2d(stft_mag_out, h->mag, spec * 8, st));  // layout (B, n_frames, n_bins)
+  if (pg_max_host) {
+    ADM_TRY(copy_d2h(pg_max_host, h->pgmax, sizeof(float), st));
+    ADM_TRY(stream_sync(st));
+  }
+  return 0;
+}
+
+}  // extern "C"

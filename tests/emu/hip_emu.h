@@ -271,6 +271,7 @@ template <class T> static inline T atomicAdd(T* p, T v) {
     return o;
   }
 }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) {
   unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
   while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}

@@ -1,0 +1,121 @@
+"""GPU probe (run on the MI355X box via gpurun): production-shape conv timings, whole-UNet forward timing,
+full-size parity vs the oracle. Writes gpurun_out/probe.log."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "audio-diffusion_amd"))
+from audiodiffusion import _native, ops  # noqa: E402
+from audiodiffusion.unet import UNet2DModel  # noqa: E402
+
+_native.load()
+dev = torch.device("cuda:0")
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+LOG = open(os.path.join(ROOT, "gpurun_out", "probe.log"), "a")
+
+
+def log(*a):
+    s = " ".join(str(x) for x in a)
+    print(s, flush=True)
+    LOG.write(s + "\n")
+    LOG.flush()
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+CFG256 = dict(sample_size=256, in_channels=1, out_channels=1, layers_per_block=2,
+              block_out_channels=(128, 128, 256, 256, 512, 512),
+              down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
+              up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4)
+
+
+def conv_shapes():
+    B = int(os.environ.get("PROBE_B", "16"))
+    shapes = [  # (C1, C2, H, W, Cout, ks, stride, up)
+        (128, 0, 256, 256, 128, 3, 1, 0), (128, 128, 256, 256, 128, 3, 1, 0), (128, 0, 128, 128, 128, 3, 1, 0),
+        (128, 0, 64, 64, 256, 3, 1, 0), (256, 0, 64, 64, 256, 3, 1, 0), (256, 0, 32, 32, 256, 3, 1, 0),
+        (256, 0, 16, 16, 512, 3, 1, 0), (512, 0, 16, 16, 512, 3, 1, 0), (512, 0, 8, 8, 512, 3, 1, 0),
+        (512, 512, 8, 8, 512, 3, 1, 0), (512, 512, 16, 16, 512, 3, 1, 0), (256, 256, 32, 32, 256, 3, 1, 0),
+        (128, 0, 256, 256, 128, 3, 2, 0), (128, 0, 128, 128, 128, 3, 1, 1), (256, 128, 128, 128, 128, 1, 1, 0),
+        (512, 0, 16, 16, 1536, 1, 1, 0),
+    ]
+    for (C1, C2, H, W, Co, ks, st, up) in shapes:
+        x1 = torch.randn(B, C1, H, W, device=dev)
+        x2 = torch.randn(B, C2, H, W, device=dev) if C2 else None
+        w = torch.randn(Co, C1 + C2, ks, ks, device=dev) * 0.02
+        wp = ops.pack_conv_weight(w)
+        b = torch.randn(Co, device=dev)
+        gamma, beta = torch.ones(C1 + C2, device=dev), torch.zeros(C1 + C2, device=dev)
+        gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2)
+        f = lambda: ops.conv2d(x1, wp, b, ks, x2=x2, up=bool(up), stride=st, gn=gn, act=True)  # noqa: E731
+        out = f()
+        dt = timeit(f, iters=5, warm=2)
+        flops = 2.0 * out.numel() * (C1 + C2) * ks * ks
+        g = lambda: ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2)  # noqa: E731
+        dg = timeit(g, iters=5, warm=2)
+        gbytes = 4.0 * (x1.numel() + (x2.numel() if x2 is not None else 0))
+        log(f"conv B={B} {C1}+{C2}@{H}x{W}->{Co} k{ks} s{st} up{up}: {dt*1e3:8.3f} ms {flops/dt/1e12:7.2f} TF/s |"
+            f" gn_stats {dg*1e3:7.3f} ms {gbytes/dg/1e12:5.2f} TB/s")
+        if os.environ.get("PROBE_CHECK", "1") == "1" and H <= 64:
+            import torch.nn.functional as F
+            xc = torch.cat([x1, x2], 1) if x2 is not None else x1
+            xr = F.silu(F.group_norm(xc, 32, gamma, beta, 1e-5))
+            if up:
+                xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+            ref = F.conv2d(xr, w, b, stride=st, padding=ks // 2)
+            log("   vs torch(MIOpen) relerr", float((out - ref).abs().max() / ref.abs().max()))
+        del x1, x2, w, wp, out
+
+
+def unet_probe():
+    m = UNet2DModel(**CFG256).init_random(0)
+    for B in (1, 4, 16, 32):
+        x = torch.randn(B, 1, 256, 256, device=dev)
+        t = torch.tensor(500)
+        f = lambda: m(x, t)  # noqa: E731
+        f()
+        torch.cuda.synchronize()
+        dt = timeit(f, iters=3, warm=1)
+        log(f"unet fwd B={B}: {dt*1e3:9.2f} ms  {0.496*B/dt:7.2f} TF/s  ws={_native.lib().adm_unet_workspace_bytes(m._handle)/2**30:.2f} GiB")
+    return m
+
+
+def parity(m):
+    from oracle.unet import UNet2DModel as OU
+    ref = OU(**CFG256).eval()
+    ref.load_state_dict(m.state_dict())
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(1, 1, 256, 256, generator=g)
+    for t in (980, 20):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            r = ref(x, torch.tensor(t))["sample"]
+        tc = time.perf_counter() - t0
+        o = m(x.to(dev), torch.tensor(t))["sample"].cpu()
+        log(f"full-size parity t={t}: max|d|={float((o - r).abs().max()):.3e} max|ref|={float(r.abs().max()):.3f} cpu_oracle={tc:.2f}s")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["conv", "unet", "parity"]
+    log("device", torch.cuda.get_device_name(0), "probe", what)
+    if "conv" in what:
+        conv_shapes()
+    m = None
+    if "unet" in what or "parity" in what:
+        m = unet_probe()
+    if "parity" in what:
+        parity(m)
