@@ -35,6 +35,10 @@ class ConvArgs(C.Structure):
     ]
 
 
+class OpProfile(C.Structure):
+    _fields_ = [("kind", C.c_int), ("variant", C.c_int), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 class UNetConfig(C.Structure):
     _fields_ = [
         ("in_channels", C.c_int), ("out_channels", C.c_int), ("layers_per_block", C.c_int), ("n_blocks", C.c_int),
@@ -64,6 +68,8 @@ _SIGS = {
     "adm_unet_missing_params": (C.c_int, [C.c_void_p]),
     "adm_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, c_float_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "adm_unet_workspace_bytes": (C.c_size_t, [C.c_void_p]),
+    "adm_unet_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.POINTER(OpProfile), C.c_int,
+                                   C.POINTER(C.c_int), C.c_void_p]),
     "adm_sample_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(SchedCoef), C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "adm_encode_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(SchedCoef), C.c_int, C.c_int, C.c_void_p]),

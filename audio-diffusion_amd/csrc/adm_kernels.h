@@ -28,6 +28,10 @@ int launch_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int
 int launch_conv2d(const adm_conv_args& a, hipStream_t st);
 int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, hipStream_t st);
 void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);
+// kernel variant chosen by the last launch_conv2d on this thread: ks*100 + stride*10 + (bm/32) for the MFMA kernel,
+// 1000 + ... for the direct small-channel kernels (profiling only).
+int last_conv_variant();
+void set_last_conv_variant(int v);
 
 // k_attention.hip
 int launch_attention(const float* qkv, float* out, int N, int C, int T, int head_dim, hipStream_t st);

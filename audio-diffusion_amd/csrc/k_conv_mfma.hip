@@ -211,6 +211,10 @@ void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho
   }
 }
 
+static thread_local int g_last_variant = 0;
+int last_conv_variant() { return g_last_variant; }
+void set_last_conv_variant(int v) { g_last_variant = v; }
+
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 int launch_conv_small(const adm_conv_args& a, hipStream_t st);  // k_conv_small.hip
@@ -263,6 +267,7 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   p.n_ct = ceil_div(a.Cout, bm);
   p.nblk = n_pt * p.n_ct;
   const size_t smem = sizeof(float) * ((size_t)CK * p.CS + (size_t)CK * a.ks * a.ks * bm);
+  g_last_variant = a.ks * 100 + a.stride * 10 + bm / 32;
   if (a.ks == 3 && a.stride == 1) return dispatch_bm<3, 1>(p, bm, smem, st);
   if (a.ks == 3 && a.stride == 2) return dispatch_bm<3, 2>(p, bm, smem, st);
   return dispatch_bm<1, 1>(p, bm, smem, st);

@@ -99,6 +99,7 @@ int launch_conv_small(const adm_conv_args& a, hipStream_t st) {
   ADM_REQUIRE(a.x2 == nullptr || a.C2 == 0, "conv_small: virtual concat not supported");
   ADM_REQUIRE(a.stride == 1 && !a.up, "conv_small: stride 1, no upsample only");
   ADM_REQUIRE(a.chan_add == nullptr, "conv_small: chan_add not supported");
+  set_last_conv_variant(a.C1 <= 4 ? 1001 : 1002);
   if (a.C1 <= 4) {
     ADM_REQUIRE(a.gn_scale == nullptr && !a.act, "conv_small(cin): no fused norm/activation");
     ADM_REQUIRE(a.ks == 3 || a.ks == 1, "conv_small: ks");

@@ -19,13 +19,6 @@
 
 #include "adm_kernels.h"
 
-extern "C" {
-typedef struct adm_mel adm_mel_t;
-typedef struct adm_mel_config {
-  int x_res, y_res, sample_rate, n_fft, hop_length, top_db, n_iter;
-} adm_mel_config;
-}
-
 struct adm_mel {
   adm_mel_config cfg;
   int n_bins = 0, n_mels = 0, log2n = 0, nnz = 0, nnz_t = 0, nnls_cols = 0;

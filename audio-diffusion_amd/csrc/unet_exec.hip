@@ -421,8 +421,48 @@ static int plan(adm_unet* h, int B) {
   return 0;
 }
 
+struct OpTimer {  // optional per-op HIP-event timing (adm_unet_profile); disabled (null) on the product path
+  std::vector<adm_op_profile>* recs = nullptr;
+#if !defined(ADM_EMU)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+#endif
+  hipStream_t st = nullptr;
+  void begin() {
+#if !defined(ADM_EMU)
+    if (!recs) return;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, st);
+    evs.push_back({a, b});
+#endif
+  }
+  void end(int kind, int variant, double flops, double bytes) {
+    if (!recs) return;
+#if !defined(ADM_EMU)
+    (void)hipEventRecord(evs.back().second, st);
+#endif
+    adm_op_profile r; r.kind = kind; r.variant = variant; r.ms = 0.f; r.flops = flops; r.bytes = bytes;
+    recs->push_back(r);
+  }
+  void finish() {
+#if !defined(ADM_EMU)
+    if (!recs) return;
+    (void)hipStreamSynchronize(st);
+    for (size_t i = 0; i < evs.size(); ++i) {
+      (void)hipEventElapsedTime(&(*recs)[i].ms, evs[i].first, evs[i].second);
+      (void)hipEventDestroy(evs[i].first); (void)hipEventDestroy(evs[i].second);
+    }
+    evs.clear();
+#endif
+  }
+};
+
 // Enqueue one UNet forward. Timestep source: t_dev (B floats) when table == nullptr, else table[*step_dev].
-static int run_forward(adm_unet* h, const float* x, float* out, int B, const adm_sched_coef* table, hipStream_t st) {
+static int run_forward(adm_unet* h, const float* x, float* out, int B, const adm_sched_coef* table, hipStream_t st,
+                       OpTimer* tm = nullptr) {
+  OpTimer none;
+  if (!tm) tm = &none;
+  tm->st = st;
   const adm_unet_config& c = h->cfg;
   h->tensors[h->t_in].ptr = const_cast<float*>(x);
   h->tensors[h->t_out].ptr = out;
@@ -431,15 +471,19 @@ static int run_forward(adm_unet* h, const float* x, float* out, int B, const adm
                                 c.flip_sin_to_cos, P(h, "time_embedding.linear_1.weight"),
                                 P(h, "time_embedding.linear_1.bias"), P(h, "time_embedding.linear_2.weight"),
                                 P(h, "time_embedding.linear_2.bias"), dim_in, h->temb_dim, h->emb, B, st));
+  tm->begin();
   ADM_TRY(launch_temb_proj(h->emb, h->temb_w, h->temb_b, h->temb_all, B, h->temb_dim, h->temb_rows, st));
+  tm->end(4, 0, 2.0 * B * h->temb_dim * h->temb_rows, 4.0 * h->temb_dim * h->temb_rows);
   for (const Op& o : h->ops) {
     const Tensor& t1 = h->tensors[o.in1];
+    tm->begin();
     if (o.kind == Op::GN) {
       const GnBuf& g = h->gnbufs[o.gn];
       const float* x2 = o.in2 >= 0 ? h->tensors[o.in2].ptr : nullptr;
       const int C2 = o.in2 >= 0 ? h->tensors[o.in2].C : 0;
       ADM_TRY(launch_groupnorm_stats(t1.ptr, t1.C, x2, C2, B, t1.H * t1.W, c.norm_num_groups, c.norm_eps, o.g->gamma,
                                      o.g->beta, g.scale, g.shift, st));
+      tm->end(0, 0, 3.0 * B * (t1.C + C2) * t1.H * t1.W, 4.0 * B * (t1.C + C2) * t1.H * t1.W);
     } else if (o.kind == Op::CONV) {
       adm_conv_args a;
       memset(&a, 0, sizeof(a));
@@ -454,10 +498,17 @@ static int run_forward(adm_unet* h, const float* x, float* out, int B, const adm
       if (o.res >= 0) a.residual = h->tensors[o.res].ptr;
       a.out = h->tensors[o.out].ptr;
       ADM_TRY(launch_conv2d(a, st));
+      const Tensor& to = h->tensors[o.out];
+      const double Cin = a.C1 + a.C2, outel = (double)B * to.C * to.H * to.W;
+      tm->end(last_conv_variant() >= 1000 ? 3 : 1, last_conv_variant(), 2.0 * outel * Cin * o.ks * o.ks,
+              4.0 * ((double)B * Cin * t1.H * t1.W + outel * (o.res >= 0 ? 2 : 1) + (double)to.C * Cin * o.ks * o.ks));
     } else {
-      ADM_TRY(launch_attention(t1.ptr, h->tensors[o.out].ptr, B, t1.C / 3, t1.H * t1.W, o.head_dim, st));
+      const int C = t1.C / 3, T = t1.H * t1.W;
+      ADM_TRY(launch_attention(t1.ptr, h->tensors[o.out].ptr, B, C, T, o.head_dim, st));
+      tm->end(2, o.head_dim, 4.0 * B * C * (double)T * T, 16.0 * B * C * T);
     }
   }
+  tm->finish();
   return 0;
 }
 
@@ -617,6 +668,24 @@ int adm_unet_forward(adm_unet_t* h, const float* x, const float* timesteps_host,
 }
 
 size_t adm_unet_workspace_bytes(adm_unet_t* h) { return h ? h->arena_bytes : 0; }
+
+int adm_unet_profile(adm_unet_t* h, const float* x, float timestep, float* out, int B, adm_op_profile* recs, int cap,
+                     int* n_out, void* stream) {
+  ADM_REQUIRE(h && x && out && recs && n_out, "unet_profile: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  ADM_TRY(finalize(h));
+  ADM_TRY(plan(h, B));
+  std::vector<float> t(B, timestep);
+  ADM_TRY(copy_h2d(h->t_dev, t.data(), sizeof(float) * B, st));
+  ADM_TRY(stream_sync(st));
+  std::vector<adm_op_profile> v;
+  OpTimer tm;
+  tm.recs = &v;
+  ADM_TRY(run_forward(h, x, out, B, nullptr, st, &tm));
+  *n_out = (int)v.size();
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) recs[i] = v[i];
+  return 0;
+}
 
 int adm_sample_loop(adm_unet_t* h, float* x, int B, const adm_sched_coef* coef_host, int n_steps,
                     const float* step_noise, const float* mask, int mask_start, int mask_end, uint8_t* u8_out,

@@ -112,8 +112,13 @@ int adm_unet_missing_params(adm_unet_t* h);
 /* eps = unet(x, t): x,out (B,Cin,H,W)/(B,Cout,H,W) device; timesteps: B floats on the HOST (or 1 broadcast). */
 int adm_unet_forward(adm_unet_t* h, const float* x, const float* timesteps_host, int n_timesteps, float* out,
                      int B, void* stream);
-/* Debug/testing: copy an intermediate activation by name after a forward ("conv_in", "down.0.res.0", ...). */
 size_t adm_unet_workspace_bytes(adm_unet_t* h);
+/* Measurement aid (bench.py roofline leg): one eager forward with a HIP-event pair around every launch on `stream`.
+ * kind: 0 GroupNorm stats, 1 MFMA conv, 2 attention core, 3 direct small-channel conv, 4 time-embedding projection.
+ * variant (MFMA conv): ks*100 + stride*10 + cout_tile/32. flops/bytes are ALGORITHMIC (no halo / re-read terms). */
+typedef struct adm_op_profile { int kind, variant; float ms; double flops, bytes; } adm_op_profile;
+int adm_unet_profile(adm_unet_t* h, const float* x, float timestep, float* out, int B, adm_op_profile* recs, int cap,
+                     int* n_out, void* stream);
 
 /* ---------------------------------------------------------------- whole denoising loop (row P4; hipGraph)
  * Runs n_steps x {UNet forward, scheduler epilogue, mask} on `x` in place and (optionally) the final u8 image.
@@ -127,6 +132,30 @@ int adm_sample_loop(adm_unet_t* h, float* x, int B, const adm_sched_coef* coef_h
  *   x = (x - c_dir*eps) * c_inv * c_fwd + c_eps*eps  with coef {sqrt_beta=c_dir, sqrt_alpha=c_inv, k_x0=c_fwd, k_eps=c_eps}. */
 int adm_encode_loop(adm_unet_t* h, float* x, int B, const adm_sched_coef* coef_host, int n_steps, int use_graph,
                     void* stream);
+
+/* ---------------------------------------------------------------- Mel codec (rows M3-M8)
+ * Replaces Mel.audio_slice_to_image (audiodiffusion/mel.py:135-151: librosa melspectrogram + power_to_db + u8) and
+ * Mel.image_to_audio (mel.py:153-168: db_to_power + mel_to_stft NNLS + Griffin-Lim), batched over slices/images.
+ * The constant tables of a configuration are computed by the host binding exactly as librosa/scipy do:
+ * window (n_fft fp64, periodic Hann), twiddle (n_fft/2 complex fp64 exp(-2 pi i q/n)), the Slaney filterbank as CSR
+ * (fb_start/fb_count per mel row, fb_w32/fb_w64 taps) and CSC (fbt_off/fbt_idx/fbt_w64), pinv (n_bins x n_mels fp64),
+ * wss (window sum-square envelope, fp32, trimmed to hop*(x_res-1)), nnls_cols (librosa.util.nnls column blocking). */
+typedef struct adm_mel adm_mel_t;
+typedef struct adm_mel_config { int x_res, y_res, sample_rate, n_fft, hop_length, top_db, n_iter; } adm_mel_config;
+int adm_mel_create(const adm_mel_config* cfg, const double* window, const double* twiddle, const int* fb_start,
+                   const int* fb_count, const float* fb_w32, const double* fb_w64, int nnz, const int* fbt_off,
+                   const int* fbt_idx, const double* fbt_w64, const double* pinv, const float* wss, int nnls_cols,
+                   adm_mel_t** out);
+void adm_mel_destroy(adm_mel_t* h);
+/* audio: device, B slices of n_samples fp32 (is_f64=0) or fp64 (=1), slice_stride elements apart;
+ * image_out: device (B, y_res, 1 + n_samples/hop) uint8. */
+int adm_mel_forward(adm_mel_t* h, const void* audio, int is_f64, int B, long slice_stride, int n_samples,
+                    uint8_t* image_out, void* stream);
+/* images: device (B, y_res, n_frames) uint8; init_phase: device (B, n_bins, n_frames) fp64 in [0,1) (Griffin-Lim start
+ * phase / 2 pi); audio_out: device (B, hop*(n_frames-1)) fp32; stft_mag_out: NULL or device (B, n_frames, n_bins) fp64;
+ * pg_max_host: NULL or receives max |projected gradient| of the NNLS start point (librosa stops there iff <= 1e-5). */
+int adm_mel_inverse(adm_mel_t* h, const uint8_t* images, const double* init_phase, int B, int n_frames,
+                    float* audio_out, double* stft_mag_out, float* pg_max_host, void* stream);
 
 #ifdef __cplusplus
 }
