@@ -1,0 +1,61 @@
+"""Multi-process result invariance of batch-sharded sampling (SURVEY.md §8(c) anchor 7, §8(e)): world_size 2 over
+`gloo` on the CPU (kernels on the fiber emulator) must reproduce the single-process images byte for byte."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = dict(sample_size=16, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(32, 32),
+            down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"))
+
+
+def _pipe(kind):
+    for p in (ROOT, os.path.join(ROOT, "audio-diffusion_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from native_backend import select
+    select("emu")
+    from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, DDPMScheduler, Mel, UNet2DModel
+    unet = UNet2DModel(**TINY).init_random(0)
+    sched = DDIMScheduler() if kind == "ddim" else DDPMScheduler()
+    pipe = AudioDiffusionPipeline(None, unet, Mel(x_res=16, y_res=16, hop_length=64, n_fft=256, n_iter=1), sched)
+    pipe.set_progress_bar_config(disable=True)
+    return pipe
+
+
+def _worker(rank, world, port, kind, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      ADM_EMU_THREADS="2")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from audiodiffusion.distributed import sample_sharded
+    pipe = _pipe(kind)
+    out, (lo, hi) = sample_sharded(pipe, global_batch=3, steps=2, seed=5)
+    if rank == 0:
+        q.put((out.cpu().clone(), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["ddim", "ddpm"])
+def test_sharded_sampling_matches_single_process(kind):
+    from audiodiffusion.distributed import sample_sharded, shard_bounds
+    assert [shard_bounds(3, 2, r) for r in (0, 1)] == [(0, 2), (2, 3)]
+    single, _ = sample_sharded(_pipe(kind), global_batch=3, steps=2, seed=5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out, (lo, hi) = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert (lo, hi) == (0, 2)
+    assert out.shape == single.shape == (3, 16, 16)
+    assert torch.equal(out, single.cpu())
