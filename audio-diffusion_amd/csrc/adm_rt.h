@@ -13,6 +13,9 @@
   adm_emu::launch((grid), (block), (shmem), [=]() { kern(__VA_ARGS__); })
 #define ADM_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(adm_emu::S().dyn_smem)
 #define ADM_UNROLL
+// async global->LDS copy of 16 B per lane: LDS destination = wave-uniform base + lane*16 (guide §5)
+#define ADM_GLDS16(gptr, lds_wave_base) \
+  memcpy(reinterpret_cast<char*>(lds_wave_base) + (adm_emu::flat_tid() & 63) * 16, (gptr), 16)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -23,6 +26,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char adm_dyn_smem_[]; \
   type* name = reinterpret_cast<type*>(adm_dyn_smem_)
 #define ADM_UNROLL _Pragma("unroll")
+#define ADM_GLDS16(gptr, lds_wave_base)                                                               \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),             \
+                                   (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #endif
 
 namespace adm {

@@ -18,6 +18,8 @@
 // row = cout, so each store instruction writes 2 couts x 32 consecutive pixels (64-B..128-B segments, NCHW).
 // Pixel tile = NI images x TH x TW with TW = min(Wo,16), TH = min(Ho,8): 128 pixels at every UNet level
 // (256^2 ... 1x1). Algorithmic bytes per launch: 4*(N*Cin*Hs*Ws + N*Cout*Ho*Wo [+ residual]) + 4*Cout*Cin*ks^2.
+#include <cstdlib>
+
 #include "adm_kernels.h"
 
 namespace adm {
@@ -36,7 +38,7 @@ struct ConvParams {
   int lTW, lTH, tiles_x, tiles_y, n_ct, IH, IW, CS, nblk;
 };
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
 
 template <int KS, int STRIDE, int WM, int TM>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams p) {
@@ -200,6 +202,169 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Software-pipelined variant (stride 1, input patch <= 256 elements per channel plane, Cout % BM == 0):
+//   * the weight slab of chunk c+1 streams HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPRs, asynchronous) into
+//     the second half of a double buffer while the MFMAs of chunk c run;
+//   * the raw activations (+ GroupNorm scale/shift) of chunk c+1 are prefetched into registers before the MFMAs of
+//     chunk c and normalised/activated into LDS after them.
+// Two workgroups per CU (79.5 KiB LDS each), so one workgroup's stash/barrier phase hides under the other's MFMAs.
+template <int KS, int WM, int TM>
+__global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p) {
+  constexpr int WN = 4 / WM;
+  constexpr int TN = 4 / WN;
+  constexpr int BM = 32 * WM * TM;
+  constexpr int KS2 = KS * KS;
+  constexpr int WSLAB = CK * KS2 * BM;
+  ADM_DYN_SMEM(float, smem);
+  float* ldsX = smem;
+  float* ldsW0 = smem + CK * p.CS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  int lid;
+  {
+    const int b = blockIdx.x, q = p.nblk >> 3, r = p.nblk & 7, xcd = b & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int ct = lid % p.n_ct, pt = lid / p.n_ct;
+  const int tx = pt % p.tiles_x, ty = (pt / p.tiles_x) % p.tiles_y, ig = pt / (p.tiles_x * p.tiles_y);
+  const int TW = 1 << p.lTW, TH = 1 << p.lTH, NI = 128 >> (p.lTW + p.lTH);
+  const int m0 = ct * BM, n0 = ig * NI;
+  const int Ct = p.C1 + p.C2;
+  const int planeS = p.Hs * p.Ws;
+  const int IHW = p.IH * p.IW;
+
+  // gather plan: one patch element per thread (CS <= 256)
+  const bool qv = tid < NI * IHW;
+  int soff = -1, qn = n0;
+  if (qv) {
+    const int img = tid / IHW, r2 = tid - img * IHW;
+    const int ly = r2 / p.IW, lx = r2 - ly * p.IW;
+    const int gy = ty * TH + ly - p.pad_lo, gx = tx * TW + lx - p.pad_lo;
+    qn = n0 + img;
+    if (gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi && qn < p.N) {
+      const int sy = p.up ? (gy >> 1) : gy, sx = p.up ? (gx >> 1) : gx;
+      soff = sy * p.Ws + sx;
+    }
+  }
+  int poff[TN];
+  ADM_UNROLL
+  for (int tn = 0; tn < TN; ++tn) {
+    const int pp = (wn * TN + tn) * 32 + l31;
+    const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
+    poff[tn] = img * IHW + py * p.IW + px;
+  }
+  f32x16 acc[TM][TN];
+  ADM_UNROLL
+  for (int a = 0; a < TM; ++a)
+    ADM_UNROLL
+    for (int b = 0; b < TN; ++b)
+      ADM_UNROLL
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int a_lane = wm * TM * 32 + l31;
+  const bool has_gn = p.gn_scale != nullptr;
+
+  float xr[CK], gs[CK], gh[CK];
+  ADM_UNROLL
+  for (int c = 0; c < CK; ++c) { xr[c] = 0.f; gs[c] = 1.f; gh[c] = 0.f; }
+
+  auto issue = [&](int c0, int buf) {
+    const bool from1 = c0 < p.C1;
+    const float* xb = from1 ? p.x1 : p.x2;
+    const int Cb = from1 ? p.C1 : p.C2;
+    const int cb0 = from1 ? c0 : c0 - p.C1;
+    if (soff >= 0) {
+      const float* src = xb + ((long)qn * Cb + cb0) * planeS + soff;
+      ADM_UNROLL
+      for (int c = 0; c < CK; ++c) xr[c] = src[(long)c * planeS];
+      if (has_gn) {
+        const float* sp = p.gn_scale + (long)qn * Ct + c0;
+        const float* hp = p.gn_shift + (long)qn * Ct + c0;
+        ADM_UNROLL
+        for (int c = 0; c < CK; ++c) { gs[c] = sp[c]; gh[c] = hp[c]; }
+      }
+    }
+    constexpr int ROW4 = BM / 4;
+    constexpr int TOT4 = WSLAB / 4;               // multiple of 64: the tail guard below is wave-uniform
+    constexpr int NIT = (TOT4 + 255) / 256;
+    const float* wsrc = p.wp + (long)c0 * KS2 * p.Cout + m0;
+    float* wdst = ldsW0 + buf * WSLAB;
+    ADM_UNROLL
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < TOT4) {
+        const int row = idx / ROW4, c4 = idx - row * ROW4;
+        ADM_GLDS16(wsrc + (long)row * p.Cout + c4 * 4, wdst + (256 * i + wave * 64) * 4);
+      }
+    }
+  };
+
+  const int nchunks = Ct / CK;
+  issue(0, 0);
+  for (int ci = 0; ci < nchunks; ++ci) {
+    if (qv) {
+      ADM_UNROLL
+      for (int c = 0; c < CK; ++c) {
+        float v = 0.f;
+        if (soff >= 0) {
+          v = xr[c];
+          if (has_gn) v = v * gs[c] + gh[c];
+          if (p.act) v = silu_f(v);
+        }
+        ldsX[c * p.CS + tid] = v;
+      }
+    }
+    __syncthreads();  // also drains the LDS-DMA of this chunk's weight slab (issued one chunk ago)
+    if (ci + 1 < nchunks) issue((ci + 1) * CK, (ci + 1) & 1);
+    const float* ldsW = ldsW0 + (ci & 1) * WSLAB;
+    ADM_UNROLL
+    for (int tap = 0; tap < KS2; ++tap) {
+      const int toff = (tap / KS) * p.IW + (tap % KS);
+      ADM_UNROLL
+      for (int cp = 0; cp < CK / 2; ++cp) {
+        const int ch = 2 * cp + h;
+        float av[TM], bv[TN];
+        ADM_UNROLL
+        for (int a = 0; a < TM; ++a) av[a] = ldsW[(ch * KS2 + tap) * BM + a_lane + a * 32];
+        ADM_UNROLL
+        for (int b = 0; b < TN; ++b) bv[b] = ldsX[ch * p.CS + poff[b] + toff];
+        ADM_UNROLL
+        for (int a = 0; a < TM; ++a)
+          ADM_UNROLL
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  const long planeO = (long)p.Ho * p.Wo;
+  ADM_UNROLL
+  for (int tn = 0; tn < TN; ++tn) {
+    const int pp = (wn * TN + tn) * 32 + l31;
+    const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
+    const int oy = ty * TH + py, ox = tx * TW + px, n = n0 + img;
+    if (n >= p.N || oy >= p.Ho || ox >= p.Wo) continue;
+    ADM_UNROLL
+    for (int tm = 0; tm < TM; ++tm) {
+      ADM_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[tm][tn][r];
+        if (p.bias != nullptr) v += p.bias[co];
+        if (p.chan_add != nullptr) v += p.chan_add[(long)n * p.chan_add_stride + co];
+        const long o = ((long)n * p.Cout + co) * planeO + (long)oy * p.Wo + ox;
+        if (p.residual != nullptr) v += p.residual[o];
+        p.out[o] = v;
+      }
+    }
+  }
+}
+
 void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo) {
   const int Hi = up ? 2 * H : H, Wi = up ? 2 * W : W;
   if (stride == 1) {
@@ -219,8 +384,40 @@ static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; 
 
 int launch_conv_small(const adm_conv_args& a, hipStream_t st);  // k_conv_small.hip
 
+#if !defined(ADM_EMU)
+template <class K>
+static void allow_big_lds(K kernel, size_t smem) {
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+}
+#else
+template <class K> static void allow_big_lds(K, size_t) {}
+#endif
+
+static bool use_pf() {
+  static const int v = [] { const char* e = getenv("ADM_CONV_PF"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+
+template <int KS>
+static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
+  const size_t smem = sizeof(float) * ((size_t)CK * p.CS + 2 * (size_t)CK * KS * KS * bm);
+  dim3 grid(p.nblk), block(256);
+  if (bm == 128) {
+    allow_big_lds(conv_mfma_pf_kernel<KS, 2, 2>, smem);
+    ADM_LAUNCH((conv_mfma_pf_kernel<KS, 2, 2>), grid, block, smem, st, p);
+  } else if (bm == 64) {
+    allow_big_lds(conv_mfma_pf_kernel<KS, 2, 1>, smem);
+    ADM_LAUNCH((conv_mfma_pf_kernel<KS, 2, 1>), grid, block, smem, st, p);
+  } else {
+    allow_big_lds(conv_mfma_pf_kernel<KS, 1, 1>, smem);
+    ADM_LAUNCH((conv_mfma_pf_kernel<KS, 1, 1>), grid, block, smem, st, p);
+  }
+  return ADM_CHECK_LAUNCH();
+}
+
 template <int KS, int STRIDE>
 static int dispatch_bm(const ConvParams& p, int bm, size_t smem, hipStream_t st) {
+  allow_big_lds(conv_mfma_kernel<KS, STRIDE, 2, 2>, smem);
   dim3 grid(p.nblk), block(256);
   if (bm == 128) {
     ADM_LAUNCH((conv_mfma_kernel<KS, STRIDE, 2, 2>), grid, block, smem, st, p);
@@ -268,6 +465,10 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   p.nblk = n_pt * p.n_ct;
   const size_t smem = sizeof(float) * ((size_t)CK * p.CS + (size_t)CK * a.ks * a.ks * bm);
   g_last_variant = a.ks * 100 + a.stride * 10 + bm / 32;
+  if (use_pf() && a.ks == 3 && a.stride == 1 && p.CS <= 256 && a.Cout % bm == 0) {
+    g_last_variant += 2000;
+    return dispatch_pf<3>(p, bm, st);
+  }
   if (a.ks == 3 && a.stride == 1) return dispatch_bm<3, 1>(p, bm, smem, st);
   if (a.ks == 3 && a.stride == 2) return dispatch_bm<3, 2>(p, bm, smem, st);
   return dispatch_bm<1, 1>(p, bm, smem, st);
