@@ -40,6 +40,59 @@ struct ConvParams {
 
 __device__ __forceinline__ float silu_f(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
 
+
+// Epilogue for one 32x32 accumulator tile: batch all loads (bias, time-embedding bias, residual) before use.
+// The nullable-pointer conditions are template flags: a per-element "load or not" branch makes hipcc wait vmcnt(0)
+// per element (guide §5 trap (c)) and serialises 64 dependent round trips per lane.
+template <bool HAS_CHAN, bool HAS_RES>
+__device__ __forceinline__ void store_tile(const f32x16& acc, const ConvParams& p, int co_base, int h, int n, long pix,
+                                           long planeO) {
+  float bv[16], cv[16], rv[16];
+  ADM_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+    bv[r] = p.bias[co];
+    if (HAS_CHAN) cv[r] = p.chan_add[(long)n * p.chan_add_stride + co];
+    if (HAS_RES) rv[r] = p.residual[((long)n * p.Cout + co) * planeO + pix];
+  }
+  ADM_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+    float v = acc[r] + bv[r];
+    if (HAS_CHAN) v += cv[r];
+    if (HAS_RES) v += rv[r];
+    p.out[((long)n * p.Cout + co) * planeO + pix] = v;
+  }
+}
+
+template <int TM, int TN, bool HAS_CHAN, bool HAS_RES>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], const ConvParams& p, int m_wave, int wn, int l31,
+                                         int h, int TW, int TH, int tx, int ty, int n0) {
+  const long planeO = (long)p.Ho * p.Wo;
+  ADM_UNROLL
+  for (int tn = 0; tn < TN; ++tn) {
+    const int pp = (wn * TN + tn) * 32 + l31;
+    const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
+    const int oy = ty * TH + py, ox = tx * TW + px, n = n0 + img;
+    if (n >= p.N || oy >= p.Ho || ox >= p.Wo) continue;
+    ADM_UNROLL
+    for (int tm = 0; tm < TM; ++tm)
+      store_tile<HAS_CHAN, HAS_RES>(acc[tm][tn], p, m_wave + tm * 32, h, n, (long)oy * p.Wo + ox, planeO);
+  }
+}
+
+#define ADM_CONV_EPILOGUE(TM_, TN_)                                                                          \
+  do {                                                                                                       \
+    const int m_wave_ = m0 + wm * TM_ * 32;                                                                  \
+    if (p.chan_add != nullptr) {                                                                             \
+      if (p.residual != nullptr) epilogue<TM_, TN_, true, true>(acc, p, m_wave_, wn, l31, h, TW, TH, tx, ty, n0);   \
+      else epilogue<TM_, TN_, true, false>(acc, p, m_wave_, wn, l31, h, TW, TH, tx, ty, n0);                 \
+    } else {                                                                                                 \
+      if (p.residual != nullptr) epilogue<TM_, TN_, false, true>(acc, p, m_wave_, wn, l31, h, TW, TH, tx, ty, n0);  \
+      else epilogue<TM_, TN_, false, false>(acc, p, m_wave_, wn, l31, h, TW, TH, tx, ty, n0);                \
+    }                                                                                                        \
+  } while (0)
+
 template <int KS, int STRIDE, int WM, int TM>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams p) {
   constexpr int WN = 4 / WM;
@@ -178,28 +231,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams p) {
   }
 
   // ---- epilogue: bias + temb bias + residual, NCHW store ---------------------------------------------
-  const long planeO = (long)p.Ho * p.Wo;
-  ADM_UNROLL
-  for (int tn = 0; tn < TN; ++tn) {
-    const int pp = (wn * TN + tn) * 32 + l31;
-    const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
-    const int oy = ty * TH + py, ox = tx * TW + px, n = n0 + img;
-    if (n >= p.N || oy >= p.Ho || ox >= p.Wo) continue;
-    ADM_UNROLL
-    for (int tm = 0; tm < TM; ++tm) {
-      ADM_UNROLL
-      for (int r = 0; r < 16; ++r) {
-        const int co = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co >= p.Cout) continue;
-        float v = acc[tm][tn][r];
-        if (p.bias != nullptr) v += p.bias[co];
-        if (p.chan_add != nullptr) v += p.chan_add[(long)n * p.chan_add_stride + co];
-        const long o = ((long)n * p.Cout + co) * planeO + (long)oy * p.Wo + ox;
-        if (p.residual != nullptr) v += p.residual[o];
-        p.out[o] = v;
-      }
-    }
-  }
+  ADM_CONV_EPILOGUE(TM, TN);
 }
 
 
@@ -216,10 +248,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
   constexpr int TN = 4 / WN;
   constexpr int BM = 32 * WM * TM;
   constexpr int KS2 = KS * KS;
-  constexpr int WSLAB = CK * KS2 * BM;
+  constexpr int CKP = KS == 1 ? 32 : CK;    // channels per K chunk: 1x1 has no taps, so take 32 channels (K = 32)
+  constexpr int SPL = KS == 1 ? 2 : 1;      // threads per patch element (1x1: 128 pixels -> 2 threads each)
+  constexpr int NCH = CKP / SPL;            // channels prefetched per thread
+  constexpr int WSLAB = CKP * KS2 * BM;
   ADM_DYN_SMEM(float, smem);
   float* ldsX = smem;
-  float* ldsW0 = smem + CK * p.CS;
+  float* ldsW0 = smem + CKP * p.CS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -238,11 +273,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
   const int planeS = p.Hs * p.Ws;
   const int IHW = p.IH * p.IW;
 
-  // gather plan: one patch element per thread (CS <= 256)
-  const bool qv = tid < NI * IHW;
+  // gather plan: one patch element per thread (per SPL threads for 1x1); CS <= 256 / SPL
+  const int q = SPL == 1 ? tid : (tid & 127);
+  const int csub = SPL == 1 ? 0 : (tid >> 7) * NCH;   // first channel (inside the chunk) this thread stages
+  const bool qv = q < NI * IHW;
   int soff = -1, qn = n0;
   if (qv) {
-    const int img = tid / IHW, r2 = tid - img * IHW;
+    const int img = q / IHW, r2 = q - img * IHW;
     const int ly = r2 / p.IW, lx = r2 - ly * p.IW;
     const int gy = ty * TH + ly - p.pad_lo, gx = tx * TW + lx - p.pad_lo;
     qn = n0 + img;
@@ -268,24 +305,24 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
   const int a_lane = wm * TM * 32 + l31;
   const bool has_gn = p.gn_scale != nullptr;
 
-  float xr[CK], gs[CK], gh[CK];
+  float xr[NCH], gs[NCH], gh[NCH];
   ADM_UNROLL
-  for (int c = 0; c < CK; ++c) { xr[c] = 0.f; gs[c] = 1.f; gh[c] = 0.f; }
+  for (int c = 0; c < NCH; ++c) { xr[c] = 0.f; gs[c] = 1.f; gh[c] = 0.f; }
 
   auto issue = [&](int c0, int buf) {
     const bool from1 = c0 < p.C1;
     const float* xb = from1 ? p.x1 : p.x2;
     const int Cb = from1 ? p.C1 : p.C2;
-    const int cb0 = from1 ? c0 : c0 - p.C1;
+    const int cb0 = (from1 ? c0 : c0 - p.C1) + csub;
     if (soff >= 0) {
       const float* src = xb + ((long)qn * Cb + cb0) * planeS + soff;
       ADM_UNROLL
-      for (int c = 0; c < CK; ++c) xr[c] = src[(long)c * planeS];
+      for (int c = 0; c < NCH; ++c) xr[c] = src[(long)c * planeS];
       if (has_gn) {
-        const float* sp = p.gn_scale + (long)qn * Ct + c0;
-        const float* hp = p.gn_shift + (long)qn * Ct + c0;
+        const float* sp = p.gn_scale + (long)qn * Ct + c0 + csub;
+        const float* hp = p.gn_shift + (long)qn * Ct + c0 + csub;
         ADM_UNROLL
-        for (int c = 0; c < CK; ++c) { gs[c] = sp[c]; gh[c] = hp[c]; }
+        for (int c = 0; c < NCH; ++c) { gs[c] = sp[c]; gh[c] = hp[c]; }
       }
     }
     constexpr int ROW4 = BM / 4;
@@ -303,29 +340,27 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
     }
   };
 
-  const int nchunks = Ct / CK;
+  const int nchunks = Ct / CKP;
   issue(0, 0);
   for (int ci = 0; ci < nchunks; ++ci) {
     if (qv) {
+      const bool live = soff >= 0;
       ADM_UNROLL
-      for (int c = 0; c < CK; ++c) {
-        float v = 0.f;
-        if (soff >= 0) {
-          v = xr[c];
-          if (has_gn) v = v * gs[c] + gh[c];
-          if (p.act) v = silu_f(v);
-        }
-        ldsX[c * p.CS + tid] = v;
+      for (int c = 0; c < NCH; ++c) {
+        float v = xr[c] * gs[c] + gh[c];      // gs = 1, gh = 0 without GroupNorm
+        const float sv = silu_f(v);
+        v = p.act ? sv : v;
+        ldsX[(csub + c) * p.CS + q] = live ? v : 0.f;   // zero padding is applied AFTER the activation
       }
     }
     __syncthreads();  // also drains the LDS-DMA of this chunk's weight slab (issued one chunk ago)
-    if (ci + 1 < nchunks) issue((ci + 1) * CK, (ci + 1) & 1);
+    if (ci + 1 < nchunks) issue((ci + 1) * CKP, (ci + 1) & 1);
     const float* ldsW = ldsW0 + (ci & 1) * WSLAB;
     ADM_UNROLL
     for (int tap = 0; tap < KS2; ++tap) {
       const int toff = (tap / KS) * p.IW + (tap % KS);
       ADM_UNROLL
-      for (int cp = 0; cp < CK / 2; ++cp) {
+      for (int cp = 0; cp < CKP / 2; ++cp) {
         const int ch = 2 * cp + h;
         float av[TM], bv[TN];
         ADM_UNROLL
@@ -341,28 +376,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
     }
     __syncthreads();
   }
-
-  const long planeO = (long)p.Ho * p.Wo;
-  ADM_UNROLL
-  for (int tn = 0; tn < TN; ++tn) {
-    const int pp = (wn * TN + tn) * 32 + l31;
-    const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
-    const int oy = ty * TH + py, ox = tx * TW + px, n = n0 + img;
-    if (n >= p.N || oy >= p.Ho || ox >= p.Wo) continue;
-    ADM_UNROLL
-    for (int tm = 0; tm < TM; ++tm) {
-      ADM_UNROLL
-      for (int r = 0; r < 16; ++r) {
-        const int co = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float v = acc[tm][tn][r];
-        if (p.bias != nullptr) v += p.bias[co];
-        if (p.chan_add != nullptr) v += p.chan_add[(long)n * p.chan_add_stride + co];
-        const long o = ((long)n * p.Cout + co) * planeO + (long)oy * p.Wo + ox;
-        if (p.residual != nullptr) v += p.residual[o];
-        p.out[o] = v;
-      }
-    }
-  }
+  ADM_CONV_EPILOGUE(TM, TN);
 }
 
 void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo) {
@@ -393,6 +407,22 @@ static void allow_big_lds(K kernel, size_t smem) {
 template <class K> static void allow_big_lds(K, size_t) {}
 #endif
 
+// bias is read unconditionally by the epilogue: a NULL bias maps to a shared all-zero device buffer.
+static const float* zero_bias(int n) {
+  static float* z = nullptr;
+  static int cap = 0;
+  if (n > cap) {
+    void* pz = nullptr;
+    const int want = n < 8192 ? 8192 : n;
+    if (dmalloc(&pz, sizeof(float) * want) != 0) return nullptr;
+    dmemset(pz, 0, sizeof(float) * want, nullptr);
+    stream_sync(nullptr);
+    z = (float*)pz;  // the previous (smaller) buffer is intentionally leaked: launches may still read it
+    cap = want;
+  }
+  return z;
+}
+
 static bool use_pf() {
   static const int v = [] { const char* e = getenv("ADM_CONV_PF"); return e ? atoi(e) : 1; }();
   return v != 0;
@@ -400,7 +430,8 @@ static bool use_pf() {
 
 template <int KS>
 static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
-  const size_t smem = sizeof(float) * ((size_t)CK * p.CS + 2 * (size_t)CK * KS * KS * bm);
+  constexpr int CKP = KS == 1 ? 32 : CK;
+  const size_t smem = sizeof(float) * ((size_t)CKP * p.CS + 2 * (size_t)CKP * KS * KS * bm);
   dim3 grid(p.nblk), block(256);
   if (bm == 128) {
     allow_big_lds(conv_mfma_pf_kernel<KS, 2, 2>, smem);
@@ -444,7 +475,9 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   conv_out_dims(a.H, a.W, a.up, a.stride, a.ks, a.pad_lo, &p.Ho, &p.Wo);
   p.up = a.up; p.pad_lo = a.ks == 1 ? 0 : a.pad_lo;
   p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.act = a.act;
-  p.wp = a.wpacked; p.bias = a.bias; p.Cout = a.Cout;
+  ADM_REQUIRE(a.Cout % 32 == 0, "conv2d: Cout must be a multiple of 32 for the MFMA kernel");
+  p.wp = a.wpacked; p.bias = a.bias ? a.bias : zero_bias(a.Cout); p.Cout = a.Cout;
+  ADM_REQUIRE(p.bias != nullptr, "conv2d: could not allocate the zero-bias buffer");
   p.chan_add = a.chan_add; p.chan_add_stride = a.chan_add_stride;
   p.residual = a.residual; p.out = a.out;
   const int TW = p.Wo >= 16 ? 16 : p.Wo, TH = p.Ho >= 8 ? 8 : p.Ho;
@@ -461,13 +494,18 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   int bm = 32;
   if (a.Cout % 128 == 0 && (long)n_pt * (a.Cout / 128) >= 256) bm = 128;
   else if (a.Cout % 64 == 0 && (long)n_pt * (a.Cout / 64) >= 256) bm = 64;
+  // (Cout % 32 == 0 is required above, so the chosen tile always divides Cout: no cout guards in the kernels)
   p.n_ct = ceil_div(a.Cout, bm);
   p.nblk = n_pt * p.n_ct;
   const size_t smem = sizeof(float) * ((size_t)CK * p.CS + (size_t)CK * a.ks * a.ks * bm);
   g_last_variant = a.ks * 100 + a.stride * 10 + bm / 32;
-  if (use_pf() && a.ks == 3 && a.stride == 1 && p.CS <= 256 && a.Cout % bm == 0) {
+  if (use_pf() && a.stride == 1 && a.ks == 3 && p.CS <= 256) {
     g_last_variant += 2000;
     return dispatch_pf<3>(p, bm, st);
+  }
+  if (use_pf() && a.ks == 1 && p.CS == 128 && Ct % 32 == 0 && a.C1 % 32 == 0) {
+    g_last_variant += 2000;
+    return dispatch_pf<1>(p, bm, st);
   }
   if (a.ks == 3 && a.stride == 1) return dispatch_bm<3, 1>(p, bm, smem, st);
   if (a.ks == 3 && a.stride == 2) return dispatch_bm<3, 2>(p, bm, smem, st);

@@ -42,52 +42,75 @@ __global__ void __launch_bounds__(256) conv_small_cin_kernel(const float* __rest
 }
 
 // ---- Cout <= 4: 16x16 output tile per workgroup, channels staged 8 at a time through LDS ----------------
+// Weights are wave-uniform: they are read straight from global memory (scalar loads into SGPRs), not from LDS,
+// so the only LDS traffic in the inner loop is the 9 activated taps per channel.
 constexpr int SC = 8;
+template <int COUT>
 __global__ void __launch_bounds__(256) conv_small_cout_kernel(const float* __restrict__ x, int Cin, int N, int H,
                                                               int W, const float* __restrict__ gn_scale,
                                                               const float* __restrict__ gn_shift, int act,
                                                               const float* __restrict__ wp,  // [Cin][tap][Cout]
-                                                              const float* __restrict__ bias, int Cout,
+                                                              const float* __restrict__ bias,
                                                               const float* __restrict__ residual,
                                                               float* __restrict__ out, int tiles_x) {
   __shared__ float tile[SC][18][18 + 1];
-  __shared__ float wl[4][SC][9];
   const int tid = threadIdx.x;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, n = blockIdx.y;
   const int lx = tid & 15, ly = tid >> 4;
   const int ox = tx * 16 + lx, oy = ty * 16 + ly;
   const long HW = (long)H * W;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < Cin; c0 += SC) {
-    for (int e = tid; e < SC * 18 * 18; e += 256) {
-      const int c = e / 324, r = e - c * 324, yy = r / 18, xx = r - yy * 18;
+  // per-thread gather plan over the 18x18 halo (2 elements per thread: 324 = 256 + 68)
+  int goff[2];
+  ADM_UNROLL
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + 256 * k;
+    goff[k] = -2;  // -2: not mine, -1: zero padding
+    if (e < 324) {
+      const int yy = e / 18, xx = e - yy * 18;
       const int gy = ty * 16 + yy - 1, gx = tx * 16 + xx - 1;
-      float v = 0.f;
-      if (c0 + c < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        v = x[((long)n * Cin + c0 + c) * HW + (long)gy * W + gx];
-        if (gn_scale) v = v * gn_scale[(long)n * Cin + c0 + c] + gn_shift[(long)n * Cin + c0 + c];
-        if (act) v = silu_s(v);
-      }
-      tile[c][yy][xx] = v;
+      goff[k] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
     }
-    for (int e = tid; e < 4 * SC * 9; e += 256) {
-      const int co = e / (SC * 9), r = e - co * SC * 9, c = r / 9, t = r - c * 9;
-      wl[co][c][t] = (co < Cout && c0 + c < Cin) ? wp[((long)(c0 + c) * 9 + t) * Cout + co] : 0.f;
+  }
+  float acc[COUT];
+  ADM_UNROLL
+  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+  for (int c0 = 0; c0 < Cin; c0 += SC) {
+    ADM_UNROLL
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + 256 * k;
+      if (goff[k] != -2) {
+        const int yy = e / 18, xx = e - yy * 18;
+        ADM_UNROLL
+        for (int c = 0; c < SC; ++c) {
+          float v = 0.f;
+          if (goff[k] >= 0 && c0 + c < Cin) {
+            v = x[((long)n * Cin + c0 + c) * HW + goff[k]];
+            if (gn_scale) v = v * gn_scale[(long)n * Cin + c0 + c] + gn_shift[(long)n * Cin + c0 + c];
+            if (act) v = __fdividef(v, 1.0f + __expf(-v));
+          }
+          tile[c][yy][xx] = v;
+        }
+      }
     }
     __syncthreads();
+    ADM_UNROLL
     for (int c = 0; c < SC; ++c) {
-      ADM_UNROLL
-      for (int t = 0; t < 9; ++t) {
-        const float v = tile[c][ly + t / 3][lx + t % 3];
+      if (c0 + c < Cin) {
+        const float* wr = wp + (long)(c0 + c) * 9 * COUT;  // uniform address -> scalar loads
         ADM_UNROLL
-        for (int co = 0; co < 4; ++co) acc[co] = fmaf(wl[co][c][t], v, acc[co]);
+        for (int t = 0; t < 9; ++t) {
+          const float v = tile[c][ly + t / 3][lx + t % 3];
+          ADM_UNROLL
+          for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wr[t * COUT + co], v, acc[co]);
+        }
       }
     }
     __syncthreads();
   }
   if (ox < W && oy < H) {
-    for (int co = 0; co < Cout; ++co) {
-      const long o = ((long)n * Cout + co) * HW + (long)oy * W + ox;
+    ADM_UNROLL
+    for (int co = 0; co < COUT; ++co) {
+      const long o = ((long)n * COUT + co) * HW + (long)oy * W + ox;
       float v = acc[co] + (bias ? bias[co] : 0.f);
       if (residual) v += residual[o];
       out[o] = v;
@@ -118,9 +141,15 @@ int launch_conv_small(const adm_conv_args& a, hipStream_t st) {
   }
   ADM_REQUIRE(a.Cout <= 4 && a.ks == 3 && a.pad_lo == 1, "conv_small: unsupported shape (need Cin<=4 or Cout<=4, 3x3)");
   const int tiles_x = ceil_div(a.W, 16), tiles_y = ceil_div(a.H, 16);
-  ADM_LAUNCH(conv_small_cout_kernel, dim3(tiles_x * tiles_y, a.N), dim3(256), 0, st, a.x1, a.C1, a.N, a.H, a.W,
-             a.gn_scale, a.gn_shift, a.act, a.wpacked, a.bias, a.Cout, a.residual, a.out, tiles_x);
-  return ADM_CHECK_LAUNCH();
+#define ADM_COUT_CASE(CO)                                                                                          \
+  if (a.Cout == CO) {                                                                                              \
+    ADM_LAUNCH((conv_small_cout_kernel<CO>), dim3(tiles_x * tiles_y, a.N), dim3(256), 0, st, a.x1, a.C1, a.N, a.H, \
+               a.W, a.gn_scale, a.gn_shift, a.act, a.wpacked, a.bias, a.residual, a.out, tiles_x);                \
+    return ADM_CHECK_LAUNCH();                                                                                     \
+  }
+  ADM_COUT_CASE(1) ADM_COUT_CASE(2) ADM_COUT_CASE(3) ADM_COUT_CASE(4)
+#undef ADM_COUT_CASE
+  ADM_FAIL("conv_small(cout): unsupported Cout");
 }
 
 }  // namespace adm

@@ -500,7 +500,7 @@ static int run_forward(adm_unet* h, const float* x, float* out, int B, const adm
       ADM_TRY(launch_conv2d(a, st));
       const Tensor& to = h->tensors[o.out];
       const double Cin = a.C1 + a.C2, outel = (double)B * to.C * to.H * to.W;
-      tm->end(last_conv_variant() >= 1000 ? 3 : 1, last_conv_variant(), 2.0 * outel * Cin * o.ks * o.ks,
+      tm->end((last_conv_variant() >= 1000 && last_conv_variant() < 2000) ? 3 : 1, last_conv_variant(), 2.0 * outel * Cin * o.ks * o.ks,
               4.0 * ((double)B * Cin * t1.H * t1.W + outel * (o.res >= 0 ? 2 : 1) + (double)to.C * Cin * o.ks * o.ks));
     } else {
       const int C = t1.C / 3, T = t1.H * t1.W;

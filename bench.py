@@ -89,7 +89,7 @@ def roofline(unet, x, B):
         if best is None or tot < best[0]:
             best = (tot, rows)
     rows = best[1]
-    dom = [r for r in rows if r[0] == 1 and r[1] == 314]        # ks3 stride1 cout-tile 128: conv_mfma_kernel<3,1,2,2>
+    dom = [r for r in rows if r[0] == 1 and r[1] == 2314]       # ks3 stride1 cout-tile 128, pipelined: conv_mfma_pf_kernel<3,2,2>
     if not dom:
         dom = [r for r in rows if r[0] == 1]
     ms = sum(r[2] for r in dom)
@@ -102,7 +102,7 @@ def roofline(unet, x, B):
     breakdown = {names[k]: {"launches": e[0], "ms": round(e[1], 3), "TFLOP/s": round(e[2] / e[1] / 1e9, 2) if e[1] else None,
                             "GB/s": round(e[3] / e[1] / 1e6, 1) if e[1] else None} for k, e in by_kind.items()}
     ach = fl / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "adm::conv_mfma_kernel<3,1,2,2> (v_mfma_f32_32x32x2_f32 implicit GEMM)",
+    return {"bound": "mfma", "kernel": "adm::conv_mfma_pf_kernel<3,2,2> (v_mfma_f32_32x32x2_f32 implicit GEMM, 3x3 stride 1, 128-cout tile)",
             "achieved": round(ach, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TF, 4),
             "traffic": None, "launches_per_forward": len(dom), "avg_launch_us": round(ms / len(dom) * 1e3, 2),
             "avg_flops_per_launch": fl / len(dom), "share_of_forward_time": round(ms / sum(r[2] for r in rows), 3),

@@ -115,7 +115,8 @@ int adm_unet_forward(adm_unet_t* h, const float* x, const float* timesteps_host,
 size_t adm_unet_workspace_bytes(adm_unet_t* h);
 /* Measurement aid (bench.py roofline leg): one eager forward with a HIP-event pair around every launch on `stream`.
  * kind: 0 GroupNorm stats, 1 MFMA conv, 2 attention core, 3 direct small-channel conv, 4 time-embedding projection.
- * variant (MFMA conv): ks*100 + stride*10 + cout_tile/32. flops/bytes are ALGORITHMIC (no halo / re-read terms). */
+ * variant (MFMA conv): ks*100 + stride*10 + cout_tile/32, +2000 for the software-pipelined kernel
+ * (conv_mfma_pf_kernel); 1001/1002 = direct small-Cin / small-Cout kernels. flops/bytes are ALGORITHMIC. */
 typedef struct adm_op_profile { int kind, variant; float ms; double flops, bytes; } adm_op_profile;
 int adm_unet_profile(adm_unet_t* h, const float* x, float timestep, float* out, int B, adm_op_profile* recs, int cap,
                      int* n_out, void* stream);
