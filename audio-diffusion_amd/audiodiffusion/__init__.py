@@ -22,6 +22,7 @@ from .mel import Mel  # noqa: E402,F401
 from .pipeline_audio_diffusion import AudioDiffusionPipeline  # noqa: E402
 from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: E402,F401
 from .unet import UNet2DModel  # noqa: E402,F401
+from .vae import AutoencoderKL  # noqa: E402,F401
 
 try:  # progress bars are optional plumbing
     from tqdm.auto import tqdm  # noqa: E402

@@ -32,6 +32,7 @@ class ConvArgs(C.Structure):
         ("chan_add", C.c_void_p), ("chan_add_stride", C.c_int),
         ("residual", C.c_void_p),
         ("out", C.c_void_p),
+        ("x1_bstride", C.c_long), ("x2_bstride", C.c_long), ("w_bstride", C.c_long),
     ]
 
 
@@ -76,6 +77,12 @@ _SIGS = {
 }
 # entry points added by later translation units (k_mel.hip); bound when present in the header AND the library
 _OPTIONAL_SIGS = {
+    "adm_vae_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "adm_vae_destroy": (None, [C.c_void_p]),
+    "adm_vae_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "adm_vae_latent_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "adm_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "adm_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "adm_mel_create": (C.c_int, [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.POINTER(C.c_void_p)]),
     "adm_mel_destroy": (None, [C.c_void_p]),
     "adm_mel_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),

@@ -23,6 +23,7 @@ from . import ops
 from .mel import Mel
 from .schedulers import DDIMScheduler, DDPMScheduler, randn_tensor
 from .unet import UNet2DModel
+from .vae import AutoencoderKL
 
 
 class PipelineOutput(dict):
@@ -35,7 +36,7 @@ class UNet2DConditionModel:  # placeholder type so `isinstance` checks of the re
         raise NotImplementedError("conditional generation (UNet2DConditionModel) is outside the hot path (SURVEY.md §8(f))")
 
 
-_CLASSES = {"UNet2DModel": UNet2DModel, "DDIMScheduler": DDIMScheduler, "DDPMScheduler": DDPMScheduler, "Mel": Mel}
+_CLASSES = {"AutoencoderKL": AutoencoderKL, "UNet2DModel": UNet2DModel, "DDIMScheduler": DDIMScheduler, "DDPMScheduler": DDPMScheduler, "Mel": Mel}
 
 
 class DiffusionPipeline:
@@ -111,7 +112,7 @@ class DiffusionPipeline:
             lib = "audio_diffusion" if isinstance(m, Mel) else "diffusers"
             index[name] = [lib, type(m).__name__]
             sub = os.path.join(path, name)
-            if isinstance(m, UNet2DModel):
+            if isinstance(m, (UNet2DModel, AutoencoderKL)):
                 m.save_pretrained(sub, safe_serialization=safe_serialization)
             else:
                 m.save_pretrained(sub)
@@ -122,7 +123,7 @@ class DiffusionPipeline:
 class AudioDiffusionPipeline(DiffusionPipeline):
     """
     Parameters (as the reference, `pipeline_audio_diffusion.py:39-61`):
-        vqvae: AutoencoderKL for latent audio diffusion or None (latent models: not on this round's path)
+        vqvae: AutoencoderKL for latent audio diffusion or None
         unet: UNet2DModel
         mel: Mel — transform audio <-> spectrogram
         scheduler: DDIMScheduler or DDPMScheduler
@@ -134,8 +135,6 @@ class AudioDiffusionPipeline(DiffusionPipeline):
 
     def __init__(self, vqvae, unet, mel, scheduler):
         super().__init__()
-        if vqvae is not None:
-            raise NotImplementedError("AutoencoderKL (latent audio diffusion) is not built yet on this path")
         self.register_modules(unet=unet, scheduler=scheduler, mel=mel, vqvae=vqvae)
 
     def get_default_steps(self) -> int:
@@ -243,6 +242,12 @@ class AudioDiffusionPipeline(DiffusionPipeline):
             input_image = (input_image / 255) * 2 - 1
             input_images = torch.tensor(input_image[np.newaxis, :, :], dtype=torch.float).to(self.device)
 
+            if self.vqvae is not None:
+                input_images = self.vqvae.encode(torch.unsqueeze(input_images, 0)).latent_dist.sample(
+                    generator=generator
+                )[0]
+                input_images = 0.18215 * input_images
+
             if start_step > 0:
                 images[0, 0] = self.scheduler.add_noise(input_images, noise, self.scheduler.timesteps[start_step - 1])
 
@@ -255,7 +260,13 @@ class AudioDiffusionPipeline(DiffusionPipeline):
 
         use_mask = mask if (mask is not None and (mask_start > 0 or mask_end > 0)) else None
         images, u8 = self._denoise(images, start_step, eta, step_generator, use_mask, mask_start, mask_end,
-                                   step_noise=step_noise)
+                                   step_noise=step_noise, want_u8=self.vqvae is None)
+
+        if self.vqvae is not None:
+            # 0.18215 was scaling factor used in training to ensure unit variance (pipeline:187-190); the 1/0.18215
+            # multiply is folded into the decoder launch
+            images = self.vqvae.decode(images, _in_scale=1 / 0.18215)["sample"]
+            u8 = ops.dequant_u8(images).permute(0, 2, 3, 1).contiguous()
         final_float = images
 
         if u8 is None:  # multi-channel: dequantise then NHWC (pipeline:192-194)

@@ -36,6 +36,13 @@ void set_last_conv_variant(int v);
 // k_attention.hip
 int launch_attention(const float* qkv, float* out, int N, int C, int T, int head_dim, hipStream_t st);
 
+// k_vae.hip
+int launch_softmax_channels(float* s, int N, int J, int T, float scale, hipStream_t st);
+int launch_transpose_ct(const float* in, long in_bs, float* out, int N, int C, int T, hipStream_t st);
+int launch_gaussian_sample(const float* moments, const float* noise, float* out, int N, int Cz, long HW, float out_scale,
+                           hipStream_t st);
+int launch_scale(const float* x, float* out, float s, long n, hipStream_t st);
+
 // k_temb.hip
 // emb[b][:] = linear_2(silu(linear_1(sinusoid(t_b)))); t from host-provided device array or coef table.
 int launch_time_embedding(const float* t_dev, int t_stride, const adm_sched_coef* table, const int* step_dev,

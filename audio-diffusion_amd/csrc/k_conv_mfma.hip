@@ -36,6 +36,7 @@ struct ConvParams {
   const float* chan_add; int chan_add_stride;
   const float* residual; float* out;
   int lTW, lTH, tiles_x, tiles_y, n_ct, IH, IW, CS, nblk;
+  long x1_bs, x2_bs, wp_bs;  // batch strides (elements) of x1/x2 (channel-slice views) and of per-sample weights (0: shared)
 };
 
 __device__ __forceinline__ float silu_f(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams p) {
     // ---- stage the activated input patch ----------------------------------------------------------
     const bool from1 = c0 < p.C1;
     const float* xb = from1 ? p.x1 : p.x2;
-    const int Cb = from1 ? p.C1 : p.C2;
+    const long xbs = from1 ? p.x1_bs : p.x2_bs;
     const int cb0 = from1 ? c0 : c0 - p.C1;
     ADM_UNROLL
     for (int qi = 0; qi < MAXQ; ++qi) {
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams p) {
         ADM_UNROLL
         for (int c = 0; c < CK; ++c) {
           v[c] = 0.f;
-          if (soff >= 0) v[c] = xb[((long)n * Cb + cb0 + c) * planeS + soff];
+          if (soff >= 0) v[c] = xb[(long)n * xbs + (long)(cb0 + c) * planeS + soff];
         }
         if (p.gn_scale != nullptr && soff >= 0) {
           ADM_UNROLL
@@ -199,7 +200,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams p) {
     {
       constexpr int ROW4 = BM / 4;
       constexpr int TOT4 = CK * KS2 * ROW4;
-      const float* wsrc = p.wp + (long)c0 * KS2 * p.Cout + m0;
+      const float* wsrc = p.wp + (long)n0 * p.wp_bs + (long)c0 * KS2 * p.Cout + m0;
       for (int idx = tid; idx < TOT4; idx += 256) {
         const int row = idx / ROW4, c4 = idx - row * ROW4;
         float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -312,10 +313,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
   auto issue = [&](int c0, int buf) {
     const bool from1 = c0 < p.C1;
     const float* xb = from1 ? p.x1 : p.x2;
-    const int Cb = from1 ? p.C1 : p.C2;
+    const long xbs = from1 ? p.x1_bs : p.x2_bs;
     const int cb0 = (from1 ? c0 : c0 - p.C1) + csub;
     if (soff >= 0) {
-      const float* src = xb + ((long)qn * Cb + cb0) * planeS + soff;
+      const float* src = xb + (long)qn * xbs + (long)cb0 * planeS + soff;
       ADM_UNROLL
       for (int c = 0; c < NCH; ++c) xr[c] = src[(long)c * planeS];
       if (has_gn) {
@@ -328,7 +329,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
     constexpr int ROW4 = BM / 4;
     constexpr int TOT4 = WSLAB / 4;               // multiple of 64: the tail guard below is wave-uniform
     constexpr int NIT = (TOT4 + 255) / 256;
-    const float* wsrc = p.wp + (long)c0 * KS2 * p.Cout + m0;
+    const float* wsrc = p.wp + (long)n0 * p.wp_bs + (long)c0 * KS2 * p.Cout + m0;
     float* wdst = ldsW0 + buf * WSLAB;
     ADM_UNROLL
     for (int i = 0; i < NIT; ++i) {
@@ -480,6 +481,9 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   ADM_REQUIRE(p.bias != nullptr, "conv2d: could not allocate the zero-bias buffer");
   p.chan_add = a.chan_add; p.chan_add_stride = a.chan_add_stride;
   p.residual = a.residual; p.out = a.out;
+  p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
+  p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
+  p.wp_bs = a.w_bstride;
   const int TW = p.Wo >= 16 ? 16 : p.Wo, TH = p.Ho >= 8 ? 8 : p.Ho;
   ADM_REQUIRE((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "conv2d: output dims below 16x8 must be powers of two");
   p.lTW = ilog2(TW); p.lTH = ilog2(TH);
@@ -490,6 +494,7 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   p.CS = (NI * p.IH * p.IW + 3) & ~3;
   ADM_REQUIRE(p.CS <= MAXQ * 256, "conv2d: input patch too large for the gather plan");
   const int n_pt = p.tiles_x * p.tiles_y * img_groups;
+  ADM_REQUIRE(a.w_bstride == 0 || NI == 1, "conv2d: per-sample weights need one image per tile (output >= 16x8)");
   // cout tile: largest of 128/64/32 that still gives >= 1 workgroup per CU (256 CUs), else the smallest.
   int bm = 32;
   if (a.Cout % 128 == 0 && (long)n_pt * (a.Cout / 128) >= 256) bm = 128;

@@ -1,0 +1,121 @@
+// net_exec.h — generic flat-op-list executor shared by the UNet2DModel and AutoencoderKL executors.
+// A `Net` is built once from a diffusers config: tensors (NCHW fp32, batch dimension added at plan time), per-(n,c)
+// GroupNorm scale/shift buffers, and ops (GroupNorm statistics, fused MFMA convolution, attention cores, and the two
+// helper ops of the single-head VAE attention). Activations are planned into an arena by liveness.
+#pragma once
+#include <deque>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "adm_kernels.h"
+
+namespace adm {
+
+struct ParamSlot {
+  std::vector<long> shape;
+  size_t numel = 0;
+  float* dev = nullptr;
+  bool set = false;
+};
+
+struct ParamStore {
+  std::map<std::string, ParamSlot> params;
+  void declare(const std::string& key, std::vector<long> shape);
+  void declare_conv(const std::string& p, int co, int ci, int ks);
+  void declare_lin(const std::string& p, int co, int ci);
+  void declare_gn(const std::string& p, int c);
+  void declare_resnet(const std::string& p, int ci, int co, int temb);  // temb <= 0: no time_emb_proj
+  void declare_attn(const std::string& p, int c);
+  int set(const char* key, const float* host_data, size_t numel);       // accepts deprecated attention names
+  int missing(std::string* names) const;
+  float* P(const std::string& k) const { return params.at(k).dev; }
+  void free_all();
+};
+
+struct ConvW {
+  float* wp = nullptr;
+  float* bias = nullptr;
+  int Cin = 0, Cout = 0, ks = 3;
+};
+struct GNW {
+  float* gamma = nullptr;
+  float* beta = nullptr;
+  int C = 0;
+};
+struct Tensor {
+  int C = 0, H = 0, W = 0;
+  float* ptr = nullptr;
+  int last_use = -1;
+  bool external = false;
+};
+struct GnBuf {
+  int C = 0;
+  float* scale = nullptr;
+  float* shift = nullptr;
+};
+struct Op {
+  enum Kind { GN, CONV, ATTN, SOFTMAXC, TRANSP } kind = CONV;
+  int in1 = -1, in2 = -1, out = -1, res = -1, gn = -1;
+  int in1_coff = 0, in1_C = 0;      // channel-slice view of in1 (in1_C == 0: whole tensor)
+  int wt = -1, wt_coff = 0;         // CONV with per-sample weights taken from tensor `wt` (channel offset wt_coff)
+  int dyn_cout = 0;                 // ... producing this many output channels
+  int up = 0, stride = 1, ks = 3, pad_lo = 1, act = 0;
+  const ConvW* w = nullptr;
+  const GNW* g = nullptr;
+  int temb_off = -1;
+  int head_dim = 0;
+  float scale = 1.f;
+};
+
+struct OpTimer;  // unet_exec.hip (profiling aid)
+
+struct Net {
+  ParamStore* ps = nullptr;
+  int groups = 32;
+  float eps = 1e-5f;
+  int head_dim_cfg = 8;
+  std::deque<ConvW> convs;
+  std::deque<GNW> gns;
+  std::vector<Tensor> tensors;
+  std::vector<GnBuf> gnbufs;
+  std::vector<Op> ops;
+  std::vector<void*> owned;
+  std::vector<std::pair<std::string, int>> temb_rows;  // (time_emb_proj prefix, Cout) in op order (UNet only)
+  int t_in = -1, t_out = -1;
+  int planned_B = 0;
+  std::vector<void*> arena;
+  size_t arena_bytes = 0;
+
+  // ---- construction -----------------------------------------------------------------------------------
+  int dalloc(void** p, size_t bytes);
+  int make_conv(const std::string& p, int co, int ci, int ks, const ConvW** out);
+  const GNW* make_gn(const std::string& p, int c);
+  int new_tensor(int C, int H, int W, bool ext = false);
+  int gn_op(int in1, int in2, const GNW* g);
+  int conv_op(int in1, int in2, const ConvW* w, int gn, int act, int up, int stride, int pad_lo, int res, int temb_off,
+              int out_ext = -1);
+  int resnet(const std::string& p, int x1, int x2, int ci, int co, bool temb, int* rc);
+  int attention(const std::string& p, int x, int C, int head_dim, int* rc);  // head_dim <= 64: fused small-head kernel
+  void finish_liveness();
+
+  // ---- execution ----------------------------------------------------------------------------------------
+  int arena_alloc(void** p, size_t bytes);
+  void free_plan();
+  int plan(int B);
+  int run(const float* x, float* out, int B, const float* temb_all, int temb_stride, hipStream_t st, OpTimer* tm);
+  void destroy();
+};
+
+struct OpTimer {  // optional per-op HIP-event timing; disabled (recs == nullptr) on the product path
+  std::vector<adm_op_profile>* recs = nullptr;
+#if !defined(ADM_EMU)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+#endif
+  hipStream_t st = nullptr;
+  void begin();
+  void end(int kind, int variant, double flops, double bytes);
+  void finish();
+};
+
+}  // namespace adm

@@ -1,0 +1,332 @@
+// net_exec.hip — implementation of the generic flat-op-list executor (see net_exec.h).
+#include "net_exec.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace adm {
+
+// ---------------------------------------------------------------------------------------------- ParamStore
+void ParamStore::declare(const std::string& key, std::vector<long> shape) {
+  ParamSlot s;
+  s.shape = shape;
+  s.numel = 1;
+  for (long d : shape) s.numel *= (size_t)d;
+  params[key] = s;
+}
+void ParamStore::declare_conv(const std::string& p, int co, int ci, int ks) {
+  declare(p + ".weight", {co, ci, ks, ks});
+  declare(p + ".bias", {co});
+}
+void ParamStore::declare_lin(const std::string& p, int co, int ci) {
+  declare(p + ".weight", {co, ci});
+  declare(p + ".bias", {co});
+}
+void ParamStore::declare_gn(const std::string& p, int c) {
+  declare(p + ".weight", {c});
+  declare(p + ".bias", {c});
+}
+void ParamStore::declare_resnet(const std::string& p, int ci, int co, int temb) {
+  declare_gn(p + ".norm1", ci);
+  declare_conv(p + ".conv1", co, ci, 3);
+  if (temb > 0) declare_lin(p + ".time_emb_proj", co, temb);
+  declare_gn(p + ".norm2", co);
+  declare_conv(p + ".conv2", co, co, 3);
+  if (ci != co) declare_conv(p + ".conv_shortcut", co, ci, 1);
+}
+void ParamStore::declare_attn(const std::string& p, int c) {
+  declare_gn(p + ".group_norm", c);
+  declare_lin(p + ".to_q", c, c);
+  declare_lin(p + ".to_k", c, c);
+  declare_lin(p + ".to_v", c, c);
+  declare_lin(p + ".to_out.0", c, c);
+}
+int ParamStore::set(const char* key, const float* host_data, size_t numel) {
+  std::string k(key);
+  static const char* oldn[4] = {".query.", ".key.", ".value.", ".proj_attn."};
+  static const char* newn[4] = {".to_q.", ".to_k.", ".to_v.", ".to_out.0."};
+  if (k.find(".attentions.") != std::string::npos)
+    for (int i = 0; i < 4; ++i) {
+      size_t pos = k.find(oldn[i]);
+      if (pos != std::string::npos) k.replace(pos, strlen(oldn[i]), newn[i]);
+    }
+  auto it = params.find(k);
+  ADM_REQUIRE(it != params.end(), "set_param: unexpected key " + k);
+  ADM_REQUIRE(it->second.numel == numel, "set_param: size mismatch for " + k);
+  if (!it->second.dev) ADM_TRY(dmalloc((void**)&it->second.dev, sizeof(float) * numel));
+  ADM_TRY(copy_h2d(it->second.dev, host_data, sizeof(float) * numel, nullptr));
+  ADM_TRY(stream_sync(nullptr));
+  it->second.set = true;
+  return 0;
+}
+int ParamStore::missing(std::string* names) const {
+  int n = 0;
+  for (auto& kv : params)
+    if (!kv.second.set) { ++n; if (names && n <= 16) *names += kv.first + " "; }
+  return n;
+}
+void ParamStore::free_all() {
+  for (auto& kv : params)
+    if (kv.second.dev) { dfree(kv.second.dev); kv.second.dev = nullptr; }
+}
+
+// ---------------------------------------------------------------------------------------------- OpTimer
+void OpTimer::begin() {
+#if !defined(ADM_EMU)
+  if (!recs) return;
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  (void)hipEventRecord(a, st);
+  evs.push_back({a, b});
+#endif
+}
+void OpTimer::end(int kind, int variant, double flops, double bytes) {
+  if (!recs) return;
+#if !defined(ADM_EMU)
+  (void)hipEventRecord(evs.back().second, st);
+#endif
+  adm_op_profile r; r.kind = kind; r.variant = variant; r.ms = 0.f; r.flops = flops; r.bytes = bytes;
+  recs->push_back(r);
+}
+void OpTimer::finish() {
+#if !defined(ADM_EMU)
+  if (!recs) return;
+  (void)hipStreamSynchronize(st);
+  for (size_t i = 0; i < evs.size(); ++i) {
+    (void)hipEventElapsedTime(&(*recs)[i].ms, evs[i].first, evs[i].second);
+    (void)hipEventDestroy(evs[i].first); (void)hipEventDestroy(evs[i].second);
+  }
+  evs.clear();
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------- Net: build
+int Net::dalloc(void** p, size_t bytes) {
+  ADM_TRY(dmalloc(p, bytes));
+  owned.push_back(*p);
+  return 0;
+}
+int Net::make_conv(const std::string& p, int co, int ci, int ks, const ConvW** out) {
+  ConvW w;
+  w.Cin = ci; w.Cout = co; w.ks = ks;
+  ADM_TRY(dalloc((void**)&w.wp, sizeof(float) * (size_t)co * ci * ks * ks));
+  ADM_TRY(launch_pack_conv_weight(ps->P(p + ".weight"), w.wp, co, ci, ks, nullptr));
+  w.bias = ps->P(p + ".bias");
+  convs.push_back(w);
+  *out = &convs.back();
+  return 0;
+}
+const GNW* Net::make_gn(const std::string& p, int c) {
+  GNW g;
+  g.gamma = ps->P(p + ".weight"); g.beta = ps->P(p + ".bias"); g.C = c;
+  gns.push_back(g);
+  return &gns.back();
+}
+int Net::new_tensor(int C, int H, int W, bool ext) {
+  Tensor t; t.C = C; t.H = H; t.W = W; t.external = ext;
+  tensors.push_back(t);
+  return (int)tensors.size() - 1;
+}
+int Net::gn_op(int in1, int in2, const GNW* g) {
+  GnBuf b; b.C = g->C;
+  gnbufs.push_back(b);
+  Op o; o.kind = Op::GN; o.in1 = in1; o.in2 = in2; o.g = g; o.gn = (int)gnbufs.size() - 1;
+  ops.push_back(o);
+  return o.gn;
+}
+int Net::conv_op(int in1, int in2, const ConvW* w, int gn, int act, int up, int stride, int pad_lo, int res,
+                 int temb_off, int out_ext) {
+  const Tensor& ti = tensors[in1];
+  int Ho, Wo;
+  conv_out_dims(ti.H, ti.W, up, stride, w->ks, pad_lo, &Ho, &Wo);
+  Op o; o.kind = Op::CONV; o.in1 = in1; o.in2 = in2; o.w = w; o.gn = gn; o.act = act; o.up = up; o.stride = stride;
+  o.ks = w->ks; o.pad_lo = w->ks == 3 ? pad_lo : 0; o.res = res; o.temb_off = temb_off;
+  o.out = out_ext >= 0 ? out_ext : new_tensor(w->Cout, Ho, Wo);
+  ops.push_back(o);
+  return o.out;
+}
+int Net::resnet(const std::string& p, int x1, int x2, int ci, int co, bool temb, int* rc) {
+  const ConvW *c1, *c2, *sc = nullptr;
+  if ((*rc = make_conv(p + ".conv1", co, ci, 3, &c1))) return -1;
+  if ((*rc = make_conv(p + ".conv2", co, co, 3, &c2))) return -1;
+  if (ci != co && (*rc = make_conv(p + ".conv_shortcut", co, ci, 1, &sc))) return -1;
+  int temb_off = -1;
+  if (temb) {
+    temb_off = 0;
+    for (auto& r : temb_rows) temb_off += r.second;
+    temb_rows.push_back({p + ".time_emb_proj", co});
+  }
+  const int g1 = gn_op(x1, x2, make_gn(p + ".norm1", ci));
+  const int hmid = conv_op(x1, x2, c1, g1, 1, 0, 1, 1, -1, temb_off);
+  const int g2 = gn_op(hmid, -1, make_gn(p + ".norm2", co));
+  int res = x1;
+  if (sc) res = conv_op(x1, x2, sc, -1, 0, 0, 1, 0, -1, -1);
+  return conv_op(hmid, -1, c2, g2, 1, 0, 1, 1, res, -1);
+}
+int Net::attention(const std::string& p, int x, int C, int head_dim, int* rc) {
+  // q|k|v stacked into one 1x1 conv: weights (3C, C), bias 3C; GroupNorm (no SiLU) folded into its load path
+  ConvW qkv; qkv.Cin = C; qkv.Cout = 3 * C; qkv.ks = 1;
+  float* stacked = nullptr;
+  if ((*rc = dalloc((void**)&stacked, sizeof(float) * (size_t)3 * C * C))) return -1;
+  if ((*rc = dalloc((void**)&qkv.wp, sizeof(float) * (size_t)3 * C * C))) return -1;
+  if ((*rc = dalloc((void**)&qkv.bias, sizeof(float) * (size_t)3 * C))) return -1;
+  const char* names[3] = {".to_q", ".to_k", ".to_v"};
+  for (int i = 0; i < 3; ++i) {
+    copy_d2d(stacked + (size_t)i * C * C, ps->P(p + names[i] + ".weight"), sizeof(float) * (size_t)C * C, nullptr);
+    copy_d2d(qkv.bias + (size_t)i * C, ps->P(p + names[i] + ".bias"), sizeof(float) * (size_t)C, nullptr);
+  }
+  if ((*rc = launch_pack_conv_weight(stacked, qkv.wp, 3 * C, C, 1, nullptr))) return -1;
+  convs.push_back(qkv);
+  const ConvW* wqkv = &convs.back();
+  const ConvW* wo;
+  if ((*rc = make_conv(p + ".to_out.0", C, C, 1, &wo))) return -1;
+  const int g = gn_op(x, -1, make_gn(p + ".group_norm", C));
+  const int t_qkv = conv_op(x, -1, wqkv, g, 0, 0, 1, 0, -1, -1);
+  const Tensor tx = tensors[x];
+  const int T = tx.H * tx.W;
+  if (head_dim <= 64) {  // UNet form: many small heads -> fused per-head kernel
+    Op o; o.kind = Op::ATTN; o.in1 = t_qkv; o.head_dim = head_dim;
+    o.out = new_tensor(C, tx.H, tx.W);
+    ops.push_back(o);
+    return conv_op(o.out, -1, wo, -1, 0, 0, 1, 0, x, -1);
+  }
+  // VAE form: one head, d = C. Both products run on the MFMA 1x1 kernel with per-sample weights:
+  //   S'[j][t] = sum_c K[c][j] Q[c][t]   (weights = k slice, whose [c][j] memory IS the packed [Cin][Cout] layout)
+  //   softmax over j (channel axis) with scale d^-0.5
+  //   O[c][t]  = sum_j V[c][j] P[j][t]   (weights = V^T, produced by a transpose op)
+  if (head_dim != C) { set_error("attention: only 1 head (head_dim == channels) or head_dim <= 64 are implemented"); *rc = -1; return -1; }
+  Op s; s.kind = Op::CONV; s.in1 = t_qkv; s.in1_coff = 0; s.in1_C = C; s.wt = t_qkv; s.wt_coff = C; s.dyn_cout = T;
+  s.ks = 1; s.pad_lo = 0; s.out = new_tensor(T, tx.H, tx.W);
+  ops.push_back(s);
+  Op sm; sm.kind = Op::SOFTMAXC; sm.in1 = s.out; sm.out = s.out; sm.scale = 1.0f / sqrtf((float)head_dim);
+  ops.push_back(sm);
+  Op tr; tr.kind = Op::TRANSP; tr.in1 = t_qkv; tr.in1_coff = 2 * C; tr.in1_C = C; tr.out = new_tensor(T, C, 1);
+  ops.push_back(tr);
+  Op pv; pv.kind = Op::CONV; pv.in1 = s.out; pv.wt = tr.out; pv.wt_coff = 0; pv.dyn_cout = C; pv.ks = 1; pv.pad_lo = 0;
+  pv.out = new_tensor(C, tx.H, tx.W);
+  ops.push_back(pv);
+  return conv_op(pv.out, -1, wo, -1, 0, 0, 1, 0, x, -1);
+}
+void Net::finish_liveness() {
+  for (size_t i = 0; i < ops.size(); ++i) {
+    const Op& o = ops[i];
+    for (int t : {o.in1, o.in2, o.res, o.wt})
+      if (t >= 0) tensors[t].last_use = (int)i;
+    if (o.kind == Op::SOFTMAXC) tensors[o.out].last_use = (int)i;  // in place
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- Net: run
+int Net::arena_alloc(void** p, size_t bytes) {
+  ADM_TRY(dmalloc(p, bytes));
+  arena.push_back(*p);
+  arena_bytes += bytes;
+  return 0;
+}
+void Net::free_plan() {
+  for (void* p : arena) dfree(p);
+  arena.clear();
+  arena_bytes = 0;
+  planned_B = 0;
+}
+void Net::destroy() {
+  free_plan();
+  for (void* p : owned) dfree(p);
+  owned.clear();
+}
+// Assign activation buffers for batch B: exact-size free lists driven by liveness.
+int Net::plan(int B) {
+  if (planned_B == B) return 0;
+  free_plan();
+  std::multimap<size_t, float*> freelist;
+  std::vector<std::vector<int>> dying(ops.size());
+  for (size_t t = 0; t < tensors.size(); ++t)
+    if (!tensors[t].external && tensors[t].last_use >= 0) dying[tensors[t].last_use].push_back((int)t);
+  for (size_t i = 0; i < ops.size(); ++i) {
+    const Op& o = ops[i];
+    if (o.out >= 0 && !tensors[o.out].external && o.kind != Op::SOFTMAXC) {
+      Tensor& t = tensors[o.out];
+      const size_t bytes = sizeof(float) * (size_t)B * t.C * t.H * t.W;
+      auto it = freelist.find(bytes);
+      if (it != freelist.end()) { t.ptr = it->second; freelist.erase(it); }
+      else ADM_TRY(arena_alloc((void**)&t.ptr, bytes));
+    }
+    for (int t : dying[i]) {
+      const Tensor& tt = tensors[t];
+      freelist.insert({sizeof(float) * (size_t)B * tt.C * tt.H * tt.W, tt.ptr});
+    }
+  }
+  for (GnBuf& g : gnbufs) {
+    ADM_TRY(arena_alloc((void**)&g.scale, sizeof(float) * (size_t)B * g.C));
+    ADM_TRY(arena_alloc((void**)&g.shift, sizeof(float) * (size_t)B * g.C));
+  }
+  planned_B = B;
+  return 0;
+}
+
+int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_stride, hipStream_t st, OpTimer* tm) {
+  OpTimer none;
+  if (!tm) tm = &none;
+  tm->st = st;
+  tensors[t_in].ptr = const_cast<float*>(x);
+  tensors[t_out].ptr = out;
+  for (const Op& o : ops) {
+    const Tensor& t1 = tensors[o.in1];
+    tm->begin();
+    if (o.kind == Op::GN) {
+      const GnBuf& g = gnbufs[o.gn];
+      const float* x2 = o.in2 >= 0 ? tensors[o.in2].ptr : nullptr;
+      const int C2 = o.in2 >= 0 ? tensors[o.in2].C : 0;
+      ADM_TRY(launch_groupnorm_stats(t1.ptr, t1.C, x2, C2, B, t1.H * t1.W, groups, eps, o.g->gamma, o.g->beta, g.scale,
+                                     g.shift, st));
+      tm->end(0, 0, 3.0 * B * (t1.C + C2) * t1.H * t1.W, 4.0 * B * (t1.C + C2) * t1.H * t1.W);
+    } else if (o.kind == Op::CONV) {
+      adm_conv_args a;
+      memset(&a, 0, sizeof(a));
+      const long plane = (long)t1.H * t1.W;
+      a.x1 = t1.ptr + (long)o.in1_coff * plane;
+      a.C1 = o.in1_C ? o.in1_C : t1.C;
+      a.x1_bstride = (long)t1.C * plane;
+      if (o.in2 >= 0) { a.x2 = tensors[o.in2].ptr; a.C2 = tensors[o.in2].C; }
+      a.N = B; a.H = t1.H; a.W = t1.W;
+      a.up = o.up; a.stride = o.stride; a.ks = o.ks; a.pad_lo = o.pad_lo;
+      if (o.gn >= 0) { a.gn_scale = gnbufs[o.gn].scale; a.gn_shift = gnbufs[o.gn].shift; }
+      a.act = o.act;
+      if (o.wt >= 0) {  // per-sample weights living in an activation tensor
+        const Tensor& tw = tensors[o.wt];
+        const long wplane = (long)tw.H * tw.W;
+        a.wpacked = tw.ptr + (long)o.wt_coff * wplane;
+        a.w_bstride = (long)tw.C * wplane;
+        a.bias = nullptr;
+        a.Cout = o.dyn_cout;
+      } else {
+        a.wpacked = o.w->wp; a.bias = o.w->bias; a.Cout = o.w->Cout;
+      }
+      if (o.temb_off >= 0 && temb_all) { a.chan_add = temb_all + o.temb_off; a.chan_add_stride = temb_stride; }
+      if (o.res >= 0) a.residual = tensors[o.res].ptr;
+      a.out = tensors[o.out].ptr;
+      ADM_TRY(launch_conv2d(a, st));
+      const Tensor& to = tensors[o.out];
+      const double Cin = a.C1 + a.C2, outel = (double)B * to.C * to.H * to.W;
+      const int var = last_conv_variant();
+      tm->end((var >= 1000 && var < 2000) ? 3 : 1, var, 2.0 * outel * Cin * o.ks * o.ks,
+              4.0 * ((double)B * Cin * t1.H * t1.W + outel * (o.res >= 0 ? 2 : 1) + (double)to.C * Cin * o.ks * o.ks));
+    } else if (o.kind == Op::ATTN) {
+      const int C = t1.C / 3, T = t1.H * t1.W;
+      ADM_TRY(launch_attention(t1.ptr, tensors[o.out].ptr, B, C, T, o.head_dim, st));
+      tm->end(2, o.head_dim, 4.0 * B * C * (double)T * T, 16.0 * B * C * T);
+    } else if (o.kind == Op::SOFTMAXC) {
+      const int T = t1.H * t1.W;
+      ADM_TRY(launch_softmax_channels(t1.ptr, B, t1.C, T, o.scale, st));
+      tm->end(5, 0, 5.0 * B * t1.C * T, 8.0 * B * t1.C * T);
+    } else {  // TRANSP: channel slice (C, T) -> (T, C)
+      const int T = t1.H * t1.W;
+      ADM_TRY(launch_transpose_ct(t1.ptr + (long)o.in1_coff * T, (long)t1.C * T, tensors[o.out].ptr, B, o.in1_C, T, st));
+      tm->end(6, 0, 0.0, 8.0 * B * o.in1_C * T);
+    }
+  }
+  tm->finish();
+  return 0;
+}
+
+}  // namespace adm

@@ -77,6 +77,9 @@ typedef struct adm_conv_args {
   const float* chan_add; int chan_add_stride;
   const float* residual;
   float* out;
+  /* optional (0 = default): batch strides in elements of x1/x2 when they are channel slices of wider tensors, and
+   * of `wpacked` when every sample has its own weights (activation x activation products, e.g. Q K^T). */
+  long x1_bstride, x2_bstride, w_bstride;
 } adm_conv_args;
 int adm_conv2d(const adm_conv_args* a, void* stream);
 /* (Cout,Cin,ks,ks) -> [Cin][ks*ks][Cout]; both device pointers. */
@@ -133,6 +136,28 @@ int adm_sample_loop(adm_unet_t* h, float* x, int B, const adm_sched_coef* coef_h
  *   x = (x - c_dir*eps) * c_inv * c_fwd + c_eps*eps  with coef {sqrt_beta=c_dir, sqrt_alpha=c_inv, k_x0=c_fwd, k_eps=c_eps}. */
 int adm_encode_loop(adm_unet_t* h, float* x, int B, const adm_sched_coef* coef_host, int n_steps, int use_graph,
                     void* stream);
+
+/* ---------------------------------------------------------------- AutoencoderKL executor (rows V1-V3, config 4)
+ * Replaces `vqvae.encode(x).latent_dist.sample(generator)` (pipeline_audio_diffusion.py:144; train_unet.py:104,233)
+ * and `vqvae.decode(z)["sample"]` (pipeline_audio_diffusion.py:190). Architecture per audiodiffusion/utils.py:132-153:
+ * Down/UpDecoderBlock2D stacks, GroupNorm eps 1e-6, single-head mid-block attention. */
+typedef struct adm_vae adm_vae_t;
+typedef struct adm_vae_config {
+  int in_channels, out_channels, latent_channels, layers_per_block, n_blocks;
+  int block_out_channels[8];
+  int norm_num_groups;
+  int sample_h, sample_w;
+} adm_vae_config;
+int adm_vae_create(const adm_vae_config* cfg, adm_vae_t** out);
+void adm_vae_destroy(adm_vae_t* h);
+int adm_vae_set_param(adm_vae_t* h, const char* key, const float* host_data, size_t numel);
+int adm_vae_latent_dims(adm_vae_t* h, int* lat_h, int* lat_w);
+/* z_out (B,Cz,h,w) = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * out_scale, noise (B,Cz,h,w) or NULL (= mode);
+ * moments_out: NULL or (B,2*Cz,h,w) receives quant_conv(encoder(x)). out_scale carries the reference's 0.18215. */
+int adm_vae_encode(adm_vae_t* h, const float* x, const float* noise, float out_scale, float* z_out, float* moments_out,
+                   int B, void* stream);
+/* out (B,Cout,H,W) = decoder(post_quant_conv(in_scale * z)); in_scale carries the reference's 1/0.18215. */
+int adm_vae_decode(adm_vae_t* h, const float* z, float in_scale, float* out, int B, void* stream);
 
 /* ---------------------------------------------------------------- Mel codec (rows M3-M8)
  * Replaces Mel.audio_slice_to_image (audiodiffusion/mel.py:135-151: librosa melspectrogram + power_to_db + u8) and

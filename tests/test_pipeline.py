@@ -130,3 +130,50 @@ def test_save_load_roundtrip_and_facade(tmp_path):
     assert img.size == (16, 16) and sr == 4000 and audio.ndim == 1
     with pytest.raises(NotImplementedError):
         AudioDiffusion.loop_it(audio, sr)
+
+
+# ---------------------------------------------------------------- latent audio diffusion (config 4: AutoencoderKL)
+VAE_TINY = dict(sample_size=(32, 32), in_channels=1, out_channels=1, latent_channels=1, layers_per_block=1,
+                block_out_channels=(32, 64), down_block_types=("DownEncoderBlock2D",) * 2,
+                up_block_types=("UpDecoderBlock2D",) * 2)
+MEL32 = dict(x_res=32, y_res=32, hop_length=64, n_fft=256, n_iter=2, sample_rate=4000)
+
+
+def _build_latent():
+    from audiodiffusion import AudioDiffusionPipeline, AutoencoderKL, DDIMScheduler, Mel, UNet2DModel
+    from oracle.vae import AutoencoderKL as OracleVAE
+    torch.manual_seed(0)
+    ref_unet, ref_vae = OracleUNet(**TINY).eval(), OracleVAE(**VAE_TINY).eval()
+    unet = UNet2DModel(**TINY).load_state_dict(ref_unet.state_dict())
+    vae = AutoencoderKL(**VAE_TINY).load_state_dict(ref_vae.state_dict())
+    ref = opipe.AudioDiffusionPipeline(ref_vae, ref_unet, omel.Mel(**MEL32), osched.DDIMScheduler())
+    mine = AudioDiffusionPipeline(vae, unet, Mel(**MEL32), DDIMScheduler())
+    mine.set_progress_bar_config(disable=True)
+    return ref, mine
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_latent_pipeline_matches_oracle(backend, tmp_path):
+    dev = select(backend)
+    ref, mine = _build_latent()
+    g = torch.Generator().manual_seed(11)
+    noise = torch.randn(2, 1, 16, 16, generator=g)
+    ri, rf = ref(batch_size=2, steps=3, noise=noise.clone(), audio=False, return_float=True)
+    mi, mf = mine(batch_size=2, steps=3, noise=noise.clone().to(dev), audio=False, return_float=True)
+    assert rf.shape == mf.shape == (2, 1, 32, 32)            # decoded by the VAE (pipeline:187-190)
+    assert float((mf.cpu() - rf).abs().max()) <= 1e-3 * max(1.0, float(rf.abs().max()))
+    _cmp_images(mi, ri)
+    # audio-conditioned start through vqvae.encode(...).latent_dist.sample(generator) (pipeline:143-147)
+    rng = np.random.default_rng(0)
+    raw = (0.3 * rng.standard_normal(32 * 64 + 10)).astype(np.float32)
+    kw = dict(raw_audio=raw, slice=0, start_step=1, steps=3, audio=False, return_float=True)
+    n1 = torch.randn(1, 1, 16, 16, generator=g)
+    ri, rf = ref(noise=n1.clone(), generator=torch.Generator().manual_seed(5), **kw)
+    mi, mf = mine(noise=n1.clone().to(dev), generator=torch.Generator().manual_seed(5), **kw)
+    assert float((mf.cpu() - rf).abs().max()) <= 5e-2      # conditioning image quantised independently (<= 1 LSB apart)
+    if backend == "emu":
+        from audiodiffusion import AudioDiffusionPipeline
+        mine.save_pretrained(str(tmp_path / "latent"))
+        assert (tmp_path / "latent" / "vqvae" / "config.json").exists()
+        again = AudioDiffusionPipeline.from_pretrained(str(tmp_path / "latent"))
+        assert again.vqvae is not None and again.vqvae.config["latent_channels"] == 1

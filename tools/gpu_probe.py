@@ -119,3 +119,36 @@ if __name__ == "__main__":
         m = unet_probe()
     if "parity" in what:
         parity(m)
+
+
+def vae_probe():
+    """Config-4 class shapes: AutoencoderKL (128,256,512,512) at 256x256 -> latent 32x32; parity vs oracle at B=1."""
+    from audiodiffusion.vae import AutoencoderKL
+    from oracle.vae import AutoencoderKL as OV
+    cfg = dict(sample_size=(256, 256), in_channels=1, out_channels=1, latent_channels=1, layers_per_block=2,
+               block_out_channels=(128, 256, 512, 512), down_block_types=("DownEncoderBlock2D",) * 4,
+               up_block_types=("UpDecoderBlock2D",) * 4)
+    v = AutoencoderKL(**cfg).init_random(0)
+    ref = OV(**cfg).eval()
+    ref.load_state_dict(v.state_dict())
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 1, 256, 256, generator=g)
+    with torch.no_grad():
+        d = ref.encode(x).latent_dist
+        nz = torch.randn(d.mean.shape, generator=g)
+        rz = d.sample(noise=nz)
+        rd = ref.decode(rz)["sample"]
+    mz = v.encode(x.to(dev)).latent_dist.sample(noise=nz.to(dev))
+    md = v.decode(rz.to(dev))["sample"]
+    log(f"vae parity: enc max|d|={float((mz.cpu()-rz).abs().max()):.3e} (max|z|={float(rz.abs().max()):.3f}) "
+        f"dec max|d|={float((md.cpu()-rd).abs().max()):.3e} (max|ref|={float(rd.abs().max()):.3f})")
+    for B in (1, 16):
+        xb = torch.randn(B, 1, 256, 256, device=dev)
+        zb = torch.randn(B, 1, 32, 32, device=dev)
+        te = timeit(lambda: v.encode(xb).latent_dist.mode(), iters=3, warm=1)
+        td = timeit(lambda: v.decode(zb), iters=3, warm=1)
+        log(f"vae B={B}: encode {te*1e3:8.2f} ms ({0.272*B/te:6.1f} TF/s)  decode {td*1e3:8.2f} ms ({0.622*B/td:6.1f} TF/s)")
+
+
+if __name__ == "__main__" and "vae" in sys.argv[1:]:
+    vae_probe()
