@@ -33,6 +33,7 @@ class ConvArgs(C.Structure):
         ("residual", C.c_void_p),
         ("out", C.c_void_p),
         ("x1_bstride", C.c_long), ("x2_bstride", C.c_long), ("w_bstride", C.c_long),
+        ("wino_packed", C.c_void_p),
     ]
 
 
@@ -53,6 +54,7 @@ _SIGS = {
     "adm_version": (C.c_int, []),
     "adm_last_error": (C.c_char_p, []),
     "adm_is_device_build": (C.c_int, []),
+    "adm_last_conv_variant": (C.c_int, []),
     "adm_sched_step": (C.c_int, [C.c_void_p] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
     "adm_add_noise": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                 C.c_int, C.c_int, C.c_long, C.c_void_p]),
@@ -61,6 +63,7 @@ _SIGS = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adm_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "adm_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "adm_pack_winograd_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "adm_conv_out_dims": (None, [C.c_int] * 6 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "adm_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "adm_unet_create": (C.c_int, [C.POINTER(UNetConfig), C.POINTER(C.c_void_p)]),

@@ -82,8 +82,17 @@ def pack_conv_weight(w):
     return wp
 
 
+def pack_winograd_weight(w):
+    """(Cout,Cin,3,3) -> Winograd-domain U = G g G^T as [Cin][16][Cout]."""
+    _f32(w)
+    co, ci = w.shape[:2]
+    wu = torch.empty((ci, 16, co), dtype=torch.float32, device=w.device)
+    N.check(N.lib().adm_pack_winograd_weight(N.ptr(w), N.ptr(wu), co, ci, N.stream_for(w)))
+    return wu
+
+
 def conv2d(x1, wpacked, bias, ks, x2=None, up=False, stride=1, pad_lo=1, gn=None, act=False, chan_add=None,
-           residual=None):
+           residual=None, wino=None):
     """Fused convolution (see include/adm.h adm_conv_args)."""
     _f32(x1)
     Nn, C1, H, W = x1.shape
@@ -104,6 +113,7 @@ def conv2d(x1, wpacked, bias, ks, x2=None, up=False, stride=1, pad_lo=1, gn=None
         assert chan_add.dtype == torch.float32 and chan_add.stride(1) == 1
         a.chan_add, a.chan_add_stride = C.c_void_p(chan_add.data_ptr()), chan_add.stride(0)
     a.residual = N.ptr(residual)
+    a.wino_packed = N.ptr(wino)
     a.out = N.ptr(out)
     N.check(N.lib().adm_conv2d(C.byref(a), N.stream_for(x1)))
     return out

@@ -33,6 +33,12 @@ void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho
 int last_conv_variant();
 void set_last_conv_variant(int v);
 
+// k_conv_wino.hip
+int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st);
+bool winograd_enabled();
+bool winograd_eligible(const adm_conv_args& a);
+int launch_conv_winograd(const adm_conv_args& a, hipStream_t st);
+
 // k_attention.hip
 int launch_attention(const float* qkv, float* out, int N, int C, int T, int head_dim, hipStream_t st);
 

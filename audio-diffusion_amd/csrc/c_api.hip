@@ -14,6 +14,7 @@ extern "C" {
 
 int adm_version(void) { return 100; }
 const char* adm_last_error(void) { return adm::last_error(); }
+int adm_last_conv_variant(void) { return adm::last_conv_variant(); }
 int adm_is_device_build(void) {
 #if defined(ADM_EMU)
   return 0;
@@ -55,6 +56,11 @@ int adm_conv2d(const adm_conv_args* a, void* stream) {
 int adm_pack_conv_weight(const float* w, float* wpacked, int Cout, int Cin, int ks, void* stream) {
   ADM_REQUIRE(w && wpacked, "pack_conv_weight: null argument");
   return launch_pack_conv_weight(w, wpacked, Cout, Cin, ks, (hipStream_t)stream);
+}
+
+int adm_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, void* stream) {
+  ADM_REQUIRE(w && wu, "pack_winograd_weight: null argument");
+  return launch_pack_winograd_weight(w, wu, Cout, Cin, (hipStream_t)stream);
 }
 
 void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo) {

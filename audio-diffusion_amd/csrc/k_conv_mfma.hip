@@ -409,7 +409,9 @@ template <class K> static void allow_big_lds(K, size_t) {}
 #endif
 
 // bias is read unconditionally by the epilogue: a NULL bias maps to a shared all-zero device buffer.
-static const float* zero_bias(int n) {
+const float* conv_zero_bias(int n);
+static const float* zero_bias(int n) { return conv_zero_bias(n); }
+const float* conv_zero_bias(int n) {
   static float* z = nullptr;
   static int cap = 0;
   if (n > cap) {
@@ -469,6 +471,7 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   if (Ct % CK != 0 || a.C1 % CK != 0 || a.Cout % 4 != 0 || a.Cout < 32)
     return launch_conv_small(a, st);  // conv_in / conv_out class (tiny Cin or Cout): direct kernel
   ADM_REQUIRE(!(a.ks == 1 && (a.stride != 1 || a.up)), "conv2d: 1x1 supports stride 1, no upsample");
+  if (winograd_enabled() && winograd_eligible(a)) return launch_conv_winograd(a, st);
   ConvParams p;
   p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2;
   p.N = a.N; p.Hs = a.H; p.Ws = a.W;

@@ -1,0 +1,304 @@
+// k_conv_wino.hip — Winograd F(2x2,3x3) variant of the fused 3x3 stride-1 convolution (fp32 throughout).
+//
+// Same fusions and the same LDS patch as k_conv_mfma.hip's pipelined kernel (virtual concat, nearest-x2 upsample,
+// zero padding, GroupNorm affine + SiLU on load; bias + temb bias + residual in the epilogue), but the 9-tap
+// correlation is replaced by 16 element-wise products in the Winograd domain: 2.25x fewer MFMA FLOPs per output.
+//   Y = A^T [ (G g G^T) . (B^T d B) ] A        per 4x4 input tile d -> 2x2 output tile, summed over input channels
+// GEMM view: for each of the 16 Winograd positions xi: M[xi][co][tile] += U[xi][co][c] * V[xi][c][tile].
+// Workgroup (4 waves): 32 couts x one 8x16-pixel output tile = 32 Winograd tiles (4 rows x 8 cols); wave w owns
+// xi = 4w..4w+3 (4 accumulator fragments of 32 couts x 32 tiles on v_mfma_f32_32x32x2_f32). Per K chunk of 8 channels:
+//   stash  : prefetched raw activations -> GN/SiLU -> ldsX (haloed 10x18 patch per channel)           [barrier]
+//   transf : one (channel, tile) per thread: V = B^T d B (32 adds) -> ldsV[buf][xi][c][tile]           [barrier]
+//   issue  : next chunk's activations -> registers; next chunk's U slab -> LDS by global_load_lds (double buffer)
+//   MFMA   : 4 xi x 4 channel pairs = 16 MFMAs per wave (A = U[xi][c][co], B = V[xi][c][tile])
+// U is pre-transformed once per layer: [Cin][16][Cout] (pack_winograd_weight). Epilogue: all 16 M fragments go through
+// LDS, each thread applies A^T M A for 4 (cout, tile) pairs and stores 2x2 pixels.
+// Numerics: fp32 Winograd F(2,3) differs from direct summation by O(1e-6) relative — far inside the 1e-3 parity bar.
+#include <cstdlib>
+
+#include "adm_kernels.h"
+
+namespace adm {
+
+struct WinoParams {
+  const float* x1; const float* x2; int C1, C2;
+  int N, Hs, Ws, Hi, Wi, Ho, Wo, up;
+  const float* gn_scale; const float* gn_shift; int act;
+  const float* wu; const float* bias; int Cout;
+  const float* chan_add; int chan_add_stride;
+  const float* residual; float* out;
+  int tiles_x, tiles_y, n_ct, nblk;
+  long x1_bs, x2_bs;
+};
+
+__device__ __forceinline__ float silu_w(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
+
+constexpr int WCK = 8;            // input channels per chunk
+constexpr int WPH = 10, WPW = 18; // haloed patch of an 8x16 output tile
+constexpr int WCS = WPH * WPW;    // 180
+constexpr int WBM = 32;           // couts per workgroup
+constexpr int WUSLAB = WCK * 16 * WBM;   // 4096 floats = 16 KiB
+constexpr int WVSLAB = 16 * WCK * 32;    // 4096 floats
+
+template <bool HAS_CHAN, bool HAS_RES>
+__device__ __forceinline__ void wino_store(const WinoParams& p, const float* ldsM, int tid, int m0, int n, int ty0,
+                                           int tx0) {
+  const long planeO = (long)p.Ho * p.Wo;
+  ADM_UNROLL
+  for (int k = 0; k < 4; ++k) {
+    const int pair = tid + 256 * k;           // 1024 (cout, tile) pairs
+    const int co_l = pair >> 5, tile = pair & 31;
+    const int tyy = tile >> 3, txx = tile & 7;
+    float m[16];
+    ADM_UNROLL
+    for (int xi = 0; xi < 16; ++xi) m[xi] = ldsM[(xi * WBM + co_l) * 32 + tile];
+    // Y = A^T M A with A^T = [[1,1,1,0],[0,1,-1,-1]]
+    float t0[4], t1[4];
+    ADM_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      t0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+      t1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+    }
+    float y[2][2];
+    y[0][0] = t0[0] + t0[1] + t0[2]; y[0][1] = t0[1] - t0[2] - t0[3];
+    y[1][0] = t1[0] + t1[1] + t1[2]; y[1][1] = t1[1] - t1[2] - t1[3];
+    const int co = m0 + co_l;
+    const float b = p.bias[co] + (HAS_CHAN ? p.chan_add[(long)n * p.chan_add_stride + co] : 0.f);
+    const int oy = ty0 + 2 * tyy, ox = tx0 + 2 * txx;
+    ADM_UNROLL
+    for (int a = 0; a < 2; ++a) {
+      const long o = ((long)n * p.Cout + co) * planeO + (long)(oy + a) * p.Wo + ox;
+      float2 v = make_float2(y[a][0] + b, y[a][1] + b);
+      if (HAS_RES) {
+        const float2 r = *reinterpret_cast<const float2*>(p.residual + o);
+        v.x += r.x; v.y += r.y;
+      }
+      *reinterpret_cast<float2*>(p.out + o) = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
+  ADM_DYN_SMEM(float, smem);
+  float* ldsX = smem;                       // WCK * 180  (padded to 1472)
+  float* ldsV = smem + 1472;                // 2 * WVSLAB
+  float* ldsU = ldsV + 2 * WVSLAB;          // 2 * WUSLAB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  int lid;
+  {
+    const int b = blockIdx.x, q = p.nblk >> 3, r = p.nblk & 7, xcd = b & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int ct = lid % p.n_ct, pt = lid / p.n_ct;
+  const int tx = pt % p.tiles_x, ty = (pt / p.tiles_x) % p.tiles_y, n = pt / (p.tiles_x * p.tiles_y);
+  const int m0 = ct * WBM;
+  const int Ct = p.C1 + p.C2;
+  const int planeS = p.Hs * p.Ws;
+
+  // gather plan: one patch element per thread (180 of 256 threads)
+  const bool qv = tid < WCS;
+  int soff = -1;
+  if (qv) {
+    const int ly = tid / WPW, lx = tid - ly * WPW;
+    const int gy = ty * 8 + ly - 1, gx = tx * 16 + lx - 1;
+    if (gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi) {
+      const int sy = p.up ? (gy >> 1) : gy, sx = p.up ? (gx >> 1) : gx;
+      soff = sy * p.Ws + sx;
+    }
+  }
+  // transform role: channel tc, Winograd tile tt (row tt>>3, col tt&7) -> patch origin (2*row, 2*col)
+  const int tc = tid >> 5, tt = tid & 31;
+  const int torg = tc * WCS + (2 * (tt >> 3)) * WPW + 2 * (tt & 7);
+
+  f32x16 acc[4];
+  ADM_UNROLL
+  for (int a = 0; a < 4; ++a)
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  const bool has_gn = p.gn_scale != nullptr;
+  float xr[WCK], gs[WCK], gh[WCK];
+  ADM_UNROLL
+  for (int c = 0; c < WCK; ++c) { xr[c] = 0.f; gs[c] = 1.f; gh[c] = 0.f; }
+
+  auto issue = [&](int c0, int buf) {
+    const bool from1 = c0 < p.C1;
+    const float* xb = from1 ? p.x1 : p.x2;
+    const long xbs = from1 ? p.x1_bs : p.x2_bs;
+    const int cb0 = from1 ? c0 : c0 - p.C1;
+    if (soff >= 0) {
+      const float* src = xb + (long)n * xbs + (long)cb0 * planeS + soff;
+      ADM_UNROLL
+      for (int c = 0; c < WCK; ++c) xr[c] = src[(long)c * planeS];
+      if (has_gn) {
+        const float* sp = p.gn_scale + (long)n * Ct + c0;
+        const float* hp = p.gn_shift + (long)n * Ct + c0;
+        ADM_UNROLL
+        for (int c = 0; c < WCK; ++c) { gs[c] = sp[c]; gh[c] = hp[c]; }
+      }
+    }
+    // U slab of this chunk: rows (c, xi) of WBM couts; [Cin][16][Cout] in global
+    const float* usrc = p.wu + (long)c0 * 16 * p.Cout + m0;
+    float* udst = ldsU + buf * WUSLAB;
+    ADM_UNROLL
+    for (int i = 0; i < 4; ++i) {  // 1024 float4 = 4 per thread
+      const int idx = tid + 256 * i;
+      const int row = idx >> 3, c4 = idx & 7;
+      ADM_GLDS16(usrc + (long)row * p.Cout + c4 * 4, udst + (256 * i + wave * 64) * 4);
+    }
+  };
+
+  const int nchunks = Ct / WCK;
+  issue(0, 0);
+  for (int ci = 0; ci < nchunks; ++ci) {
+    if (qv) {
+      const bool live = soff >= 0;
+      ADM_UNROLL
+      for (int c = 0; c < WCK; ++c) {
+        float v = xr[c] * gs[c] + gh[c];
+        const float sv = silu_w(v);
+        v = p.act ? sv : v;
+        ldsX[c * WCS + tid] = live ? v : 0.f;
+      }
+    }
+    __syncthreads();  // patch visible; previous chunk's MFMAs done everywhere (V[buf^1], U[buf^1] free); U DMA of ci landed
+    {
+      // V = B^T d B for (channel tc, tile tt); B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
+      float d[4][4];
+      ADM_UNROLL
+      for (int i = 0; i < 4; ++i)
+        ADM_UNROLL
+        for (int j = 0; j < 4; ++j) d[i][j] = ldsX[torg + i * WPW + j];
+      float t[4][4];
+      ADM_UNROLL
+      for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[0][j] - d[2][j];
+        t[1][j] = d[1][j] + d[2][j];
+        t[2][j] = d[2][j] - d[1][j];
+        t[3][j] = d[1][j] - d[3][j];
+      }
+      float* vdst = ldsV + (ci & 1) * WVSLAB + tc * 32 + tt;
+      ADM_UNROLL
+      for (int i = 0; i < 4; ++i) {
+        vdst[(i * 4 + 0) * (WCK * 32)] = t[i][0] - t[i][2];
+        vdst[(i * 4 + 1) * (WCK * 32)] = t[i][1] + t[i][2];
+        vdst[(i * 4 + 2) * (WCK * 32)] = t[i][2] - t[i][1];
+        vdst[(i * 4 + 3) * (WCK * 32)] = t[i][1] - t[i][3];
+      }
+    }
+    __syncthreads();  // V of this chunk visible; ldsX free for the next stash
+    if (ci + 1 < nchunks) issue((ci + 1) * WCK, (ci + 1) & 1);
+    const float* U = ldsU + (ci & 1) * WUSLAB;
+    const float* V = ldsV + (ci & 1) * WVSLAB;
+    ADM_UNROLL
+    for (int a = 0; a < 4; ++a) {
+      const int xi = wave * 4 + a;
+      ADM_UNROLL
+      for (int cp = 0; cp < WCK / 2; ++cp) {
+        const int ch = 2 * cp + h;
+        const float av = U[(ch * 16 + xi) * WBM + l31];
+        const float bv = V[(xi * WCK + ch) * 32 + l31];
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- epilogue: M fragments -> LDS [xi][cout][tile], inverse transform, fused bias/temb/residual, 2x2 stores -----
+  float* ldsM = smem;  // 16*32*32 floats = 64 KiB (the launch reserves max(main, epilogue))
+  ADM_UNROLL
+  for (int a = 0; a < 4; ++a) {
+    const int xi = wave * 4 + a;
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int co_l = (r & 3) + 8 * (r >> 2) + 4 * h;
+      ldsM[(xi * WBM + co_l) * 32 + l31] = acc[a][r];
+    }
+  }
+  __syncthreads();
+  if (p.chan_add != nullptr) {
+    if (p.residual != nullptr) wino_store<true, true>(p, ldsM, tid, m0, n, ty * 8, tx * 16);
+    else wino_store<true, false>(p, ldsM, tid, m0, n, ty * 8, tx * 16);
+  } else {
+    if (p.residual != nullptr) wino_store<false, true>(p, ldsM, tid, m0, n, ty * 8, tx * 16);
+    else wino_store<false, false>(p, ldsM, tid, m0, n, ty * 8, tx * 16);
+  }
+}
+
+// (Cout,Cin,3,3) -> U = G g G^T laid out [Cin][16][Cout]; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ void pack_winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin) {
+  const long total = (long)Cout * Cin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout), c = (int)(i / Cout);
+    const float* g = w + ((long)co * Cin + c) * 9;
+    float t[4][3];
+    for (int j = 0; j < 3; ++j) {
+      t[0][j] = g[0 * 3 + j];
+      t[1][j] = 0.5f * (g[0 * 3 + j] + g[1 * 3 + j] + g[2 * 3 + j]);
+      t[2][j] = 0.5f * (g[0 * 3 + j] - g[1 * 3 + j] + g[2 * 3 + j]);
+      t[3][j] = g[2 * 3 + j];
+    }
+    for (int a = 0; a < 4; ++a) {
+      const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]),
+                  u3 = t[a][2];
+      float* dst = wu + ((long)c * 16 + a * 4) * Cout + co;
+      dst[0] = u0; dst[Cout] = u1; dst[2L * Cout] = u2; dst[3L * Cout] = u3;
+    }
+  }
+}
+
+int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st) {
+  long g = ((long)Cout * Cin + 255) / 256;
+  if (g > 4096) g = 4096;
+  ADM_LAUNCH(pack_winograd_weight_kernel, dim3((unsigned)g), dim3(256), 0, st, w, wu, Cout, Cin);
+  return ADM_CHECK_LAUNCH();
+}
+
+bool winograd_enabled() {
+  static const int v = [] { const char* e = getenv("ADM_CONV_WINO"); return e ? atoi(e) : 0; }();
+  return v != 0;
+}
+
+// Eligibility: 3x3 stride 1 "same", output at least 8x16 with Wo % 16 == 0 and Ho % 8 == 0, Cin % 8, Cout % 32.
+bool winograd_eligible(const adm_conv_args& a) {
+  if (a.ks != 3 || a.stride != 1 || a.pad_lo != 1 || a.w_bstride != 0 || a.wino_packed == nullptr) return false;
+  const int C2 = a.x2 ? a.C2 : 0;
+  const int Hi = a.up ? 2 * a.H : a.H, Wi = a.up ? 2 * a.W : a.W;
+  return Wi % 16 == 0 && Hi % 8 == 0 && (a.C1 + C2) % 8 == 0 && a.C1 % 8 == 0 && a.Cout % 32 == 0;
+}
+
+const float* conv_zero_bias(int n);  // k_conv_mfma.hip
+
+int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
+  WinoParams p;
+  const int C2 = a.x2 ? a.C2 : 0;
+  p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2;
+  p.N = a.N; p.Hs = a.H; p.Ws = a.W;
+  p.Hi = a.up ? 2 * a.H : a.H; p.Wi = a.up ? 2 * a.W : a.W;
+  p.Ho = p.Hi; p.Wo = p.Wi; p.up = a.up;
+  p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.act = a.act;
+  p.wu = a.wino_packed; p.bias = a.bias ? a.bias : conv_zero_bias(a.Cout); p.Cout = a.Cout;
+  ADM_REQUIRE(p.bias != nullptr, "conv_winograd: zero-bias buffer");
+  p.chan_add = a.chan_add; p.chan_add_stride = a.chan_add_stride;
+  p.residual = a.residual; p.out = a.out;
+  p.tiles_x = p.Wo / 16; p.tiles_y = p.Ho / 8; p.n_ct = a.Cout / WBM;
+  p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
+  p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
+  p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
+  const size_t smem = sizeof(float) * 16 * WBM * 32;  // 64 KiB >= main-loop need (1472 + 2*4096 + 2*4096 floats = 71.4 KB?)
+  const size_t main_need = sizeof(float) * (1472 + 2 * WVSLAB + 2 * WUSLAB);
+  const size_t need = smem > main_need ? smem : main_need;
+#if !defined(ADM_EMU)
+  static bool once = [] {
+    (void)hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    return true;
+  }();
+  (void)once;
+#endif
+  set_last_conv_variant(4000 + 311);
+  ADM_LAUNCH(conv_wino_kernel, dim3(p.nblk), dim3(256), need, st, p);
+  return ADM_CHECK_LAUNCH();
+}
+
+}  // namespace adm

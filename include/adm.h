@@ -24,6 +24,8 @@ int adm_version(void);
 const char* adm_last_error(void);
 /* 1 if built for the device (hipcc, gfx950), 0 for the CPU-emulation test build. */
 int adm_is_device_build(void);
+/* Kernel variant the last adm_conv2d on this thread dispatched to (see adm_op_profile.variant; 4311 = Winograd). */
+int adm_last_conv_variant(void);
 
 /* ---------------------------------------------------------------- scheduler epilogue (rows S2,S3,P4,P5)
  * One fused elementwise kernel replacing DDIMScheduler.step / DDPMScheduler.step
@@ -80,10 +82,15 @@ typedef struct adm_conv_args {
   /* optional (0 = default): batch strides in elements of x1/x2 when they are channel slices of wider tensors, and
    * of `wpacked` when every sample has its own weights (activation x activation products, e.g. Q K^T). */
   long x1_bstride, x2_bstride, w_bstride;
+  /* optional: the same 3x3 weights pre-transformed by adm_pack_winograd_weight ([Cin][16][Cout]); when present and the
+   * shape is eligible (stride 1, output >= 8x16) the Winograd F(2x2,3x3) kernel may be used (ADM_CONV_WINO=1). */
+  const float* wino_packed;
 } adm_conv_args;
 int adm_conv2d(const adm_conv_args* a, void* stream);
 /* (Cout,Cin,ks,ks) -> [Cin][ks*ks][Cout]; both device pointers. */
 int adm_pack_conv_weight(const float* w, float* wpacked, int Cout, int Cin, int ks, void* stream);
+/* (Cout,Cin,3,3) -> Winograd-domain weights U = G g G^T, layout [Cin][16][Cout]; both device pointers. */
+int adm_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, void* stream);
 void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);
 
 /* Self-attention core (row U6): qkv is (N, 3*C, T) with channels [q | k | v], head h = channels

@@ -1,0 +1,43 @@
+"""Winograd F(2x2,3x3) variant of the fused 3x3 convolution (opt-in, ADM_CONV_WINO=1) vs torch fp32."""
+import os
+
+os.environ["ADM_CONV_WINO"] = "1"  # read once by the library; only convs that pass `wino=` can take this path
+
+import pytest  # noqa: E402
+import torch  # noqa: E402
+
+from native_backend import BACKENDS, select  # noqa: E402
+from test_kernels import _conv_ref, _rand, _relerr  # noqa: E402
+
+CASES = [
+    # (N, C1, C2, H, W, Cout, up, gn, act, temb, res)
+    (1, 32, 0, 8, 16, 32, 0, 1, 1, 1, 1),
+    (2, 32, 32, 16, 32, 64, 0, 1, 1, 0, 1),
+    (1, 32, 0, 8, 8, 32, 1, 0, 0, 1, 0),      # upsample folded: 8x8 -> 16x16
+    (1, 64, 0, 16, 16, 96, 0, 1, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
+def test_conv_winograd(backend, case):
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, C1, C2, H, W, Cout, up, use_gn, act, use_temb, use_res = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    w = _rand((Cout, Ct, 3, 3), 3, dev, scale=(Ct * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
+    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
+    out = ops.conv2d(x1, ops.pack_conv_weight(w), b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb,
+                     residual=res, wino=ops.pack_winograd_weight(w))
+    assert _native.lib().adm_last_conv_variant() == 4311, "the Winograd kernel was not selected"
+    c = lambda t: None if t is None else t.cpu()  # noqa: E731
+    ref = _conv_ref(c(x1), c(x2), c(w), c(b), 3, 1, up, (c(gamma), c(beta)) if use_gn else None, act, c(temb), c(res))
+    assert out.shape == ref.shape
+    assert _relerr(out, ref) < 1e-4, _relerr(out, ref)

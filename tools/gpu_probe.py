@@ -61,7 +61,8 @@ def conv_shapes():
         b = torch.randn(Co, device=dev)
         gamma, beta = torch.ones(C1 + C2, device=dev), torch.zeros(C1 + C2, device=dev)
         gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2)
-        f = lambda: ops.conv2d(x1, wp, b, ks, x2=x2, up=bool(up), stride=st, gn=gn, act=True)  # noqa: E731
+        wu = ops.pack_winograd_weight(w) if (ks == 3 and st == 1 and os.environ.get('ADM_CONV_WINO') == '1') else None
+        f = lambda: ops.conv2d(x1, wp, b, ks, x2=x2, up=bool(up), stride=st, gn=gn, act=True, wino=wu)  # noqa: E731
         out = f()
         dt = timeit(f, iters=5, warm=2)
         flops = 2.0 * out.numel() * (C1 + C2) * ks * ks
@@ -152,3 +153,37 @@ def vae_probe():
 
 if __name__ == "__main__" and "vae" in sys.argv[1:]:
     vae_probe()
+
+
+def mel_probe():
+    import numpy as np
+    from audiodiffusion.mel import Mel
+    from oracle import mel as omel
+    m, om = Mel(), omel.Mel()
+    rng = np.random.default_rng(0)
+    for B in (1, 32, 256):
+        ys = (0.3 * rng.standard_normal((B, m.slice_size))).astype(np.float32)
+        t = torch.from_numpy(ys).to(dev)
+        out = torch.empty((B, 256, 256), dtype=torch.uint8, device=dev)
+        h = m._ensure_handle()
+        from audiodiffusion import _native as N
+        f = lambda: N.check(N.lib().adm_mel_forward(h, N.ptr(t), 0, B, ys.shape[1], ys.shape[1], N.ptr(out), None))  # noqa: E731
+        tf = timeit(f, iters=5, warm=2)
+        imgs = out.cpu().numpy()
+        img_t = torch.from_numpy(imgs).to(dev)
+        phase = torch.rand((B, 1025, 256), dtype=torch.float64, device=dev)
+        aud = torch.empty((B, 130560), dtype=torch.float32, device=dev)
+        g = lambda: N.check(N.lib().adm_mel_inverse(h, N.ptr(img_t), N.ptr(phase), B, 256, N.ptr(aud), None, None, None))  # noqa: E731
+        ti = timeit(g, iters=2, warm=1)
+        log(f"mel B={B}: audio->image {tf*1e3:8.3f} ms ({B/tf:9.1f} slices/s, {B*131071*4/tf/1e9:6.1f} GB/s in)  "
+            f"image->audio {ti*1e3:9.2f} ms ({B/ti:8.1f} clips/s)")
+    # CPU oracle, single call each (the reference runs these serially per image)
+    y = (0.3 * rng.standard_normal(m.slice_size)).astype(np.float32)
+    om.load_audio(raw_audio=y)
+    t0 = time.perf_counter(); img = om.audio_slice_to_image(0); t1 = time.perf_counter()
+    om.image_to_audio(img); t2 = time.perf_counter()
+    log(f"mel CPU oracle: audio->image {1e3*(t1-t0):.1f} ms, image->audio {1e3*(t2-t1):.1f} ms per call")
+
+
+if __name__ == "__main__" and "mel" in sys.argv[1:]:
+    mel_probe()
