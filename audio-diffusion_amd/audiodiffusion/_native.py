@@ -80,6 +80,10 @@ _SIGS = {
 }
 # entry points added by later translation units (k_mel.hip); bound when present in the header AND the library
 _OPTIONAL_SIGS = {
+    "adm_mse_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "adm_grad_norm_clip": (C.c_int, [C.c_void_p, C.c_long, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "adm_adamw_ema_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long] + [C.c_float] * 5 +
+                           [C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
     "adm_vae_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "adm_vae_destroy": (None, [C.c_void_p]),
     "adm_vae_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),

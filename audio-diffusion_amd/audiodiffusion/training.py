@@ -1,0 +1,160 @@
+"""Optimizer side of `scripts/train_unet.py` on flat device buffers.
+
+Reference call sites: `train_unet.py:166-190` (AdamW lr 1e-4, betas (0.95, 0.999), wd 1e-6, eps 1e-8; cosine schedule
+with 500 warm-up steps; `EMAModel(model, inv_gamma=1.0, power=3/4, max_value=0.9999)`), `:250` add_noise
+(`schedulers.add_noise`), `:258` `F.mse_loss`, `:261-267` clip_grad_norm_(1.0) / optimizer.step / lr_scheduler.step /
+ema_model.step, and the data-parallel gradient all-reduce that `accelerator.backward` performs through DDP (`:259`,
+`config/accelerate_multi_gpu.yaml:3`).
+
+Every per-parameter pass is ONE fused HIP kernel over a flat fp32 buffer (csrc/k_train.hip) instead of ~450 per-tensor
+launches; loss / norm / clip scalars stay on the device (no host sync inside a step). The gradient all-reduce uses
+`torch.distributed` (backend "nccl" == RCCL over xGMI on the MI355X node) in ~25 MB buckets of the flat gradient buffer.
+The UNet backward itself (the kernels that fill the gradient buffer) is the next build step — see DESIGN.md §7.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+
+
+class FlatBuffer:
+    """name -> view bookkeeping over one contiguous fp32 device allocation (parameters, grads, moments, EMA)."""
+
+    def __init__(self, specs, device):
+        self.offsets, off = {}, 0
+        for name, shape in specs:
+            n = math.prod(shape)
+            self.offsets[name] = (off, tuple(shape))
+            off += (n + 3) // 4 * 4  # keep every tensor 16-byte aligned for float4 access
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+
+    def view(self, name):
+        off, shape = self.offsets[name]
+        return self.data[off:off + math.prod(shape)].view(shape)
+
+    def load(self, state_dict):
+        for k, v in state_dict.items():
+            self.view(k).copy_(v)
+        return self
+
+
+def mse_loss(pred, target, want_grad=True):
+    """F.mse_loss (train_unet.py:258). Returns (loss: 0-d device tensor, dloss/dpred or None)."""
+    pred, target = pred.contiguous(), target.contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    scratch = torch.zeros(1, dtype=torch.float64, device=pred.device)
+    N.check(N.lib().adm_mse_loss(N.ptr(pred), N.ptr(target), pred.numel(), N.ptr(loss), N.ptr(grad), N.ptr(scratch),
+                                 N.stream_for(pred)))
+    return loss[0], grad
+
+
+def clip_grad_norm_(flat_grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ over the flat gradient buffer (train_unet.py:261-262). Returns a device tensor
+    [total_norm, clip_coef]; the scaling itself is fused into `AdamW.step(clip=...)`."""
+    out = torch.empty(2, dtype=torch.float32, device=flat_grads.device)
+    scratch = torch.zeros(1, dtype=torch.float64, device=flat_grads.device)
+    N.check(N.lib().adm_grad_norm_clip(N.ptr(flat_grads), flat_grads.numel(), float(max_norm), N.ptr(out), N.ptr(scratch),
+                                       N.stream_for(flat_grads)))
+    return out
+
+
+class EMAModel:
+    """diffusers==0.24.0 training_utils.EMAModel as the reference constructs it (train_unet.py:185-190): passing a
+    module enables the warm-up schedule decay = min(1 - (1 + step/inv_gamma)^-power, max_value)."""
+
+    def __init__(self, flat_params, inv_gamma=1.0, power=3 / 4, max_value=0.9999, min_decay=0.0, update_after_step=0):
+        self.shadow = flat_params.clone()
+        self.inv_gamma, self.power, self.decay, self.min_decay = inv_gamma, power, max_value, min_decay
+        self.update_after_step = update_after_step
+        self.optimization_step = 0
+        self.cur_decay_value = 0.0
+
+    def get_decay(self, optimization_step):
+        step = max(0, optimization_step - self.update_after_step - 1)
+        if step <= 0:
+            return 0.0
+        cur = 1 - (1 + step / self.inv_gamma) ** -self.power
+        return max(min(cur, self.decay), self.min_decay)
+
+    def next_decay(self):
+        """Advance the step counter and return the decay `AdamW.step(ema=..., ema_decay=...)` must apply."""
+        self.optimization_step += 1
+        self.cur_decay_value = self.get_decay(self.optimization_step)
+        return self.cur_decay_value
+
+    def copy_to(self, flat_params):
+        flat_params.copy_(self.shadow)
+
+
+class AdamW:
+    """torch.optim.AdamW over one flat parameter buffer; optional fused clip factor and EMA update."""
+
+    def __init__(self, flat_params, lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8):
+        self.params = flat_params
+        self.lr, self.betas, self.weight_decay, self.eps = lr, betas, weight_decay, eps
+        self.exp_avg = torch.zeros_like(flat_params)
+        self.exp_avg_sq = torch.zeros_like(flat_params)
+        self.step_count = 0
+
+    def step(self, flat_grads, clip=None, ema=None, ema_decay=0.0):
+        self.step_count += 1
+        clip_ptr = None if clip is None else C.c_void_p(clip.data_ptr() + 4)  # [norm, coef] -> coef
+        N.check(N.lib().adm_adamw_ema_step(
+            N.ptr(self.params), N.ptr(flat_grads), N.ptr(self.exp_avg), N.ptr(self.exp_avg_sq),
+            N.ptr(ema.shadow) if ema is not None else None, self.params.numel(), float(self.lr), float(self.betas[0]),
+            float(self.betas[1]), float(self.eps), float(self.weight_decay), self.step_count, clip_ptr, float(ema_decay),
+            N.stream_for(self.params)))
+
+
+def get_cosine_schedule_with_warmup(num_warmup_steps, num_training_steps, num_cycles=0.5):
+    """diffusers.optimization.get_scheduler("cosine", ...) multiplier (train_unet.py:174-179)."""
+    def lr_lambda(current_step):
+        if current_step < num_warmup_steps:
+            return float(current_step) / float(max(1, num_warmup_steps))
+        progress = float(current_step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+    return lr_lambda
+
+
+class LambdaLR:
+    def __init__(self, optimizer, lr_lambda):
+        self.opt, self.fn, self.base_lr, self.last_epoch = optimizer, lr_lambda, optimizer.lr, 0
+        self.opt.lr = self.base_lr * self.fn(0)
+
+    def step(self):
+        self.last_epoch += 1
+        self.opt.lr = self.base_lr * self.fn(self.last_epoch)
+
+    def get_last_lr(self):
+        return [self.opt.lr]
+
+
+class GradAllReducer:
+    """DDP-style gradient averaging of the flat gradient buffer: ~25 MB buckets (DDP's default bucket_cap_mb), each an
+    async all-reduce so buckets pipeline over the xGMI links; `finish()` waits and applies the 1/world scaling that DDP
+    applies. No collective is issued under gradient accumulation micro-steps (`no_sync`, train_unet.py:252)."""
+
+    def __init__(self, flat_grads, bucket_mb=25, group=None):
+        self.g, self.group = flat_grads, group
+        per = max(1, int(bucket_mb * (1 << 20)) // 4)
+        self.bounds = [(i, min(i + per, flat_grads.numel())) for i in range(0, flat_grads.numel(), per)]
+        self.pending = []
+
+    def start(self):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        for lo, hi in self.bounds:
+            self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        if not self.pending:
+            return
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        self.g.div_(dist.get_world_size(self.group))

@@ -166,6 +166,20 @@ int adm_vae_encode(adm_vae_t* h, const float* x, const float* noise, float out_s
 /* out (B,Cout,H,W) = decoder(post_quant_conv(in_scale * z)); in_scale carries the reference's 1/0.18215. */
 int adm_vae_decode(adm_vae_t* h, const float* z, float in_scale, float* out, int B, void* stream);
 
+/* ---------------------------------------------------------------- training-step optimizer side (rows T4,T6,T7,T9)
+ * scripts/train_unet.py:258-267 over FLAT fp32 buffers (all parameters / grads / moments / EMA shadow contiguous).
+ * Nothing here synchronises with the host: scalars (loss, norm, clip factor) stay on the device. */
+/* F.mse_loss (:258): loss_out[0] = mean((pred-target)^2); grad_out (NULL ok) = 2(pred-target)/n; scratch: double[1]. */
+int adm_mse_loss(const float* pred, const float* target, long n, float* loss_out, float* grad_out, double* scratch,
+                 void* stream);
+/* clip_grad_norm_ (:261-262): norm_clip_out = {||g||_2, min(1, max_norm/(||g||_2+1e-6))}; scratch: double[1]. */
+int adm_grad_norm_clip(const float* grads, long n, float max_norm, float* norm_clip_out, double* scratch, void* stream);
+/* torch.optim.AdamW step (:263; lr/betas/wd/eps :166-172) fused with the clip factor (device scalar, NULL = 1) and
+ * diffusers EMAModel.step (:265-266; ema == NULL skips): shadow -= (1-ema_decay)*(shadow-param). step is 1-based. */
+int adm_adamw_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, long n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int step, const float* clip_coef_dev,
+                       float ema_decay, void* stream);
+
 /* ---------------------------------------------------------------- Mel codec (rows M3-M8)
  * Replaces Mel.audio_slice_to_image (audiodiffusion/mel.py:135-151: librosa melspectrogram + power_to_db + u8) and
  * Mel.image_to_audio (mel.py:153-168: db_to_power + mel_to_stft NNLS + Griffin-Lim), batched over slices/images.
