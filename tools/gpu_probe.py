@@ -187,3 +187,20 @@ def mel_probe():
 
 if __name__ == "__main__" and "mel" in sys.argv[1:]:
     mel_probe()
+
+
+def train_probe():
+    """Optimizer side at the real parameter count (113.67 M): bytes/s of the fused AdamW+EMA and the norm pass."""
+    from audiodiffusion import training as T
+    n = 113_668_609
+    p = torch.randn(n, device=dev)
+    g = torch.randn(n, device=dev) * 0.01
+    opt = T.AdamW(p)
+    ema = T.EMAModel(p)
+    f = lambda: opt.step(g, clip=T.clip_grad_norm_(g, 1.0), ema=ema, ema_decay=0.999)  # noqa: E731
+    dt = timeit(f, iters=10, warm=2)
+    log(f"train: clip-norm + AdamW + EMA over {n/1e6:.1f}M params: {dt*1e3:.3f} ms  ({(4+36)*n/dt/1e12:.2f} TB/s algorithmic)")
+
+
+if __name__ == "__main__" and "train" in sys.argv[1:]:
+    train_probe()
