@@ -63,6 +63,7 @@ _SIGS = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adm_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "adm_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "adm_pack_conv_weight_T": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "adm_pack_winograd_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "adm_conv_out_dims": (None, [C.c_int] * 6 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "adm_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -79,7 +80,19 @@ _SIGS = {
     "adm_encode_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(SchedCoef), C.c_int, C.c_int, C.c_void_p]),
 }
 # entry points added by later translation units (k_mel.hip); bound when present in the header AND the library
+_vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _OPTIONAL_SIGS = {
+    "adm_groupnorm_stats_ex": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "adm_groupnorm_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "adm_conv_wgrad_workspace": (_l, [C.POINTER(ConvArgs)]),
+    "adm_conv2d_wgrad": (_i, [C.POINTER(ConvArgs), _vp, _vp, _i, _vp, _vp]),
+    "adm_sumpool2x2": (_i, [_vp, _vp, _i, _i, _l, _i, _vp]),
+    "adm_accumulate": (_i, [_vp, _l, _vp, _l, _l, _i, _i, _vp]),
+    "adm_chan_sums": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "adm_attention_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "adm_linear_backward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "adm_conv_small_cin_wgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "adm_conv_small_cout_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "adm_mse_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adm_grad_norm_clip": (C.c_int, [C.c_void_p, C.c_long, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adm_adamw_ema_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long] + [C.c_float] * 5 +

@@ -82,6 +82,15 @@ def pack_conv_weight(w):
     return wp
 
 
+def pack_conv_weight_T(w):
+    """(Cout,Cin,ks,ks) -> backward-data packing [Cout][ks*ks][Cin] (transposed + flipped)."""
+    _f32(w)
+    co, ci, ks, _ = w.shape
+    wp = torch.empty((co, ks * ks, ci), dtype=torch.float32, device=w.device)
+    N.check(N.lib().adm_pack_conv_weight_T(N.ptr(w), N.ptr(wp), co, ci, ks, N.stream_for(w)))
+    return wp
+
+
 def pack_winograd_weight(w):
     """(Cout,Cin,3,3) -> Winograd-domain U = G g G^T as [Cin][16][Cout]."""
     _f32(w)
@@ -104,7 +113,7 @@ def conv2d(x1, wpacked, bias, ks, x2=None, up=False, stride=1, pad_lo=1, gn=None
     a.x1, a.C1 = N.ptr(x1), C1
     a.x2, a.C2 = (N.ptr(x2), x2.shape[1]) if x2 is not None else (None, 0)
     a.N, a.H, a.W = Nn, H, W
-    a.up, a.stride, a.ks, a.pad_lo = int(up), stride, ks, pad_lo
+    a.up, a.stride, a.ks, a.pad_lo = int(up), stride, ks, pad_lo  # up: 0 none, 1/True nearest x2, 2 zero-insertion x2
     if gn is not None:
         a.gn_scale, a.gn_shift = N.ptr(gn[0]), N.ptr(gn[1])
     a.act = int(act)
@@ -126,3 +135,118 @@ def attention(qkv, head_dim):
     out = torch.empty((Nn, C3 // 3, H, W), dtype=torch.float32, device=qkv.device)
     N.check(N.lib().adm_attention(N.ptr(qkv), N.ptr(out), Nn, C3 // 3, H * W, head_dim, N.stream_for(qkv)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------- backward ops (training)
+def _conv_args(x1, wpacked, bias, ks, x2, up, stride, pad_lo, gn, act, Cout):
+    Nn, C1, H, W = x1.shape
+    a = N.ConvArgs()
+    a.x1, a.C1 = N.ptr(x1), C1
+    a.x2, a.C2 = (N.ptr(x2), x2.shape[1]) if x2 is not None else (None, 0)
+    a.N, a.H, a.W = Nn, H, W
+    a.up, a.stride, a.ks, a.pad_lo = int(up), stride, ks, pad_lo
+    if gn is not None:
+        a.gn_scale, a.gn_shift = N.ptr(gn[0]), N.ptr(gn[1])
+    a.act = int(act)
+    a.wpacked, a.bias, a.Cout = N.ptr(wpacked), N.ptr(bias), Cout
+    return a
+
+
+def sumpool2x2(x, out=None, accumulate=False):
+    """(N,C,2H,2W) -> (N,C,H,W) sum over 2x2 blocks: backward of the folded nearest-x2 upsample."""
+    _f32(x)
+    Nn, Cc, H, W = x.shape
+    out = torch.empty((Nn, Cc, H // 2, W // 2), dtype=torch.float32, device=x.device) if out is None else out
+    N.check(N.lib().adm_sumpool2x2(N.ptr(x), N.ptr(out), H, W, Nn * Cc, int(accumulate), N.stream_for(x)))
+    return out
+
+
+def groupnorm_stats_ex(x1, gamma, beta, groups, eps, x2=None):
+    """Like groupnorm_stats but also returns (N, groups, 2) [mean, rstd] for the backward pass."""
+    Nn, C1 = x1.shape[:2]
+    C2 = x2.shape[1] if x2 is not None else 0
+    HW = x1[0, 0].numel()
+    scale = torch.empty((Nn, C1 + C2), dtype=torch.float32, device=x1.device)
+    shift = torch.empty_like(scale)
+    mr = torch.empty((Nn, groups, 2), dtype=torch.float32, device=x1.device)
+    N.check(N.lib().adm_groupnorm_stats_ex(N.ptr(x1), C1, N.ptr(x2), C2, Nn, HW, groups, float(eps), N.ptr(gamma),
+                                           N.ptr(beta), N.ptr(scale), N.ptr(shift), N.ptr(mr), N.stream_for(x1)))
+    return scale, shift, mr
+
+
+def groupnorm_backward(x1, da, mean_rstd, gamma, beta, groups, act, x2=None):
+    """Backward of a = act(GroupNorm(cat(x1,x2))): returns (dx1, dx2 or None, dgamma, dbeta)."""
+    Nn, C1 = x1.shape[:2]
+    C2 = x2.shape[1] if x2 is not None else 0
+    HW = x1[0, 0].numel()
+    dev = x1.device
+    dg, db = torch.zeros(C1 + C2, device=dev), torch.zeros(C1 + C2, device=dev)
+    s12 = torch.empty((Nn, groups, 2), dtype=torch.float32, device=dev)
+    dx1 = torch.empty_like(x1)
+    dx2 = torch.empty_like(x2) if x2 is not None else None
+    N.check(N.lib().adm_groupnorm_backward(N.ptr(x1), C1, N.ptr(x2), C2, N.ptr(da.contiguous()), Nn, HW, groups,
+                                           N.ptr(mean_rstd), N.ptr(gamma), N.ptr(beta), int(act), N.ptr(s12), N.ptr(dg),
+                                           N.ptr(db), N.ptr(dx1), 0, N.ptr(dx2), 0, N.stream_for(x1)))
+    return dx1, dx2, dg, db
+
+
+def conv2d_wgrad(x1, dy, Cout, ks, x2=None, up=False, stride=1, pad_lo=1, gn=None, act=False):
+    """dW (Cout,Cin,ks,ks) of the fused conv, with the load-path activation recomputed."""
+    _f32(x1), _f32(dy)
+    Ct = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
+    a = _conv_args(x1, dy, None, ks, x2, up, stride, pad_lo, gn, act, Cout)  # wpacked unused by wgrad
+    ws_n = N.lib().adm_conv_wgrad_workspace(C.byref(a))
+    ws = torch.empty(ws_n, dtype=torch.float32, device=x1.device)
+    dW = torch.zeros((Cout, Ct, ks, ks), dtype=torch.float32, device=x1.device)
+    N.check(N.lib().adm_conv2d_wgrad(C.byref(a), N.ptr(dy), N.ptr(dW), 0, N.ptr(ws), N.stream_for(x1)))
+    return dW
+
+
+def chan_sums(dy):
+    """(N,C,H,W) -> (per-(n,c) sums (N,C), per-c sums (C,))."""
+    _f32(dy)
+    Nn, Cc = dy.shape[:2]
+    nc = torch.empty((Nn, Cc), dtype=torch.float32, device=dy.device)
+    c = torch.zeros(Cc, dtype=torch.float32, device=dy.device)
+    N.check(N.lib().adm_chan_sums(N.ptr(dy), Nn, Cc, dy[0, 0].numel(), N.ptr(nc), Cc, 0, N.ptr(c), N.stream_for(dy)))
+    return nc, c
+
+
+def attention_backward(qkv, dout, head_dim):
+    _f32(qkv), _f32(dout)
+    Nn, C3, H, W = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    N.check(N.lib().adm_attention_backward(N.ptr(qkv), N.ptr(dout), N.ptr(dqkv), Nn, C3 // 3, H * W, head_dim,
+                                           N.stream_for(qkv)))
+    return dqkv
+
+
+def linear_backward(dY, X, W, x_silu=False):
+    """Y = b + W @ f(X) with f = silu if x_silu: returns (dW, db, dX)."""
+    B, J = dY.shape
+    K = X.shape[1]
+    dW, db = torch.zeros((J, K), device=dY.device), torch.zeros(J, device=dY.device)
+    dX = torch.empty((B, K), device=dY.device)
+    N.check(N.lib().adm_linear_backward(N.ptr(dY.contiguous()), J, N.ptr(X), N.ptr(W), B, J, K, int(x_silu), N.ptr(dW),
+                                        N.ptr(db), N.ptr(dX), N.stream_for(dY)))
+    return dW, db, dX
+
+
+def conv_small_cin_wgrad(x, dy):
+    Nn, Ci, H, W = x.shape
+    Co = dy.shape[1]
+    dW = torch.zeros((Co, Ci, 3, 3), device=x.device)
+    N.check(N.lib().adm_conv_small_cin_wgrad(N.ptr(x), Ci, Nn, H, W, N.ptr(dy), Co, N.ptr(dW), N.stream_for(x)))
+    return dW
+
+
+def conv_small_cout_backward(x, w, dy, gn=None, act=False):
+    """conv_out class (Cout <= 4): returns (da, dW) with da the gradient w.r.t. the activated input."""
+    Nn, Ci, H, W = x.shape
+    Co = dy.shape[1]
+    da = torch.empty_like(x)
+    dW = torch.zeros((Co, Ci, 3, 3), device=x.device)
+    N.check(N.lib().adm_conv_small_cout_backward(N.ptr(x), Ci, Nn, H, W, N.ptr(gn[0]) if gn else None,
+                                                 N.ptr(gn[1]) if gn else None, int(act), N.ptr(w), N.ptr(dy), Co,
+                                                 N.ptr(da), N.ptr(dW), N.stream_for(x)))
+    return da, dW

@@ -22,11 +22,13 @@ int launch_dequant(const float* x, uint8_t* out, long n, hipStream_t st);
 
 // k_groupnorm.hip
 int launch_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int groups, float eps,
-                           const float* gamma, const float* beta, float* scale, float* shift, hipStream_t st);
+                           const float* gamma, const float* beta, float* scale, float* shift, hipStream_t st,
+                           float* mean_rstd = nullptr);
 
 // k_conv_mfma.hip / k_conv_small.hip
 int launch_conv2d(const adm_conv_args& a, hipStream_t st);
 int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, hipStream_t st);
+int launch_pack_conv_weight_T(const float* w, float* wpT, int Cout, int Cin, int ks, hipStream_t st);
 void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);
 // kernel variant chosen by the last launch_conv2d on this thread: ks*100 + stride*10 + (bm/32) for the MFMA kernel,
 // 1000 + ... for the direct small-channel kernels (profiling only).
@@ -38,6 +40,26 @@ int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hi
 bool winograd_enabled();
 bool winograd_eligible(const adm_conv_args& a);
 int launch_conv_winograd(const adm_conv_args& a, hipStream_t st);
+
+// k_backward.hip / k_conv_wgrad.hip (training)
+int launch_sumpool2x2(const float* in, float* out, int H, int W, long planes, int accumulate, hipStream_t st);
+int launch_accumulate(float* dst, long dst_bs, const float* src, long src_bs, long per_sample, int N, int accumulate,
+                      hipStream_t st);
+int launch_chan_sums(const float* dy, int N, int C, int HW, float* out_nc, int nc_stride, int nc_accumulate, float* out_c,
+                     hipStream_t st);
+int launch_gn_backward(const float* x1, int C1, const float* x2, int C2, const float* da, int N, int HW, int groups,
+                       const float* mean_rstd, const float* gamma, const float* beta, int act, float* s12_scratch,
+                       float* dgamma, float* dbeta, float* dx1, int acc1, float* dx2, int acc2, hipStream_t st);
+int launch_attention_bwd(const float* qkv, const float* dout, float* dqkv, int N, int C, int T, int head_dim,
+                         hipStream_t st);
+int launch_linear_bwd(const float* dY, int ldy, const float* X, const float* W, int B, int J, int K, int x_silu, float* dW,
+                      float* db, float* dX, hipStream_t st);
+int launch_conv_small_cin_wgrad(const float* x, int Cin, int N, int H, int W, const float* dy, int Cout, float* dW,
+                                hipStream_t st);
+int launch_conv_small_cout_bwd(const float* x, int Cin, int N, int H, int W, const float* gn_scale, const float* gn_shift,
+                               int act, const float* w, const float* dy, int Cout, float* da, float* dW, hipStream_t st);
+long conv_wgrad_workspace(const adm_conv_args& a, int* split_out);
+int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int accumulate, float* workspace, hipStream_t st);
 
 // k_attention.hip
 int launch_attention(const float* qkv, float* out, int N, int C, int T, int head_dim, hipStream_t st);

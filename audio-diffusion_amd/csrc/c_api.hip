@@ -58,6 +58,11 @@ int adm_pack_conv_weight(const float* w, float* wpacked, int Cout, int Cin, int 
   return launch_pack_conv_weight(w, wpacked, Cout, Cin, ks, (hipStream_t)stream);
 }
 
+int adm_pack_conv_weight_T(const float* w, float* wpT, int Cout, int Cin, int ks, void* stream) {
+  ADM_REQUIRE(w && wpT, "pack_conv_weight_T: null argument");
+  return launch_pack_conv_weight_T(w, wpT, Cout, Cin, ks, (hipStream_t)stream);
+}
+
 int adm_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, void* stream) {
   ADM_REQUIRE(w && wu, "pack_winograd_weight: null argument");
   return launch_pack_winograd_weight(w, wu, Cout, Cin, (hipStream_t)stream);

@@ -1,0 +1,433 @@
+// k_backward.hip — backward kernels of the UNet training step that are NOT convolutions (SURVEY.md §8(a) T4/T5;
+// reference: `accelerator.backward(loss)` of scripts/train_unet.py:259, i.e. torch autograd of the U-sum forward).
+// Data-gradients of the convolutions reuse the forward MFMA kernel (transposed/flipped weights, zero-insertion for the
+// stride-2 convs); weight-gradients are in k_conv_wgrad.hip. Here:
+//   sumpool2x2        : backward of the nearest-x2 upsample folded into Upsample2D's conv load path
+//   accumulate        : dst (+)= src                      (residual / skip-connection gradient fan-in)
+//   chan_sums         : per-(n,c) and per-c sums over pixels (time-embedding bias and conv bias gradients)
+//   gn_bwd_stats/apply: GroupNorm(+SiLU) backward through the fused "normalise on load" path, virtual-concat aware
+//   attn_bwd          : small-head self-attention core backward (recomputes the probabilities)
+//   linear_bwd_*      : the tiny time-embedding MLP / time_emb_proj layers
+//   conv_in/out small : gradients of the two degenerate convolutions (Cin = 1, Cout = 1)
+// All are HBM- or latency-bound; fp32 with fp64 accumulation in the reductions.
+#include "adm_kernels.h"
+
+namespace adm {
+
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_grad(float y) {  // d silu(y) / dy
+  const float s = sigmoid_f(y);
+  return s * (1.0f + y * (1.0f - s));
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+  ADM_UNROLL
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+// Block-wide sum of two doubles (256 threads); every thread gets the result.
+__device__ __forceinline__ void block_sum2(double& a, double& b, double (*red)[4]) {
+  a = wave_sum_d(a); b = wave_sum_d(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+  __syncthreads();
+  a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sumpool2x2_kernel(const float* __restrict__ in, float* out, int H, int W,
+                                                         long planes, int accumulate) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long total = planes * Ho * Wo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wo);
+    const long r = i / Wo;
+    const int y = (int)(r % Ho);
+    const long pl = r / Ho;
+    const float* p = in + (pl * H + 2 * y) * W + 2 * x;
+    const float v = p[0] + p[1] + p[W] + p[W + 1];
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+
+// dst[n][c][p] (+)= src[n][c][p] with independent batch strides (dst may be a channel slice of a wider tensor)
+__global__ void __launch_bounds__(256) accumulate_kernel(float* dst, long dst_bs, const float* __restrict__ src,
+                                                         long src_bs, long per_sample, int N, int accumulate) {
+  const long total = per_sample * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / per_sample, r = i - n * per_sample;
+    const float v = src[n * src_bs + r];
+    float* d = dst + n * dst_bs + r;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+// out_nc[n*nc_stride + c] (=|+=) sum_p dy[n][c][p]  (NULL ok);  out_c[c] += sum_{n,p} dy (atomic; NULL ok)
+__global__ void __launch_bounds__(256) chan_sums_kernel(const float* __restrict__ dy, int C, int HW,
+                                                        float* out_nc, int nc_stride, int nc_accumulate,
+                                                        float* out_c) {
+  __shared__ double red[2][4];
+  const int c = blockIdx.x, n = blockIdx.y;
+  const float* p = dy + ((long)n * C + c) * HW;
+  double s = 0.0, z = 0.0;
+  for (int i = threadIdx.x; i < HW; i += 256) s += (double)p[i];
+  block_sum2(s, z, red);
+  if (threadIdx.x == 0) {
+    if (out_nc) {
+      float* o = out_nc + (long)n * nc_stride + c;
+      *o = nc_accumulate ? *o + (float)s : (float)s;
+    }
+    if (out_c) atomicAdd(out_c + c, (float)s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GroupNorm(+SiLU) backward, pass 1: per (n, group) s1 = mean(g*gamma), s2 = mean(g*gamma*xhat) over the group, and the
+// affine gradients dgamma[c] += sum g*xhat, dbeta[c] += sum g (atomics over n). g = da * silu'(y) (or da).
+__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restrict__ x1, int C1,
+                                                           const float* __restrict__ x2, int C2,
+                                                           const float* __restrict__ da, int HW, int groups,
+                                                           const float* __restrict__ mean_rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int act,
+                                                           float* __restrict__ s12, float* dgamma, float* dbeta) {
+  __shared__ double red[2][4];
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int C = C1 + C2, cg = C / groups;
+  const float mean = mean_rstd[((long)n * groups + g) * 2], rstd = mean_rstd[((long)n * groups + g) * 2 + 1];
+  double S1 = 0.0, S2 = 0.0;
+  for (int cl = 0; cl < cg; ++cl) {
+    const int c = g * cg + cl;
+    const float* xs = c < C1 ? x1 + ((long)n * C1 + c) * HW : x2 + ((long)n * C2 + (c - C1)) * HW;
+    const float* ds = da + ((long)n * C + c) * HW;
+    const float gm = gamma[c], bt = beta[c];
+    double a = 0.0, b = 0.0;  // sum g, sum g*xhat
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      const float xh = (xs[i] - mean) * rstd;
+      float gy = ds[i];
+      if (act) gy *= silu_grad(xh * gm + bt);
+      a += (double)gy;
+      b += (double)gy * xh;
+    }
+    block_sum2(a, b, red);
+    if (threadIdx.x == 0) {
+      atomicAdd(dbeta + c, (float)a);
+      atomicAdd(dgamma + c, (float)b);
+    }
+    S1 += a * gm;
+    S2 += b * gm;
+  }
+  if (threadIdx.x == 0) {
+    const double m = (double)cg * HW;
+    s12[((long)n * groups + g) * 2] = (float)(S1 / m);
+    s12[((long)n * groups + g) * 2 + 1] = (float)(S2 / m);
+  }
+}
+
+// pass 2: dx = rstd * (g*gamma - s1 - xhat*s2), routed to the gradient buffers of x1 / x2 (each (=|+=)).
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ x1, int C1,
+                                                           const float* __restrict__ x2, int C2,
+                                                           const float* __restrict__ da, int HW, int groups,
+                                                           const float* __restrict__ mean_rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int act,
+                                                           const float* __restrict__ s12, float* dx1, int acc1,
+                                                           float* dx2, int acc2) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int C = C1 + C2, cg = C / groups, g = c / cg;
+  const float mean = mean_rstd[((long)n * groups + g) * 2], rstd = mean_rstd[((long)n * groups + g) * 2 + 1];
+  const float s1 = s12[((long)n * groups + g) * 2], s2 = s12[((long)n * groups + g) * 2 + 1];
+  const bool first = c < C1;
+  const float* xs = first ? x1 + ((long)n * C1 + c) * HW : x2 + ((long)n * C2 + (c - C1)) * HW;
+  float* dxs = first ? dx1 + ((long)n * C1 + c) * HW : dx2 + ((long)n * C2 + (c - C1)) * HW;
+  const int acc = first ? acc1 : acc2;
+  const float* ds = da + ((long)n * C + c) * HW;
+  const float gm = gamma[c], bt = beta[c];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const float xh = (xs[i] - mean) * rstd;
+    float gy = ds[i];
+    if (act) gy *= silu_grad(xh * gm + bt);
+    const float v = rstd * (gy * gm - s1 - xh * s2);
+    dxs[i] = acc ? dxs[i] + v : v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Small-head attention core backward: qkv (N,3C,T), dout (N,C,T) -> dqkv (N,3C,T). One workgroup per (n, head).
+// Phase A (thread = query i): softmax stats m_i, l_i, D_i = dout_i . out_i, and dq_i.
+// Phase B (thread = key j)  : dk_j, dv_j. Probabilities are recomputed (flash-attention backward form).
+template <int D>
+__global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                       float* __restrict__ dqkv, int C, int T, float scale) {
+  ADM_DYN_SMEM(float, smem);
+  float* Qs = smem;                 // [T][D]
+  float* Ks = Qs + T * D;
+  float* Vs = Ks + T * D;
+  float* Os = Vs + T * D;           // dout [T][D]
+  float* Ms = Os + T * D;           // m_i
+  float* Ls = Ms + T;               // 1 / l_i
+  float* Ds = Ls + T;               // D_i
+  const int head = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const float* qb = qkv + ((long)n * 3 * C + head * D) * T;
+  const float* kb = qb + (long)C * T;
+  const float* vb = kb + (long)C * T;
+  const float* ob = dout + ((long)n * C + head * D) * T;
+  for (int e = tid; e < D * T; e += blockDim.x) {
+    const int d = e / T, j = e - d * T;
+    Qs[j * D + d] = qb[e]; Ks[j * D + d] = kb[e]; Vs[j * D + d] = vb[e]; Os[j * D + d] = ob[e];
+  }
+  __syncthreads();
+  float* dqb = dqkv + ((long)n * 3 * C + head * D) * T;
+  float* dkb = dqb + (long)C * T;
+  float* dvb = dkb + (long)C * T;
+  for (int i = tid; i < T; i += blockDim.x) {
+    float q[D], go[D];
+    ADM_UNROLL
+    for (int d = 0; d < D; ++d) { q[d] = Qs[i * D + d]; go[d] = Os[i * D + d]; }
+    float m = -3.0e38f;
+    for (int j = 0; j < T; ++j) {
+      float s = 0.f;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) s = fmaf(q[d], Ks[j * D + d], s);
+      m = fmaxf(m, s * scale);
+    }
+    float l = 0.f, dsum = 0.f;   // l = sum p~, dsum = sum p~ (go . v_j)
+    for (int j = 0; j < T; ++j) {
+      float s = 0.f, gv = 0.f;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) { s = fmaf(q[d], Ks[j * D + d], s); gv = fmaf(go[d], Vs[j * D + d], gv); }
+      const float pj = __expf(s * scale - m);
+      l += pj;
+      dsum = fmaf(pj, gv, dsum);
+    }
+    const float inv = 1.0f / l;
+    const float Di = dsum * inv;   // = dout_i . out_i
+    Ms[i] = m; Ls[i] = inv; Ds[i] = Di;
+    float dq[D];
+    ADM_UNROLL
+    for (int d = 0; d < D; ++d) dq[d] = 0.f;
+    for (int j = 0; j < T; ++j) {
+      float s = 0.f, gv = 0.f;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) { s = fmaf(q[d], Ks[j * D + d], s); gv = fmaf(go[d], Vs[j * D + d], gv); }
+      const float p = __expf(s * scale - m) * inv;
+      const float dsij = p * (gv - Di) * scale;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) dq[d] = fmaf(dsij, Ks[j * D + d], dq[d]);
+    }
+    ADM_UNROLL
+    for (int d = 0; d < D; ++d) dqb[(long)d * T + i] = dq[d];
+  }
+  __syncthreads();
+  for (int j = tid; j < T; j += blockDim.x) {
+    float k[D], v[D], dk[D], dv[D];
+    ADM_UNROLL
+    for (int d = 0; d < D; ++d) { k[d] = Ks[j * D + d]; v[d] = Vs[j * D + d]; dk[d] = 0.f; dv[d] = 0.f; }
+    for (int i = 0; i < T; ++i) {
+      float s = 0.f, gv = 0.f;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) { s = fmaf(Qs[i * D + d], k[d], s); gv = fmaf(Os[i * D + d], v[d], gv); }
+      const float p = __expf(s * scale - Ms[i]) * Ls[i];
+      const float dsij = p * (gv - Ds[i]) * scale;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) {
+        dk[d] = fmaf(dsij, Qs[i * D + d], dk[d]);
+        dv[d] = fmaf(p, Os[i * D + d], dv[d]);
+      }
+    }
+    ADM_UNROLL
+    for (int d = 0; d < D; ++d) { dkb[(long)d * T + j] = dk[d]; dvb[(long)d * T + j] = dv[d]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tiny dense layers (time embedding MLP, time_emb_proj): Y[b][j] = bias[j] + sum_k W[j][k] X[b][k]
+// dW[j][k] += sum_b dY[b][j] X'[b][k], db[j] += sum_b dY[b][j], with X' = silu(X) when x_silu (time_emb_proj input)
+__global__ void __launch_bounds__(256) linear_bwd_weight_kernel(const float* __restrict__ dY, int ldy,
+                                                                const float* __restrict__ X, int B, int J, int K,
+                                                                int x_silu, float* dW, float* db) {
+  const long total = (long)J * K;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e / K), k = (int)(e - (long)j * K);
+    float acc = 0.f, accb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float xv = X[(long)b * K + k];
+      if (x_silu) xv = xv * sigmoid_f(xv);
+      const float g = dY[(long)b * ldy + j];
+      acc = fmaf(g, xv, acc);
+      accb += g;
+    }
+    dW[e] += acc;
+    if (k == 0) db[j] += accb;
+  }
+}
+// dX[b][k] = sum_j dY[b][j] W[j][k]  (then * silu'(X[b][k]) when x_silu: gradient w.r.t. the pre-activation input)
+__global__ void __launch_bounds__(256) linear_bwd_input_kernel(const float* __restrict__ dY, int ldy,
+                                                               const float* __restrict__ W, const float* __restrict__ X,
+                                                               int B, int J, int K, int x_silu,
+                                                               float* __restrict__ dX) {
+  const int total = B * K;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int b = e / K, k = e - b * K;
+    float acc = 0.f;
+    for (int j = 0; j < J; ++j) acc = fmaf(dY[(long)b * ldy + j], W[(long)j * K + k], acc);
+    if (x_silu) acc *= silu_grad(X[(long)b * K + k]);
+    dX[e] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_in class (Cin <= 4): dW[co][c][tap] += sum_{n,p} dy[n][co][p] x[n][c][p+tap]; one workgroup per cout.
+__global__ void __launch_bounds__(256) conv_small_cin_wgrad_kernel(const float* __restrict__ x, int Cin, int N, int H,
+                                                                   int W, const float* __restrict__ dy, int Cout,
+                                                                   float* dW /* (Cout,Cin,3,3) */) {
+  __shared__ double red[2][4];
+  const int co = blockIdx.x;
+  const long HW = (long)H * W;
+  double acc[36];
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  for (long e = threadIdx.x; e < (long)N * HW; e += 256) {
+    const int n = (int)(e / HW);
+    const long p = e - (long)n * HW;
+    const int y = (int)(p / W), xx = (int)(p % W);
+    const float g = dy[((long)n * Cout + co) * HW + p];
+    for (int c = 0; c < Cin; ++c)
+      for (int t = 0; t < 9; ++t) {
+        const int gy = y + t / 3 - 1, gx = xx + t % 3 - 1;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) acc[c * 9 + t] += (double)g * x[((long)n * Cin + c) * HW + (long)gy * W + gx];
+      }
+  }
+  for (int k = 0; k < Cin * 9; ++k) {
+    double a = acc[k], z = 0.0;
+    block_sum2(a, z, red);
+    if (threadIdx.x == 0) dW[(long)co * Cin * 9 + k] += (float)a;
+  }
+}
+
+// conv_out class (Cout <= 4) data gradient: da[n][c][p] = sum_co sum_tap dy[n][co][p - (tap - center)] w[co][c][tap]
+__global__ void __launch_bounds__(256) conv_small_cout_dgrad_kernel(const float* __restrict__ dy, int Cout, int N, int H,
+                                                                    int W, const float* __restrict__ w /* (Cout,Cin,3,3) */,
+                                                                    int Cin, float* __restrict__ da) {
+  const long HW = (long)H * W;
+  const long total = (long)N * Cin * HW;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long p = e % HW;
+    const long r = e / HW;
+    const int c = (int)(r % Cin), n = (int)(r / Cin);
+    const int y = (int)(p / W), xx = (int)(p % W);
+    float acc = 0.f;
+    for (int co = 0; co < Cout; ++co)
+      for (int t = 0; t < 9; ++t) {
+        const int oy = y - (t / 3 - 1), ox = xx - (t % 3 - 1);   // output pixel whose tap t touched (y, xx)
+        if (oy >= 0 && oy < H && ox >= 0 && ox < W)
+          acc = fmaf(dy[((long)n * Cout + co) * HW + (long)oy * W + ox], w[((long)co * Cin + c) * 9 + t], acc);
+      }
+    da[e] = acc;
+  }
+}
+
+// conv_out class weight gradient with the fused GN+SiLU prologue recomputed: one workgroup per input channel.
+__global__ void __launch_bounds__(256) conv_small_cout_wgrad_kernel(const float* __restrict__ x, int Cin, int N, int H,
+                                                                    int W, const float* __restrict__ gn_scale,
+                                                                    const float* __restrict__ gn_shift, int act,
+                                                                    const float* __restrict__ dy, int Cout,
+                                                                    float* dW /* (Cout,Cin,3,3) */) {
+  __shared__ double red[2][4];
+  const int c = blockIdx.x;
+  const long HW = (long)H * W;
+  double acc[36];
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  for (long e = threadIdx.x; e < (long)N * HW; e += 256) {
+    const int n = (int)(e / HW);
+    const long p = e - (long)n * HW;
+    const int y = (int)(p / W), xx = (int)(p % W);
+    float a = x[((long)n * Cin + c) * HW + p];
+    if (gn_scale) a = a * gn_scale[(long)n * Cin + c] + gn_shift[(long)n * Cin + c];
+    if (act) a = a * sigmoid_f(a);
+    // a at (y,xx) is tap t of output pixel (y - (t/3-1), xx - (t%3-1))
+    for (int co = 0; co < Cout; ++co)
+      for (int t = 0; t < 9; ++t) {
+        const int oy = y - (t / 3 - 1), ox = xx - (t % 3 - 1);
+        if (oy >= 0 && oy < H && ox >= 0 && ox < W)
+          acc[co * 9 + t] += (double)a * dy[((long)n * Cout + co) * HW + (long)oy * W + ox];
+      }
+  }
+  for (int k = 0; k < Cout * 9; ++k) {
+    double a = acc[k], z = 0.0;
+    block_sum2(a, z, red);
+    if (threadIdx.x == 0) dW[((long)(k / 9) * Cin + c) * 9 + (k % 9)] += (float)a;
+  }
+}
+
+static inline unsigned bgrid(long n) {
+  long g = (n + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+int launch_sumpool2x2(const float* in, float* out, int H, int W, long planes, int accumulate, hipStream_t st) {
+  ADM_REQUIRE(H % 2 == 0 && W % 2 == 0, "sumpool2x2: odd size");
+  ADM_LAUNCH(sumpool2x2_kernel, dim3(bgrid(planes * (H / 2) * (W / 2))), dim3(256), 0, st, in, out, H, W, planes, accumulate);
+  return ADM_CHECK_LAUNCH();
+}
+int launch_accumulate(float* dst, long dst_bs, const float* src, long src_bs, long per_sample, int N, int accumulate,
+                      hipStream_t st) {
+  ADM_LAUNCH(accumulate_kernel, dim3(bgrid(per_sample * N)), dim3(256), 0, st, dst, dst_bs, src, src_bs, per_sample, N,
+             accumulate);
+  return ADM_CHECK_LAUNCH();
+}
+int launch_chan_sums(const float* dy, int N, int C, int HW, float* out_nc, int nc_stride, int nc_accumulate, float* out_c,
+                     hipStream_t st) {
+  ADM_LAUNCH(chan_sums_kernel, dim3(C, N), dim3(256), 0, st, dy, C, HW, out_nc, nc_stride, nc_accumulate, out_c);
+  return ADM_CHECK_LAUNCH();
+}
+int launch_gn_backward(const float* x1, int C1, const float* x2, int C2, const float* da, int N, int HW, int groups,
+                       const float* mean_rstd, const float* gamma, const float* beta, int act, float* s12_scratch,
+                       float* dgamma, float* dbeta, float* dx1, int acc1, float* dx2, int acc2, hipStream_t st) {
+  if (x2 == nullptr) C2 = 0;
+  ADM_LAUNCH(gn_bwd_stats_kernel, dim3(groups, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd, gamma,
+             beta, act, s12_scratch, dgamma, dbeta);
+  int gx = (HW + 1023) / 1024;
+  if (gx < 1) gx = 1;
+  ADM_LAUNCH(gn_bwd_apply_kernel, dim3(gx, C1 + C2, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd,
+             gamma, beta, act, (const float*)s12_scratch, dx1, acc1, dx2, acc2);
+  return ADM_CHECK_LAUNCH();
+}
+int launch_attention_bwd(const float* qkv, const float* dout, float* dqkv, int N, int C, int T, int head_dim,
+                         hipStream_t st) {
+  ADM_REQUIRE(C % head_dim == 0, "attention_bwd: C not divisible by head_dim");
+  const int heads = C / head_dim;
+  const int bs = T >= 256 ? 256 : ((T + 63) / 64) * 64;
+  const size_t smem = sizeof(float) * ((size_t)4 * T * head_dim + 3 * T);
+  ADM_REQUIRE(smem <= 64 * 1024, "attention_bwd: head slab exceeds 64 KiB of LDS");
+  const float scale = 1.0f / sqrtf((float)head_dim);
+#define ADM_ATTB_CASE(DD)                                                                                   \
+  if (head_dim == DD) {                                                                                     \
+    ADM_LAUNCH((attn_bwd_kernel<DD>), dim3(heads, N), dim3(bs), smem, st, qkv, dout, dqkv, C, T, scale);     \
+    return ADM_CHECK_LAUNCH();                                                                              \
+  }
+  ADM_ATTB_CASE(8) ADM_ATTB_CASE(4) ADM_ATTB_CASE(16) ADM_ATTB_CASE(32)
+#undef ADM_ATTB_CASE
+  ADM_FAIL("attention_bwd: unsupported head_dim (4/8/16/32)");
+}
+int launch_linear_bwd(const float* dY, int ldy, const float* X, const float* W, int B, int J, int K, int x_silu, float* dW,
+                      float* db, float* dX, hipStream_t st) {
+  if (dW) ADM_LAUNCH(linear_bwd_weight_kernel, dim3(bgrid((long)J * K)), dim3(256), 0, st, dY, ldy, X, B, J, K, x_silu, dW, db);
+  if (dX) ADM_LAUNCH(linear_bwd_input_kernel, dim3(bgrid((long)B * K)), dim3(256), 0, st, dY, ldy, W, X, B, J, K, x_silu, dX);
+  return ADM_CHECK_LAUNCH();
+}
+int launch_conv_small_cin_wgrad(const float* x, int Cin, int N, int H, int W, const float* dy, int Cout, float* dW,
+                                hipStream_t st) {
+  ADM_REQUIRE(Cin <= 4, "conv_small_cin_wgrad: Cin <= 4");
+  ADM_LAUNCH(conv_small_cin_wgrad_kernel, dim3(Cout), dim3(256), 0, st, x, Cin, N, H, W, dy, Cout, dW);
+  return ADM_CHECK_LAUNCH();
+}
+int launch_conv_small_cout_bwd(const float* x, int Cin, int N, int H, int W, const float* gn_scale, const float* gn_shift,
+                               int act, const float* w, const float* dy, int Cout, float* da, float* dW, hipStream_t st) {
+  ADM_REQUIRE(Cout <= 4, "conv_small_cout_bwd: Cout <= 4");
+  if (da) ADM_LAUNCH(conv_small_cout_dgrad_kernel, dim3(bgrid((long)N * Cin * H * W)), dim3(256), 0, st, dy, Cout, N, H, W, w, Cin, da);
+  if (dW) ADM_LAUNCH(conv_small_cout_wgrad_kernel, dim3(Cin), dim3(256), 0, st, x, Cin, N, H, W, gn_scale, gn_shift, act, dy, Cout, dW);
+  return ADM_CHECK_LAUNCH();
+}
+
+}  // namespace adm

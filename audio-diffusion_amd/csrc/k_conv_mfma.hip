@@ -137,7 +137,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams p) {
       const int ly = r2 / p.IW, lx = r2 - ly * p.IW;
       const int gy = ty * TH * STRIDE + ly - p.pad_lo, gx = tx * TW * STRIDE + lx - p.pad_lo;
       q_img[qi] = img;
-      if (gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi && n0 + img < p.N) {
+      if (gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi && n0 + img < p.N &&
+          !(p.up == 2 && ((gy | gx) & 1))) {   // up == 2: zero-insertion (transposed stride-2 conv, backward pass)
         const int sy = p.up ? (gy >> 1) : gy, sx = p.up ? (gx >> 1) : gx;
         q_soff[qi] = sy * p.Ws + sx;
       }
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
     const int ly = r2 / p.IW, lx = r2 - ly * p.IW;
     const int gy = ty * TH + ly - p.pad_lo, gx = tx * TW + lx - p.pad_lo;
     qn = n0 + img;
-    if (gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi && qn < p.N) {
+    if (gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi && qn < p.N && !(p.up == 2 && ((gy | gx) & 1))) {
       const int sy = p.up ? (gy >> 1) : gy, sx = p.up ? (gx >> 1) : gx;
       soff = sy * p.Ws + sx;
     }
@@ -476,6 +477,7 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2;
   p.N = a.N; p.Hs = a.H; p.Ws = a.W;
   p.Hi = a.up ? 2 * a.H : a.H; p.Wi = a.up ? 2 * a.W : a.W;
+  ADM_REQUIRE(a.up == 0 || a.up == 1 || a.up == 2, "conv2d: up must be 0 (none), 1 (nearest x2) or 2 (zero-insertion x2)");
   conv_out_dims(a.H, a.W, a.up, a.stride, a.ks, a.pad_lo, &p.Ho, &p.Wo);
   p.up = a.up; p.pad_lo = a.ks == 1 ? 0 : a.pad_lo;
   p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.act = a.act;
@@ -529,6 +531,26 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
     const int tap = (int)(r % KS2), c = (int)(r / KS2);
     wp[i] = w[((long)co * Cin + c) * KS2 + tap];
   }
+}
+
+// Backward-data weights: the gradient w.r.t. a conv's input is a "same" conv of dy with the channel-transposed,
+// spatially flipped kernel: (Cout,Cin,ks,ks) -> [Cout][ks*ks][Cin] with wpT[co][t][c] = w[co][c][ks*ks-1-t].
+__global__ void pack_weight_T_kernel(const float* __restrict__ w, float* __restrict__ wpT, int Cout, int Cin, int KS2) {
+  const long total = (long)Cout * Cin * KS2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cin);
+    const long r = i / Cin;
+    const int t = (int)(r % KS2), co = (int)(r / KS2);
+    wpT[i] = w[((long)co * Cin + c) * KS2 + (KS2 - 1 - t)];
+  }
+}
+
+int launch_pack_conv_weight_T(const float* w, float* wpT, int Cout, int Cin, int ks, hipStream_t st) {
+  const long total = (long)Cout * Cin * ks * ks;
+  long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  ADM_LAUNCH(pack_weight_T_kernel, dim3((unsigned)g), dim3(256), 0, st, w, wpT, Cout, Cin, ks * ks);
+  return ADM_CHECK_LAUNCH();
 }
 
 int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, hipStream_t st) {

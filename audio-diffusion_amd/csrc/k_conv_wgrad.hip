@@ -1,0 +1,204 @@
+// k_conv_wgrad.hip — weight gradient of the fused convolution on the exact-f32 matrix core.
+//   dW[co][c][tap] = sum_{n, oy, ox} dy[n][co][oy][ox] * a[n][c][oy*s + ky - pad][ox*s + kx - pad]
+// where a = act(gn(concat(x1,x2))) (optionally nearest-x2 upsampled) is RECOMPUTED in the load path exactly as the
+// forward kernel does (k_conv_mfma.hip), so the normalised/activated tensor never exists in HBM in training either.
+// GEMM view: M = Cout, N = (tap, c), K = output pixels. Workgroup = 4 waves: 128 couts x {32 channels x 9 taps | 128
+// channels (1x1)}; wave w owns cout rows [32w, 32w+32) and all column tiles (9 resp. 4 accumulator fragments).
+// K runs over 64-pixel tiles (NI images x TH x TW, TW = min(Wo,16), TH = min(Ho,4)); per tile:
+//   ldsD [64 px][129]     dy transposed on the way in, so the A operand (32 couts of one pixel) is conflict-free;
+//   ldsP [channels][odd]  the haloed activated patch, odd channel stride -> the B operand (32 channels of one tap) too.
+// Split-K: every workgroup reduces a contiguous range of pixel tiles and writes its 128 x (channels x taps) partial
+// in final (Cout,Cin,ks,ks) order to a workspace slab; wgrad_reduce_kernel sums the slabs into the gradient buffer.
+// Algorithmic FLOPs = forward FLOPs of the same layer; bytes = dy + x read once per (cout-tile, channel-chunk) pair.
+#include "adm_kernels.h"
+
+namespace adm {
+
+struct WgradParams {
+  const float* x1; const float* x2; int C1, C2;
+  const float* dy; int Cout;
+  int N, Hs, Ws, Hi, Wi, Ho, Wo, up, pad_lo;
+  const float* gn_scale; const float* gn_shift; int act;
+  float* part;              // [split][Cout*Cin*ks*ks]
+  int lTW, lTH, tiles_x, tiles_y, n_ptiles, IH, IW, PS /* odd channel stride of the patch */;
+  int n_ct, n_chunks, split, tiles_per_block;
+  long x1_bs, x2_bs;
+};
+
+__device__ __forceinline__ float silu_g(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
+
+template <int KS, int STRIDE>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p) {
+  constexpr int KS2 = KS * KS;
+  constexpr int NT = KS == 3 ? 9 : 4;     // column tiles (of 32 channels) per wave
+  constexpr int CB = KS == 3 ? 32 : 128;  // channels per workgroup
+  constexpr int DLD = 129;
+  ADM_DYN_SMEM(float, smem);
+  float* ldsD = smem;                // 64 * 129
+  float* ldsP = smem + 64 * DLD;     // CB * PS
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  int b = blockIdx.x;
+  const int sp = b % p.split; b /= p.split;
+  const int chunk = b % p.n_chunks, ct = b / p.n_chunks;
+  const int m0 = ct * 128, c0 = chunk * CB;
+  const int Ct = p.C1 + p.C2;
+  const int TW = 1 << p.lTW, TH = 1 << p.lTH, NI = 64 >> (p.lTW + p.lTH);
+  const int IHW = p.IH * p.IW, planeS = p.Hs * p.Ws;
+  const long planeO = (long)p.Ho * p.Wo;
+
+  f32x16 acc[NT];
+  ADM_UNROLL
+  for (int t = 0; t < NT; ++t)
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int t_begin = sp * p.tiles_per_block;
+  int t_end = t_begin + p.tiles_per_block;
+  if (t_end > p.n_ptiles) t_end = p.n_ptiles;
+  for (int pt = t_begin; pt < t_end; ++pt) {
+    const int tx = pt % p.tiles_x, ty = (pt / p.tiles_x) % p.tiles_y, ig = pt / (p.tiles_x * p.tiles_y);
+    const int n0 = ig * NI;
+    // ---- dy tile, transposed into [px][co] --------------------------------------------------------------
+    for (int e = tid; e < 128 * 64; e += 256) {
+      const int co = e >> 6, pp = e & 63;
+      const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
+      const int oy = ty * TH + py, ox = tx * TW + px, n = n0 + img;
+      float v = 0.f;
+      if (m0 + co < p.Cout && n < p.N && oy < p.Ho && ox < p.Wo)
+        v = p.dy[((long)n * p.Cout + m0 + co) * planeO + (long)oy * p.Wo + ox];
+      ldsD[pp * DLD + co] = v;
+    }
+    // ---- activated input patch ----------------------------------------------------------------------------
+    for (int e = tid; e < CB * NI * IHW; e += 256) {
+      const int c = e / (NI * IHW), q = e - c * (NI * IHW);
+      const int img = q / IHW, r2 = q - img * IHW;
+      const int ly = r2 / p.IW, lx = r2 - ly * p.IW;
+      const int gy = ty * TH * STRIDE + ly - p.pad_lo, gx = tx * TW * STRIDE + lx - p.pad_lo;
+      const int n = n0 + img, cc = c0 + c;
+      float v = 0.f;
+      if (cc < Ct && n < p.N && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi) {
+        const int sy = p.up ? (gy >> 1) : gy, sx = p.up ? (gx >> 1) : gx;
+        v = cc < p.C1 ? p.x1[(long)n * p.x1_bs + (long)cc * planeS + sy * p.Ws + sx]
+                      : p.x2[(long)n * p.x2_bs + (long)(cc - p.C1) * planeS + sy * p.Ws + sx];
+        if (p.gn_scale != nullptr) v = v * p.gn_scale[(long)n * Ct + cc] + p.gn_shift[(long)n * Ct + cc];
+        if (p.act) v = silu_g(v);
+      }
+      ldsP[c * p.PS + q] = v;
+    }
+    __syncthreads();
+    // ---- 32 k-steps (pixel pairs) x NT MFMAs -----------------------------------------------------------------
+    for (int s = 0; s < 32; ++s) {
+      const int pp = 2 * s + h;
+      const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
+      const int poff = img * IHW + py * STRIDE * p.IW + px * STRIDE;
+      const float av = ldsD[pp * DLD + wave * 32 + l31];
+      ADM_UNROLL
+      for (int t = 0; t < NT; ++t) {
+        float bv;
+        if (KS == 3) bv = ldsP[l31 * p.PS + poff + (t / 3) * p.IW + (t % 3)];
+        else bv = ldsP[(t * 32 + l31) * p.PS + poff];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- partial result in (Cout,Cin,ks,ks) order --------------------------------------------------------------
+  float* out = p.part + (long)sp * p.Cout * Ct * KS2;
+  ADM_UNROLL
+  for (int t = 0; t < NT; ++t) {
+    const int cc = KS == 3 ? c0 + l31 : c0 + t * 32 + l31;
+    const int tap = KS == 3 ? t : 0;
+    if (cc >= Ct) continue;
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (co < p.Cout) out[((long)co * Ct + cc) * KS2 + tap] = acc[t][r];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int split, long numel,
+                                                           float* dW, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long)gridDim.x * blockDim.x) {
+    float s = accumulate ? dW[i] : 0.f;
+    for (int k = 0; k < split; ++k) s += part[(long)k * numel + i];
+    dW[i] = s;
+  }
+}
+
+static inline int ilog2w(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// workspace floats needed by launch_conv_wgrad for this shape
+long conv_wgrad_workspace(const adm_conv_args& a, int* split_out) {
+  const int C2 = a.x2 ? a.C2 : 0, Ct = a.C1 + C2;
+  int Ho, Wo;
+  conv_out_dims(a.H, a.W, a.up, a.stride, a.ks, a.pad_lo, &Ho, &Wo);
+  const int TW = Wo >= 16 ? 16 : Wo, TH = Ho >= 4 ? 4 : Ho;
+  const int NI = 64 / (TW * TH);
+  const int n_ptiles = ceil_div(Wo, TW) * ceil_div(Ho, TH) * ceil_div(a.N, NI);
+  const int CB = a.ks == 3 ? 32 : 128;
+  const int pairs = ceil_div(a.Cout, 128) * ceil_div(Ct, CB);
+  int split = ceil_div(768, pairs);
+  if (split > n_ptiles) split = n_ptiles;
+  if (split < 1) split = 1;
+  if (split_out) *split_out = split;
+  return (long)split * a.Cout * Ct * a.ks * a.ks;
+}
+
+int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int accumulate, float* workspace,
+                      hipStream_t st) {
+  ADM_REQUIRE(a.ks == 3 || a.ks == 1, "conv_wgrad: ks must be 1 or 3");
+  ADM_REQUIRE(a.stride == 1 || (a.stride == 2 && a.ks == 3), "conv_wgrad: stride 2 only for 3x3");
+  WgradParams p;
+  const int C2 = a.x2 ? a.C2 : 0, Ct = a.C1 + C2;
+  p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2; p.dy = dy; p.Cout = a.Cout;
+  p.N = a.N; p.Hs = a.H; p.Ws = a.W;
+  p.Hi = a.up ? 2 * a.H : a.H; p.Wi = a.up ? 2 * a.W : a.W;
+  conv_out_dims(a.H, a.W, a.up, a.stride, a.ks, a.pad_lo, &p.Ho, &p.Wo);
+  p.up = a.up; p.pad_lo = a.ks == 1 ? 0 : a.pad_lo;
+  p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.act = a.act;
+  p.part = workspace;
+  const int TW = p.Wo >= 16 ? 16 : p.Wo, TH = p.Ho >= 4 ? 4 : p.Ho;
+  ADM_REQUIRE((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "conv_wgrad: small output dims must be powers of two");
+  p.lTW = ilog2w(TW); p.lTH = ilog2w(TH);
+  const int NI = 64 / (TW * TH);
+  p.tiles_x = ceil_div(p.Wo, TW); p.tiles_y = ceil_div(p.Ho, TH);
+  p.n_ptiles = p.tiles_x * p.tiles_y * ceil_div(a.N, NI);
+  p.IH = (TH - 1) * a.stride + a.ks; p.IW = (TW - 1) * a.stride + a.ks;
+  p.PS = (NI * p.IH * p.IW) | 1;
+  const int CB = a.ks == 3 ? 32 : 128;
+  p.n_ct = ceil_div(a.Cout, 128); p.n_chunks = ceil_div(Ct, CB);
+  conv_wgrad_workspace(a, &p.split);
+  p.tiles_per_block = ceil_div(p.n_ptiles, p.split);
+  p.split = ceil_div(p.n_ptiles, p.tiles_per_block);  // no empty workgroups
+  p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
+  p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
+  const size_t smem = sizeof(float) * ((size_t)64 * 129 + (size_t)CB * p.PS);
+  ADM_REQUIRE(smem <= 80 * 1024, "conv_wgrad: patch too large for LDS");
+  const long numel = (long)a.Cout * Ct * a.ks * a.ks;
+  dim3 grid(p.n_ct * p.n_chunks * p.split), block(256);
+#if !defined(ADM_EMU)
+  static bool once = [] {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    return true;
+  }();
+  (void)once;
+#endif
+  if (a.ks == 3 && a.stride == 1) {
+    ADM_LAUNCH((conv_wgrad_kernel<3, 1>), grid, block, smem, st, p);
+  } else if (a.ks == 3) {
+    ADM_LAUNCH((conv_wgrad_kernel<3, 2>), grid, block, smem, st, p);
+  } else {
+    ADM_LAUNCH((conv_wgrad_kernel<1, 1>), grid, block, smem, st, p);
+  }
+  long g = (numel + 255) / 256;
+  if (g > 4096) g = 4096;
+  ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, p.split, numel, dW,
+             accumulate);
+  return ADM_CHECK_LAUNCH();
+}
+
+}  // namespace adm

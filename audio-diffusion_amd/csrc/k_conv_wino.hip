@@ -262,7 +262,7 @@ bool winograd_enabled() {
 
 // Eligibility: 3x3 stride 1 "same", output at least 8x16 with Wo % 16 == 0 and Ho % 8 == 0, Cin % 8, Cout % 32.
 bool winograd_eligible(const adm_conv_args& a) {
-  if (a.ks != 3 || a.stride != 1 || a.pad_lo != 1 || a.w_bstride != 0 || a.wino_packed == nullptr) return false;
+  if (a.ks != 3 || a.stride != 1 || a.pad_lo != 1 || a.w_bstride != 0 || a.wino_packed == nullptr || a.up > 1) return false;
   const int C2 = a.x2 ? a.C2 : 0;
   const int Hi = a.up ? 2 * a.H : a.H, Wi = a.up ? 2 * a.W : a.W;
   return Wi % 16 == 0 && Hi % 8 == 0 && (a.C1 + C2) % 8 == 0 && a.C1 % 8 == 0 && a.Cout % 32 == 0;

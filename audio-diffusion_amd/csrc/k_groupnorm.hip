@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
                                                        const float* __restrict__ x2, int C2, int HW, int groups,
                                                        float eps, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ scale,
-                                                       float* __restrict__ shift) {
+                                                       float* __restrict__ shift, float* __restrict__ mean_rstd) {
   const int g = blockIdx.x, n = blockIdx.y;
   const int C = C1 + C2, cg = C / groups;
   const int tid = threadIdx.x;
@@ -61,6 +61,10 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
     if (var < 0.0) var = 0.0;
     stat[0] = (float)mean;
     stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (mean_rstd) {  // kept for the backward pass (training)
+      mean_rstd[((long)n * groups + g) * 2] = stat[0];
+      mean_rstd[((long)n * groups + g) * 2 + 1] = stat[1];
+    }
   }
   __syncthreads();
   const float mean = stat[0], rstd = stat[1];
@@ -73,11 +77,12 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
 }
 
 int launch_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int groups, float eps,
-                           const float* gamma, const float* beta, float* scale, float* shift, hipStream_t st) {
+                           const float* gamma, const float* beta, float* scale, float* shift, hipStream_t st,
+                           float* mean_rstd) {
   if (x2 == nullptr) C2 = 0;
   ADM_REQUIRE((C1 + C2) % groups == 0, "groupnorm: channels not divisible by groups");
   ADM_LAUNCH(gn_stats_kernel, dim3(groups, N), dim3(256), 0, st, x1, C1, x2, C2, HW, groups, eps, gamma, beta, scale,
-             shift);
+             shift, mean_rstd);
   return ADM_CHECK_LAUNCH();
 }
 

@@ -64,7 +64,8 @@ int adm_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N,
                         const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 
 /* Fused 2-D convolution (rows U2-U5,U7,U8): implicit GEMM on v_mfma_f32_32x32x2_f32.
- *   in  = concat(x1[C1], x2[C2]) (x2 may be NULL), optional nearest x2 upsample (up=1) of the input,
+ *   in  = concat(x1[C1], x2[C2]) (x2 may be NULL), optional nearest x2 upsample (up=1) or zero-insertion x2 (up=2,
+ *         the transposed stride-2 conv of the backward pass) of the input,
  *   optional per-(n,c) affine (gn_scale/gn_shift from adm_groupnorm_stats) and SiLU (act=1) applied on load,
  *   out = conv(in, w, stride, pad) + bias[co] + chan_add[n][co] (NULL ok) + residual[n][co][y][x] (NULL ok).
  * wpacked: weights repacked by adm_pack_conv_weight to [Cin][ks*ks][Cout]. H,W are the *source* dims of x1/x2.
@@ -89,6 +90,10 @@ typedef struct adm_conv_args {
 int adm_conv2d(const adm_conv_args* a, void* stream);
 /* (Cout,Cin,ks,ks) -> [Cin][ks*ks][Cout]; both device pointers. */
 int adm_pack_conv_weight(const float* w, float* wpacked, int Cout, int Cin, int ks, void* stream);
+/* Backward-data form: (Cout,Cin,ks,ks) -> [Cout][ks*ks][Cin] (channel-transposed, spatially flipped). Feeding it to
+ * adm_conv2d with x1 = dy (Cout channels) yields d(input): stride-1 convs directly; stride-2 convs with up = 2
+ * (zero-insertion); nearest-upsampled convs give the gradient at the upsampled resolution (then adm_sumpool2x2). */
+int adm_pack_conv_weight_T(const float* w, float* wpT, int Cout, int Cin, int ks, void* stream);
 /* (Cout,Cin,3,3) -> Winograd-domain weights U = G g G^T, layout [Cin][16][Cout]; both device pointers. */
 int adm_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, void* stream);
 void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);
