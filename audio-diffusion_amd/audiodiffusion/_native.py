@@ -82,6 +82,11 @@ _SIGS = {
 # entry points added by later translation units (k_mel.hip); bound when present in the header AND the library
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _OPTIONAL_SIGS = {
+    "adm_unet_bind_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
+    "adm_unet_enable_training": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
+    "adm_unet_refresh_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "adm_unet_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int, C.c_void_p]),
     "adm_groupnorm_stats_ex": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "adm_groupnorm_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "adm_conv_wgrad_workspace": (_l, [C.POINTER(ConvArgs)]),

@@ -146,6 +146,13 @@ class UNet2DModel:
         if self._handle is not None and self._handle_hw == hw:
             return self._handle
         self._free()
+        h = self._create_handle()
+        for k, v in self._sd.items():
+            self._upload(k, v)
+        return h
+
+    def _create_handle(self):
+        hw = self._hw()
         c = self.config
         nc = N.UNetConfig()
         nc.in_channels, nc.out_channels = c.in_channels, c.out_channels
@@ -161,8 +168,6 @@ class UNet2DModel:
         h = C.c_void_p()
         N.check(N.lib().adm_unet_create(C.byref(nc), C.byref(h)))
         self._handle, self._handle_hw = h, hw
-        for k, v in self._sd.items():
-            self._upload(k, v)
         return h
 
     def _upload(self, key, t):
@@ -252,6 +257,46 @@ class UNet2DModel:
         return UNetOutput(sample=out)
 
     __call__ = forward
+
+    # ---- training (scripts/train_unet.py:257-267) ---------------------------------------------------------------
+    def enable_training(self, sample_hw=None):
+        """Moves the master parameters into ONE flat device buffer (so the fused AdamW/EMA kernel updates them in a single
+        launch) and switches the native executor to training mode (activations kept, gradient buffers, wgrad/dgrad
+        weight packings). Returns (flat_params, flat_grads) — torch views the optimizer side works on."""
+        from .training import FlatBuffer
+        if sample_hw is not None:
+            self.sample_size = tuple(sample_hw)
+        self._free()
+        dev = torch.device("cuda:0") if N.is_device_build() else torch.device("cpu")
+        specs = [(k, s) for k, s, _ in param_specs(self.config)]
+        self.flat = FlatBuffer(specs, dev).load(self._sd)
+        self.flat_grads = torch.zeros_like(self.flat.data)
+        h = self._create_handle()
+        lib = N.lib()
+        for k, _ in specs:
+            N.check(lib.adm_unet_bind_param(h, k.encode(), C.c_void_p(self.flat.view(k).data_ptr())))
+        N.check(lib.adm_unet_enable_training(h, N.ptr(self.flat.data), self.flat.numel))
+        self._training = True
+        return self.flat.data, self.flat_grads
+
+    def train_step(self, noisy, timesteps, target):
+        """loss = mse(unet(noisy, t), target) and its gradient w.r.t. every parameter (into `flat_grads`)."""
+        assert getattr(self, "_training", False), "call enable_training() first"
+        x, tgt = noisy.contiguous(), target.contiguous()
+        B = x.shape[0]
+        t = self._timesteps(timesteps, B)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        N.check(N.lib().adm_unet_forward_backward(self._handle, N.ptr(x), C.cast(t.data_ptr(), N.c_float_p), t.numel(),
+                                                  N.ptr(tgt), N.ptr(loss), N.ptr(self.flat_grads), B, N.stream_for(x)))
+        return loss[0]
+
+    def refresh_weights(self):
+        """Re-pack the derived weight layouts after the optimizer changed the flat master parameters."""
+        N.check(N.lib().adm_unet_refresh_weights(self._handle, None))
+
+    def sync_state_dict_from_flat(self):
+        for k in list(self._sd.keys()):
+            self._sd[k] = self.flat.view(k).detach().cpu().clone()
 
     # ---- diffusers on-disk layout ------------------------------------------------------------------------
     @classmethod

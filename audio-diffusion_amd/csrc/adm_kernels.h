@@ -75,7 +75,8 @@ int launch_scale(const float* x, float* out, float s, long n, hipStream_t st);
 // emb[b][:] = linear_2(silu(linear_1(sinusoid(t_b)))); t from host-provided device array or coef table.
 int launch_time_embedding(const float* t_dev, int t_stride, const adm_sched_coef* table, const int* step_dev,
                           const float* freqs, int half_dim, int flip, const float* w1, const float* b1, const float* w2,
-                          const float* b2, int dim_in, int dim_emb, float* emb, int B, hipStream_t st);
+                          const float* b2, int dim_in, int dim_emb, float* emb, int B, hipStream_t st,
+                          float* save_sinus = nullptr, float* save_z = nullptr);
 // out[b][r] = bias[r] + sum_k W[r][k] * silu(emb[b][k])   for all resnets' time_emb_proj rows at once.
 int launch_temb_proj(const float* emb, const float* w, const float* bias, float* out, int B, int K, int R,
                      hipStream_t st);

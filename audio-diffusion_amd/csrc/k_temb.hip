@@ -18,7 +18,9 @@ __global__ void __launch_bounds__(256) time_embedding_kernel(const float* __rest
                                                              const float* __restrict__ freqs, int half_dim, int flip,
                                                              const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
-                                                             int dim_in, int dim_emb, float* __restrict__ emb) {
+                                                             int dim_in, int dim_emb, float* __restrict__ emb,
+                                                             float* __restrict__ save_sinus,
+                                                             float* __restrict__ save_z) {
   ADM_DYN_SMEM(float, smem);
   float* sinus = smem;          // dim_in
   float* hid = smem + dim_in;   // dim_emb
@@ -31,11 +33,14 @@ __global__ void __launch_bounds__(256) time_embedding_kernel(const float* __rest
     else { sinus[i] = s; sinus[half_dim + i] = c; }
   }
   __syncthreads();
+  if (save_sinus)  // training: inputs of linear_1 kept for its weight gradient
+    for (int i = tid; i < dim_in; i += blockDim.x) save_sinus[(long)b * dim_in + i] = sinus[i];
   for (int j = tid; j < dim_emb; j += blockDim.x) {
     float acc = b1[j];
     const float* wr = w1 + (long)j * dim_in;
     for (int k = 0; k < dim_in; ++k) acc = fmaf(wr[k], sinus[k], acc);
     hid[j] = silu_t(acc);
+    if (save_z) save_z[(long)b * dim_emb + j] = acc;  // pre-activation of linear_1 (training)
   }
   __syncthreads();
   for (int j = tid; j < dim_emb; j += blockDim.x) {
@@ -76,11 +81,12 @@ __global__ void __launch_bounds__(256) temb_proj_kernel(const float* __restrict_
 
 int launch_time_embedding(const float* t_dev, int t_stride, const adm_sched_coef* table, const int* step_dev,
                           const float* freqs, int half_dim, int flip, const float* w1, const float* b1, const float* w2,
-                          const float* b2, int dim_in, int dim_emb, float* emb, int B, hipStream_t st) {
+                          const float* b2, int dim_in, int dim_emb, float* emb, int B, hipStream_t st,
+                          float* save_sinus, float* save_z) {
   ADM_REQUIRE(t_dev != nullptr || (table != nullptr && step_dev != nullptr), "time_embedding: no timestep source");
   const size_t smem = sizeof(float) * (size_t)(dim_in + dim_emb);
   ADM_LAUNCH(time_embedding_kernel, dim3(B), dim3(256), smem, st, t_dev, t_stride, table, step_dev, freqs, half_dim,
-             flip, w1, b1, w2, b2, dim_in, dim_emb, emb);
+             flip, w1, b1, w2, b2, dim_in, dim_emb, emb, save_sinus, save_z);
   return ADM_CHECK_LAUNCH();
 }
 

@@ -17,6 +17,7 @@ struct ParamSlot {
   size_t numel = 0;
   float* dev = nullptr;
   bool set = false;
+  bool external = false;  // bound into a caller-owned flat buffer (training): never freed here
 };
 
 struct ParamStore {
@@ -28,15 +29,20 @@ struct ParamStore {
   void declare_resnet(const std::string& p, int ci, int co, int temb);  // temb <= 0: no time_emb_proj
   void declare_attn(const std::string& p, int c);
   int set(const char* key, const float* host_data, size_t numel);       // accepts deprecated attention names
+  int bind(const char* key, float* dev_ptr);                            // training: parameter lives in a flat buffer
   int missing(std::string* names) const;
   float* P(const std::string& k) const { return params.at(k).dev; }
   void free_all();
 };
 
 struct ConvW {
-  float* wp = nullptr;
-  float* bias = nullptr;
+  float* wp = nullptr;    // forward packing [Cin][tap][Cout]
+  float* wpT = nullptr;   // backward-data packing [Cout][tap][Cin] (training only)
+  float* bias = nullptr;  // master bias (for q|k|v: the stacked copy)
   int Cin = 0, Cout = 0, ks = 3;
+  std::string key;        // diffusers prefix of the master parameter ("" for derived weights)
+  std::string qkv_prefix; // non-empty: q|k|v stacked from <prefix>.to_q/.to_k/.to_v
+  float* stacked = nullptr;  // (3C, C) stacked master copy of q|k|v
 };
 struct GNW {
   float* gamma = nullptr;
@@ -48,11 +54,15 @@ struct Tensor {
   float* ptr = nullptr;
   int last_use = -1;
   bool external = false;
+  float* grad = nullptr;  // training: gradient buffer (same shape), ginit = already holds a contribution
+  bool ginit = false;
 };
 struct GnBuf {
   int C = 0;
   float* scale = nullptr;
   float* shift = nullptr;
+  float* mean_rstd = nullptr;  // training: (B, groups, 2)
+  const GNW* g = nullptr;      // the affine parameters this buffer was computed with
 };
 struct Op {
   enum Kind { GN, CONV, ATTN, SOFTMAXC, TRANSP } kind = CONV;
@@ -86,6 +96,12 @@ struct Net {
   int planned_B = 0;
   std::vector<void*> arena;
   size_t arena_bytes = 0;
+  // training
+  bool training = false;             // keep every activation, allocate gradient buffers, maintain wpT
+  const float* params_base = nullptr;  // flat master parameter buffer and the matching flat gradient buffer
+  float* grads_base = nullptr;
+  float *tmp_da = nullptr, *wgrad_ws = nullptr, *s12 = nullptr, *tmp_w = nullptr;
+  size_t tmp_da_floats = 0, wgrad_ws_floats = 0, tmp_w_floats = 0;
 
   // ---- construction -----------------------------------------------------------------------------------
   int dalloc(void** p, size_t bytes);
@@ -104,6 +120,12 @@ struct Net {
   void free_plan();
   int plan(int B);
   int run(const float* x, float* out, int B, const float* temb_all, int temb_stride, hipStream_t st, OpTimer* tm);
+  // training: re-pack every derived weight from the (updated) master parameters
+  int refresh_weights(hipStream_t st);
+  // training: reverse pass. grad of t_out must be in tensors[t_out].grad (set by the caller); writes parameter
+  // gradients into grads_base (+ offset of the master parameter) and dtemb_all (B, temb_stride) when non-NULL.
+  int run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st);
+  float* grad_of(const float* master_param) const { return grads_base + (master_param - params_base); }
   void destroy();
 };
 

@@ -59,6 +59,15 @@ int ParamStore::set(const char* key, const float* host_data, size_t numel) {
   it->second.set = true;
   return 0;
 }
+int ParamStore::bind(const char* key, float* dev_ptr) {
+  auto it = params.find(key);
+  ADM_REQUIRE(it != params.end(), std::string("bind_param: unexpected key ") + key);
+  if (it->second.dev && !it->second.external) dfree(it->second.dev);
+  it->second.dev = dev_ptr;
+  it->second.external = true;
+  it->second.set = true;
+  return 0;
+}
 int ParamStore::missing(std::string* names) const {
   int n = 0;
   for (auto& kv : params)
@@ -67,7 +76,7 @@ int ParamStore::missing(std::string* names) const {
 }
 void ParamStore::free_all() {
   for (auto& kv : params)
-    if (kv.second.dev) { dfree(kv.second.dev); kv.second.dev = nullptr; }
+    if (kv.second.dev && !kv.second.external) { dfree(kv.second.dev); kv.second.dev = nullptr; }
 }
 
 // ---------------------------------------------------------------------------------------------- OpTimer
@@ -106,14 +115,39 @@ int Net::dalloc(void** p, size_t bytes) {
   owned.push_back(*p);
   return 0;
 }
+static int pack_one(Net* net, ConvW& w, hipStream_t st) {
+  const float* src = w.stacked;
+  if (!w.qkv_prefix.empty()) {
+    const int C = w.Cin;
+    const char* names[3] = {".to_q", ".to_k", ".to_v"};
+    for (int i = 0; i < 3; ++i) {
+      ADM_TRY(copy_d2d(w.stacked + (size_t)i * C * C, net->ps->P(w.qkv_prefix + names[i] + ".weight"), sizeof(float) * (size_t)C * C, st));
+      ADM_TRY(copy_d2d(w.bias + (size_t)i * C, net->ps->P(w.qkv_prefix + names[i] + ".bias"), sizeof(float) * (size_t)C, st));
+    }
+  } else {
+    src = net->ps->P(w.key + ".weight");
+    w.bias = net->ps->P(w.key + ".bias");
+  }
+  ADM_TRY(launch_pack_conv_weight(src, w.wp, w.Cout, w.Cin, w.ks, st));
+  if (net->training) {
+    if (!w.wpT) ADM_TRY(net->dalloc((void**)&w.wpT, sizeof(float) * (size_t)w.Cout * w.Cin * w.ks * w.ks));
+    ADM_TRY(launch_pack_conv_weight_T(src, w.wpT, w.Cout, w.Cin, w.ks, st));
+  }
+  return 0;
+}
+
 int Net::make_conv(const std::string& p, int co, int ci, int ks, const ConvW** out) {
   ConvW w;
-  w.Cin = ci; w.Cout = co; w.ks = ks;
+  w.Cin = ci; w.Cout = co; w.ks = ks; w.key = p;
   ADM_TRY(dalloc((void**)&w.wp, sizeof(float) * (size_t)co * ci * ks * ks));
-  ADM_TRY(launch_pack_conv_weight(ps->P(p + ".weight"), w.wp, co, ci, ks, nullptr));
-  w.bias = ps->P(p + ".bias");
   convs.push_back(w);
+  ADM_TRY(pack_one(this, convs.back(), nullptr));
   *out = &convs.back();
+  return 0;
+}
+
+int Net::refresh_weights(hipStream_t st) {
+  for (ConvW& w : convs) ADM_TRY(pack_one(this, w, st));
   return 0;
 }
 const GNW* Net::make_gn(const std::string& p, int c) {
@@ -128,7 +162,7 @@ int Net::new_tensor(int C, int H, int W, bool ext) {
   return (int)tensors.size() - 1;
 }
 int Net::gn_op(int in1, int in2, const GNW* g) {
-  GnBuf b; b.C = g->C;
+  GnBuf b; b.C = g->C; b.g = g;
   gnbufs.push_back(b);
   Op o; o.kind = Op::GN; o.in1 = in1; o.in2 = in2; o.g = g; o.gn = (int)gnbufs.size() - 1;
   ops.push_back(o);
@@ -165,18 +199,12 @@ int Net::resnet(const std::string& p, int x1, int x2, int ci, int co, bool temb,
 }
 int Net::attention(const std::string& p, int x, int C, int head_dim, int* rc) {
   // q|k|v stacked into one 1x1 conv: weights (3C, C), bias 3C; GroupNorm (no SiLU) folded into its load path
-  ConvW qkv; qkv.Cin = C; qkv.Cout = 3 * C; qkv.ks = 1;
-  float* stacked = nullptr;
-  if ((*rc = dalloc((void**)&stacked, sizeof(float) * (size_t)3 * C * C))) return -1;
+  ConvW qkv; qkv.Cin = C; qkv.Cout = 3 * C; qkv.ks = 1; qkv.qkv_prefix = p;
+  if ((*rc = dalloc((void**)&qkv.stacked, sizeof(float) * (size_t)3 * C * C))) return -1;
   if ((*rc = dalloc((void**)&qkv.wp, sizeof(float) * (size_t)3 * C * C))) return -1;
   if ((*rc = dalloc((void**)&qkv.bias, sizeof(float) * (size_t)3 * C))) return -1;
-  const char* names[3] = {".to_q", ".to_k", ".to_v"};
-  for (int i = 0; i < 3; ++i) {
-    copy_d2d(stacked + (size_t)i * C * C, ps->P(p + names[i] + ".weight"), sizeof(float) * (size_t)C * C, nullptr);
-    copy_d2d(qkv.bias + (size_t)i * C, ps->P(p + names[i] + ".bias"), sizeof(float) * (size_t)C, nullptr);
-  }
-  if ((*rc = launch_pack_conv_weight(stacked, qkv.wp, 3 * C, C, 1, nullptr))) return -1;
   convs.push_back(qkv);
+  if ((*rc = pack_one(this, convs.back(), nullptr))) return -1;
   const ConvW* wqkv = &convs.back();
   const ConvW* wo;
   if ((*rc = make_conv(p + ".to_out.0", C, C, 1, &wo))) return -1;
@@ -247,18 +275,50 @@ int Net::plan(int B) {
     if (o.out >= 0 && !tensors[o.out].external && o.kind != Op::SOFTMAXC) {
       Tensor& t = tensors[o.out];
       const size_t bytes = sizeof(float) * (size_t)B * t.C * t.H * t.W;
-      auto it = freelist.find(bytes);
+      auto it = training ? freelist.end() : freelist.find(bytes);
       if (it != freelist.end()) { t.ptr = it->second; freelist.erase(it); }
       else ADM_TRY(arena_alloc((void**)&t.ptr, bytes));
     }
-    for (int t : dying[i]) {
-      const Tensor& tt = tensors[t];
-      freelist.insert({sizeof(float) * (size_t)B * tt.C * tt.H * tt.W, tt.ptr});
-    }
+    if (!training)
+      for (int t : dying[i]) {
+        const Tensor& tt = tensors[t];
+        freelist.insert({sizeof(float) * (size_t)B * tt.C * tt.H * tt.W, tt.ptr});
+      }
   }
   for (GnBuf& g : gnbufs) {
     ADM_TRY(arena_alloc((void**)&g.scale, sizeof(float) * (size_t)B * g.C));
     ADM_TRY(arena_alloc((void**)&g.shift, sizeof(float) * (size_t)B * g.C));
+    if (training) ADM_TRY(arena_alloc((void**)&g.mean_rstd, sizeof(float) * (size_t)B * groups * 2));
+  }
+  if (training) {
+    // gradient buffer for every tensor except the network input; scratch sized for the largest layer
+    size_t max_da = 0, max_ws = 0, max_w = 0;
+    for (size_t t = 0; t < tensors.size(); ++t) {
+      Tensor& tt = tensors[t];
+      if ((int)t == t_in) continue;
+      ADM_TRY(arena_alloc((void**)&tt.grad, sizeof(float) * (size_t)B * tt.C * tt.H * tt.W));
+    }
+    for (const Op& o : ops) {
+      if (o.kind != Op::CONV || o.wt >= 0) continue;
+      const Tensor& t1 = tensors[o.in1];
+      const int C2 = o.in2 >= 0 ? tensors[o.in2].C : 0, Ct = (o.in1_C ? o.in1_C : t1.C) + C2;
+      const int Hi = o.up ? 2 * t1.H : t1.H, Wi = o.up ? 2 * t1.W : t1.W;
+      const size_t da = (size_t)B * Ct * Hi * Wi;
+      if (da > max_da) max_da = da;
+      adm_conv_args a; memset(&a, 0, sizeof(a));
+      a.x1 = t1.ptr; a.C1 = t1.C; a.C2 = C2; a.x2 = C2 ? t1.ptr : nullptr; a.N = B; a.H = t1.H; a.W = t1.W;
+      a.up = o.up; a.stride = o.stride; a.ks = o.ks; a.pad_lo = o.pad_lo; a.Cout = o.w->Cout;
+      if (Ct > 4 && o.w->Cout > 4) {
+        const size_t ws = (size_t)conv_wgrad_workspace(a, nullptr);
+        if (ws > max_ws) max_ws = ws;
+      }
+      const size_t wn = (size_t)o.w->Cout * Ct * o.ks * o.ks;
+      if (wn > max_w) max_w = wn;
+    }
+    ADM_TRY(arena_alloc((void**)&tmp_da, sizeof(float) * max_da)); tmp_da_floats = max_da;
+    ADM_TRY(arena_alloc((void**)&wgrad_ws, sizeof(float) * (max_ws ? max_ws : 4))); wgrad_ws_floats = max_ws;
+    ADM_TRY(arena_alloc((void**)&tmp_w, sizeof(float) * (max_w + 4096))); tmp_w_floats = max_w + 4096;
+    ADM_TRY(arena_alloc((void**)&s12, sizeof(float) * (size_t)B * groups * 2));
   }
   planned_B = B;
   return 0;
@@ -278,7 +338,7 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
       const float* x2 = o.in2 >= 0 ? tensors[o.in2].ptr : nullptr;
       const int C2 = o.in2 >= 0 ? tensors[o.in2].C : 0;
       ADM_TRY(launch_groupnorm_stats(t1.ptr, t1.C, x2, C2, B, t1.H * t1.W, groups, eps, o.g->gamma, o.g->beta, g.scale,
-                                     g.shift, st));
+                                     g.shift, st, g.mean_rstd));
       tm->end(0, 0, 3.0 * B * (t1.C + C2) * t1.H * t1.W, 4.0 * B * (t1.C + C2) * t1.H * t1.W);
     } else if (o.kind == Op::CONV) {
       adm_conv_args a;
@@ -326,6 +386,127 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
     }
   }
   tm->finish();
+  return 0;
+}
+
+}  // namespace adm
+
+// ---------------------------------------------------------------------------------------------- Net: backward
+// Reverse pass over the op list (training). Gradient fan-in uses per-tensor "already initialised" flags: the first
+// contribution writes, later ones accumulate, so no gradient buffer needs a memset. Parameter gradients go to
+// grads_base at the offset of their master parameter (the caller zeroes that flat buffer once per step).
+namespace adm {
+
+int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) {
+  ADM_REQUIRE(training && params_base && grads_base, "run_backward: training mode is not enabled");
+  for (Tensor& t : tensors) t.ginit = false;
+  tensors[t_out].ginit = true;
+  auto contribute = [&](int t, const float* src, long src_bs, int C) -> int {
+    Tensor& tt = tensors[t];
+    if (t == t_in) return 0;
+    const long plane = (long)tt.H * tt.W;
+    ADM_REQUIRE(C == tt.C, "run_backward: partial-channel gradient fan-in is not supported");
+    ADM_TRY(launch_accumulate(tt.grad, (long)tt.C * plane, src, src_bs, (long)C * plane, B, tt.ginit ? 1 : 0, st));
+    tt.ginit = true;
+    return 0;
+  };
+  for (int i = (int)ops.size() - 1; i >= 0; --i) {
+    const Op& o = ops[i];
+    if (o.kind == Op::GN) continue;
+    Tensor& t1 = tensors[o.in1];
+    if (o.kind == Op::ATTN) {
+      Tensor& to = tensors[o.out];
+      ADM_REQUIRE(to.ginit && !t1.ginit, "run_backward: attention gradient state");
+      ADM_TRY(launch_attention_bwd(t1.ptr, to.grad, t1.grad, B, t1.C / 3, t1.H * t1.W, o.head_dim, st));
+      t1.ginit = true;
+      continue;
+    }
+    ADM_REQUIRE(o.kind == Op::CONV && o.wt < 0, "run_backward: op kind not supported in training (UNet ops only)");
+    Tensor& to = tensors[o.out];
+    ADM_REQUIRE(to.ginit, "run_backward: output gradient missing");
+    const float* dy = to.grad;
+    const long plane_o = (long)to.H * to.W;
+    const int C1 = t1.C, C2 = o.in2 >= 0 ? tensors[o.in2].C : 0, Ct = C1 + C2, Cout = to.C;
+    const int Hi = o.up ? 2 * t1.H : t1.H, Wi = o.up ? 2 * t1.W : t1.W;
+    const float* x2 = o.in2 >= 0 ? tensors[o.in2].ptr : nullptr;
+    const bool qkv = !o.w->qkv_prefix.empty();
+    // ---- residual fan-in --------------------------------------------------------------------------------
+    if (o.res >= 0) ADM_TRY(contribute(o.res, dy, (long)Cout * plane_o, Cout));
+    // ---- bias (+ time-embedding bias) gradients ------------------------------------------------------------
+    float* dW = qkv ? tmp_w : grad_of(ps->P(o.w->key + ".weight"));
+    float* dbias = qkv ? tmp_w + (size_t)Cout * Ct : grad_of(ps->P(o.w->key + ".bias"));
+    if (qkv) ADM_TRY(dmemset(dbias, 0, sizeof(float) * Cout, st));
+    ADM_TRY(launch_chan_sums(dy, B, Cout, (int)plane_o, (o.temb_off >= 0 && dtemb_all) ? dtemb_all + o.temb_off : nullptr,
+                             temb_stride, 0, dbias, st));
+    // ---- weight gradient -----------------------------------------------------------------------------------
+    const float* gsc = o.gn >= 0 ? gnbufs[o.gn].scale : nullptr;
+    const float* gsh = o.gn >= 0 ? gnbufs[o.gn].shift : nullptr;
+    const bool small_cin = Ct <= 4, small_cout = Cout <= 4;
+    if (small_cin) {
+      ADM_REQUIRE(o.ks == 3 && o.stride == 1 && !o.up && o.gn < 0 && !o.act, "run_backward: conv_in class shape");
+      ADM_TRY(launch_conv_small_cin_wgrad(t1.ptr, Ct, B, t1.H, t1.W, dy, Cout, dW, st));
+    } else if (small_cout) {
+      ADM_REQUIRE(o.ks == 3 && o.stride == 1 && !o.up && C2 == 0, "run_backward: conv_out class shape");
+      ADM_REQUIRE(tmp_da_floats >= (size_t)B * Ct * Hi * Wi, "run_backward: scratch too small");
+      ADM_TRY(launch_conv_small_cout_bwd(t1.ptr, Ct, B, t1.H, t1.W, gsc, gsh, o.act, ps->P(o.w->key + ".weight"), dy, Cout,
+                                         tmp_da, dW, st));
+    } else {
+      adm_conv_args a;
+      memset(&a, 0, sizeof(a));
+      a.x1 = t1.ptr; a.C1 = C1; a.x2 = x2; a.C2 = C2; a.N = B; a.H = t1.H; a.W = t1.W;
+      a.up = o.up; a.stride = o.stride; a.ks = o.ks; a.pad_lo = o.pad_lo;
+      a.gn_scale = gsc; a.gn_shift = gsh; a.act = o.act; a.Cout = Cout;
+      ADM_TRY(launch_conv_wgrad(a, dy, dW, 0, wgrad_ws, st));
+    }
+    if (qkv) {  // scatter the stacked q|k|v gradients to the three master parameters
+      const int C = Ct;
+      const char* names[3] = {".to_q", ".to_k", ".to_v"};
+      for (int k = 0; k < 3; ++k) {
+        ADM_TRY(copy_d2d(grad_of(ps->P(o.w->qkv_prefix + names[k] + ".weight")), tmp_w + (size_t)k * C * C,
+                         sizeof(float) * (size_t)C * C, st));
+        ADM_TRY(copy_d2d(grad_of(ps->P(o.w->qkv_prefix + names[k] + ".bias")), dbias + (size_t)k * C, sizeof(float) * C, st));
+      }
+    }
+    // ---- data gradient ---------------------------------------------------------------------------------------
+    if (o.in1 == t_in) continue;  // the network input needs no gradient
+    const bool direct = o.gn < 0 && !o.up && o.in2 < 0 && !small_cout;
+    if (!small_cout) {
+      ADM_REQUIRE(o.ks == 1 || o.pad_lo == 1, "run_backward: only symmetric padding is supported");
+      adm_conv_args a;
+      memset(&a, 0, sizeof(a));
+      a.x1 = dy; a.C1 = Cout; a.N = B; a.H = to.H; a.W = to.W;
+      a.up = o.stride == 2 ? 2 : 0; a.stride = 1; a.ks = o.ks; a.pad_lo = o.ks == 3 ? 1 : 0;
+      a.wpacked = o.w->wpT; a.bias = nullptr; a.Cout = Ct;
+      if (direct) {
+        a.out = t1.grad;
+        if (t1.ginit) a.residual = t1.grad;   // accumulate in the epilogue (same thread reads then writes)
+      } else {
+        ADM_REQUIRE(tmp_da_floats >= (size_t)B * Ct * Hi * Wi, "run_backward: scratch too small");
+        a.out = tmp_da;
+      }
+      ADM_TRY(launch_conv2d(a, st));
+      if (direct) { t1.ginit = true; continue; }
+    }
+    const long plane_i = (long)t1.H * t1.W;
+    if (o.gn >= 0) {
+      ADM_REQUIRE(!o.up, "run_backward: GroupNorm + upsample in one conv is not supported");
+      const GnBuf& gb = gnbufs[o.gn];
+      Tensor* t2 = o.in2 >= 0 ? &tensors[o.in2] : nullptr;
+      ADM_TRY(launch_gn_backward(t1.ptr, C1, x2, C2, tmp_da, B, (int)plane_i, groups, gb.mean_rstd, gb.g->gamma, gb.g->beta,
+                                 o.act, s12, grad_of(gb.g->gamma), grad_of(gb.g->beta), t1.grad, t1.ginit ? 1 : 0,
+                                 t2 ? t2->grad : nullptr, (t2 && t2->ginit) ? 1 : 0, st));
+      t1.ginit = true;
+      if (t2) t2->ginit = true;
+    } else if (o.up) {
+      ADM_REQUIRE(o.in2 < 0 && !o.act, "run_backward: upsample conv with concat/activation is not supported");
+      ADM_TRY(launch_sumpool2x2(tmp_da, t1.grad, Hi, Wi, (long)B * Ct, t1.ginit ? 1 : 0, st));
+      t1.ginit = true;
+    } else {
+      ADM_REQUIRE(!o.act, "run_backward: activation without GroupNorm is not supported");
+      ADM_TRY(contribute(o.in1, tmp_da, (long)Ct * plane_i, C1));
+      if (o.in2 >= 0) ADM_TRY(contribute(o.in2, tmp_da + (long)C1 * plane_i, (long)Ct * plane_i, C2));
+    }
+  }
   return 0;
 }
 

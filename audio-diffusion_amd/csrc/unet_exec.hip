@@ -18,6 +18,9 @@
 
 #include "net_exec.h"
 
+extern "C" int adm_mse_loss(const float* pred, const float* target, long n, float* loss_out, float* grad_out,
+                            double* scratch, void* stream);
+
 using namespace adm;
 
 struct adm_unet {
@@ -35,6 +38,11 @@ struct adm_unet {
   adm_sched_coef* coef_dev = nullptr;
   int coef_cap = 0;
   int* step_dev = nullptr;
+  // training
+  bool training = false;
+  long params_numel = 0;
+  float *dtemb_all = nullptr, *demb = nullptr, *dz = nullptr, *save_sinus = nullptr, *save_z = nullptr;
+  double* scratch_d = nullptr;
 #if !defined(ADM_EMU)
   hipStream_t own_stream = nullptr;
   hipGraphExec_t gexec = nullptr;
@@ -96,6 +104,17 @@ static int dalloc(adm_unet* h, void** p, size_t bytes) {
 
 static float* P(adm_unet* h, const std::string& k) { return h->ps.P(k); }
 
+// stacked copy of all time_emb_proj matrices (re-done after every optimizer step in training)
+static int restack_temb(adm_unet* h, hipStream_t st) {
+  int off = 0;
+  for (auto& r : h->net.temb_rows) {
+    ADM_TRY(copy_d2d(h->temb_w + (size_t)off * h->temb_dim, P(h, r.first + ".weight"), sizeof(float) * (size_t)r.second * h->temb_dim, st));
+    ADM_TRY(copy_d2d(h->temb_b + off, P(h, r.first + ".bias"), sizeof(float) * (size_t)r.second, st));
+    off += r.second;
+  }
+  return 0;
+}
+
 static int finalize(adm_unet* h) {
   if (h->finalized) return 0;
   std::string missing;
@@ -108,6 +127,7 @@ static int finalize(adm_unet* h) {
   b.ps = &h->ps;
   b.groups = c.norm_num_groups;
   b.eps = c.norm_eps;
+  b.training = h->training;
   int rc = 0;
   b.t_in = b.new_tensor(c.in_channels, c.sample_h, c.sample_w, true);
   const ConvW* w;
@@ -167,12 +187,7 @@ static int finalize(adm_unet* h) {
   h->temb_rows = R;
   ADM_TRY(dalloc(h, (void**)&h->temb_w, sizeof(float) * (size_t)R * h->temb_dim));
   ADM_TRY(dalloc(h, (void**)&h->temb_b, sizeof(float) * (size_t)R));
-  int off = 0;
-  for (auto& r : b.temb_rows) {
-    copy_d2d(h->temb_w + (size_t)off * h->temb_dim, P(h, r.first + ".weight"), sizeof(float) * (size_t)r.second * h->temb_dim, nullptr);
-    copy_d2d(h->temb_b + off, P(h, r.first + ".bias"), sizeof(float) * (size_t)r.second, nullptr);
-    off += r.second;
-  }
+  ADM_TRY(restack_temb(h, nullptr));
   // sinusoid frequencies: exp(-ln(10000) * i / (half - freq_shift)) in fp32, as diffusers computes them
   const int half = boc[0] / 2;
   std::vector<float> fr(half);
@@ -216,6 +231,14 @@ static int plan(adm_unet* h, int B) {
   ADM_TRY(extra_alloc(h, (void**)&h->eps_buf,
                       sizeof(float) * (size_t)B * h->cfg.out_channels * h->cfg.sample_h * h->cfg.sample_w));
   ADM_TRY(extra_alloc(h, (void**)&h->step_dev, sizeof(int)));
+  if (h->training) {
+    ADM_TRY(extra_alloc(h, (void**)&h->dtemb_all, sizeof(float) * (size_t)B * h->temb_rows));
+    ADM_TRY(extra_alloc(h, (void**)&h->demb, sizeof(float) * (size_t)B * h->temb_dim));
+    ADM_TRY(extra_alloc(h, (void**)&h->dz, sizeof(float) * (size_t)B * h->temb_dim));
+    ADM_TRY(extra_alloc(h, (void**)&h->save_sinus, sizeof(float) * (size_t)B * h->cfg.block_out_channels[0]));
+    ADM_TRY(extra_alloc(h, (void**)&h->save_z, sizeof(float) * (size_t)B * h->temb_dim));
+    ADM_TRY(extra_alloc(h, (void**)&h->scratch_d, sizeof(double)));
+  }
   h->planned_B = B;
   return 0;
 }
@@ -228,7 +251,8 @@ static int run_forward(adm_unet* h, const float* x, float* out, int B, const adm
   ADM_TRY(launch_time_embedding(table ? nullptr : h->t_dev, 1, table, h->step_dev, h->freqs, dim_in / 2,
                                 c.flip_sin_to_cos, P(h, "time_embedding.linear_1.weight"),
                                 P(h, "time_embedding.linear_1.bias"), P(h, "time_embedding.linear_2.weight"),
-                                P(h, "time_embedding.linear_2.bias"), dim_in, h->temb_dim, h->emb, B, st));
+                                P(h, "time_embedding.linear_2.bias"), dim_in, h->temb_dim, h->emb, B, st,
+                                h->training ? h->save_sinus : nullptr, h->training ? h->save_z : nullptr));
   if (tm) { tm->st = st; tm->begin(); }
   ADM_TRY(launch_temb_proj(h->emb, h->temb_w, h->temb_b, h->temb_all, B, h->temb_dim, h->temb_rows, st));
   if (tm) tm->end(4, 0, 2.0 * B * h->temb_dim * h->temb_rows, 4.0 * h->temb_dim * h->temb_rows);
@@ -371,6 +395,70 @@ int adm_unet_forward(adm_unet_t* h, const float* x, const float* timesteps_host,
   ADM_TRY(copy_h2d(h->t_dev, t.data(), sizeof(float) * B, st));
   ADM_TRY(stream_sync(st));  // t is a stack/vector buffer: make the copy complete before returning
   return run_forward(h, x, out, B, nullptr, st);
+}
+
+int adm_unet_bind_param(adm_unet_t* h, const char* key, float* dev_ptr) {
+  ADM_REQUIRE(h && key && dev_ptr, "unet_bind_param: null argument");
+  ADM_REQUIRE(!h->finalized, "unet_bind_param: model already finalized");
+  return h->ps.bind(key, dev_ptr);
+}
+
+int adm_unet_enable_training(adm_unet_t* h, const float* params_base, long numel) {
+  ADM_REQUIRE(h && params_base && numel > 0, "unet_enable_training: bad argument");
+  ADM_REQUIRE(!h->finalized, "unet_enable_training: must be called before the first forward");
+  for (auto& kv : h->ps.params)
+    ADM_REQUIRE(kv.second.set && kv.second.dev >= params_base && kv.second.dev + kv.second.numel <= params_base + numel,
+                "unet_enable_training: parameter " + kv.first + " is not bound inside the flat buffer");
+  h->training = true;
+  h->params_numel = numel;
+  h->net.params_base = params_base;
+  return 0;
+}
+
+int adm_unet_refresh_weights(adm_unet_t* h, void* stream) {
+  ADM_REQUIRE(h && h->finalized, "unet_refresh_weights: model not finalized");
+  ADM_TRY(h->net.refresh_weights((hipStream_t)stream));
+  return restack_temb(h, (hipStream_t)stream);
+}
+
+// One training forward + backward (scripts/train_unet.py:257-259 without the optimizer): loss_dev[0] = mse(unet(x, t),
+// target); grads_base (flat, same offsets as the parameter buffer) receives d loss / d parameters.
+int adm_unet_forward_backward(adm_unet_t* h, const float* x, const float* timesteps_host, int n_timesteps,
+                              const float* target, float* loss_dev, float* grads_base, int B, void* stream) {
+  ADM_REQUIRE(h && x && timesteps_host && target && loss_dev && grads_base, "unet_forward_backward: null argument");
+  ADM_REQUIRE(h->training, "unet_forward_backward: call adm_unet_enable_training first");
+  ADM_REQUIRE(n_timesteps == 1 || n_timesteps == B, "unet_forward_backward: need 1 or B timesteps");
+  hipStream_t st = (hipStream_t)stream;
+  ADM_TRY(finalize(h));
+  ADM_TRY(plan(h, B));
+  std::vector<float> t(B);
+  for (int i = 0; i < B; ++i) t[i] = timesteps_host[n_timesteps == 1 ? 0 : i];
+  ADM_TRY(copy_h2d(h->t_dev, t.data(), sizeof(float) * B, st));
+  ADM_TRY(stream_sync(st));
+  ADM_TRY(run_forward(h, x, h->eps_buf, B, nullptr, st));
+  Net& net = h->net;
+  const adm_unet_config& c = h->cfg;
+  const long n_out = (long)B * c.out_channels * c.sample_h * c.sample_w;
+  ADM_TRY(adm_mse_loss(h->eps_buf, target, n_out, loss_dev, net.tensors[net.t_out].grad, h->scratch_d, st));
+  net.grads_base = grads_base;
+  ADM_TRY(dmemset(grads_base, 0, sizeof(float) * (size_t)h->params_numel, st));
+  ADM_TRY(net.run_backward(B, h->dtemb_all, h->temb_rows, st));
+  // ---- time-embedding path: time_emb_proj (per resnet), then the 2-layer MLP ---------------------------------
+  const int K = h->temb_dim, R = h->temb_rows, dim_in = c.block_out_channels[0];
+  int off = 0;
+  for (auto& r : net.temb_rows) {
+    ADM_TRY(launch_linear_bwd(h->dtemb_all + off, R, h->emb, nullptr, B, r.second, K, 1,
+                              net.grad_of(P(h, r.first + ".weight")), net.grad_of(P(h, r.first + ".bias")), nullptr, st));
+    off += r.second;
+  }
+  ADM_TRY(launch_linear_bwd(h->dtemb_all, R, h->emb, h->temb_w, B, R, K, 1, nullptr, nullptr, h->demb, st));
+  ADM_TRY(launch_linear_bwd(h->demb, K, h->save_z, P(h, "time_embedding.linear_2.weight"), B, K, K, 1,
+                            net.grad_of(P(h, "time_embedding.linear_2.weight")),
+                            net.grad_of(P(h, "time_embedding.linear_2.bias")), h->dz, st));
+  ADM_TRY(launch_linear_bwd(h->dz, K, h->save_sinus, nullptr, B, K, dim_in, 0,
+                            net.grad_of(P(h, "time_embedding.linear_1.weight")),
+                            net.grad_of(P(h, "time_embedding.linear_1.bias")), nullptr, st));
+  return 0;
 }
 
 size_t adm_unet_workspace_bytes(adm_unet_t* h) { return h ? h->net.arena_bytes : 0; }

@@ -136,6 +136,18 @@ typedef struct adm_op_profile { int kind, variant; float ms; double flops, bytes
 int adm_unet_profile(adm_unet_t* h, const float* x, float timestep, float* out, int B, adm_op_profile* recs, int cap,
                      int* n_out, void* stream);
 
+/* ---- training (rows T4,T5; scripts/train_unet.py:257-259): the master parameters live in ONE caller-owned flat fp32
+ * device buffer (so the fused optimizer kernel can update them in a single launch); call order:
+ *   create -> adm_unet_bind_param for every key -> adm_unet_enable_training -> adm_unet_forward_backward ...
+ *   -> (optimizer step on the flat buffer) -> adm_unet_refresh_weights -> next step. */
+int adm_unet_bind_param(adm_unet_t* h, const char* key, float* dev_ptr);
+int adm_unet_enable_training(adm_unet_t* h, const float* params_base, long numel);
+int adm_unet_refresh_weights(adm_unet_t* h, void* stream);
+/* loss_dev[0] = mean((unet(x,t) - target)^2); grads_base (flat, same offsets as the parameter buffer) = d loss/d params.
+ * Every activation is kept for the reverse pass; GroupNorm/SiLU are recomputed in the weight-gradient load path. */
+int adm_unet_forward_backward(adm_unet_t* h, const float* x, const float* timesteps_host, int n_timesteps,
+                              const float* target, float* loss_dev, float* grads_base, int B, void* stream);
+
 /* ---------------------------------------------------------------- whole denoising loop (row P4; hipGraph)
  * Runs n_steps x {UNet forward, scheduler epilogue, mask} on `x` in place and (optionally) the final u8 image.
  * coef_host: n_steps adm_sched_coef (host) including .timestep; step_noise: NULL or device

@@ -1,0 +1,67 @@
+"""Whole-UNet training step parity (SURVEY.md §7.1 phase 10 exit test): loss and d loss/d parameter of the native
+forward+backward vs torch autograd on the oracle UNet, identical weights / inputs; then one fused AdamW+EMA step."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from native_backend import BACKENDS, select
+from oracle.unet import UNet2DModel as OracleUNet
+
+TINY = dict(sample_size=16, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(32, 64),
+            down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"))
+TINY3 = dict(sample_size=(8, 16), in_channels=1, out_channels=1, layers_per_block=2, block_out_channels=(32, 32, 64),
+             down_block_types=("DownBlock2D", "AttnDownBlock2D", "DownBlock2D"),
+             up_block_types=("UpBlock2D", "AttnUpBlock2D", "UpBlock2D"))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("cfg,B", [(TINY, 2), (TINY3, 3)], ids=["tiny2", "tiny3"])
+def test_forward_backward_matches_autograd(backend, cfg, B):
+    dev = select(backend)
+    from audiodiffusion.unet import UNet2DModel
+    torch.manual_seed(0)
+    ref = OracleUNet(**cfg)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "norm" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    mine = UNet2DModel(**cfg).load_state_dict(ref.state_dict())
+    flat, grads = mine.enable_training()
+    ss = cfg["sample_size"]
+    hw = (ss, ss) if isinstance(ss, int) else ss
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((B, 1) + tuple(hw), generator=g)
+    tgt = torch.randn((B, 1) + tuple(hw), generator=g)
+    ts = torch.tensor([5, 500, 999][:B])
+    loss_ref = F.mse_loss(ref(x, ts)["sample"], tgt)
+    loss_ref.backward()
+    loss = mine.train_step(x.to(dev), ts, tgt.to(dev))
+    assert abs(float(loss) - float(loss_ref.detach())) <= 1e-5 * float(loss_ref.detach())
+    # Tolerance 2e-4 relative to each tensor's own gradient scale; gradients that are mathematically zero (a bias feeding
+    # a GroupNorm whose groups are single channels, to_k.bias under the softmax) are 1e-9 noise on both sides and are
+    # compared against the global gradient scale instead.
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters())
+    checked = 0
+    for name, p in ref.named_parameters():
+        off = mine.flat.offsets[name][0]
+        got = grads[off:off + p.numel()].view(p.shape).cpu()
+        scale = max(float(p.grad.abs().max()), 1e-3 * gmax)
+        err = float((got - p.grad).abs().max()) / scale
+        checked += 1
+        assert err < 2e-4, (name, err)
+    assert checked == len(list(ref.parameters()))
+    # one optimizer step on the flat buffers, then the refreshed weights must drive the next forward
+    from audiodiffusion import training as T
+    opt = T.AdamW(flat, lr=1e-3)
+    ema = T.EMAModel(flat)
+    clip = T.clip_grad_norm_(grads, 1.0)
+    opt.step(grads, clip=clip, ema=ema, ema_decay=ema.next_decay())
+    mine.refresh_weights()
+    ref_opt = torch.optim.AdamW(ref.parameters(), lr=1e-3, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+    ref_opt.step()
+    ref_opt.zero_grad()
+    loss2_ref = F.mse_loss(ref(x, ts)["sample"], tgt)
+    loss2 = mine.train_step(x.to(dev), ts, tgt.to(dev))
+    assert abs(float(loss2) - float(loss2_ref.detach())) <= 1e-4 * float(loss2_ref.detach())
+    assert float(loss2) < float(loss)
