@@ -278,30 +278,41 @@ __global__ void __launch_bounds__(256) linear_bwd_input_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// conv_in class (Cin <= 4): dW[co][c][tap] += sum_{n,p} dy[n][co][p] x[n][c][p+tap]; one workgroup per cout.
-__global__ void __launch_bounds__(256) conv_small_cin_wgrad_kernel(const float* __restrict__ x, int Cin, int N, int H,
-                                                                   int W, const float* __restrict__ dy, int Cout,
+// conv_in class (Cin <= 4): dW[co][c][tap] += sum_{n,p} dy[n][co][p] x[n][c][p+tap]; one workgroup per (cout, n),
+// register accumulators (compile-time Cin), one atomic per (tap, c) per workgroup.
+template <int CIN>
+__global__ void __launch_bounds__(256) conv_small_cin_wgrad_kernel(const float* __restrict__ x, int H, int W,
+                                                                   const float* __restrict__ dy, int Cout,
                                                                    float* dW /* (Cout,Cin,3,3) */) {
   __shared__ double red[2][4];
-  const int co = blockIdx.x;
-  const long HW = (long)H * W;
-  double acc[36];
-  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-  for (long e = threadIdx.x; e < (long)N * HW; e += 256) {
-    const int n = (int)(e / HW);
-    const long p = e - (long)n * HW;
-    const int y = (int)(p / W), xx = (int)(p % W);
-    const float g = dy[((long)n * Cout + co) * HW + p];
-    for (int c = 0; c < Cin; ++c)
+  const int co = blockIdx.x, n = blockIdx.y;
+  const int HW = H * W;
+  float acc[CIN * 9];
+  ADM_UNROLL
+  for (int k = 0; k < CIN * 9; ++k) acc[k] = 0.f;
+  const float* dyp = dy + ((long)n * Cout + co) * HW;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int y = p / W, xx = p - y * W;
+    const float g = dyp[p];
+    ADM_UNROLL
+    for (int c = 0; c < CIN; ++c) {
+      const float* xp = x + ((long)n * CIN + c) * HW;
+      ADM_UNROLL
       for (int t = 0; t < 9; ++t) {
         const int gy = y + t / 3 - 1, gx = xx + t % 3 - 1;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) acc[c * 9 + t] += (double)g * x[((long)n * Cin + c) * HW + (long)gy * W + gx];
+        const float v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xp[gy * W + gx] : 0.f;
+        acc[c * 9 + t] = fmaf(g, v, acc[c * 9 + t]);
       }
+    }
   }
-  for (int k = 0; k < Cin * 9; ++k) {
-    double a = acc[k], z = 0.0;
+  ADM_UNROLL
+  for (int k = 0; k < CIN * 9; k += 2) {
+    double a = acc[k], z = (k + 1 < CIN * 9) ? acc[k + 1] : 0.0;
     block_sum2(a, z, red);
-    if (threadIdx.x == 0) dW[(long)co * Cin * 9 + k] += (float)a;
+    if (threadIdx.x == 0) {
+      atomicAdd(dW + (long)co * CIN * 9 + k, (float)a);
+      if (k + 1 < CIN * 9) atomicAdd(dW + (long)co * CIN * 9 + k + 1, (float)z);
+    }
   }
 }
 
@@ -327,36 +338,45 @@ __global__ void __launch_bounds__(256) conv_small_cout_dgrad_kernel(const float*
   }
 }
 
-// conv_out class weight gradient with the fused GN+SiLU prologue recomputed: one workgroup per input channel.
-__global__ void __launch_bounds__(256) conv_small_cout_wgrad_kernel(const float* __restrict__ x, int Cin, int N, int H,
-                                                                    int W, const float* __restrict__ gn_scale,
+// conv_out class weight gradient with the fused GN+SiLU prologue recomputed: one workgroup per (input channel, n).
+template <int COUT>
+__global__ void __launch_bounds__(256) conv_small_cout_wgrad_kernel(const float* __restrict__ x, int Cin, int H, int W,
+                                                                    const float* __restrict__ gn_scale,
                                                                     const float* __restrict__ gn_shift, int act,
-                                                                    const float* __restrict__ dy, int Cout,
+                                                                    const float* __restrict__ dy,
                                                                     float* dW /* (Cout,Cin,3,3) */) {
   __shared__ double red[2][4];
-  const int c = blockIdx.x;
-  const long HW = (long)H * W;
-  double acc[36];
-  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-  for (long e = threadIdx.x; e < (long)N * HW; e += 256) {
-    const int n = (int)(e / HW);
-    const long p = e - (long)n * HW;
-    const int y = (int)(p / W), xx = (int)(p % W);
-    float a = x[((long)n * Cin + c) * HW + p];
-    if (gn_scale) a = a * gn_scale[(long)n * Cin + c] + gn_shift[(long)n * Cin + c];
+  const int c = blockIdx.x, n = blockIdx.y;
+  const int HW = H * W;
+  float acc[COUT * 9];
+  ADM_UNROLL
+  for (int k = 0; k < COUT * 9; ++k) acc[k] = 0.f;
+  const float* xp = x + ((long)n * Cin + c) * HW;
+  const float sc = gn_scale ? gn_scale[(long)n * Cin + c] : 1.f, sh = gn_scale ? gn_shift[(long)n * Cin + c] : 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int y = p / W, xx = p - y * W;
+    float a = xp[p] * sc + sh;
     if (act) a = a * sigmoid_f(a);
     // a at (y,xx) is tap t of output pixel (y - (t/3-1), xx - (t%3-1))
-    for (int co = 0; co < Cout; ++co)
+    ADM_UNROLL
+    for (int co = 0; co < COUT; ++co) {
+      const float* dyp = dy + ((long)n * COUT + co) * HW;
+      ADM_UNROLL
       for (int t = 0; t < 9; ++t) {
         const int oy = y - (t / 3 - 1), ox = xx - (t % 3 - 1);
-        if (oy >= 0 && oy < H && ox >= 0 && ox < W)
-          acc[co * 9 + t] += (double)a * dy[((long)n * Cout + co) * HW + (long)oy * W + ox];
+        const float g = (oy >= 0 && oy < H && ox >= 0 && ox < W) ? dyp[oy * W + ox] : 0.f;
+        acc[co * 9 + t] = fmaf(a, g, acc[co * 9 + t]);
       }
+    }
   }
-  for (int k = 0; k < Cout * 9; ++k) {
-    double a = acc[k], z = 0.0;
+  ADM_UNROLL
+  for (int k = 0; k < COUT * 9; k += 2) {
+    double a = acc[k], z = (k + 1 < COUT * 9) ? acc[k + 1] : 0.0;
     block_sum2(a, z, red);
-    if (threadIdx.x == 0) dW[((long)(k / 9) * Cin + c) * 9 + (k % 9)] += (float)a;
+    if (threadIdx.x == 0) {
+      atomicAdd(dW + ((long)(k / 9) * Cin + c) * 9 + (k % 9), (float)a);
+      if (k + 1 < COUT * 9) atomicAdd(dW + ((long)((k + 1) / 9) * Cin + c) * 9 + ((k + 1) % 9), (float)z);
+    }
   }
 }
 
@@ -418,15 +438,25 @@ int launch_linear_bwd(const float* dY, int ldy, const float* X, const float* W, 
 }
 int launch_conv_small_cin_wgrad(const float* x, int Cin, int N, int H, int W, const float* dy, int Cout, float* dW,
                                 hipStream_t st) {
-  ADM_REQUIRE(Cin <= 4, "conv_small_cin_wgrad: Cin <= 4");
-  ADM_LAUNCH(conv_small_cin_wgrad_kernel, dim3(Cout), dim3(256), 0, st, x, Cin, N, H, W, dy, Cout, dW);
+  ADM_REQUIRE(Cin >= 1 && Cin <= 4, "conv_small_cin_wgrad: Cin <= 4");
+  dim3 grid(Cout, N), block(256);
+  if (Cin == 1) { ADM_LAUNCH((conv_small_cin_wgrad_kernel<1>), grid, block, 0, st, x, H, W, dy, Cout, dW); }
+  else if (Cin == 2) { ADM_LAUNCH((conv_small_cin_wgrad_kernel<2>), grid, block, 0, st, x, H, W, dy, Cout, dW); }
+  else if (Cin == 3) { ADM_LAUNCH((conv_small_cin_wgrad_kernel<3>), grid, block, 0, st, x, H, W, dy, Cout, dW); }
+  else { ADM_LAUNCH((conv_small_cin_wgrad_kernel<4>), grid, block, 0, st, x, H, W, dy, Cout, dW); }
   return ADM_CHECK_LAUNCH();
 }
 int launch_conv_small_cout_bwd(const float* x, int Cin, int N, int H, int W, const float* gn_scale, const float* gn_shift,
                                int act, const float* w, const float* dy, int Cout, float* da, float* dW, hipStream_t st) {
   ADM_REQUIRE(Cout <= 4, "conv_small_cout_bwd: Cout <= 4");
   if (da) ADM_LAUNCH(conv_small_cout_dgrad_kernel, dim3(bgrid((long)N * Cin * H * W)), dim3(256), 0, st, dy, Cout, N, H, W, w, Cin, da);
-  if (dW) ADM_LAUNCH(conv_small_cout_wgrad_kernel, dim3(Cin), dim3(256), 0, st, x, Cin, N, H, W, gn_scale, gn_shift, act, dy, Cout, dW);
+  if (dW) {
+    dim3 grid(Cin, N), block(256);
+    if (Cout == 1) { ADM_LAUNCH((conv_small_cout_wgrad_kernel<1>), grid, block, 0, st, x, Cin, H, W, gn_scale, gn_shift, act, dy, dW); }
+    else if (Cout == 2) { ADM_LAUNCH((conv_small_cout_wgrad_kernel<2>), grid, block, 0, st, x, Cin, H, W, gn_scale, gn_shift, act, dy, dW); }
+    else if (Cout == 3) { ADM_LAUNCH((conv_small_cout_wgrad_kernel<3>), grid, block, 0, st, x, Cin, H, W, gn_scale, gn_shift, act, dy, dW); }
+    else { ADM_LAUNCH((conv_small_cout_wgrad_kernel<4>), grid, block, 0, st, x, Cin, H, W, gn_scale, gn_shift, act, dy, dW); }
+  }
   return ADM_CHECK_LAUNCH();
 }
 

@@ -10,6 +10,8 @@
 // Split-K: every workgroup reduces a contiguous range of pixel tiles and writes its 128 x (channels x taps) partial
 // in final (Cout,Cin,ks,ks) order to a workspace slab; wgrad_reduce_kernel sums the slabs into the gradient buffer.
 // Algorithmic FLOPs = forward FLOPs of the same layer; bytes = dy + x read once per (cout-tile, channel-chunk) pair.
+#include <cstdlib>
+
 #include "adm_kernels.h"
 
 namespace adm {
@@ -118,6 +120,140 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Software-pipelined variant (stride 1; patch of at most 128 elements per channel): the NEXT pixel tile's dy values and
+// raw activations are loaded into registers before the 288 (resp. 128) MFMAs of the current tile and are
+// normalised/activated/transposed into LDS after them, so global-load latency hides under the matrix work.
+// One workgroup per CU (up to 512 VGPRs per lane: 144 accumulators + 48 prefetch registers + addresses, no spills).
+template <int KS>
+__global__ void __launch_bounds__(256, 1) conv_wgrad_pf_kernel(const WgradParams p) {
+  constexpr int KS2 = KS * KS;
+  constexpr int NT = KS == 3 ? 9 : 4;
+  constexpr int CB = KS == 3 ? 32 : 128;
+  constexpr int NPX = KS == 3 ? 16 : 32;   // patch elements per thread: CB * (<=128 | 64) / 256
+  constexpr int DLD = 129;
+  ADM_DYN_SMEM(float, smem);
+  float* ldsD = smem;
+  float* ldsP = smem + 64 * DLD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  int b = blockIdx.x;
+  const int sp = b % p.split; b /= p.split;
+  const int chunk = b % p.n_chunks, ct = b / p.n_chunks;
+  const int m0 = ct * 128, c0 = chunk * CB;
+  const int Ct = p.C1 + p.C2;
+  const int TW = 1 << p.lTW, TH = 1 << p.lTH, NI = 64 >> (p.lTW + p.lTH);
+  const int IHW = p.IH * p.IW, planeS = p.Hs * p.Ws, PE = NI * IHW;   // PE <= 128 (KS=3) / == 64 (KS=1)
+  const long planeO = (long)p.Ho * p.Wo;
+  const int n_el = CB * PE;
+
+  f32x16 acc[NT];
+  ADM_UNROLL
+  for (int t = 0; t < NT; ++t)
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // per-thread roles, constant over tiles: dy -> pixel pp = tid & 63, couts (tid >> 6) + 4 i;
+  // patch -> elements e = tid + 256 j  (channel ec[j], patch position eq[j])
+  const int pp_d = tid & 63, co_d0 = tid >> 6;
+  const int dpx = pp_d & (TW - 1), dpy = (pp_d >> p.lTW) & (TH - 1), dimg = pp_d >> (p.lTW + p.lTH);
+  float dyr[32], xr[NPX];
+  unsigned xvalid = 0;   // bit j: patch element j of this thread is inside the image (else zero padding)
+  int n0_st = 0;         // first image of the tile held in registers
+
+  auto issue = [&](int pt) {
+    const int tx = pt % p.tiles_x, ty = (pt / p.tiles_x) % p.tiles_y, ig = pt / (p.tiles_x * p.tiles_y);
+    const int n0 = ig * NI;
+    n0_st = n0;
+    xvalid = 0;
+    {
+      const int oy = ty * TH + dpy, ox = tx * TW + dpx, n = n0 + dimg;
+      const bool ok = n < p.N && oy < p.Ho && ox < p.Wo;
+      const float* src = p.dy + ((long)n * p.Cout + m0 + co_d0) * planeO + (long)oy * p.Wo + ox;
+      ADM_UNROLL
+      for (int i = 0; i < 32; ++i)
+        dyr[i] = (ok && m0 + co_d0 + 4 * i < p.Cout) ? src[(long)(4 * i) * planeO] : 0.f;
+    }
+    ADM_UNROLL
+    for (int j = 0; j < NPX; ++j) {
+      const int e = tid + 256 * j;
+      xr[j] = 0.f;
+      if (e < n_el) {
+        const int c = e / PE, q = e - c * PE;
+        const int img = q / IHW, r2 = q - img * IHW;
+        const int ly = r2 / p.IW, lx = r2 - ly * p.IW;
+        const int gy = ty * TH + ly - p.pad_lo, gx = tx * TW + lx - p.pad_lo;
+        const int n = n0 + img, cc = c0 + c;
+        if (cc < Ct && n < p.N && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi) {
+          const int sy = p.up ? (gy >> 1) : gy, sx = p.up ? (gx >> 1) : gx;
+          xvalid |= 1u << j;
+          xr[j] = cc < p.C1 ? p.x1[(long)n * p.x1_bs + (long)cc * planeS + sy * p.Ws + sx]
+                            : p.x2[(long)n * p.x2_bs + (long)(cc - p.C1) * planeS + sy * p.Ws + sx];
+        }
+      }
+    }
+  };
+  auto stash = [&]() {
+    ADM_UNROLL
+    for (int i = 0; i < 32; ++i) ldsD[pp_d * DLD + co_d0 + 4 * i] = dyr[i];
+    ADM_UNROLL
+    for (int j = 0; j < NPX; ++j) {
+      const int e = tid + 256 * j;
+      if (e < n_el) {
+        const int c = e / PE, q = e - c * PE;
+        float v = xr[j];
+        if ((xvalid >> j) & 1u) {
+          if (p.gn_scale != nullptr) {
+            const long gi = (long)(n0_st + q / IHW) * Ct + c0 + c;
+            v = v * p.gn_scale[gi] + p.gn_shift[gi];
+          }
+          if (p.act) v = silu_g(v);
+        } else {
+          v = 0.f;
+        }
+        ldsP[c * p.PS + q] = v;
+      }
+    }
+  };
+
+  const int t_begin = sp * p.tiles_per_block;
+  int t_end = t_begin + p.tiles_per_block;
+  if (t_end > p.n_ptiles) t_end = p.n_ptiles;
+  if (t_begin < t_end) issue(t_begin);
+  for (int pt = t_begin; pt < t_end; ++pt) {
+    stash();
+    __syncthreads();
+    if (pt + 1 < t_end) issue(pt + 1);
+    for (int s = 0; s < 32; ++s) {
+      const int pp = 2 * s + h;
+      const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
+      const int poff = img * IHW + py * p.IW + px;
+      const float av = ldsD[pp * DLD + wave * 32 + l31];
+      ADM_UNROLL
+      for (int t = 0; t < NT; ++t) {
+        float bv;
+        if (KS == 3) bv = ldsP[l31 * p.PS + poff + (t / 3) * p.IW + (t % 3)];
+        else bv = ldsP[(t * 32 + l31) * p.PS + poff];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* out = p.part + (long)sp * p.Cout * Ct * KS2;
+  ADM_UNROLL
+  for (int t = 0; t < NT; ++t) {
+    const int cc = KS == 3 ? c0 + l31 : c0 + t * 32 + l31;
+    const int tap = KS == 3 ? t : 0;
+    if (cc >= Ct) continue;
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (co < p.Cout) out[((long)co * Ct + cc) * KS2 + tap] = acc[t][r];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int split, long numel,
                                                            float* dW, int accumulate) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long)gridDim.x * blockDim.x) {
@@ -183,11 +319,19 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_pf_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_pf_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     return true;
   }();
   (void)once;
 #endif
-  if (a.ks == 3 && a.stride == 1) {
+  static const int use_pf = [] { const char* e = getenv("ADM_WGRAD_PF"); return e ? atoi(e) : 1; }();
+  const int PE = NI * p.IH * p.IW;
+  if (use_pf && a.stride == 1 && a.ks == 3 && PE <= 128) {
+    ADM_LAUNCH((conv_wgrad_pf_kernel<3>), grid, block, smem, st, p);
+  } else if (use_pf && a.ks == 1) {
+    ADM_LAUNCH((conv_wgrad_pf_kernel<1>), grid, block, smem, st, p);
+  } else if (a.ks == 3 && a.stride == 1) {
     ADM_LAUNCH((conv_wgrad_kernel<3, 1>), grid, block, smem, st, p);
   } else if (a.ks == 3) {
     ADM_LAUNCH((conv_wgrad_kernel<3, 2>), grid, block, smem, st, p);

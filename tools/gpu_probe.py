@@ -204,3 +204,51 @@ def train_probe():
 
 if __name__ == "__main__" and "train" in sys.argv[1:]:
     train_probe()
+
+
+def trainstep_probe():
+    """Full-size training step (config 5 shape, fp32): forward+backward+clip+AdamW+EMA, B per GPU from PROBE_B."""
+    from audiodiffusion import training as T
+    B = int(os.environ.get("PROBE_B", "8"))
+    m = UNet2DModel(**CFG256).init_random(0)
+    flat, grads = m.enable_training()
+    opt, ema = T.AdamW(flat), T.EMAModel(flat)
+    x = torch.randn(B, 1, 256, 256, device=dev)
+    tgt = torch.randn(B, 1, 256, 256, device=dev)
+    ts = torch.randint(0, 1000, (B,))
+
+    def step():
+        loss = m.train_step(x, ts, tgt)
+        clip = T.clip_grad_norm_(grads, 1.0)
+        opt.step(grads, clip=clip, ema=ema, ema_decay=ema.next_decay())
+        m.refresh_weights()
+        return loss
+
+    l0 = float(step())
+    torch.cuda.synchronize()
+    dt = timeit(step, iters=3, warm=1)
+    l1 = float(step())
+    log(f"train step B={B}: {dt*1e3:9.2f} ms  {B/dt:7.2f} samples/s  {3*0.496*B/dt:7.2f} TF/s(3x fwd flops)  loss {l0:.4f} -> {l1:.4f}  "
+        f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB torch + native arena")
+    if os.environ.get("PROBE_CHECK", "1") == "1" and B <= 2:
+        import torch.nn.functional as F
+        from oracle.unet import UNet2DModel as OU
+        m2 = UNet2DModel(**CFG256).init_random(1)
+        ref = OU(**CFG256)
+        ref.load_state_dict(m2.state_dict())
+        flat2, grads2 = m2.enable_training()
+        xc, tc = x[:1].cpu(), tgt[:1].cpu()
+        lr = F.mse_loss(ref(xc, ts[:1])["sample"], tc)
+        lr.backward()
+        lm = m2.train_step(x[:1].contiguous(), ts[:1], tgt[:1].contiguous())
+        gmax = max(float(p.grad.abs().max()) for p in ref.parameters())
+        worst = 0.0
+        for name, p in ref.named_parameters():
+            off = m2.flat.offsets[name][0]
+            got = grads2[off:off + p.numel()].view(p.shape).cpu()
+            worst = max(worst, float((got - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-3 * gmax))
+        log(f"full-size grad parity B=1: loss {float(lm):.6f} vs {float(lr.detach()):.6f}; worst per-tensor rel err {worst:.2e}")
+
+
+if __name__ == "__main__" and "trainstep" in sys.argv[1:]:
+    trainstep_probe()
