@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""MI355X-native drop-in for `scripts/train_unet.py` of teticio/audio-diffusion (unconditional pixel-space path).
+
+Same CLI flag names and defaults as the reference (`scripts/train_unet.py:354-420`) for everything on the hot path; the
+training step (`:226-267`) runs as: fused add_noise kernel -> native UNet forward+backward (`adm_unet_forward_backward`)
+-> bucketed gradient all-reduce over RCCL/xGMI (`torch.distributed`, one process per GPU; replaces accelerate's DDP,
+`config/accelerate_multi_gpu.yaml`) -> fused clip + AdamW + EMA kernel -> weight re-pack. Checkpoints are written in the
+diffusers layout by `AudioDiffusionPipeline.save_pretrained` every `--save_model_epochs` (`:286-311`).
+
+Launch:  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_unet.py --dataset_name ...
+Not implemented (raise): --encodings (conditional), --vae (latent training), mixed precision, hub push, tensorboard.
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, DDPMScheduler, Mel, UNet2DModel  # noqa: E402
+from audiodiffusion import training as T  # noqa: E402
+
+
+def synthetic_dataset(n, resolution, seed=7):
+    """N u8 images ~ round(255*sigmoid(N(0,1) smoothed 5x5)), fixed seed."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 1, resolution[0], resolution[1], generator=g)
+    k = torch.ones(1, 1, 5, 5) / 25.0
+    x = torch.nn.functional.conv2d(x, k, padding=2) * 5.0
+    return torch.round(255 * torch.sigmoid(x)).to(torch.uint8)
+
+
+def load_images(args, resolution):
+    if args.dataset_name == "synthetic":
+        return synthetic_dataset(args.synthetic_size, resolution)
+    from datasets import load_dataset, load_from_disk
+    if os.path.exists(args.dataset_name):
+        ds = load_from_disk(args.dataset_name)["train"]
+    else:
+        ds = load_dataset(args.dataset_name, args.dataset_config_name, cache_dir=args.cache_dir, split="train")
+    imgs = [np.frombuffer(im.tobytes(), dtype="uint8").reshape(im.height, im.width) for im in ds["image"]]
+    return torch.from_numpy(np.stack(imgs))[:, None]
+
+
+def main(args):
+    if args.encodings is not None or args.vae is not None:
+        raise NotImplementedError("conditional / latent training is outside this path")
+    if args.mixed_precision != "no":
+        raise NotImplementedError("only fp32 training is implemented (mixed_precision='no', the reference default)")
+    if args.gradient_accumulation_steps != 1:
+        raise NotImplementedError("gradient accumulation is not implemented (288 GB HBM fits batch 16+ at 256x256)")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = torch.cuda.is_available()
+    if on_gpu:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+    if world > 1:
+        dist.init_process_group("nccl" if on_gpu else "gloo")
+    output_dir = os.environ.get("SM_MODEL_DIR", None) or args.output_dir
+
+    resolution = (args.resolution, args.resolution) if isinstance(args.resolution, int) else args.resolution
+    images = load_images(args, resolution)                         # (N,1,H,W) uint8
+    resolution = tuple(images.shape[2:])
+    if args.from_pretrained is not None:
+        pipeline = AudioDiffusionPipeline.from_pretrained(args.from_pretrained)
+        mel, model = pipeline.mel, pipeline.unet
+    else:
+        model = UNet2DModel(sample_size=resolution, in_channels=1, out_channels=1, layers_per_block=2,
+                            block_out_channels=(128, 128, 256, 256, 512, 512),
+                            down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
+                            up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4).init_random(args.seed)
+        mel = Mel(x_res=resolution[1], y_res=resolution[0], hop_length=args.hop_length, sample_rate=args.sample_rate,
+                  n_fft=args.n_fft)
+    noise_scheduler = (DDPMScheduler if args.scheduler == "ddpm" else DDIMScheduler)(num_train_timesteps=args.num_train_steps)
+
+    flat, grads = model.enable_training(resolution)              # identical init on every rank (same seed / checkpoint)
+    optimizer = T.AdamW(flat, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
+                        weight_decay=args.adam_weight_decay, eps=args.adam_epsilon)
+    n_local = len(images) // world
+    steps_per_epoch = n_local // args.train_batch_size
+    lr_scheduler = T.LambdaLR(optimizer, T.get_cosine_schedule_with_warmup(args.lr_warmup_steps, steps_per_epoch * args.num_epochs)
+                              if args.lr_scheduler == "cosine" else (lambda s: 1.0))
+    ema = T.EMAModel(flat, inv_gamma=args.ema_inv_gamma, power=args.ema_power, max_value=args.ema_max_decay) if args.use_ema else None
+    reducer = T.GradAllReducer(grads)
+
+    global_step = 0
+    for epoch in range(args.num_epochs):
+        if epoch < args.start_epoch:                               # train_unet.py:216-224: replay the LR schedule
+            for _ in range(steps_per_epoch):
+                lr_scheduler.step()
+                global_step += 1
+            if ema is not None:
+                ema.optimization_step = global_step
+            continue
+        g = torch.Generator().manual_seed(args.seed + epoch)
+        perm = torch.randperm(len(images), generator=g)[rank::world]   # DataLoader(shuffle=True), sharded by rank
+        t0, seen = time.perf_counter(), 0
+        for it in range(steps_per_epoch):
+            idx = perm[it * args.train_batch_size:(it + 1) * args.train_batch_size]
+            clean = (images[idx].to(dev).float() / 255.0 - 0.5) / 0.5     # ToTensor + Normalize([0.5],[0.5]) (:73-78)
+            noise = torch.randn(clean.shape).to(dev)                          # CPU RNG then H2D, as :238
+            timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (clean.shape[0],)).long()
+            noisy = noise_scheduler.add_noise(clean.contiguous(), noise, timesteps)
+            loss = model.train_step(noisy, timesteps, noise)
+            reducer.start()
+            reducer.finish()
+            clip = T.clip_grad_norm_(grads, 1.0)
+            optimizer.step(grads, clip=clip, ema=ema, ema_decay=ema.next_decay() if ema is not None else 0.0)
+            lr_scheduler.step()
+            model.refresh_weights()
+            global_step += 1
+            seen += clean.shape[0] * world
+            if rank == 0 and (it % args.log_every == 0 or it == steps_per_epoch - 1):
+                print(f"epoch {epoch} step {global_step} loss {float(loss):.5f} lr {lr_scheduler.get_last_lr()[0]:.3e} "
+                      f"ema_decay {ema.cur_decay_value if ema else 0:.5f} {seen / (time.perf_counter() - t0):.1f} samples/s",
+                      flush=True)
+        if world > 1:
+            dist.barrier()
+        if rank == 0 and ((epoch + 1) % args.save_model_epochs == 0 or epoch == args.num_epochs - 1):
+            if ema is not None:
+                ema.copy_to(flat)                                   # train_unet.py:292-294: EMA weights go INTO the live model
+                model.refresh_weights()
+            model.sync_state_dict_from_flat()
+            AudioDiffusionPipeline(vqvae=None, unet=model, mel=mel, scheduler=noise_scheduler).save_pretrained(output_dir)
+        if world > 1:
+            dist.broadcast(flat, src=0)                             # keep replicas identical after the EMA copy
+            model.refresh_weights()
+            dist.barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser(description="MI355X-native training script (reference: scripts/train_unet.py).")
+    parser.add_argument("--local_rank", type=int, default=-1)
+    parser.add_argument("--dataset_name", type=str, default="synthetic")
+    parser.add_argument("--dataset_config_name", type=str, default=None)
+    parser.add_argument("--output_dir", type=str, default="ddpm-model-64")
+    parser.add_argument("--overwrite_output_dir", type=bool, default=False)
+    parser.add_argument("--cache_dir", type=str, default=None)
+    parser.add_argument("--train_batch_size", type=int, default=16)
+    parser.add_argument("--eval_batch_size", type=int, default=16)
+    parser.add_argument("--num_epochs", type=int, default=100)
+    parser.add_argument("--save_images_epochs", type=int, default=10)
+    parser.add_argument("--save_model_epochs", type=int, default=10)
+    parser.add_argument("--gradient_accumulation_steps", type=int, default=1)
+    parser.add_argument("--learning_rate", type=float, default=1e-4)
+    parser.add_argument("--lr_scheduler", type=str, default="cosine")
+    parser.add_argument("--lr_warmup_steps", type=int, default=500)
+    parser.add_argument("--adam_beta1", type=float, default=0.95)
+    parser.add_argument("--adam_beta2", type=float, default=0.999)
+    parser.add_argument("--adam_weight_decay", type=float, default=1e-6)
+    parser.add_argument("--adam_epsilon", type=float, default=1e-08)
+    parser.add_argument("--use_ema", type=bool, default=True)
+    parser.add_argument("--ema_inv_gamma", type=float, default=1.0)
+    parser.add_argument("--ema_power", type=float, default=3 / 4)
+    parser.add_argument("--ema_max_decay", type=float, default=0.9999)
+    parser.add_argument("--mixed_precision", type=str, default="no", choices=["no", "fp16", "bf16"])
+    parser.add_argument("--hop_length", type=int, default=512)
+    parser.add_argument("--sample_rate", type=int, default=22050)
+    parser.add_argument("--n_fft", type=int, default=2048)
+    parser.add_argument("--from_pretrained", type=str, default=None)
+    parser.add_argument("--start_epoch", type=int, default=0)
+    parser.add_argument("--num_train_steps", type=int, default=1000)
+    parser.add_argument("--scheduler", type=str, default="ddpm", help="ddpm or ddim")
+    parser.add_argument("--vae", type=str, default=None)
+    parser.add_argument("--encodings", type=str, default=None)
+    # additions (not in the reference)
+    parser.add_argument("--resolution", type=int, default=256, help="image size of the synthetic dataset")
+    parser.add_argument("--synthetic_size", type=int, default=2048)
+    parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--log_every", type=int, default=10)
+    main(parser.parse_args())

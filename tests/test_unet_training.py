@@ -65,3 +65,59 @@ def test_forward_backward_matches_autograd(backend, cfg, B):
     loss2 = mine.train_step(x.to(dev), ts, tgt.to(dev))
     assert abs(float(loss2) - float(loss2_ref.detach())) <= 1e-4 * float(loss2_ref.detach())
     assert float(loss2) < float(loss)
+
+
+# ---------------------------------------------------------------- data-parallel equivalence
+def _ddp_worker(rank, world, port, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "audio-diffusion_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      ADM_EMU_THREADS="2")
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from native_backend import select
+    select("emu")
+    from audiodiffusion import training as T
+    from audiodiffusion.unet import UNet2DModel
+    m = UNet2DModel(**TINY).init_random(0)
+    flat, grads = m.enable_training()
+    g = torch.Generator().manual_seed(1)
+    x, tgt = torch.randn(4, 1, 16, 16, generator=g), torch.randn(4, 1, 16, 16, generator=g)
+    ts = torch.tensor([5, 500, 999, 250])
+    sl = slice(rank * 2, rank * 2 + 2)
+    m.train_step(x[sl].contiguous(), ts[sl], tgt[sl].contiguous())
+    r = T.GradAllReducer(grads, bucket_mb=0.05)
+    r.start(), r.finish()
+    if rank == 0:
+        q.put(grads.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_equal_full_batch():
+    """2 ranks x (B/2) with the bucketed all-reduce == 1 rank x B, to fp32 tolerance (DDP semantics, train_unet.py:259)."""
+    import os
+    import torch.multiprocessing as mp
+    select("emu")
+    from audiodiffusion.unet import UNet2DModel
+    m = UNet2DModel(**TINY).init_random(0)
+    flat, grads = m.enable_training()
+    g = torch.Generator().manual_seed(1)
+    x, tgt = torch.randn(4, 1, 16, 16, generator=g), torch.randn(4, 1, 16, 16, generator=g)
+    m.train_step(x, torch.tensor([5, 500, 999, 250]), tgt)
+    full = grads.clone()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert float((got - full).abs().max()) <= 2e-5 * float(full.abs().max())
