@@ -47,7 +47,62 @@ def parse():
     p.add_argument("--ddim-steps", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--mode", choices=["sample", "train"], default="sample",
+                   help="sample (default): BASELINE.json's metric. train: config 5 (scripts/train_unet.py step, fp32).")
+    p.add_argument("--train-batch-per-gpu", type=int, default=16)
     return p.parse_args()
+
+
+def train_main(a, world, rank, dev):
+    """Extra (non-default) leg: one step = fused add_noise + native UNet forward+backward + bucketed gradient all-reduce +
+    clip + fused AdamW/EMA + weight re-pack at 256x256, fp32, batch 16 per GPU, synthetic data (BASELINE.json config 5)."""
+    from audiodiffusion import DDPMScheduler, UNet2DModel
+    from audiodiffusion import training as T
+    B = a.train_batch_per_gpu
+    unet = UNet2DModel(**CFG256).init_random(0)
+    flat, grads = unet.enable_training()
+    opt, ema, red = T.AdamW(flat), T.EMAModel(flat), T.GradAllReducer(grads)
+    sched = DDPMScheduler()
+    g = torch.Generator().manual_seed(7 + rank)
+    clean = (torch.rand(B, 1, 256, 256, generator=g) * 2 - 1).to(dev)
+    noise = torch.randn(B, 1, 256, 256, generator=g).to(dev)
+    ts = torch.randint(0, 1000, (B,), generator=g)
+
+    def step():
+        noisy = sched.add_noise(clean, noise, ts)
+        loss = unet.train_step(noisy, ts, noise)
+        red.start(), red.finish()
+        opt.step(grads, clip=T.clip_grad_norm_(grads, 1.0), ema=ema, ema_decay=ema.next_decay())
+        unet.refresh_weights()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    sync()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        elapsed = float(el.item())
+        value = world * B * a.steps / elapsed
+        print(json.dumps({
+            "metric": "training samples/sec (256x256 UNet2D, fwd+bwd+AdamW+EMA)", "value": round(value, 3),
+            "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"scripts/train_unet.py step, 256x256, batch {B}/GPU, fp32 (reference default mixed_precision=no)",
+                       "global_batch": world * B, "parallelism": f"data parallel x{world}, bucketed RCCL all-reduce"},
+            "fp32_TFLOPs_3x_fwd": round(value * 3 * F1_TFLOP / world, 2), "final_loss": float(loss)}), flush=True)
 
 
 def cpu_baseline(sd, n_threads):
@@ -121,6 +176,13 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    if a.mode == "train":
+        train_main(a, world, rank, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, Mel, UNet2DModel
     unet = UNet2DModel(**CFG256).init_random(0)          # identical seeded weights on every rank

@@ -36,7 +36,7 @@ def _worker(rank, world, port, kind, q):
     pipe = _pipe(kind)
     out, (lo, hi) = sample_sharded(pipe, global_batch=3, steps=2, seed=5)
     if rank == 0:
-        q.put((out.cpu().clone(), (lo, hi)))
+        q.put((out.cpu().numpy().copy(), (lo, hi)))  # by value: the producer may exit before the parent reads
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,6 +53,7 @@ def test_sharded_sampling_matches_single_process(kind):
     for p in procs:
         p.start()
     out, (lo, hi) = q.get(timeout=600)
+    out = torch.from_numpy(out)
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0

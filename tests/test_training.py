@@ -88,7 +88,7 @@ def _worker(rank, world, port, q):
     r = GradAllReducer(g, bucket_mb=1 / 16)  # 16384-float buckets -> several buckets in flight
     r.start(), r.finish()
     if rank == 0:
-        q.put(g.clone())
+        q.put(g.numpy().copy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,7 +100,7 @@ def test_grad_allreduce_gloo_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = q.get(timeout=120)
+    out = torch.from_numpy(q.get(timeout=120))
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0

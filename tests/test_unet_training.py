@@ -93,7 +93,7 @@ def _ddp_worker(rank, world, port, q):
     r = T.GradAllReducer(grads, bucket_mb=0.05)
     r.start(), r.finish()
     if rank == 0:
-        q.put(grads.clone())
+        q.put(grads.cpu().numpy().copy())  # by value: the producer may exit before the parent reads
     dist.barrier()
     dist.destroy_process_group()
 
@@ -116,7 +116,7 @@ def test_data_parallel_gradients_equal_full_batch():
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=600)
+    got = torch.from_numpy(q.get(timeout=600))
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
