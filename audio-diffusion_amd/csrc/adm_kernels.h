@@ -38,6 +38,7 @@ void set_last_conv_variant(int v);
 // k_conv_wino.hip
 int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st);
 bool winograd_enabled();
+void set_winograd_mode(int m);  // 0 off, 1 Winograd v1, 2 wave-specialised Winograd v2
 bool winograd_eligible(const adm_conv_args& a);
 int launch_conv_winograd(const adm_conv_args& a, hipStream_t st);
 

@@ -16,6 +16,10 @@
 // async global->LDS copy of 16 B per lane: LDS destination = wave-uniform base + lane*16 (guide §5)
 #define ADM_GLDS16(gptr, lds_wave_base) \
   memcpy(reinterpret_cast<char*>(lds_wave_base) + (adm_emu::flat_tid() & 63) * 16, (gptr), 16)
+// workgroup barrier that lets the newest N vector-memory loads of this wave stay in flight (emulation: plain barrier)
+#define ADM_BARRIER_KEEP_VMEM(N) __syncthreads()
+#define ADM_SCHED_FENCE() ((void)0)
+#define ADM_RCP(x) (1.0f / (x))
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -29,6 +33,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ADM_GLDS16(gptr, lds_wave_base)                                                               \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),             \
                                    (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+// Raw s_barrier with a COUNTED vmcnt: everything older than the newest N VMEM operations of this wave (in particular an
+// LDS-DMA issued before them) has landed, the newest N loads keep flying across the barrier; LDS traffic is drained.
+// (__syncthreads() would emit vmcnt(0) whenever an LDS-DMA is outstanding and drain the prefetch as well; guide §5.)
+#define ADM_SCHED_FENCE()                  \
+  do {                                     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+// v_rcp_f32 (1 ulp) instead of the ~12-instruction IEEE division sequence that `/` and __fdividef expand to
+#define ADM_RCP(x) __builtin_amdgcn_rcpf(x)
+#define ADM_BARRIER_KEEP_VMEM(N)                                            \
+  do {                                                                      \
+    asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory");        \
+    __builtin_amdgcn_s_barrier();                                           \
+    asm volatile("" ::: "memory");                                          \
+  } while (0)
 #endif
 
 namespace adm {

@@ -39,7 +39,7 @@ struct ConvParams {
   long x1_bs, x2_bs, wp_bs;  // batch strides (elements) of x1/x2 (channel-slice views) and of per-sample weights (0: shared)
 };
 
-__device__ __forceinline__ float silu_f(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
 
 
 // Epilogue for one 32x32 accumulator tile: batch all loads (bias, time-embedding bias, residual) before use.
@@ -345,6 +345,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
   const int nchunks = Ct / CKP;
   issue(0, 0);
   for (int ci = 0; ci < nchunks; ++ci) {
+#if !defined(ADM_EMU)
+    __builtin_amdgcn_s_setprio(3);   // the short stash/issue phase should not queue behind the other workgroup's MFMAs
+#endif
     if (qv) {
       const bool live = soff >= 0;
       ADM_UNROLL
@@ -357,6 +360,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
     }
     __syncthreads();  // also drains the LDS-DMA of this chunk's weight slab (issued one chunk ago)
     if (ci + 1 < nchunks) issue((ci + 1) * CKP, (ci + 1) & 1);
+#if !defined(ADM_EMU)
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const float* ldsW = ldsW0 + (ci & 1) * WSLAB;
     ADM_UNROLL
     for (int tap = 0; tap < KS2; ++tap) {

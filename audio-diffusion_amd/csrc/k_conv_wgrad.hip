@@ -27,7 +27,7 @@ struct WgradParams {
   long x1_bs, x2_bs;
 };
 
-__device__ __forceinline__ float silu_g(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_g(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
 
 template <int KS, int STRIDE>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p) {

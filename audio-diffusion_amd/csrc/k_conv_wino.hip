@@ -31,7 +31,7 @@ struct WinoParams {
   long x1_bs, x2_bs;
 };
 
-__device__ __forceinline__ float silu_w(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_w(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
 
 constexpr int WCK = 8;            // input channels per chunk
 constexpr int WPH = 10, WPW = 18; // haloed patch of an 8x16 output tile
@@ -226,6 +226,258 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// v2: wave-specialised Winograd kernel. 512 threads = 8 waves per workgroup (one workgroup per CU):
+//   waves 0-3 (consumers): wave w owns xi = 4w..4w+3 x two 32-cout groups = 8 accumulator fragments (128 VGPRs) and
+//       issues nothing but LDS operand reads and 32 MFMAs per 8-channel chunk;
+//   waves 4-7 (producers): thread (channel c = t>>5, Winograd tile = t&31) loads the 4x4 input window of the NEXT chunk
+//       straight from global memory (L1/L2 absorb the 4x window overlap), applies GroupNorm affine + SiLU + zero padding,
+//       transforms it (V = B^T d B) in registers and writes the 16 V values to the other half of a double buffer; the
+//       same waves stream the next chunk's U slab (8 ch x 16 xi x 64 couts) L2 -> LDS with global_load_lds.
+// One __syncthreads per chunk; MFMA and VALU/LDS/VMEM pipes of each SIMD are fed by different waves, so the matrix
+// pipe only waits when the producers are slower than 32 MFMAs (2048 cycles).
+constexpr int W2BM = 64;
+constexpr int W2USLAB = WCK * 16 * W2BM;   // 8192 floats = 32 KiB
+constexpr int W2VSLAB = 16 * WCK * 32;     // 4096 floats = 16 KiB
+
+template <bool HAS_CHAN, bool HAS_RES>
+__device__ __forceinline__ void wino2_store(const WinoParams& p, const float* ldsM, int tid, int m0, int n, int ty0,
+                                            int tx0) {
+  const long planeO = (long)p.Ho * p.Wo;
+  ADM_UNROLL
+  for (int k = 0; k < 4; ++k) {
+    const int pair = tid + 512 * k;            // 2048 (cout, tile) pairs
+    const int co_l = pair >> 5, tile = pair & 31;
+    const int tyy = tile >> 3, txx = tile & 7;
+    float m[16];
+    ADM_UNROLL
+    for (int xi = 0; xi < 16; ++xi) m[xi] = ldsM[(xi * W2BM + co_l) * 32 + tile];
+    float t0[4], t1[4];
+    ADM_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      t0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+      t1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+    }
+    float y[2][2];
+    y[0][0] = t0[0] + t0[1] + t0[2]; y[0][1] = t0[1] - t0[2] - t0[3];
+    y[1][0] = t1[0] + t1[1] + t1[2]; y[1][1] = t1[1] - t1[2] - t1[3];
+    const int co = m0 + co_l;
+    const float b = p.bias[co] + (HAS_CHAN ? p.chan_add[(long)n * p.chan_add_stride + co] : 0.f);
+    const int oy = ty0 + 2 * tyy, ox = tx0 + 2 * txx;
+    ADM_UNROLL
+    for (int a = 0; a < 2; ++a) {
+      const long o = ((long)n * p.Cout + co) * planeO + (long)(oy + a) * p.Wo + ox;
+      float2 v = make_float2(y[a][0] + b, y[a][1] + b);
+      if (HAS_RES) {
+        const float2 r = *reinterpret_cast<const float2*>(p.residual + o);
+        v.x += r.x; v.y += r.y;
+      }
+      *reinterpret_cast<float2*>(p.out + o) = v;
+    }
+  }
+}
+
+struct Wino2Geom {
+  int n, ty, tx, m0, Ct, planeS, nchunks;
+};
+
+// Producer role (waves 4..7): stage V (transformed activations) and U (filters) of chunk c+1 while chunk c is consumed.
+// Barrier protocol (every wave of the workgroup executes the same NUMBER of barriers): 1 after the prologue, 1 per
+// chunk, 1 after the consumers' fragment stash.
+template <bool HAS_GN>
+__device__ __forceinline__ void wino2_producer(const WinoParams& p, const Wino2Geom& g, float* ldsV, float* ldsU,
+                                               int tid, int wave) {
+  const int pt_id = tid & 255;
+  const int pc = pt_id >> 5, ptile = pt_id & 31;
+  // source offsets of the 4x4 window inside a channel plane (clamped to 0 where the window leaves the image: the load
+  // is then unconditional — the counted barrier below relies on an exact VMEM instruction count — and the value is
+  // zeroed after the activation through `wvalid`)
+  int woff[16];
+  unsigned wvalid = 0;
+  {
+    const int gy0 = g.ty * 8 + 2 * (ptile >> 3) - 1, gx0 = g.tx * 16 + 2 * (ptile & 7) - 1;
+    ADM_UNROLL
+    for (int i = 0; i < 4; ++i)
+      ADM_UNROLL
+      for (int j = 0; j < 4; ++j) {
+        const int gy = gy0 + i, gx = gx0 + j;
+        const bool ok = gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+        const int sy = p.up ? (gy >> 1) : gy, sx = p.up ? (gx >> 1) : gx;
+        woff[i * 4 + j] = ok ? sy * p.Ws + sx : 0;
+        wvalid |= ok ? 1u << (i * 4 + j) : 0u;
+      }
+  }
+  constexpr bool has_gn = HAS_GN;         // compile-time: the producer's VMEM instruction count must be exact
+  // two window register sets: while set A (chunk c+1) is transformed, set B (chunk c+2) is already in flight
+  float xwA[16], xwB[16];
+  float gscA = 1.f, gshA = 0.f, gscB = 1.f, gshB = 0.f;
+  auto load_window = [&](int ci, float (&xw)[16], float& gsc, float& gsh) {   // raw 4x4 window + GN scale/shift
+    const int cc = ci * WCK + pc;
+    const float* src = cc < p.C1 ? p.x1 + (long)g.n * p.x1_bs + (long)cc * g.planeS
+                                 : p.x2 + (long)g.n * p.x2_bs + (long)(cc - p.C1) * g.planeS;
+    ADM_UNROLL
+    for (int i = 0; i < 16; ++i) xw[i] = src[woff[i]];
+    if (has_gn) { gsc = p.gn_scale[(long)g.n * g.Ct + cc]; gsh = p.gn_shift[(long)g.n * g.Ct + cc]; }
+  };
+  auto transform_store = [&](int ci, const float (&xw)[16], float gsc, float gsh) {   // window -> ldsV[ci & 1]
+    float d[16];
+    ADM_UNROLL
+    for (int i = 0; i < 16; ++i) {
+      float v = xw[i] * gsc + gsh;
+      const float sv = silu_w(v);
+      v = p.act ? sv : v;
+      d[i] = ((wvalid >> i) & 1u) ? v : 0.f;     // zero padding is applied after the activation
+    }
+    float t[4][4];
+    ADM_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = d[0 * 4 + j] - d[2 * 4 + j];
+      t[1][j] = d[1 * 4 + j] + d[2 * 4 + j];
+      t[2][j] = d[2 * 4 + j] - d[1 * 4 + j];
+      t[3][j] = d[1 * 4 + j] - d[3 * 4 + j];
+    }
+    float* vdst = ldsV + (ci & 1) * W2VSLAB + pc * 32 + ptile;
+    ADM_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      vdst[(i * 4 + 0) * (WCK * 32)] = t[i][0] - t[i][2];
+      vdst[(i * 4 + 1) * (WCK * 32)] = t[i][1] + t[i][2];
+      vdst[(i * 4 + 2) * (WCK * 32)] = t[i][2] - t[i][1];
+      vdst[(i * 4 + 3) * (WCK * 32)] = t[i][1] - t[i][3];
+    }
+  };
+  // prologue: chunk 0 transformed, chunk 1 window in flight
+  load_window(0, xwA, gscA, gshA);
+  transform_store(0, xwA, gscA, gshA);
+  load_window(1, xwB, gscB, gshB);
+  ADM_BARRIER_KEEP_VMEM(63);
+  // The chunk loop is unrolled by two (nchunks is even, checked by the launcher) with its last pair peeled, so the
+  // instruction stream is branch-free: the window loads of chunk c+2 go into the register set that is NOT being
+  // transformed and stay in flight across the barrier (vmcnt(63) = no vector-memory wait; the compiler's own counted
+  // waits sit at the first use). The producers issue no LDS-DMA: next to one, hipcc waits vmcnt(0) for every plain load.
+  int ci = 0;
+  for (; ci + 2 < g.nchunks; ci += 2) {
+    load_window(ci + 2, xwA, gscA, gshA);
+    transform_store(ci + 1, xwB, gscB, gshB);
+    ADM_BARRIER_KEEP_VMEM(63);
+    load_window(ci + 3, xwB, gscB, gshB);
+    transform_store(ci + 2, xwA, gscA, gshA);
+    ADM_BARRIER_KEEP_VMEM(63);
+  }
+  transform_store(ci + 1, xwB, gscB, gshB);   // last pair: chunk nchunks-1 is the only operand still to be staged
+  ADM_BARRIER_KEEP_VMEM(0);                // chunk ci consumed, chunk ci+1 staged
+  ADM_BARRIER_KEEP_VMEM(0);                // chunk ci+1 consumed: operand buffers are dead
+  ADM_BARRIER_KEEP_VMEM(0);                // consumers' fragments are in ldsM
+}
+
+// Consumer role (waves 0..3): wave w owns transform points 4w..4w+3, all 64 couts, all 32 tiles: 8 accumulator
+// fragments (128 VGPRs), 32 MFMAs per chunk.
+__device__ __forceinline__ void wino2_consumer(const WinoParams& p, const Wino2Geom& g, const float* ldsV, float* ldsU,
+                                               float* ldsM, int tid, int wave) {
+  const int lane = tid & 63;
+  const int l31 = lane & 31, h = lane >> 5;
+  auto issue_u = [&](int ci) {             // U slab of chunk ci -> ldsU[ci & 1]: 2048 float4 by 256 threads, LDS-DMA
+    const float* usrc = p.wu + (long)ci * WCK * 16 * p.Cout + g.m0;
+    float* udst = ldsU + (ci & 1) * W2USLAB;
+    ADM_UNROLL
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 4, c4 = idx & 15;
+      ADM_GLDS16(usrc + (long)row * p.Cout + c4 * 4, udst + (256 * i + wave * 64) * 4);
+    }
+  };
+  issue_u(0);
+  f32x16 acc[4][2];
+  ADM_UNROLL
+  for (int a = 0; a < 4; ++a)
+    ADM_UNROLL
+    for (int f = 0; f < 2; ++f)
+      ADM_UNROLL
+      for (int r = 0; r < 16; ++r) acc[a][f][r] = 0.f;
+  // Per chunk: 4 transform points x 4 channel pairs x 2 cout fragments = 32 MFMAs on 48 operand words. The words are
+  // read into registers FIRST, then the barrier (which frees both operand buffers of this chunk for the producers and
+  // for the next-but-one U slab), then the LDS-DMA of chunk c+2, then the MFMAs from registers: the matrix pipe works
+  // while the producers transform and the DMA flies, and the LDS latency is paid once per chunk instead of per MFMA pair
+  // (read -> wait -> MFMA pair interleaving held the pipe at ~45 %).
+  ADM_BARRIER_KEEP_VMEM(0);                // prologue done: U(0), V(0) in place
+  if (g.nchunks > 1) issue_u(1);
+  for (int ci = 0; ci < g.nchunks; ++ci) {
+    const float* U = ldsU + (ci & 1) * W2USLAB;
+    const float* V = ldsV + (ci & 1) * W2VSLAB;
+    float bv[4][WCK / 2], a0[4][WCK / 2], a1[4][WCK / 2];
+    ADM_UNROLL
+    for (int a = 0; a < 4; ++a) {
+      const int xi = wave * 4 + a;
+      ADM_UNROLL
+      for (int cp = 0; cp < WCK / 2; ++cp) {
+        const int ch = 2 * cp + h;
+        bv[a][cp] = V[(xi * WCK + ch) * 32 + l31];
+        a0[a][cp] = U[(ch * 16 + xi) * W2BM + l31];
+        a1[a][cp] = U[(ch * 16 + xi) * W2BM + 32 + l31];
+      }
+    }
+    ADM_BARRIER_KEEP_VMEM(0);              // operands of chunk ci are in registers; U(ci+1) (this wave's part) landed
+    if (ci + 2 < g.nchunks) issue_u(ci + 2);
+    ADM_SCHED_FENCE();
+    ADM_UNROLL
+    for (int a = 0; a < 4; ++a) {
+      ADM_UNROLL
+      for (int cp = 0; cp < WCK / 2; ++cp) {
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[a][cp], bv[a][cp], acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[a][cp], bv[a][cp], acc[a][1], 0, 0, 0);
+      }
+    }
+  }
+  // fragments -> ldsM [xi][cout][tile] (aliases the operand buffers, dead after the barrier above)
+  ADM_UNROLL
+  for (int a = 0; a < 4; ++a) {
+    const int xi = wave * 4 + a;
+    ADM_UNROLL
+    for (int f = 0; f < 2; ++f)
+      ADM_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int co_l = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        ldsM[(xi * W2BM + co_l) * 32 + l31] = acc[a][f][r];
+      }
+  }
+  ADM_BARRIER_KEEP_VMEM(0);
+}
+
+__global__ void __launch_bounds__(512, 2) conv_wino2_kernel(const WinoParams p) {
+  ADM_DYN_SMEM(float, smem);
+  float* ldsV = smem;                       // 2 * W2VSLAB
+  float* ldsU = smem + 2 * W2VSLAB;         // 2 * W2USLAB
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  int lid;
+  {
+    const int b = blockIdx.x, q = p.nblk >> 3, r = p.nblk & 7, xcd = b & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int ct = lid % p.n_ct, pt = lid / p.n_ct;
+  Wino2Geom g;
+  g.tx = pt % p.tiles_x; g.ty = (pt / p.tiles_x) % p.tiles_y; g.n = pt / (p.tiles_x * p.tiles_y);
+  g.m0 = ct * W2BM;
+  g.Ct = p.C1 + p.C2;
+  g.planeS = p.Hs * p.Ws;
+  g.nchunks = g.Ct / WCK;
+  // roles are wave-uniform; each role has its own register allocation (the accumulators live only in the consumers)
+  if (wave >= 4) {
+    if (p.gn_scale != nullptr) wino2_producer<true>(p, g, ldsV, ldsU, tid, wave);
+    else wino2_producer<false>(p, g, ldsV, ldsU, tid, wave);
+  } else wino2_consumer(p, g, ldsV, ldsU, smem, tid, wave);
+  // ---- epilogue: inverse transform of ldsM (128 KiB) by all 512 threads ------------------------------------------
+  const float* ldsM = smem;
+  if (p.chan_add != nullptr) {
+    if (p.residual != nullptr) wino2_store<true, true>(p, ldsM, tid, g.m0, g.n, g.ty * 8, g.tx * 16);
+    else wino2_store<true, false>(p, ldsM, tid, g.m0, g.n, g.ty * 8, g.tx * 16);
+  } else {
+    if (p.residual != nullptr) wino2_store<false, true>(p, ldsM, tid, g.m0, g.n, g.ty * 8, g.tx * 16);
+    else wino2_store<false, false>(p, ldsM, tid, g.m0, g.n, g.ty * 8, g.tx * 16);
+  }
+}
+
+
 // (Cout,Cin,3,3) -> U = G g G^T laid out [Cin][16][Cout]; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 __global__ void pack_winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin) {
   const long total = (long)Cout * Cin;
@@ -255,10 +507,14 @@ int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hi
   return ADM_CHECK_LAUNCH();
 }
 
-bool winograd_enabled() {
-  static const int v = [] { const char* e = getenv("ADM_CONV_WINO"); return e ? atoi(e) : 0; }();
-  return v != 0;
+
+static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment on first use
+void set_winograd_mode(int m) { g_wino_mode = m; }
+static int wino_mode() {
+  if (g_wino_mode < 0) { const char* e = getenv("ADM_CONV_WINO"); g_wino_mode = e ? atoi(e) : 0; }
+  return g_wino_mode;
 }
+bool winograd_enabled() { return wino_mode() != 0; }
 
 // Eligibility: 3x3 stride 1 "same", output at least 8x16 with Wo % 16 == 0 and Ho % 8 == 0, Cin % 8, Cout % 32.
 bool winograd_eligible(const adm_conv_args& a) {
@@ -286,7 +542,22 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
   p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
-  const size_t smem = sizeof(float) * 16 * WBM * 32;  // 64 KiB >= main-loop need (1472 + 2*4096 + 2*4096 floats = 71.4 KB?)
+  if (wino_mode() == 2 && a.Cout % W2BM == 0 && (a.C1 + C2) % (2 * WCK) == 0) {   // wave-specialised kernel (even chunk count)
+    p.n_ct = a.Cout / W2BM;
+    p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
+    const size_t need2 = sizeof(float) * 16 * W2BM * 32;  // 128 KiB (epilogue) >= 2*16 + 2*32 KiB (main loop)
+#if !defined(ADM_EMU)
+    static bool once2 = [] {
+      (void)hipFuncSetAttribute((const void*)conv_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      return true;
+    }();
+    (void)once2;
+#endif
+    set_last_conv_variant(4000 + 312);
+    ADM_LAUNCH(conv_wino2_kernel, dim3(p.nblk), dim3(512), need2, st, p);
+    return ADM_CHECK_LAUNCH();
+  }
+  const size_t smem = sizeof(float) * 16 * WBM * 32;  // 64 KiB
   const size_t main_need = sizeof(float) * (1472 + 2 * WVSLAB + 2 * WUSLAB);
   const size_t need = smem > main_need ? smem : main_need;
 #if !defined(ADM_EMU)

@@ -1,8 +1,4 @@
 """Winograd F(2x2,3x3) variant of the fused 3x3 convolution (opt-in, ADM_CONV_WINO=1) vs torch fp32."""
-import os
-
-os.environ["ADM_CONV_WINO"] = "1"  # read once by the library; only convs that pass `wino=` can take this path
-
 import pytest  # noqa: E402
 import torch  # noqa: E402
 
@@ -15,13 +11,27 @@ CASES = [
     (2, 32, 32, 16, 32, 64, 0, 1, 1, 0, 1),
     (1, 32, 0, 8, 8, 32, 1, 0, 0, 1, 0),      # upsample folded: 8x8 -> 16x16
     (1, 64, 0, 16, 16, 96, 0, 1, 0, 0, 0),
+    (1, 32, 0, 8, 8, 64, 1, 0, 0, 1, 0),      # v2-eligible: upsample folded, 64 couts
+    (2, 64, 0, 8, 16, 128, 0, 1, 1, 1, 1),    # v2-eligible: two cout tiles, all epilogue terms
 ]
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("mode", [1, 2], ids=["v1", "v2wavespec"])
 @pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
-def test_conv_winograd(backend, case):
+def test_conv_winograd(backend, case, mode):
     dev = select(backend)
+    from audiodiffusion import _native, ops
+    if mode == 2 and case[5] % 64 != 0:
+        pytest.skip("v2 tiles 64 output channels")
+    _native.check(_native.lib().adm_set_option(b"conv_wino", mode))
+    try:
+        _run_case(dev, case, 4311 if mode == 1 else 4312)
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_wino", 0))
+
+
+def _run_case(dev, case, want_variant):
     from audiodiffusion import _native, ops
     Nn, C1, C2, H, W, Cout, up, use_gn, act, use_temb, use_res = case
     x1 = _rand((Nn, C1, H, W), 1, dev)
@@ -36,7 +46,7 @@ def test_conv_winograd(backend, case):
     res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
     out = ops.conv2d(x1, ops.pack_conv_weight(w), b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb,
                      residual=res, wino=ops.pack_winograd_weight(w))
-    assert _native.lib().adm_last_conv_variant() == 4311, "the Winograd kernel was not selected"
+    assert _native.lib().adm_last_conv_variant() == want_variant, "the Winograd kernel was not selected"
     c = lambda t: None if t is None else t.cpu()  # noqa: E731
     ref = _conv_ref(c(x1), c(x2), c(w), c(b), 3, 1, up, (c(gamma), c(beta)) if use_gn else None, act, c(temb), c(res))
     assert out.shape == ref.shape
