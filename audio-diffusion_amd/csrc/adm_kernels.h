@@ -36,9 +36,10 @@ int last_conv_variant();
 void set_last_conv_variant(int v);
 
 // k_conv_wino.hip
+const float* conv_zero_bias(int n);  // shared all-zero device buffer of >= n floats (k_conv_mfma.hip)
 int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st);
 bool winograd_enabled();
-void set_winograd_mode(int m);  // 0 off, 1 Winograd v1, 2 wave-specialised Winograd v2
+void set_winograd_mode(int m);  // 0 off, 1 v1, 2 wave-specialised v2, 3 persistent v3 (default), -1 = default
 bool winograd_eligible(const adm_conv_args& a);
 int launch_conv_winograd(const adm_conv_args& a, hipStream_t st);
 

@@ -18,8 +18,11 @@
   memcpy(reinterpret_cast<char*>(lds_wave_base) + (adm_emu::flat_tid() & 63) * 16, (gptr), 16)
 // workgroup barrier that lets the newest N vector-memory loads of this wave stay in flight (emulation: plain barrier)
 #define ADM_BARRIER_KEEP_VMEM(N) __syncthreads()
+#define ADM_GLDS16_RAW(gptr, lds_wave_base) ADM_GLDS16(gptr, lds_wave_base)
+#define ADM_WAIT_VMEM(N) ((void)0)
 #define ADM_SCHED_FENCE() ((void)0)
 #define ADM_RCP(x) (1.0f / (x))
+#define ADM_UNIFORM(x) (x)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -33,6 +36,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ADM_GLDS16(gptr, lds_wave_base)                                                               \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),             \
                                    (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+// The same LDS-DMA written as inline asm: invisible to hipcc's wait-count insertion. Next to a builtin LDS-DMA the compiler
+// waits vmcnt(0) at the first use of ANY plain load (guide §5, "mixing load kinds"); hidden like this, its counted waits
+// for the wave's plain loads only see those loads — they over-wait by the DMA pieces in between (safe: vector memory
+// returns in order) and the DMA itself is drained by hand with ADM_WAIT_VMEM / ADM_BARRIER_KEEP_VMEM.
+#define ADM_GLDS16_RAW(gptr, lds_wave_base)                                                                        \
+  do {                                                                                                             \
+    const unsigned m0v_ = __builtin_amdgcn_readfirstlane(                                                          \
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lds_wave_base));                            \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v_), "v"(gptr) : "memory"); \
+  } while (0)
+#define ADM_WAIT_VMEM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 // Raw s_barrier with a COUNTED vmcnt: everything older than the newest N VMEM operations of this wave (in particular an
 // LDS-DMA issued before them) has landed, the newest N loads keep flying across the barrier; LDS traffic is drained.
 // (__syncthreads() would emit vmcnt(0) whenever an LDS-DMA is outstanding and drain the prefetch as well; guide §5.)
@@ -43,11 +57,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
   } while (0)
 // v_rcp_f32 (1 ulp) instead of the ~12-instruction IEEE division sequence that `/` and __fdividef expand to
 #define ADM_RCP(x) __builtin_amdgcn_rcpf(x)
+// a value known to be wave-uniform, moved to an SGPR so that tests on it become scalar branches
+#define ADM_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define ADM_BARRIER_KEEP_VMEM(N)                                            \
   do {                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                      \
     asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory");        \
     __builtin_amdgcn_s_barrier();                                           \
     asm volatile("" ::: "memory");                                          \
+    __builtin_amdgcn_sched_barrier(0);                                      \
   } while (0)
 #endif
 

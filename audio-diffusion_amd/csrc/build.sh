@@ -14,7 +14,7 @@ if [ "${1:-hip}" = "emu" ]; then
   mkdir -p "$root/tests/emu/obj"
   for s in "${srcs[@]}"; do
     o="$root/tests/emu/obj/${s%.hip}.o"
-    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ adm_rt.h -nt "$o" ] || [ adm_kernels.h -nt "$o" ] || [ "$root/tests/emu/hip_emu.h" -nt "$o" ] || [ "$root/include/adm.h" -nt "$o" ]; then
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ adm_rt.h -nt "$o" ] || [ adm_kernels.h -nt "$o" ] || [ net_exec.h -nt "$o" ] || [ "$root/tests/emu/hip_emu.h" -nt "$o" ] || [ "$root/include/adm.h" -nt "$o" ]; then
       g++ -O2 -g -std=c++17 -fPIC -DADM_EMU -I"$root/tests/emu" -x c++ -c "$s" -o "$o" -Wall -Wno-unknown-pragmas -Wno-unused-variable -Wno-unused-function -Wno-sign-compare -Wno-psabi &
     fi
     objs+=("$o")
@@ -28,7 +28,7 @@ else
   objs=()
   for s in "${srcs[@]}"; do
     o="$here/obj/${s%.hip}.o"
-    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ adm_rt.h -nt "$o" ] || [ adm_kernels.h -nt "$o" ] || [ "$root/include/adm.h" -nt "$o" ]; then
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ adm_rt.h -nt "$o" ] || [ adm_kernels.h -nt "$o" ] || [ net_exec.h -nt "$o" ] || [ "$root/include/adm.h" -nt "$o" ]; then
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" &
     fi
     objs+=("$o")

@@ -14,6 +14,8 @@
 // U is pre-transformed once per layer: [Cin][16][Cout] (pack_winograd_weight). Epilogue: all 16 M fragments go through
 // LDS, each thread applies A^T M A for 4 (cout, tile) pairs and stores 2x2 pixels.
 // Numerics: fp32 Winograd F(2,3) differs from direct summation by O(1e-6) relative — far inside the 1e-3 parity bar.
+#include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
 #include "adm_kernels.h"
@@ -29,6 +31,7 @@ struct WinoParams {
   const float* residual; float* out;
   int tiles_x, tiles_y, n_ct, nblk;
   long x1_bs, x2_bs;
+  unsigned long long* prof;   // optional cycle counters of the wave-specialised kernel (ADM_WINO_PROF=1), else NULL
 };
 
 __device__ __forceinline__ float silu_w(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
@@ -478,6 +481,412 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_kernel(const WinoParams p) 
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v3 — persistent, wave-specialised Winograd kernel (mode 3). What v2's measurements asked for:
+//   * the producers' per-thread 4x4 window gathers (16 dword loads, every input pixel fetched 4x, GN+SiLU applied 4x)
+//     saturated the CU's vector-memory path (-30 % when ablated): the raw haloed patch of a chunk (8 ch x 10 x 18) is now
+//     fetched ONCE with float4 row loads two chunks ahead, activated once, and staged in a small LDS patch buffer from
+//     which the 4x4 windows are read;
+//   * the 128 KiB LDS round trip of the inverse transform and the per-tile prologue/epilogue bubble (1 workgroup per CU,
+//     nothing to overlap with) are gone: consumers use v_mfma_f32_16x16x4_f32 with wave w owning ALL 16 Winograd points
+//     of a 32-cout x 16-tile sub-block, so A^T M A is lane-local (the 16 points of a (cout, tile) pair sit in the same
+//     lane/register slot of 16 accumulators) and outputs go straight from registers to HBM; workgroups are persistent
+//     (grid = #CUs, tiles strided) and the producers run into the next tile while the consumers finish the current one;
+//   * operand words are read 4 Winograd points ahead of the MFMAs that use them (rolling 24-register window), the
+//     per-chunk barrier sits where the last read of the chunk has long landed, so the matrix pipe never waits on LDS.
+// Barrier protocol (one workgroup barrier per 8-channel chunk; G = running chunk index over all tiles of the block):
+//   barrier G certifies  (a) V(G+1) is complete [producers], (b) every consumer has read chunk G into registers,
+//                        (c) each consumer's part of U(G+1) has landed (vmcnt(0) before its barrier).
+//   After it the producers write V(G+2) and the consumers DMA U(G+2) into the buffers chunk G occupied.
+// LDS: V 2x16 KiB + U 2x32 KiB + patch 2x5.6 KiB = 107.25 KiB. V and U images are swizzled by 16 words on odd channels so
+// the four k-rows of a 16x16x4 operand read hit disjoint banks.
+constexpr int W3BM = 64;
+constexpr int W3USLAB = WCK * 16 * W3BM;    // 8192 floats
+constexpr int W3VSLAB = 16 * WCK * 32;      // 4096 floats
+constexpr int W3PSLAB = WCK * WPH * WPW + 264;   // 1440 floats (x2-upsample variant: 480) + one dummy word per producer lane
+constexpr int W3LDS = 2 * W3VSLAB + 2 * W3USLAB + 2 * W3PSLAB;
+
+struct Wino3Tile { int n, ty, tx, m0; };
+
+__device__ __forceinline__ Wino3Tile wino3_tile(const WinoParams& p, int v) {
+  // bijective XCD-aware remap of the virtual block id (v & 7 == XCD of the persistent block that owns it)
+  const int q = p.nblk >> 3, r = p.nblk & 7, xcd = v & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+  const int ct = lid % p.n_ct, pt = lid / p.n_ct;
+  Wino3Tile t;
+  t.tx = pt % p.tiles_x; t.ty = (pt / p.tiles_x) % p.tiles_y; t.n = pt / (p.tiles_x * p.tiles_y);
+  t.m0 = ct * W3BM;
+  return t;
+}
+
+#if defined(ADM_EMU)
+#define W3_CLK() 0ull
+#define W3_BARRIER(N, prof, d, b) ADM_BARRIER_KEEP_VMEM(N)
+#else
+#define W3_CLK() ((unsigned long long)__builtin_readcyclecounter())
+// barrier with optional accounting of the cycles spent in the counter drain (slot d) and in the barrier itself (slot b)
+#define W3_BARRIER(N, prof, d, b)                                   \
+  do {                                                              \
+    if (PROF) {                                                     \
+      const unsigned long long t0_ = W3_CLK();                      \
+      asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); \
+      const unsigned long long t1_ = W3_CLK();                      \
+      ADM_BARRIER_KEEP_VMEM(N);                                     \
+      const unsigned long long t2_ = W3_CLK();                      \
+      (prof)[d] += t1_ - t0_; (prof)[b] += t2_ - t1_;               \
+    } else {                                                        \
+      ADM_BARRIER_KEEP_VMEM(N);                                     \
+    }                                                               \
+  } while (0)
+#endif
+
+// ---- producer role: 256 threads (waves 4..7) ------------------------------------------------------------------------
+// Issue budget: a wave issues at most one instruction every ~4 cycles, so a producer wave has ~400 issue slots per
+// 2048-cycle chunk and every scalar/branch/address instruction counts. Hence: per-tile (not per-chunk) 32-bit element
+// offsets against a wave-uniform chunk base pointer, no per-lane predication (disabled lanes write to dummy LDS words,
+// whole-wave roles are scalar branches), the tile cursor's integer divisions behind a real (non-speculated) branch.
+struct Wino3Raw {                     // one chunk's raw activations of this thread, prefetched two chunks ahead
+  float4 a, b;                        // item 0 / item 1 when it is a float4 row piece (UP: scalars in .x)
+  float h;                            // item 1 when it is a halo element
+  float sc0, sh0, sc1, sh1;           // GroupNorm scale / shift of the two items' channels
+  unsigned ok;                        // bit k: item k lies inside the image (zero padding otherwise)
+};
+
+template <bool UP, bool WIDE1, bool PROF>
+__device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV, float* ldsP, int tid, int b0, int bs) {
+  unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_start = W3_CLK();
+  const int Ct = p.C1 + p.C2;
+  const int planeS = p.Hs * p.Ws;
+  const int nch = Ct / WCK;
+  const int ntile = (p.nblk - b0 + bs - 1) / bs;
+  const int total = ntile * nch;      // chunks this workgroup stages
+  // Non-UP: every thread stages float4 row piece f = tid (item 0); producer wave 0 (WIDE1) also stages pieces 256..319,
+  // waves 1..3 the 160 halo elements (item 1) — the role is a template parameter so that no load sits under a runtime
+  // branch (a conditional load costs a register copy plus a premature vmcnt wait at the join). UP (source-resolution
+  // patch 8 x 6 x 10): two scalars e = tid and 256 + tid. Items beyond the patch go to a private dummy word.
+  constexpr bool wide1 = !UP && WIDE1;
+  int it_ch[2], it_row[2], it_col[2], it_pofs[2];
+  const int dummy = WCK * WPH * WPW + tid;
+  if (UP) {
+    ADM_UNROLL
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + 256 * k;
+      const bool en = e < 480;
+      const int ec = en ? e : 0;
+      it_ch[k] = ec / 60; it_row[k] = (ec % 60) / 10; it_col[k] = ec % 10;
+      it_pofs[k] = en ? ec : dummy;
+    }
+  } else {
+    const int row0 = tid >> 2, q0 = tid & 3;
+    it_ch[0] = row0 / WPH; it_row[0] = row0 % WPH; it_col[0] = 4 * q0;       // image x = tx*16 + col
+    it_pofs[0] = row0 * WPW + 1 + 4 * q0;
+    if (wide1) {
+      const int f = 256 + tid;
+      const int row = f >> 2, q = f & 3;
+      it_ch[1] = row / WPH; it_row[1] = row % WPH; it_col[1] = 4 * q;
+      it_pofs[1] = row * WPW + 1 + 4 * q;
+    } else {
+      const int hI = tid - 64;
+      const bool en = hI < 160;
+      const int hc = en ? hI : 0;
+      const int hrow = hc >> 1, side = hc & 1;
+      it_ch[1] = hrow / WPH; it_row[1] = hrow % WPH; it_col[1] = side ? 16 : -1;
+      it_pofs[1] = en ? hrow * WPW + (side ? 17 : 0) : dummy;
+    }
+  }
+  // stage C: window origin of this thread's (channel, tile) inside the patch
+  const int pc = tid >> 5, ptile = tid & 31;
+  const int tyy = ptile >> 3, txx = ptile & 7;
+  const int wbase = UP ? pc * 60 + tyy * 10 + txx : pc * WCS + 2 * tyy * WPW + 2 * txx;
+  const int vofs = pc * 32 + ((ptile + 16 * (pc & 1)) & 31);   // + xi * 256
+
+  // ---- stage A cursor: (tile, chunk) of the next global load ----------------------------------------------------------------
+  int a_v = b0, a_ci = 0, a_left = total;
+  int a_off0 = 0, a_off1 = 0;         // element offset of the items inside the sample: channel plane + row + column
+  unsigned a_ok = 0;
+  const float *a_x1 = nullptr, *a_x2 = nullptr, *a_gs = nullptr, *a_gh = nullptr;   // per-tile wave-uniform bases
+  auto a_geometry = [&]() {
+    const Wino3Tile t = wino3_tile(p, a_v);
+    a_x1 = p.x1 + (long)t.n * p.x1_bs;
+    a_x2 = p.x2 + (long)t.n * p.x2_bs - (long)p.C1 * planeS;     // indexed with the concatenated channel number
+    a_gs = p.gn_scale + (long)t.n * Ct;
+    a_gh = p.gn_shift + (long)t.n * Ct;
+    a_ok = 0;
+    int off[2];
+    ADM_UNROLL
+    for (int k = 0; k < 2; ++k) {
+      const int sy = UP ? t.ty * 4 - 1 + it_row[k] : t.ty * 8 - 1 + it_row[k];
+      const int sx = UP ? t.tx * 8 - 1 + it_col[k] : t.tx * 16 + it_col[k];
+      const bool ok = sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws;   // interior pieces: only the row can fall outside
+      off[k] = it_ch[k] * planeS + (ok ? sy * p.Ws + sx : 0);
+      a_ok |= ok ? 1u << k : 0u;
+    }
+    a_off0 = off[0]; a_off1 = off[1];
+  };
+  a_geometry();
+  auto stage_a = [&](Wino3Raw& r) {           // issue the global loads of chunk (a_v, a_ci); then advance the cursor
+    const int c0 = a_ci * WCK;
+    const float* base = (c0 < p.C1 ? a_x1 : a_x2) + (long)c0 * planeS;
+    if (UP) {
+      r.a.x = base[a_off0];
+      r.b.x = base[a_off1];
+    } else {
+      r.a = *reinterpret_cast<const float4*>(base + a_off0);
+      if (wide1) r.b = *reinterpret_cast<const float4*>(base + a_off1);   // each path loads into its own registers:
+      else r.h = base[a_off1];                                            // no merge copies, no wait at the join
+    }
+    r.sc0 = a_gs[c0 + it_ch[0]]; r.sh0 = a_gh[c0 + it_ch[0]];
+    r.sc1 = a_gs[c0 + it_ch[1]]; r.sh1 = a_gh[c0 + it_ch[1]];
+    r.ok = a_ok;
+    // advance; past the end the cursor stays on the last chunk (the loads stay unconditional, their data is never used)
+    if (a_left > 1) {
+      --a_left;
+      if (++a_ci == nch) {
+        ADM_SCHED_FENCE();             // keeps the divisions of wino3_tile behind this branch (no if-conversion)
+        a_ci = 0; a_v += bs;
+        a_geometry();
+      }
+    }
+  };
+  auto act1 = [&](float x, float sc, float sh, unsigned ok) {   // GroupNorm affine + SiLU; zero padding applies after it
+    const float v = x * sc + sh;
+    return ok ? silu_w(v) : 0.f;
+  };
+  auto stage_b = [&](const Wino3Raw& r, int g) {        // raw -> activation -> patch buffer g & 1
+    float* P = ldsP + (g & 1) * W3PSLAB;
+    if (UP) {
+      P[it_pofs[0]] = act1(r.a.x, r.sc0, r.sh0, r.ok & 1u);
+      P[it_pofs[1]] = act1(r.b.x, r.sc1, r.sh1, r.ok & 2u);
+    } else {
+      float* P0 = P + it_pofs[0];
+      P0[0] = act1(r.a.x, r.sc0, r.sh0, r.ok & 1u); P0[1] = act1(r.a.y, r.sc0, r.sh0, r.ok & 1u);
+      P0[2] = act1(r.a.z, r.sc0, r.sh0, r.ok & 1u); P0[3] = act1(r.a.w, r.sc0, r.sh0, r.ok & 1u);
+      float* P1 = P + it_pofs[1];
+      if (wide1) {
+        P1[0] = act1(r.b.x, r.sc1, r.sh1, r.ok & 2u); P1[1] = act1(r.b.y, r.sc1, r.sh1, r.ok & 2u);
+        P1[2] = act1(r.b.z, r.sc1, r.sh1, r.ok & 2u); P1[3] = act1(r.b.w, r.sc1, r.sh1, r.ok & 2u);
+      } else {
+        P1[0] = act1(r.h, r.sc1, r.sh1, r.ok & 2u);
+      }
+    }
+  };
+  auto stage_c = [&](int g) {                // patch g & 1 -> 4x4 window -> V = B^T d B -> V buffer g & 1
+    const float* P = ldsP + (g & 1) * W3PSLAB + wbase;
+    float d[16];
+    ADM_UNROLL
+    for (int i = 0; i < 4; ++i)
+      ADM_UNROLL
+      for (int j = 0; j < 4; ++j) d[i * 4 + j] = UP ? P[((i + 1) >> 1) * 10 + ((j + 1) >> 1)] : P[i * WPW + j];
+    float t[4][4];
+    ADM_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = d[0 * 4 + j] - d[2 * 4 + j];
+      t[1][j] = d[1 * 4 + j] + d[2 * 4 + j];
+      t[2][j] = d[2 * 4 + j] - d[1 * 4 + j];
+      t[3][j] = d[1 * 4 + j] - d[3 * 4 + j];
+    }
+    float* vdst = ldsV + (g & 1) * W3VSLAB + vofs;
+    ADM_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      vdst[(i * 4 + 0) * (WCK * 32)] = t[i][0] - t[i][2];
+      vdst[(i * 4 + 1) * (WCK * 32)] = t[i][1] + t[i][2];
+      vdst[(i * 4 + 2) * (WCK * 32)] = t[i][2] - t[i][1];
+      vdst[(i * 4 + 3) * (WCK * 32)] = t[i][1] - t[i][3];
+    }
+  };
+  // ---- pipeline: interval g stages V(g) [C], the patch of g+1 [B] and the global loads of g+3 [A] ---------------------------
+  Wino3Raw r0, r1;
+  r0.b = make_float4(0.f, 0.f, 0.f, 0.f); r1.b = r0.b; r0.a = r0.b; r1.a = r0.b; r0.h = 0.f; r1.h = 0.f;
+  stage_a(r0);                 // chunk 0
+  stage_a(r1);                 // chunk 1
+  stage_b(r0, 0);
+  stage_a(r0);                 // chunk 2
+  ADM_BARRIER_KEEP_VMEM(63);   // barrier "-2": patch(0) visible to every producer wave
+  unsigned long long tq = W3_CLK(), tn;
+#define W3_LAP(slot) do { if (PROF) { tn = W3_CLK(); pr[slot] += tn - tq; tq = tn; } } while (0)
+  for (int g = 0; g < total; g += 2) {      // total is even (nch is)
+    stage_c(g);                W3_LAP(3);
+    stage_b(r1, g + 1);        W3_LAP(4);
+    stage_a(r1);               W3_LAP(5);   // chunk g + 3
+    W3_BARRIER(63, pr, 1, 2);  // barrier g - 1
+    if (PROF) tq = W3_CLK();
+    stage_c(g + 1);            W3_LAP(3);
+    stage_b(r0, g + 2);        W3_LAP(4);
+    stage_a(r0);               W3_LAP(5);   // chunk g + 4
+    W3_BARRIER(63, pr, 1, 2);  // barrier g
+    if (PROF) tq = W3_CLK();
+  }
+#undef W3_LAP
+  ADM_BARRIER_KEEP_VMEM(0);    // barrier total - 1 (the consumers' last chunk)
+  if (PROF && tid == 0) {
+    pr[0] = W3_CLK() - t_start;
+    for (int i = 0; i < 8; ++i) atomicAdd(p.prof + 8 + i, pr[i]);
+  }
+}
+
+// ---- consumer role: 256 threads (waves 0..3) ------------------------------------------------------------------------
+template <bool PROF>
+__device__ __forceinline__ void wino3_consumer(const WinoParams& p, const float* ldsV, float* ldsU, int tid, int wave,
+                                               int b0, int bs) {
+  unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_start = W3_CLK();
+  const int lane = tid & 63;
+  const int li = lane & 15, k4 = lane >> 4;
+  const int cw = wave & 1, tw = wave >> 1;
+  const int nch = (p.C1 + p.C2) / WCK;
+  const int ntile = (p.nblk - b0 + bs - 1) / bs;
+  const int total = ntile * nch;
+  // operand word addresses: chunk buffer + (compile-time xi / k-step terms) + these lane terms
+  const int vlane = k4 * 32 + ((16 * tw + li + 16 * (k4 & 1)) & 31);
+  const int ulane0 = k4 * 16 * W3BM + ((32 * cw + li + 16 * (k4 & 1)) & 63);
+  const int ulane1 = k4 * 16 * W3BM + ((32 * cw + 16 + li + 16 * (k4 & 1)) & 63);
+  // ---- U DMA cursor --------------------------------------------------------------------------------------------------
+  int d_v = b0, d_ci = 0, d_g = 0;
+  int d_m0 = wino3_tile(p, d_v).m0;
+  int d_off[8];                            // source element offset of this lane's 8 float4 pieces inside a U slab
+  ADM_UNROLL
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 256 * i;
+    const int row = idx >> 4, c4 = idx & 15;            // row = ch * 16 + xi of the LDS image, c4 = float4 slot
+    const int sc4 = (c4 - 4 * ((row >> 4) & 1)) & 15;    // odd channels are stored rotated by 16 couts
+    d_off[i] = row * p.Cout + sc4 * 4;
+  }
+  auto issue_u = [&]() {                   // U slab of running chunk d_g -> ldsU[d_g & 1]; 2048 float4 by 256 threads
+    if (d_g < total) {
+      const float* usrc = p.wu + (long)d_ci * WCK * 16 * p.Cout + d_m0;   // wave-uniform
+      float* udst = ldsU + (d_g & 1) * W3USLAB + wave * 256;
+      ADM_UNROLL
+      for (int i = 0; i < 8; ++i) ADM_GLDS16(usrc + d_off[i], udst + 1024 * i);
+      ++d_g;
+      if (++d_ci == nch) {
+        d_ci = 0; d_v += bs;
+        if (d_v < p.nblk) d_m0 = wino3_tile(p, d_v).m0;
+      }
+    }
+  };
+  issue_u();                               // U(0)
+  issue_u();                               // U(1)
+  ADM_BARRIER_KEEP_VMEM(63);               // barrier "-2" (producers' patch hand-over)
+  ADM_BARRIER_KEEP_VMEM(0);                // barrier "-1": V(0) complete, U(0) landed
+
+  f32x4 acc[16][2];
+  float rb[4][2], ra[4][2][2];             // rolling operand window: 4 Winograd points ahead
+  int g = 0;                               // running chunk index
+  for (int v = b0; v < p.nblk; v += bs) {
+    const Wino3Tile t = wino3_tile(p, v);
+    ADM_UNROLL
+    for (int xi = 0; xi < 16; ++xi)
+      ADM_UNROLL
+      for (int c = 0; c < 2; ++c)
+        ADM_UNROLL
+        for (int r = 0; r < 4; ++r) acc[xi][c][r] = 0.f;
+    // epilogue constants of this lane's 8 couts, fetched now so their latency hides behind the whole tile
+    float cb[2][4];
+    ADM_UNROLL
+    for (int c = 0; c < 2; ++c)
+      ADM_UNROLL
+      for (int r = 0; r < 4; ++r) {
+        const int co = t.m0 + 32 * cw + 16 * c + 4 * k4 + r;
+        cb[c][r] = p.bias[co] + p.chan_add[(long)t.n * p.chan_add_stride + co];
+      }
+    auto read_group = [&](int slot, int gg, int xi) {     // operand words of Winograd point xi of running chunk gg
+      const float* V = ldsV + (gg & 1) * W3VSLAB + vlane;
+      const float* U = ldsU + (gg & 1) * W3USLAB;
+      ADM_UNROLL
+      for (int ks = 0; ks < 2; ++ks) {
+        rb[slot][ks] = V[(xi * WCK + 4 * ks) * 32];
+        ra[slot][ks][0] = U[(4 * ks * 16 + xi) * W3BM + ulane0];
+        ra[slot][ks][1] = U[(4 * ks * 16 + xi) * W3BM + ulane1];
+      }
+    };
+    ADM_UNROLL
+    for (int xi = 0; xi < 4; ++xi) read_group(xi, g, xi);
+    for (int ci = 0; ci < nch; ++ci, ++g) {
+      const bool more = ci + 1 < nch;      // the rolling window does not cross into the next tile
+      ADM_UNROLL
+      for (int xi = 0; xi < 16; ++xi) {
+        const int s = xi & 3;
+        ADM_UNROLL
+        for (int ks = 0; ks < 2; ++ks) {
+          acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[s][ks][0], rb[s][ks], acc[xi][0], 0, 0, 0);
+          acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[s][ks][1], rb[s][ks], acc[xi][1], 0, 0, 0);
+        }
+        if (xi == 12) {                    // every read of chunk g was issued >= 1 step ago: free its buffers
+          W3_BARRIER(0, pr, 1, 2);         // barrier g
+          issue_u();                       // U(g + 2)
+        }
+        if (xi < 12) read_group(s, g, xi + 4);
+        else if (more) read_group(s, g + 1, xi - 12);
+        ADM_SCHED_FENCE();
+      }
+    }
+    // ---- lane-local inverse transform Y = A^T M A and store: lane holds (cout = 4*k4 + r, tile = li) of each block ------
+    const unsigned long long t_epi = W3_CLK();
+    const int tile = 16 * tw + li;
+    const int oy = t.ty * 8 + 2 * (tile >> 3), ox = t.tx * 16 + 2 * (tile & 7);
+    const long planeO = (long)p.Ho * p.Wo;
+    ADM_UNROLL
+    for (int c = 0; c < 2; ++c) {
+      float2 res[4][2];
+      if (p.residual != nullptr) {
+        ADM_UNROLL
+        for (int r = 0; r < 4; ++r) {
+          const int co = t.m0 + 32 * cw + 16 * c + 4 * k4 + r;
+          const long o = ((long)t.n * p.Cout + co) * planeO + (long)oy * p.Wo + ox;
+          res[r][0] = *reinterpret_cast<const float2*>(p.residual + o);
+          res[r][1] = *reinterpret_cast<const float2*>(p.residual + o + p.Wo);
+        }
+      } else {
+        ADM_UNROLL
+        for (int r = 0; r < 4; ++r) { res[r][0] = make_float2(0.f, 0.f); res[r][1] = make_float2(0.f, 0.f); }
+      }
+      ADM_UNROLL
+      for (int r = 0; r < 4; ++r) {
+        float t0[4], t1[4];
+        ADM_UNROLL
+        for (int j = 0; j < 4; ++j) {
+          t0[j] = acc[0 * 4 + j][c][r] + acc[1 * 4 + j][c][r] + acc[2 * 4 + j][c][r];
+          t1[j] = acc[1 * 4 + j][c][r] - acc[2 * 4 + j][c][r] - acc[3 * 4 + j][c][r];
+        }
+        const float b = cb[c][r];
+        const int co = t.m0 + 32 * cw + 16 * c + 4 * k4 + r;
+        const long o = ((long)t.n * p.Cout + co) * planeO + (long)oy * p.Wo + ox;
+        float2 y0 = make_float2(t0[0] + t0[1] + t0[2] + b + res[r][0].x, t0[1] - t0[2] - t0[3] + b + res[r][0].y);
+        float2 y1 = make_float2(t1[0] + t1[1] + t1[2] + b + res[r][1].x, t1[1] - t1[2] - t1[3] + b + res[r][1].y);
+        *reinterpret_cast<float2*>(p.out + o) = y0;
+        *reinterpret_cast<float2*>(p.out + o + p.Wo) = y1;
+      }
+    }
+    if (PROF) pr[3] += W3_CLK() - t_epi;
+  }
+  if (PROF && tid == 0) {
+    pr[0] = W3_CLK() - t_start;
+    for (int i = 0; i < 8; ++i) atomicAdd(p.prof + i, pr[i]);
+  }
+}
+
+template <bool UP, bool PROF>
+__global__ void __launch_bounds__(512, 2) conv_wino3_kernel(const WinoParams p) {
+  ADM_DYN_SMEM(float, smem);
+  float* ldsV = smem;
+  float* ldsU = smem + 2 * W3VSLAB;
+  float* ldsP = smem + 2 * W3VSLAB + 2 * W3USLAB;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  // roles are wave-uniform and have separate register allocations (accumulators only in the consumers)
+  if (wave >= 4) {
+#if !defined(ADM_EMU)
+    // The second-dispatched half of a 512-thread workgroup loses the per-SIMD VALU arbitration (priority, then age) to
+    // its MFMA-issuing partner. The producers are the short, latency-critical role: static priority for the whole kernel.
+    __builtin_amdgcn_s_setprio(1);
+#endif
+    if (!UP && wave == 4) wino3_producer<UP, true, PROF>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
+    else wino3_producer<UP, false, PROF>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
+  }
+  else wino3_consumer<PROF>(p, ldsV, ldsU, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // (Cout,Cin,3,3) -> U = G g G^T laid out [Cin][16][Cout]; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 __global__ void pack_winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin) {
   const long total = (long)Cout * Cin;
@@ -508,10 +917,12 @@ int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hi
 }
 
 
-static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment on first use
+// 0 direct MFMA kernel only | 1 Winograd v1 | 2 wave-specialised v2 | 3 persistent wave-specialised v3 (default: measured
+// 1.33x on the whole UNet forward); shapes a mode cannot take fall back to the direct kernel.
+static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 3) on first use
 void set_winograd_mode(int m) { g_wino_mode = m; }
 static int wino_mode() {
-  if (g_wino_mode < 0) { const char* e = getenv("ADM_CONV_WINO"); g_wino_mode = e ? atoi(e) : 0; }
+  if (g_wino_mode < 0) { const char* e = getenv("ADM_CONV_WINO"); g_wino_mode = e ? atoi(e) : 3; }
   return g_wino_mode;
 }
 bool winograd_enabled() { return wino_mode() != 0; }
@@ -542,6 +953,49 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
   p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
+  if (wino_mode() == 3 && a.Cout % W3BM == 0 && (a.C1 + C2) % (2 * WCK) == 0 && a.gn_scale != nullptr && a.act &&
+      (reinterpret_cast<uintptr_t>(a.x1) & 15) == 0 && (a.x2 == nullptr || (reinterpret_cast<uintptr_t>(a.x2) & 15) == 0) &&
+      p.x1_bs % 4 == 0 && p.x2_bs % 4 == 0) {                    // persistent wave-specialised kernel
+    p.n_ct = a.Cout / W3BM;
+    p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
+    if (p.chan_add == nullptr) { p.chan_add = conv_zero_bias(a.Cout); p.chan_add_stride = 0; }
+    ADM_REQUIRE(p.chan_add != nullptr, "conv_winograd: zero-bias buffer");
+    const size_t need3 = sizeof(float) * W3LDS;
+#if !defined(ADM_EMU)
+    static int n_cu = [] {
+      (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
+      (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
+      (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
+      int dev = 0, n = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return n > 0 ? n : 256;
+    }();
+#else
+    const int n_cu = 3;                                          // exercise persistence (several tiles per block) on the emulator
+#endif
+    const int grid = p.nblk < n_cu ? p.nblk : n_cu;
+    set_last_conv_variant(4000 + 313);
+    p.prof = nullptr;
+#if !defined(ADM_EMU)
+    static const bool want_prof = getenv("ADM_WINO_PROF") != nullptr;
+    if (want_prof && !a.up) {   // developer aid: per-role cycle accounting, printed after every launch (synchronous)
+      static unsigned long long* dprof = [] { void* q = nullptr; (void)hipMalloc(&q, 16 * sizeof(unsigned long long)); return (unsigned long long*)q; }();
+      (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
+      p.prof = dprof;
+      ADM_LAUNCH((conv_wino3_kernel<false, true>), dim3(grid), dim3(512), need3, st, p);
+      unsigned long long h[16];
+      (void)hipMemcpyAsync(h, dprof, sizeof(h), hipMemcpyDeviceToHost, st);
+      (void)hipStreamSynchronize(st);
+      const double nb = grid;
+      fprintf(stderr, "[wino3 prof] per-block cycles: consumer total %.0f drain %.0f barrier %.0f epilogue %.0f | producer total %.0f drain %.0f barrier %.0f C %.0f B %.0f A %.0f\n",
+              h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[8] / nb, h[9] / nb, h[10] / nb, h[11] / nb, h[12] / nb, h[13] / nb);
+      return ADM_CHECK_LAUNCH();
+    }
+#endif
+    if (a.up) ADM_LAUNCH((conv_wino3_kernel<true, false>), dim3(grid), dim3(512), need3, st, p);
+    else ADM_LAUNCH((conv_wino3_kernel<false, false>), dim3(grid), dim3(512), need3, st, p);
+    return ADM_CHECK_LAUNCH();
+  }
   if (wino_mode() == 2 && a.Cout % W2BM == 0 && (a.C1 + C2) % (2 * WCK) == 0) {   // wave-specialised kernel (even chunk count)
     p.n_ct = a.Cout / W2BM;
     p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;

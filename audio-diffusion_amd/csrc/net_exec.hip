@@ -129,6 +129,10 @@ static int pack_one(Net* net, ConvW& w, hipStream_t st) {
     w.bias = net->ps->P(w.key + ".bias");
   }
   ADM_TRY(launch_pack_conv_weight(src, w.wp, w.Cout, w.Cin, w.ks, st));
+  if (w.ks == 3 && w.qkv_prefix.empty() && winograd_enabled() && w.Cout % 32 == 0 && w.Cin % 8 == 0) {
+    if (!w.wu) ADM_TRY(net->dalloc((void**)&w.wu, sizeof(float) * (size_t)w.Cout * w.Cin * 16));
+    ADM_TRY(launch_pack_winograd_weight(src, w.wu, w.Cout, w.Cin, st));
+  }
   if (net->training) {
     if (!w.wpT) ADM_TRY(net->dalloc((void**)&w.wpT, sizeof(float) * (size_t)w.Cout * w.Cin * w.ks * w.ks));
     ADM_TRY(launch_pack_conv_weight_T(src, w.wpT, w.Cout, w.Cin, w.ks, st));
@@ -265,6 +269,8 @@ void Net::destroy() {
 // Assign activation buffers for batch B: exact-size free lists driven by liveness.
 int Net::plan(int B) {
   if (planned_B == B) return 0;
+  // the shared all-zero bias buffer is created lazily with a device allocation: do it here, outside any stream capture
+  ADM_REQUIRE(conv_zero_bias(8192) != nullptr, "plan: zero-bias buffer");
   free_plan();
   std::multimap<size_t, float*> freelist;
   std::vector<std::vector<int>> dying(ops.size());
@@ -361,6 +367,7 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
         a.Cout = o.dyn_cout;
       } else {
         a.wpacked = o.w->wp; a.bias = o.w->bias; a.Cout = o.w->Cout;
+        if (o.stride == 1) a.wino_packed = o.w->wu;   // eligibility (shape, mode) is decided by the launcher
       }
       if (o.temb_off >= 0 && temb_all) { a.chan_add = temb_all + o.temb_off; a.chan_add_stride = temb_stride; }
       if (o.res >= 0) a.residual = tensors[o.res].ptr;

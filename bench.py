@@ -144,11 +144,19 @@ def roofline(unet, x, B):
         if best is None or tot < best[0]:
             best = (tot, rows)
     rows = best[1]
-    dom = [r for r in rows if r[0] == 1 and r[1] == 2314]       # ks3 stride1 cout-tile 128, pipelined: conv_mfma_pf_kernel<3,2,2>
-    if not dom:
-        dom = [r for r in rows if r[0] == 1]
-    ms = sum(r[2] for r in dom)
-    fl = sum(r[3] for r in dom)
+    # dominant kernel = the convolution variant with the largest share of the forward
+    KERNELS = {
+        4313: "adm::conv_wino3_kernel<false> (Winograd F(2x2,3x3) 3x3 stride-1 conv, v_mfma_f32_16x16x4_f32, persistent "
+              "wave-specialised: 4 producer + 4 consumer waves, 64-cout x 8x16-pixel tile)",
+        2314: "adm::conv_mfma_pf_kernel<3,2,2> (v_mfma_f32_32x32x2_f32 implicit GEMM, 3x3 stride 1, 128-cout tile)",
+    }
+    per_var = {}
+    for r in rows:
+        if r[0] == 1:
+            e = per_var.setdefault(r[1], [0.0, 0.0, 0])
+            e[0] += r[2]; e[1] += r[3]; e[2] += 1
+    var = max(per_var, key=lambda v: per_var[v][0])
+    ms, fl, cnt = per_var[var]
     by_kind = {}
     for k, v, t, f, b in rows:
         e = by_kind.setdefault(k, [0, 0.0, 0.0, 0.0])
@@ -156,12 +164,22 @@ def roofline(unet, x, B):
     names = {0: "groupnorm_stats", 1: "conv_mfma", 2: "attention", 3: "conv_small", 4: "temb_proj"}
     breakdown = {names[k]: {"launches": e[0], "ms": round(e[1], 3), "TFLOP/s": round(e[2] / e[1] / 1e9, 2) if e[1] else None,
                             "GB/s": round(e[3] / e[1] / 1e6, 1) if e[1] else None} for k, e in by_kind.items()}
+    breakdown["conv_by_variant"] = {str(v): {"launches": e[2], "ms": round(e[0], 3), "TFLOP/s": round(e[1] / e[0] / 1e9, 2)}
+                                    for v, e in sorted(per_var.items())}
     ach = fl / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "adm::conv_mfma_pf_kernel<3,2,2> (v_mfma_f32_32x32x2_f32 implicit GEMM, 3x3 stride 1, 128-cout tile)",
-            "achieved": round(ach, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TF, 4),
-            "traffic": None, "launches_per_forward": len(dom), "avg_launch_us": round(ms / len(dom) * 1e3, 2),
-            "avg_flops_per_launch": fl / len(dom), "share_of_forward_time": round(ms / sum(r[2] for r in rows), 3),
-            "forward_breakdown": breakdown}
+    out = {"bound": "mfma", "kernel": KERNELS.get(var, f"conv variant {var}"),
+           "achieved": round(ach, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TF, 4),
+           "traffic": None, "launches_per_forward": cnt, "avg_launch_us": round(ms / cnt * 1e3, 2),
+           "avg_flops_per_launch": fl / cnt, "share_of_forward_time": round(ms / sum(r[2] for r in rows), 3),
+           "forward_breakdown": breakdown}
+    if var // 100 == 43:
+        # `achieved` is ALGORITHMIC (direct-convolution) FLOPs per second, the contract's definition; the Winograd kernel
+        # executes 16/36 of them on the matrix pipe, so the pipe utilisation is reported separately.
+        out["executed_mfma_TFLOPs"] = round(ach / 2.25, 2)
+        out["mfma_util"] = round(ach / 2.25 / PEAK_F32_TF, 4)
+        out["note"] = ("achieved/frac use algorithmic direct-conv FLOPs (2*Cout*Cin*9*H*W*N per launch); Winograd F(2x2,3x3) "
+                       "executes 1/2.25 of them as MFMA work (mfma_util), so frac may exceed 1")
+    return out
 
 
 def main():

@@ -24,8 +24,8 @@ int adm_version(void);
 const char* adm_last_error(void);
 /* 1 if built for the device (hipcc, gfx950), 0 for the CPU-emulation test build. */
 int adm_is_device_build(void);
-/* Runtime options: "conv_wino" = 0 (direct MFMA kernel, default) | 1 (Winograd F(2x2,3x3)) | 2 (wave-specialised Winograd);
- * default comes from the ADM_CONV_WINO environment variable. */
+/* Runtime options: "conv_wino" = 0 (direct MFMA kernel only) | 1 (Winograd F(2x2,3x3) v1) | 2 (wave-specialised v2) |
+ * 3 (persistent wave-specialised v3, the default) | -1 (back to the default / ADM_CONV_WINO environment variable). */
 int adm_set_option(const char* name, int value);
 /* Kernel variant the last adm_conv2d on this thread dispatched to (see adm_op_profile.variant; 4311 = Winograd). */
 int adm_last_conv_variant(void);

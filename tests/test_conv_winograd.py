@@ -1,4 +1,4 @@
-"""Winograd F(2x2,3x3) variant of the fused 3x3 convolution (opt-in, ADM_CONV_WINO=1) vs torch fp32."""
+"""Winograd F(2x2,3x3) variants of the fused 3x3 convolution (mode 3 is the default 3x3 stride-1 path) vs torch fp32."""
 import pytest  # noqa: E402
 import torch  # noqa: E402
 
@@ -13,22 +13,27 @@ CASES = [
     (1, 64, 0, 16, 16, 96, 0, 1, 0, 0, 0),
     (1, 32, 0, 8, 8, 64, 1, 0, 0, 1, 0),      # v2-eligible: upsample folded, 64 couts
     (2, 64, 0, 8, 16, 128, 0, 1, 1, 1, 1),    # v2-eligible: two cout tiles, all epilogue terms
+    (1, 32, 0, 8, 8, 64, 1, 1, 1, 1, 0),      # v3-eligible: GroupNorm + SiLU + folded upsample
+    (3, 32, 0, 16, 32, 64, 0, 1, 1, 1, 0),    # v3: 12 tiles on a 3-block persistent grid (emulator), image borders
+    (2, 32, 32, 24, 48, 128, 0, 1, 1, 1, 1),  # v3: virtual concat, interior + border tiles, residual
 ]
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("mode", [1, 2], ids=["v1", "v2wavespec"])
+@pytest.mark.parametrize("mode", [1, 2, 3], ids=["v1", "v2wavespec", "v3persistent"])
 @pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
 def test_conv_winograd(backend, case, mode):
     dev = select(backend)
     from audiodiffusion import _native, ops
-    if mode == 2 and case[5] % 64 != 0:
-        pytest.skip("v2 tiles 64 output channels")
+    if mode >= 2 and case[5] % 64 != 0:
+        pytest.skip("v2/v3 tile 64 output channels")
+    if mode == 3 and (not case[7] or (case[1] + case[2]) % 16 != 0):
+        pytest.skip("v3 needs GroupNorm-on-load and an even number of 8-channel chunks")
     _native.check(_native.lib().adm_set_option(b"conv_wino", mode))
     try:
-        _run_case(dev, case, 4311 if mode == 1 else 4312)
+        _run_case(dev, case, 4310 + mode)
     finally:
-        _native.check(_native.lib().adm_set_option(b"conv_wino", 0))
+        _native.check(_native.lib().adm_set_option(b"conv_wino", -1))   # back to the default
 
 
 def _run_case(dev, case, want_variant):
