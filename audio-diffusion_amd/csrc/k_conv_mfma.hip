@@ -20,6 +20,8 @@
 // (256^2 ... 1x1). Algorithmic bytes per launch: 4*(N*Cin*Hs*Ws + N*Cout*Ho*Wo [+ residual]) + 4*Cout*Cin*ks^2.
 #include <cstdlib>
 
+#include <vector>
+
 #include "adm_kernels.h"
 
 namespace adm {
@@ -428,6 +430,23 @@ const float* conv_zero_bias(int n) {
     dmemset(pz, 0, sizeof(float) * want, nullptr);
     stream_sync(nullptr);
     z = (float*)pz;  // the previous (smaller) buffer is intentionally leaked: launches may still read it
+    cap = want;
+  }
+  return z;
+}
+
+// shared all-ones device buffer (identity GroupNorm scale for convolutions without a normalisation on their input)
+const float* conv_const_ones(int n) {
+  static float* z = nullptr;
+  static int cap = 0;
+  if (n > cap) {
+    const int want = n < 8192 ? 8192 : n;
+    std::vector<float> h((size_t)want, 1.0f);
+    void* pz = nullptr;
+    if (dmalloc(&pz, sizeof(float) * want) != 0) return nullptr;
+    if (copy_h2d(pz, h.data(), sizeof(float) * want, nullptr) != 0) return nullptr;
+    stream_sync(nullptr);
+    z = (float*)pz;
     cap = want;
   }
   return z;

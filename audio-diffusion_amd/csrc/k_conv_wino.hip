@@ -31,6 +31,7 @@ struct WinoParams {
   const float* residual; float* out;
   int tiles_x, tiles_y, n_ct, nblk;
   long x1_bs, x2_bs;
+  int gn_nstride;             // per-sample stride of gn_scale / gn_shift (0: shared identity rows, conv without GroupNorm)
   unsigned long long* prof;   // optional cycle counters of the wave-specialised kernel (ADM_WINO_PROF=1), else NULL
 };
 
@@ -610,8 +611,8 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
     const Wino3Tile t = wino3_tile(p, a_v);
     a_x1 = p.x1 + (long)t.n * p.x1_bs;
     a_x2 = p.x2 + (long)t.n * p.x2_bs - (long)p.C1 * planeS;     // indexed with the concatenated channel number
-    a_gs = p.gn_scale + (long)t.n * Ct;
-    a_gh = p.gn_shift + (long)t.n * Ct;
+    a_gs = p.gn_scale + (long)t.n * p.gn_nstride;
+    a_gh = p.gn_shift + (long)t.n * p.gn_nstride;
     a_ok = 0;
     int off[2];
     ADM_UNROLL
@@ -649,9 +650,11 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
       }
     }
   };
-  auto act1 = [&](float x, float sc, float sh, unsigned ok) {   // GroupNorm affine + SiLU; zero padding applies after it
+  const bool act_on = p.act != 0;
+  auto act1 = [&](float x, float sc, float sh, unsigned ok) {   // GroupNorm affine (+ SiLU); zero padding applies after it
     const float v = x * sc + sh;
-    return ok ? silu_w(v) : 0.f;
+    const float a = act_on ? silu_w(v) : v;
+    return ok ? a : 0.f;
   };
   auto stage_b = [&](const Wino3Raw& r, int g) {        // raw -> activation -> patch buffer g & 1
     float* P = ldsP + (g & 1) * W3PSLAB;
@@ -953,11 +956,16 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
   p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
-  if (wino_mode() == 3 && a.Cout % W3BM == 0 && (a.C1 + C2) % (2 * WCK) == 0 && a.gn_scale != nullptr && a.act &&
+  if (wino_mode() == 3 && a.Cout % W3BM == 0 && (a.C1 + C2) % (2 * WCK) == 0 && (a.gn_scale != nullptr || !a.act) &&
       (reinterpret_cast<uintptr_t>(a.x1) & 15) == 0 && (a.x2 == nullptr || (reinterpret_cast<uintptr_t>(a.x2) & 15) == 0) &&
       p.x1_bs % 4 == 0 && p.x2_bs % 4 == 0) {                    // persistent wave-specialised kernel
     p.n_ct = a.Cout / W3BM;
     p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
+    p.gn_nstride = a.C1 + C2;
+    if (p.gn_scale == nullptr) {                               // no GroupNorm on the load path: identity affine rows
+      p.gn_scale = conv_const_ones(a.C1 + C2); p.gn_shift = conv_zero_bias(a.C1 + C2); p.gn_nstride = 0;
+      ADM_REQUIRE(p.gn_scale != nullptr && p.gn_shift != nullptr, "conv_winograd: constant buffers");
+    }
     if (p.chan_add == nullptr) { p.chan_add = conv_zero_bias(a.Cout); p.chan_add_stride = 0; }
     ADM_REQUIRE(p.chan_add != nullptr, "conv_winograd: zero-bias buffer");
     const size_t need3 = sizeof(float) * W3LDS;

@@ -270,7 +270,7 @@ void Net::destroy() {
 int Net::plan(int B) {
   if (planned_B == B) return 0;
   // the shared all-zero bias buffer is created lazily with a device allocation: do it here, outside any stream capture
-  ADM_REQUIRE(conv_zero_bias(8192) != nullptr, "plan: zero-bias buffer");
+  ADM_REQUIRE(conv_zero_bias(8192) != nullptr && conv_const_ones(8192) != nullptr, "plan: constant buffers");
   free_plan();
   std::multimap<size_t, float*> freelist;
   std::vector<std::vector<int>> dying(ops.size());

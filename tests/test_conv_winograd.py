@@ -27,8 +27,8 @@ def test_conv_winograd(backend, case, mode):
     from audiodiffusion import _native, ops
     if mode >= 2 and case[5] % 64 != 0:
         pytest.skip("v2/v3 tile 64 output channels")
-    if mode == 3 and (not case[7] or (case[1] + case[2]) % 16 != 0):
-        pytest.skip("v3 needs GroupNorm-on-load and an even number of 8-channel chunks")
+    if mode == 3 and ((case[8] and not case[7]) or (case[1] + case[2]) % 16 != 0):
+        pytest.skip("v3 needs an even number of 8-channel chunks (and GroupNorm whenever SiLU is requested)")
     _native.check(_native.lib().adm_set_option(b"conv_wino", mode))
     try:
         _run_case(dev, case, 4310 + mode)

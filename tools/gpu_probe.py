@@ -61,7 +61,7 @@ def conv_shapes():
         b = torch.randn(Co, device=dev)
         gamma, beta = torch.ones(C1 + C2, device=dev), torch.zeros(C1 + C2, device=dev)
         gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2)
-        wu = ops.pack_winograd_weight(w) if (ks == 3 and st == 1 and os.environ.get('ADM_CONV_WINO') in ('1', '2', '3')) else None
+        wu = ops.pack_winograd_weight(w) if (ks == 3 and st == 1 and os.environ.get('ADM_CONV_WINO', '3') in ('1', '2', '3')) else None
         f = lambda: ops.conv2d(x1, wp, b, ks, x2=x2, up=bool(up), stride=st, gn=gn, act=True, wino=wu)  # noqa: E731
         out = f()
         dt = timeit(f, iters=5, warm=2)
