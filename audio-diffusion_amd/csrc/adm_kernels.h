@@ -39,6 +39,7 @@ void set_last_conv_variant(int v);
 const float* conv_zero_bias(int n);  // shared all-zero device buffer of >= n floats (k_conv_mfma.hip)
 const float* conv_const_ones(int n); // shared all-ones device buffer of >= n floats
 int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st);
+int launch_pack_winograd_weight_T(const float* w, float* wu, int Cout, int Cin, hipStream_t st);  // data-gradient filters
 bool winograd_enabled();
 void set_winograd_mode(int m);  // 0 off, 1 v1, 2 wave-specialised v2, 3 persistent v3 (default), -1 = default
 bool winograd_eligible(const adm_conv_args& a);

@@ -890,35 +890,49 @@ __global__ void __launch_bounds__(512, 2) conv_wino3_kernel(const WinoParams p) 
   else wino3_consumer<PROF>(p, ldsV, ldsU, tid, wave, (int)blockIdx.x, (int)gridDim.x);
 }
 
-// (Cout,Cin,3,3) -> U = G g G^T laid out [Cin][16][Cout]; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-__global__ void pack_winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin) {
+// (Cout,Cin,3,3) -> U = G g G^T laid out [Cin][16][Cout]; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
+// transposed != 0: filters of the DATA-GRADIENT convolution (input channels = Cout, output channels = Cin, taps flipped):
+// U' = G flip(g) G^T laid out [Cout][16][Cin].
+__global__ void pack_winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin,
+                                            int transposed) {
   const long total = (long)Cout * Cin;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int co = (int)(i % Cout), c = (int)(i / Cout);
+    int co, c;
+    if (transposed) { c = (int)(i % Cin); co = (int)(i / Cin); }     // consecutive threads -> consecutive destination words
+    else { co = (int)(i % Cout); c = (int)(i / Cout); }
     const float* g = w + ((long)co * Cin + c) * 9;
     float t[4][3];
     for (int j = 0; j < 3; ++j) {
-      t[0][j] = g[0 * 3 + j];
-      t[1][j] = 0.5f * (g[0 * 3 + j] + g[1 * 3 + j] + g[2 * 3 + j]);
-      t[2][j] = 0.5f * (g[0 * 3 + j] - g[1 * 3 + j] + g[2 * 3 + j]);
-      t[3][j] = g[2 * 3 + j];
+      const float g0 = transposed ? g[2 * 3 + (2 - j)] : g[0 * 3 + j];
+      const float g1 = transposed ? g[1 * 3 + (2 - j)] : g[1 * 3 + j];
+      const float g2 = transposed ? g[0 * 3 + (2 - j)] : g[2 * 3 + j];
+      t[0][j] = g0;
+      t[1][j] = 0.5f * (g0 + g1 + g2);
+      t[2][j] = 0.5f * (g0 - g1 + g2);
+      t[3][j] = g2;
     }
+    const long ostride = transposed ? Cin : Cout;
     for (int a = 0; a < 4; ++a) {
       const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]),
                   u3 = t[a][2];
-      float* dst = wu + ((long)c * 16 + a * 4) * Cout + co;
-      dst[0] = u0; dst[Cout] = u1; dst[2L * Cout] = u2; dst[3L * Cout] = u3;
+      float* dst = transposed ? wu + ((long)co * 16 + a * 4) * Cin + c : wu + ((long)c * 16 + a * 4) * Cout + co;
+      dst[0] = u0; dst[ostride] = u1; dst[2 * ostride] = u2; dst[3 * ostride] = u3;
     }
   }
 }
 
-int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st) {
+static int pack_winograd(const float* w, float* wu, int Cout, int Cin, int transposed, hipStream_t st) {
   long g = ((long)Cout * Cin + 255) / 256;
   if (g > 4096) g = 4096;
-  ADM_LAUNCH(pack_winograd_weight_kernel, dim3((unsigned)g), dim3(256), 0, st, w, wu, Cout, Cin);
+  ADM_LAUNCH(pack_winograd_weight_kernel, dim3((unsigned)g), dim3(256), 0, st, w, wu, Cout, Cin, transposed);
   return ADM_CHECK_LAUNCH();
 }
-
+int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st) {
+  return pack_winograd(w, wu, Cout, Cin, 0, st);
+}
+int launch_pack_winograd_weight_T(const float* w, float* wu, int Cout, int Cin, hipStream_t st) {
+  return pack_winograd(w, wu, Cout, Cin, 1, st);
+}
 
 // 0 direct MFMA kernel only | 1 Winograd v1 | 2 wave-specialised v2 | 3 persistent wave-specialised v3 (default: measured
 // 1.33x on the whole UNet forward); shapes a mode cannot take fall back to the direct kernel.

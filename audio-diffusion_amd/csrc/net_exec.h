@@ -39,6 +39,7 @@ struct ConvW {
   float* wp = nullptr;    // forward packing [Cin][tap][Cout]
   float* wpT = nullptr;   // backward-data packing [Cout][tap][Cin] (training only)
   float* wu = nullptr;    // Winograd-domain weights [Cin][16][Cout] (3x3 convs, when a Winograd mode is selected)
+  float* wuT = nullptr;   // ... of the data-gradient convolution [Cout][16][Cin] (training only)
   float* bias = nullptr;  // master bias (for q|k|v: the stacked copy)
   int Cin = 0, Cout = 0, ks = 3;
   std::string key;        // diffusers prefix of the master parameter ("" for derived weights)

@@ -136,6 +136,10 @@ static int pack_one(Net* net, ConvW& w, hipStream_t st) {
   if (net->training) {
     if (!w.wpT) ADM_TRY(net->dalloc((void**)&w.wpT, sizeof(float) * (size_t)w.Cout * w.Cin * w.ks * w.ks));
     ADM_TRY(launch_pack_conv_weight_T(src, w.wpT, w.Cout, w.Cin, w.ks, st));
+    if (w.ks == 3 && w.qkv_prefix.empty() && winograd_enabled() && w.Cin % 32 == 0 && w.Cout % 8 == 0) {
+      if (!w.wuT) ADM_TRY(net->dalloc((void**)&w.wuT, sizeof(float) * (size_t)w.Cout * w.Cin * 16));
+      ADM_TRY(launch_pack_winograd_weight_T(src, w.wuT, w.Cout, w.Cin, st));
+    }
   }
   return 0;
 }
@@ -484,6 +488,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       a.x1 = dy; a.C1 = Cout; a.N = B; a.H = to.H; a.W = to.W;
       a.up = o.stride == 2 ? 2 : 0; a.stride = 1; a.ks = o.ks; a.pad_lo = o.ks == 3 ? 1 : 0;
       a.wpacked = o.w->wpT; a.bias = nullptr; a.Cout = Ct;
+      if (o.stride == 1) a.wino_packed = o.w->wuT;   // 3x3 stride-1: the data gradient is a Winograd-eligible convolution too
       if (direct) {
         a.out = t1.grad;
         if (t1.ginit) a.residual = t1.grad;   // accumulate in the epilogue (same thread reads then writes)
