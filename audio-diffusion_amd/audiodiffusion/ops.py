@@ -100,6 +100,15 @@ def pack_winograd_weight(w):
     return wu
 
 
+def pack_winograd_weight_T(w):
+    """(Cout,Cin,3,3) -> Winograd-domain filters of the data-gradient convolution as [Cout][16][Cin]."""
+    _f32(w)
+    co, ci = w.shape[:2]
+    wu = torch.empty((co, 16, ci), dtype=torch.float32, device=w.device)
+    N.check(N.lib().adm_pack_winograd_weight_T(N.ptr(w), N.ptr(wu), co, ci, N.stream_for(w)))
+    return wu
+
+
 def conv2d(x1, wpacked, bias, ks, x2=None, up=False, stride=1, pad_lo=1, gn=None, act=False, chan_add=None,
            residual=None, wino=None):
     """Fused convolution (see include/adm.h adm_conv_args)."""

@@ -73,6 +73,11 @@ int adm_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, void*
   return launch_pack_winograd_weight(w, wu, Cout, Cin, (hipStream_t)stream);
 }
 
+int adm_pack_winograd_weight_T(const float* w, float* wuT, int Cout, int Cin, void* stream) {
+  ADM_REQUIRE(w && wuT, "pack_winograd_weight_T: null argument");
+  return launch_pack_winograd_weight_T(w, wuT, Cout, Cin, (hipStream_t)stream);
+}
+
 void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo) {
   conv_out_dims(H, W, up, stride, ks, pad_lo, Ho, Wo);
 }

@@ -99,6 +99,10 @@ int adm_pack_conv_weight(const float* w, float* wpacked, int Cout, int Cin, int 
 int adm_pack_conv_weight_T(const float* w, float* wpT, int Cout, int Cin, int ks, void* stream);
 /* (Cout,Cin,3,3) -> Winograd-domain weights U = G g G^T, layout [Cin][16][Cout]; both device pointers. */
 int adm_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, void* stream);
+/* ... of the data-gradient convolution (input channels = Cout, output channels = Cin, taps flipped): [Cout][16][Cin].
+ * Pass it as `wino_packed` together with adm_pack_conv_weight_T's packing to run the backward-data pass of a 3x3
+ * stride-1 Conv2d (what torch autograd does for scripts/train_unet.py:262 `accelerator.backward(loss)`). */
+int adm_pack_winograd_weight_T(const float* w, float* wuT, int Cout, int Cin, void* stream);
 void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);
 
 /* Self-attention core (row U6): qkv is (N, 3*C, T) with channels [q | k | v], head h = channels

@@ -56,3 +56,18 @@ def _run_case(dev, case, want_variant):
     ref = _conv_ref(c(x1), c(x2), c(w), c(b), 3, 1, up, (c(gamma), c(beta)) if use_gn else None, act, c(temb), c(res))
     assert out.shape == ref.shape
     assert _relerr(out, ref) < 1e-4, _relerr(out, ref)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv_winograd_data_gradient(backend):
+    """3x3 stride-1 backward-data pass as a Winograd convolution with transposed/flipped filters vs torch autograd."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, Cin, Cout, H, W = 2, 64, 32, 16, 32
+    w = _rand((Cout, Cin, 3, 3), 11, dev, scale=(Cin * 9) ** -0.5)
+    dy = _rand((Nn, Cout, H, W), 12, dev)
+    acc = _rand((Nn, Cin, H, W), 13, dev)          # gradient already accumulated in dx (residual fan-in)
+    dx = ops.conv2d(dy, ops.pack_conv_weight_T(w), None, 3, residual=acc, wino=ops.pack_winograd_weight_T(w))
+    assert _native.lib().adm_last_conv_variant() == 4313, "the Winograd kernel was not selected"
+    ref = torch.nn.grad.conv2d_input((Nn, Cin, H, W), w.cpu(), dy.cpu(), padding=1) + acc.cpu()
+    assert _relerr(dx, ref) < 1e-4, _relerr(dx, ref)
