@@ -204,6 +204,45 @@ int adm_adamw_ema_step(float* params, const float* grads, float* exp_avg, float*
                        float beta1, float beta2, float eps, float weight_decay, int step, const float* clip_coef_dev,
                        float ema_decay, void* stream);
 
+/* ---------------------------------------------------------------- backward ops of the training step (rows T5/T8)
+ * What `accelerator.backward(loss)` (scripts/train_unet.py:259-262) asks torch autograd to run for the ops of
+ * UNet2DModel; adm_unet_forward_backward chains them natively, these entry points expose each op for parity tests and
+ * for a host that wants to drive the backward pass itself. All pointers are device pointers. */
+/* adm_groupnorm_stats that also keeps (N, groups, 2) {mean, rstd} for the backward pass (mean_rstd may be NULL). */
+int adm_groupnorm_stats_ex(const float* x1, int C1, const float* x2, int C2, int N, int HW, int groups, float eps,
+                           const float* gamma, const float* beta, float* scale, float* shift, float* mean_rstd,
+                           void* stream);
+/* Backward of GroupNorm(+SiLU) applied on a conv's load path: da = gradient w.r.t. the activated tensor (virtual concat
+ * of x1|x2); writes/accumulates dx1, dx2 (acc1/acc2 != 0: add) and ACCUMULATES dgamma, dbeta. s12_scratch: N*groups*2. */
+int adm_groupnorm_backward(const float* x1, int C1, const float* x2, int C2, const float* da, int N, int HW, int groups,
+                           const float* mean_rstd, const float* gamma, const float* beta, int act, float* s12_scratch,
+                           float* dgamma, float* dbeta, float* dx1, int acc1, float* dx2, int acc2, void* stream);
+/* Conv2d weight gradient dW (Cout,Cin,ks,ks) of the fused convolution described by `a` (same load-path fusions) for the
+ * output gradient dy; split-K partial slabs live in `workspace` (adm_conv_wgrad_workspace floats). */
+long adm_conv_wgrad_workspace(const adm_conv_args* a);
+int adm_conv2d_wgrad(const adm_conv_args* a, const float* dy, float* dW, int accumulate, float* workspace, void* stream);
+/* gradient of the nearest-x2 upsample folded into a conv: out (planes,H/2,W/2) (+)= 2x2 sums of in (planes,H,W). */
+int adm_sumpool2x2(const float* in, float* out, int H, int W, long planes, int accumulate, void* stream);
+/* dst[n][0:per_sample] (+)= src[n][0:per_sample] with independent batch strides (gradient fan-in of channel slices). */
+int adm_accumulate(float* dst, long dst_bs, const float* src, long src_bs, long per_sample, int N, int accumulate,
+                   void* stream);
+/* per-(n,c) sums of dy over HW into out_nc (time-embedding bias gradient, NULL ok) and per-c sums into out_c (bias
+ * gradient, accumulated, NULL ok). */
+int adm_chan_sums(const float* dy, int N, int C, int HW, float* out_nc, int nc_stride, int nc_accumulate, float* out_c,
+                  void* stream);
+/* backward of adm_attention: dqkv (N,3C,T) from dout (N,C,T) and the saved qkv. */
+int adm_attention_backward(const float* qkv, const float* dout, float* dqkv, int N, int C, int T, int head_dim,
+                           void* stream);
+/* Linear Y = act(X) W^T + b: dW (J,K) += dY^T act(X), db += colsum(dY), dX = (dY W) * act'(X); x_silu: act = SiLU. */
+int adm_linear_backward(const float* dY, int ldy, const float* X, const float* W, int B, int J, int K, int x_silu,
+                        float* dW, float* db, float* dX, void* stream);
+/* conv_in (Cin <= 4) weight gradient and conv_out (Cout <= 4) weight + data gradient (the direct small-channel kernels). */
+int adm_conv_small_cin_wgrad(const float* x, int Cin, int N, int H, int W, const float* dy, int Cout, float* dW,
+                             void* stream);
+int adm_conv_small_cout_backward(const float* x, int Cin, int N, int H, int W, const float* gn_scale,
+                                 const float* gn_shift, int act, const float* w, const float* dy, int Cout, float* da,
+                                 float* dW, void* stream);
+
 /* ---------------------------------------------------------------- Mel codec (rows M3-M8)
  * Replaces Mel.audio_slice_to_image (audiodiffusion/mel.py:135-151: librosa melspectrogram + power_to_db + u8) and
  * Mel.image_to_audio (mel.py:153-168: db_to_power + mel_to_stft NNLS + Griffin-Lim), batched over slices/images.
