@@ -90,6 +90,40 @@ class EMAModel:
     def copy_to(self, flat_params):
         flat_params.copy_(self.shadow)
 
+    def step(self, flat_params):
+        """EMAModel.step on its own (the fused optimizer kernel applies the same update together with AdamW): used on
+        gradient-accumulation micro-steps, where the reference still calls `ema_model.step(model)` (train_unet.py:265-266)
+        although the optimizer does not move the parameters."""
+        d = self.next_decay()
+        self.shadow.sub_((self.shadow - flat_params) * (1.0 - d))
+        return d
+
+
+class GradAccumulator:
+    """`accelerator.accumulate(model)` (train_unet.py:252) for the flat gradient buffer: `adm_unet_forward_backward`
+    overwrites `flat_grads` on every call, so micro-step gradients are summed here; on the synchronising step the
+    sum / k (accelerate scales each micro-loss by 1 / gradient_accumulation_steps) goes back into `flat_grads` for the
+    all-reduce, clipping and the optimizer. A sync is also forced at the end of the dataloader (accelerate's
+    `sync_with_dataloader` default)."""
+
+    def __init__(self, flat_grads, steps):
+        self.grads, self.steps = flat_grads, int(steps)
+        self.acc = torch.zeros_like(flat_grads) if self.steps > 1 else None
+        self.count = 0
+
+    def add(self, last_batch=False):
+        """Call after each forward/backward; returns True when the optimizer should step (`sync_gradients`)."""
+        if self.steps <= 1:
+            return True
+        self.acc.add_(self.grads)
+        self.count += 1
+        if self.count % self.steps != 0 and not last_batch:
+            return False
+        torch.mul(self.acc, 1.0 / self.steps, out=self.grads)
+        self.acc.zero_()
+        self.count = 0
+        return True
+
 
 class AdamW:
     """torch.optim.AdamW over one flat parameter buffer; optional fused clip factor and EMA update."""

@@ -53,8 +53,6 @@ def main(args):
         raise NotImplementedError("conditional / latent training is outside this path")
     if args.mixed_precision != "no":
         raise NotImplementedError("only fp32 training is implemented (mixed_precision='no', the reference default)")
-    if args.gradient_accumulation_steps != 1:
-        raise NotImplementedError("gradient accumulation is not implemented (288 GB HBM fits batch 16+ at 256x256)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -90,6 +88,7 @@ def main(args):
                               if args.lr_scheduler == "cosine" else (lambda s: 1.0))
     ema = T.EMAModel(flat, inv_gamma=args.ema_inv_gamma, power=args.ema_power, max_value=args.ema_max_decay) if args.use_ema else None
     reducer = T.GradAllReducer(grads)
+    accum = T.GradAccumulator(grads, args.gradient_accumulation_steps)     # accelerator.accumulate(model), :252
 
     global_step = 0
     for epoch in range(args.num_epochs):
@@ -110,12 +109,15 @@ def main(args):
             timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (clean.shape[0],)).long()
             noisy = noise_scheduler.add_noise(clean.contiguous(), noise, timesteps)
             loss = model.train_step(noisy, timesteps, noise)
-            reducer.start()
-            reducer.finish()
-            clip = T.clip_grad_norm_(grads, 1.0)
-            optimizer.step(grads, clip=clip, ema=ema, ema_decay=ema.next_decay() if ema is not None else 0.0)
-            lr_scheduler.step()
-            model.refresh_weights()
+            if accum.add(last_batch=(it == steps_per_epoch - 1)):          # accelerator.sync_gradients
+                reducer.start()
+                reducer.finish()
+                clip = T.clip_grad_norm_(grads, 1.0)
+                optimizer.step(grads, clip=clip, ema=ema, ema_decay=ema.next_decay() if ema is not None else 0.0)
+                lr_scheduler.step()
+                model.refresh_weights()
+            elif ema is not None:                                           # micro-step: no collective (no_sync), optimizer and
+                ema.step(flat)                                              # scheduler skipped, EMA still stepped (:265-266)
             global_step += 1
             seen += clean.shape[0] * world
             if rank == 0 and (it % args.log_every == 0 or it == steps_per_epoch - 1):

@@ -121,3 +121,39 @@ def test_data_parallel_gradients_equal_full_batch():
         p.join(timeout=600)
         assert p.exitcode == 0
     assert float((got - full).abs().max()) <= 2e-5 * float(full.abs().max())
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_gradient_accumulation_equals_one_large_batch(backend):
+    """accelerator.accumulate (train_unet.py:252): k micro-batches with loss / k == one batch of k x the size."""
+    dev = select(backend)
+    from audiodiffusion import training as T
+    from audiodiffusion.unet import UNet2DModel
+    m = UNet2DModel(**TINY).init_random(0)
+    flat, grads = m.enable_training()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((4, 1, 16, 16), generator=g).to(dev)
+    tgt = torch.randn((4, 1, 16, 16), generator=g).to(dev)
+    ts = torch.tensor([3, 400, 700, 990])
+    m.train_step(x, ts, tgt)
+    full = grads.clone()
+    acc = T.GradAccumulator(grads, 2)
+    m.train_step(x[:2].contiguous(), ts[:2], tgt[:2].contiguous())
+    assert acc.add() is False                     # micro-step: no sync, gradients parked in the accumulator
+    m.train_step(x[2:].contiguous(), ts[2:], tgt[2:].contiguous())
+    assert acc.add() is True
+    scale = float(full.abs().max())
+    assert float((grads - full).abs().max()) <= 2e-6 * scale
+    # forced sync at the end of the dataloader keeps the 1/k scaling of the single accumulated micro-batch
+    m.train_step(x[:2].contiguous(), ts[:2], tgt[:2].contiguous())
+    half = grads.clone()
+    assert acc.add(last_batch=True) is True
+    assert float((grads - 0.5 * half).abs().max()) <= 1e-7 * scale
+    # EMA on a micro-step: the same update the fused optimizer kernel applies
+    ema = T.EMAModel(flat)
+    ema.optimization_step = 10
+    shadow0 = ema.shadow.clone()
+    flat.add_(0.01)
+    d = ema.step(flat)
+    assert 0.0 < d < 1.0
+    assert torch.allclose(ema.shadow, shadow0 - (1 - d) * (shadow0 - flat), atol=1e-7)
