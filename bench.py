@@ -172,6 +172,19 @@ def roofline(unet, x, B):
            "traffic": None, "launches_per_forward": cnt, "avg_launch_us": round(ms / cnt * 1e3, 2),
            "avg_flops_per_launch": fl / cnt, "share_of_forward_time": round(ms / sum(r[2] for r in rows), 3),
            "forward_breakdown": breakdown}
+    # HBM bytes per launch of the dominant kernel: bench.py cannot collect PMC counters itself, so it reports the committed
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass over one forward of this workload (tools/pmc_forward.py), if present.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_forward.json")))["by_variant"].get(str(var))
+    except (OSError, ValueError, KeyError):
+        pmc = None
+    if pmc and pmc.get("launches_per_forward") == cnt:
+        by = sum(r[4] for r in rows if r[0] == 1 and r[1] == var)
+        out["traffic"] = round(pmc["hbm_bytes_per_launch"])
+        out["traffic_unit"] = "B/launch"
+        out["algorithmic_bytes_per_launch"] = round(by / cnt)
+        out["traffic_source"] = ("profiles/r01_pmc_forward.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate "
+                                 "passes over one B=32 forward of this workload; includes Infinity-Cache hits")
     if var // 100 == 43:
         # `achieved` is ALGORITHMIC (direct-convolution) FLOPs per second, the contract's definition; the Winograd kernel
         # executes 16/36 of them on the matrix pipe, so the pipe utilisation is reported separately.
