@@ -25,7 +25,33 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
   const int tid = threadIdx.x;
   const long total = (long)cg * HW;
   double s = 0.0, ss = 0.0;
-  if ((HW & 3) == 0) {
+  const int HW4 = HW >> 2;
+  if ((HW & 3) == 0 && (HW4 >= 256 || (256 % HW4) == 0)) {
+    // channel-major walk without per-element divisions: `tpc` threads stream one channel plane with float4 loads (4 in
+    // flight per thread), 256 / tpc channel planes at a time
+    const int tpc = HW4 >= 256 ? 256 : HW4;
+    const int sub = tid % tpc, cstep = 256 / tpc;
+    for (int cl = tid / tpc; cl < cg; cl += cstep) {
+      const int c = g * cg + cl;
+      const float4* src = reinterpret_cast<const float4*>(c < C1 ? x1 + ((long)n * C1 + c) * HW
+                                                                  : x2 + ((long)n * C2 + (c - C1)) * HW);
+      int p = sub;
+      for (; p + 3 * tpc < HW4; p += 4 * tpc) {
+        const float4 v0 = src[p], v1 = src[p + tpc], v2 = src[p + 2 * tpc], v3 = src[p + 3 * tpc];
+        s += ((double)v0.x + (double)v0.y + (double)v0.z + (double)v0.w) + ((double)v1.x + (double)v1.y + (double)v1.z + (double)v1.w) +
+             ((double)v2.x + (double)v2.y + (double)v2.z + (double)v2.w) + ((double)v3.x + (double)v3.y + (double)v3.z + (double)v3.w);
+        ss += ((double)v0.x * v0.x + (double)v0.y * v0.y + (double)v0.z * v0.z + (double)v0.w * v0.w) +
+              ((double)v1.x * v1.x + (double)v1.y * v1.y + (double)v1.z * v1.z + (double)v1.w * v1.w) +
+              ((double)v2.x * v2.x + (double)v2.y * v2.y + (double)v2.z * v2.z + (double)v2.w * v2.w) +
+              ((double)v3.x * v3.x + (double)v3.y * v3.y + (double)v3.z * v3.z + (double)v3.w * v3.w);
+      }
+      for (; p < HW4; p += tpc) {
+        const float4 v = src[p];
+        s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+      }
+    }
+  } else if ((HW & 3) == 0) {
     for (long e = (long)tid * 4; e < total; e += 256 * 4) {
       const int cl = (int)(e / HW);
       const int p = (int)(e - (long)cl * HW);
