@@ -53,6 +53,9 @@ def conv_shapes():
         (128, 0, 256, 256, 128, 3, 2, 0), (128, 0, 128, 128, 128, 3, 1, 1), (256, 128, 128, 128, 128, 1, 1, 0),
         (512, 0, 16, 16, 1536, 1, 1, 0),
     ]
+    if os.environ.get("PROBE_SHORTCUTS"):     # the conv_shortcut class: 1x1, no GroupNorm / activation on the load path
+        shapes = [(128, 128, 256, 256, 128, 1, 1, -1), (256, 128, 128, 128, 128, 1, 1, -1), (256, 256, 64, 64, 256, 1, 1, -1),
+                  (512, 512, 16, 16, 512, 1, 1, -1)]
     for (C1, C2, H, W, Co, ks, st, up) in shapes:
         x1 = torch.randn(B, C1, H, W, device=dev)
         x2 = torch.randn(B, C2, H, W, device=dev) if C2 else None
@@ -62,7 +65,10 @@ def conv_shapes():
         gamma, beta = torch.ones(C1 + C2, device=dev), torch.zeros(C1 + C2, device=dev)
         gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2)
         wu = ops.pack_winograd_weight(w) if (ks == 3 and st == 1 and os.environ.get('ADM_CONV_WINO', '3') in ('1', '2', '3')) else None
-        f = lambda: ops.conv2d(x1, wp, b, ks, x2=x2, up=bool(up), stride=st, gn=gn, act=True, wino=wu)  # noqa: E731
+        if up < 0:
+            f = lambda: ops.conv2d(x1, wp, b, ks, x2=x2)  # noqa: E731
+        else:
+            f = lambda: ops.conv2d(x1, wp, b, ks, x2=x2, up=bool(up), stride=st, gn=gn, act=True, wino=wu)  # noqa: E731
         out = f()
         dt = timeit(f, iters=5, warm=2)
         flops = 2.0 * out.numel() * (C1 + C2) * ks * ks
@@ -71,7 +77,7 @@ def conv_shapes():
         gbytes = 4.0 * (x1.numel() + (x2.numel() if x2 is not None else 0))
         log(f"conv B={B} {C1}+{C2}@{H}x{W}->{Co} k{ks} s{st} up{up}: {dt*1e3:8.3f} ms {flops/dt/1e12:7.2f} TF/s |"
             f" gn_stats {dg*1e3:7.3f} ms {gbytes/dg/1e12:5.2f} TB/s")
-        if os.environ.get("PROBE_CHECK", "1") == "1" and H <= 64:
+        if os.environ.get("PROBE_CHECK", "1") == "1" and H <= 64 and up >= 0:
             import torch.nn.functional as F
             xc = torch.cat([x1, x2], 1) if x2 is not None else x1
             xr = F.silu(F.group_norm(xc, 32, gamma, beta, 1e-5))
