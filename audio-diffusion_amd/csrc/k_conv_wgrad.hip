@@ -25,7 +25,14 @@ struct WgradParams {
   int lTW, lTH, tiles_x, tiles_y, n_ptiles, IH, IW, PS /* odd channel stride of the patch */;
   int n_ct, n_chunks, split, tiles_per_block;
   long x1_bs, x2_bs;
+  // exact reciprocals (floor(2^32 / d) + 1) of the divisors of the per-element index math: n / d == umulhi(n, m) for
+  // n, d < 2^16 — a runtime integer division costs ~40 VALU instructions, and the patch loop did 5 per element and tile
+  unsigned mPE, mIHW, mIW, mTX, mTXY;
 };
+
+__device__ __forceinline__ int fdiv(int n, unsigned magic) {   // n / d for 0 <= n < 2^16; magic = floor(2^32 / d) + 1,
+  return magic ? (int)(((unsigned long long)(unsigned)n * magic) >> 32) : n;   // or 0 for d == 1 (not representable)
+}
 
 __device__ __forceinline__ float silu_g(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
 
@@ -126,13 +133,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
 // raw activations are loaded into registers before the 288 (resp. 128) MFMAs of the current tile and are
 // normalised/activated/transposed into LDS after them, so global-load latency hides under the matrix work.
 // One workgroup per CU (up to 512 VGPRs per lane: 144 accumulators + 48 prefetch registers + addresses, no spills).
-template <int KS>
+template <int KS, bool FAST>
 __global__ void __launch_bounds__(256, 1) conv_wgrad_pf_kernel(const WgradParams p) {
   constexpr int KS2 = KS * KS;
   constexpr int NT = KS == 3 ? 9 : 4;
   constexpr int CB = KS == 3 ? 32 : 128;
   constexpr int NPX = KS == 3 ? 16 : 32;   // patch elements per thread: CB * (<=128 | 64) / 256
   constexpr int DLD = 129;
+  constexpr bool GN_PREFETCH = FAST || KS == 3;
   ADM_DYN_SMEM(float, smem);
   float* ldsD = smem;
   float* ldsP = smem + 64 * DLD;
@@ -159,11 +167,15 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_pf_kernel(const WgradParams
   const int pp_d = tid & 63, co_d0 = tid >> 6;
   const int dpx = pp_d & (TW - 1), dpy = (pp_d >> p.lTW) & (TH - 1), dimg = pp_d >> (p.lTW + p.lTH);
   float dyr[32], xr[NPX];
+  float gsr[NPX], ghr[NPX];   // GroupNorm scale/shift of the prefetched elements: fetched WITH them — loading them in stash()
+                              // serialized 16 dependent L2 round trips per tile (each followed by vmcnt(0))
   unsigned xvalid = 0;   // bit j: patch element j of this thread is inside the image (else zero padding)
   int n0_st = 0;         // first image of the tile held in registers
 
   auto issue = [&](int pt) {
-    const int tx = pt % p.tiles_x, ty = (pt / p.tiles_x) % p.tiles_y, ig = pt / (p.tiles_x * p.tiles_y);
+    const int ig = p.n_ptiles < 65536 ? fdiv(pt, p.mTXY) : pt / (p.tiles_x * p.tiles_y);   // wave-uniform
+    const int rem = pt - ig * (p.tiles_x * p.tiles_y);
+    const int ty = fdiv(rem, p.mTX), tx = rem - ty * p.tiles_x;
     const int n0 = ig * NI;
     n0_st = n0;
     xvalid = 0;
@@ -180,9 +192,9 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_pf_kernel(const WgradParams
       const int e = tid + 256 * j;
       xr[j] = 0.f;
       if (e < n_el) {
-        const int c = e / PE, q = e - c * PE;
-        const int img = q / IHW, r2 = q - img * IHW;
-        const int ly = r2 / p.IW, lx = r2 - ly * p.IW;
+        const int c = fdiv(e, p.mPE), q = e - c * PE;
+        const int img = fdiv(q, p.mIHW), r2 = q - img * IHW;
+        const int ly = fdiv(r2, p.mIW), lx = r2 - ly * p.IW;
         const int gy = ty * TH + ly - p.pad_lo, gx = tx * TW + lx - p.pad_lo;
         const int n = n0 + img, cc = c0 + c;
         if (cc < Ct && n < p.N && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi) {
@@ -190,8 +202,69 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_pf_kernel(const WgradParams
           xvalid |= 1u << j;
           xr[j] = cc < p.C1 ? p.x1[(long)n * p.x1_bs + (long)cc * planeS + sy * p.Ws + sx]
                             : p.x2[(long)n * p.x2_bs + (long)(cc - p.C1) * planeS + sy * p.Ws + sx];
+          if (GN_PREFETCH && p.gn_scale != nullptr) {
+            const long gi = (long)n * Ct + cc;
+            gsr[j] = p.gn_scale[gi]; ghr[j] = p.gn_shift[gi];
+          }
         }
       }
+    }
+  };
+  // ---- fast prefetch path (no upsample fold, the channel chunk lies in ONE source tensor, full cout tile): everything that
+  // does not depend on the tile is computed once — the generic `issue` below re-derives channel / image / row / column
+  // and a 64-bit address with bounds branches for each of the 48 elements of every tile (~3500 instructions per tile and
+  // thread, more issue time than the tile's 288 MFMAs); here a tile costs one uniform base + per-element compares, and
+  // every load is unconditional (clamped address, zeroed through `xvalid`) so nothing waits at a branch join.
+  constexpr bool fast = FAST;   // chosen by the launcher: p.up == 0, C1 % CB == 0, Ct % CB == 0, Cout % 128 == 0
+  const float* xsrc = c0 < p.C1 ? p.x1 + (long)c0 * planeS : p.x2 + (long)(c0 - p.C1) * planeS;
+  const long xbs = c0 < p.C1 ? p.x1_bs : p.x2_bs;
+  int eoff[NPX];       // element offset relative to the tile origin: image * batch stride + channel plane + row + column
+  int epk[NPX];        // packed roles: lx | ly << 8 | img << 16 | c << 24 | enabled << 31
+  if constexpr (fast) {
+    ADM_UNROLL
+    for (int j = 0; j < NPX; ++j) {
+      const int e = tid + 256 * j;
+      const bool en = e < n_el;
+      const int ec = en ? e : 0;
+      const int c = fdiv(ec, p.mPE), q = ec - c * PE;
+      const int img = fdiv(q, p.mIHW), r2 = q - img * IHW;
+      const int ly = fdiv(r2, p.mIW), lx = r2 - ly * p.IW;
+      eoff[j] = (int)(img * xbs) + c * planeS + (ly - p.pad_lo) * p.Ws + (lx - p.pad_lo);
+      epk[j] = lx | (ly << 8) | (img << 16) | (c << 24) | (en ? (int)0x80000000 : 0);
+    }
+  }
+  auto issue_fast = [&](int pt) __attribute__((always_inline)) {
+    const int ig = p.n_ptiles < 65536 ? fdiv(pt, p.mTXY) : pt / (p.tiles_x * p.tiles_y);   // wave-uniform
+    const int rem = pt - ig * (p.tiles_x * p.tiles_y);
+    const int ty = fdiv(rem, p.mTX), tx = rem - ty * p.tiles_x;
+    const int n0 = ig * NI;
+    n0_st = n0;
+    {
+      const int oy = ty * TH + dpy, ox = tx * TW + dpx, n = n0 + dimg;
+      const bool ok = n < p.N && oy < p.Ho && ox < p.Wo;
+      const float* src = p.dy + ((long)(ok ? n : 0) * p.Cout + m0 + co_d0) * planeO + (ok ? (long)oy * p.Wo + ox : 0);
+      ADM_UNROLL
+      for (int i = 0; i < 32; ++i) {
+        const float v = src[(long)(4 * i) * planeO];
+        dyr[i] = ok ? v : 0.f;
+      }
+    }
+    const float* xt = xsrc + (long)n0 * xbs + (long)(ty * TH) * p.Ws + tx * TW;   // wave-uniform tile origin
+    const float* gs = p.gn_scale ? p.gn_scale + (long)n0 * Ct + c0 : nullptr;
+    const float* gh = p.gn_scale ? p.gn_shift + (long)n0 * Ct + c0 : nullptr;
+    const int gy0 = ty * TH - p.pad_lo, gx0 = tx * TW - p.pad_lo;
+    xvalid = 0;
+    ADM_UNROLL
+    for (int j = 0; j < NPX; ++j) {
+      const int lx = epk[j] & 255, ly = (epk[j] >> 8) & 255, img = (epk[j] >> 16) & 255, c = (epk[j] >> 24) & 127;
+      const int gy = gy0 + ly, gx = gx0 + lx;
+      const bool ok = epk[j] < 0 && n0 + img < p.N && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+      xr[j] = xt[ok ? eoff[j] : 0 - (ty * TH) * p.Ws - tx * TW];      // clamped to the first element of the chunk's plane
+      if (gs != nullptr) {
+        const int gi = ok ? img * Ct + c : 0;
+        gsr[j] = gs[gi]; ghr[j] = gh[gi];
+      }
+      xvalid |= ok ? 1u << j : 0u;
     }
   };
   auto stash = [&]() {
@@ -201,12 +274,16 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_pf_kernel(const WgradParams
     for (int j = 0; j < NPX; ++j) {
       const int e = tid + 256 * j;
       if (e < n_el) {
-        const int c = e / PE, q = e - c * PE;
+        const int c = fdiv(e, p.mPE), q = e - c * PE;
         float v = xr[j];
         if ((xvalid >> j) & 1u) {
           if (p.gn_scale != nullptr) {
-            const long gi = (long)(n0_st + q / IHW) * Ct + c0 + c;
-            v = v * p.gn_scale[gi] + p.gn_shift[gi];
+            if (GN_PREFETCH) {
+              v = v * gsr[j] + ghr[j];
+            } else {   // generic 1x1 variant: 64 more prefetch registers would spill
+              const long gi = (long)(n0_st + fdiv(q, p.mIHW)) * Ct + c0 + c;
+              v = v * p.gn_scale[gi] + p.gn_shift[gi];
+            }
           }
           if (p.act) v = silu_g(v);
         } else {
@@ -220,23 +297,35 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_pf_kernel(const WgradParams
   const int t_begin = sp * p.tiles_per_block;
   int t_end = t_begin + p.tiles_per_block;
   if (t_end > p.n_ptiles) t_end = p.n_ptiles;
-  if (t_begin < t_end) issue(t_begin);
+  if (t_begin < t_end) { if constexpr (fast) issue_fast(t_begin); else issue(t_begin); }
   for (int pt = t_begin; pt < t_end; ++pt) {
     stash();
     __syncthreads();
-    if (pt + 1 < t_end) issue(pt + 1);
-    for (int s = 0; s < 32; ++s) {
+    if (pt + 1 < t_end) { if constexpr (fast) issue_fast(pt + 1); else issue(pt + 1); }
+    // operand words of k-step s+1 are requested before the MFMAs of k-step s (one wave per SIMD: nothing else hides the
+    // LDS latency; read -> wait -> MFMA per group of three left the matrix pipe ~45 % busy)
+    auto fetch = [&](int s, float& av, float (&bv)[NT]) __attribute__((always_inline)) {
       const int pp = 2 * s + h;
       const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
       const int poff = img * IHW + py * p.IW + px;
-      const float av = ldsD[pp * DLD + wave * 32 + l31];
+      av = ldsD[pp * DLD + wave * 32 + l31];
       ADM_UNROLL
       for (int t = 0; t < NT; ++t) {
-        float bv;
-        if (KS == 3) bv = ldsP[l31 * p.PS + poff + (t / 3) * p.IW + (t % 3)];
-        else bv = ldsP[(t * 32 + l31) * p.PS + poff];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        if (KS == 3) bv[t] = ldsP[l31 * p.PS + poff + (t / 3) * p.IW + (t % 3)];
+        else bv[t] = ldsP[(t * 32 + l31) * p.PS + poff];
       }
+    };
+    float a0, a1, b0[NT], b1[NT];
+    fetch(0, a0, b0);
+    for (int s = 0; s < 32; s += 2) {
+      fetch(s + 1, a1, b1);
+      ADM_SCHED_FENCE();
+      ADM_UNROLL
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[t], acc[t], 0, 0, 0);
+      if (s + 2 < 32) fetch(s + 2, a0, b0);
+      ADM_SCHED_FENCE();
+      ADM_UNROLL
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc[t], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -310,6 +399,9 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
   p.split = ceil_div(p.n_ptiles, p.tiles_per_block);  // no empty workgroups
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
+  auto magic = [](long d) { return d <= 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned long long)d + 1ULL); };
+  p.mPE = magic((long)NI * p.IH * p.IW); p.mIHW = magic((long)p.IH * p.IW); p.mIW = magic(p.IW);
+  p.mTX = magic(p.tiles_x); p.mTXY = magic((long)p.tiles_x * p.tiles_y);
   const size_t smem = sizeof(float) * ((size_t)64 * 129 + (size_t)CB * p.PS);
   ADM_REQUIRE(smem <= 80 * 1024, "conv_wgrad: patch too large for LDS");
   const long numel = (long)a.Cout * Ct * a.ks * a.ks;
@@ -319,18 +411,24 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_pf_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_pf_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_pf_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_pf_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_pf_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_pf_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     return true;
   }();
   (void)once;
 #endif
   static const int use_pf = [] { const char* e = getenv("ADM_WGRAD_PF"); return e ? atoi(e) : 1; }();
   const int PE = NI * p.IH * p.IW;
+  // tile-invariant prefetch path: no upsample fold, every channel chunk inside one source tensor, full cout tiles
+  const bool fast = a.up == 0 && a.C1 % CB == 0 && Ct % CB == 0 && a.Cout % 128 == 0;
   if (use_pf && a.stride == 1 && a.ks == 3 && PE <= 128) {
-    ADM_LAUNCH((conv_wgrad_pf_kernel<3>), grid, block, smem, st, p);
+    if (fast) ADM_LAUNCH((conv_wgrad_pf_kernel<3, true>), grid, block, smem, st, p);
+    else ADM_LAUNCH((conv_wgrad_pf_kernel<3, false>), grid, block, smem, st, p);
   } else if (use_pf && a.ks == 1) {
-    ADM_LAUNCH((conv_wgrad_pf_kernel<1>), grid, block, smem, st, p);
+    if (fast) ADM_LAUNCH((conv_wgrad_pf_kernel<1, true>), grid, block, smem, st, p);
+    else ADM_LAUNCH((conv_wgrad_pf_kernel<1, false>), grid, block, smem, st, p);
   } else if (a.ks == 3 && a.stride == 1) {
     ADM_LAUNCH((conv_wgrad_kernel<3, 1>), grid, block, smem, st, p);
   } else if (a.ks == 3) {

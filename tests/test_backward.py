@@ -48,6 +48,10 @@ WG_CASES = [
     (2, 64, 32, 8, 8, 96, 1, 1, 0, 0, 0),       # 1x1 over concat
     (2, 32, 0, 2, 2, 32, 3, 1, 0, 1, 1),        # 2x2 level
     (1, 160, 0, 8, 16, 160, 3, 1, 0, 1, 1),     # > 128 couts / channels: several tiles and chunks
+    (3, 32, 64, 8, 32, 128, 3, 1, 0, 1, 1),     # full 128-cout tile, chunks inside x1 / x2: the tile-invariant prefetch path
+    (2, 64, 0, 16, 16, 256, 3, 1, 0, 0, 0),     # ... without GroupNorm, two cout tiles, image borders on every side
+    (2, 128, 128, 8, 8, 128, 1, 1, 0, 0, 0),    # ... 1x1 (128-channel chunks) over a concat
+    (5, 32, 0, 4, 4, 128, 3, 1, 0, 1, 1),       # ... several images per 64-pixel tile, ragged last image group
 ]
 
 
