@@ -41,6 +41,7 @@ const float* conv_const_ones(int n); // shared all-ones device buffer of >= n fl
 int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st);
 int launch_pack_winograd_weight_T(const float* w, float* wu, int Cout, int Cin, hipStream_t st);  // data-gradient filters
 bool winograd_enabled();
+void set_wgrad_max_split(int v);  // k_conv_wgrad.hip
 void set_winograd_mode(int m);  // 0 off, 1 v1, 2 wave-specialised v2, 3 persistent v3 (default), -1 = default
 bool winograd_eligible(const adm_conv_args& a);
 int launch_conv_winograd(const adm_conv_args& a, hipStream_t st);

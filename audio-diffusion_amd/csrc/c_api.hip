@@ -17,6 +17,7 @@ const char* adm_last_error(void) { return adm::last_error(); }
 int adm_set_option(const char* name, int value) {
   ADM_REQUIRE(name, "set_option: null name");
   if (std::string(name) == "conv_wino") { adm::set_winograd_mode(value); return 0; }
+  if (std::string(name) == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
   ADM_FAIL(std::string("set_option: unknown option ") + name);
 }
 int adm_last_conv_variant(void) { return adm::last_conv_variant(); }

@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_pf_kernel(const WgradParams
     n0_st = n0;
     {
       const int oy = ty * TH + dpy, ox = tx * TW + dpx, n = n0 + dimg;
-      const bool ok = n < p.N && oy < p.Ho && ox < p.Wo;
+      const bool ok = (n < p.N) & (oy < p.Ho) & (ox < p.Wo);
       const float* src = p.dy + ((long)(ok ? n : 0) * p.Cout + m0 + co_d0) * planeO + (ok ? (long)oy * p.Wo + ox : 0);
       ADM_UNROLL
       for (int i = 0; i < 32; ++i) {
@@ -258,7 +258,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_pf_kernel(const WgradParams
     for (int j = 0; j < NPX; ++j) {
       const int lx = epk[j] & 255, ly = (epk[j] >> 8) & 255, img = (epk[j] >> 16) & 255, c = (epk[j] >> 24) & 127;
       const int gy = gy0 + ly, gx = gx0 + lx;
-      const bool ok = epk[j] < 0 && n0 + img < p.N && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+      // bitwise, not short-circuit: && compiles to a branch per term and per element
+      const bool ok = (epk[j] < 0) & (n0 + img < p.N) & ((unsigned)gy < (unsigned)p.Hi) & ((unsigned)gx < (unsigned)p.Wi);
       xr[j] = xt[ok ? eoff[j] : 0 - (ty * TH) * p.Ws - tx * TW];      // clamped to the first element of the chunk's plane
       if (gs != nullptr) {
         const int gi = ok ? img * Ct + c : 0;
@@ -343,6 +344,188 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_pf_kernel(const WgradParams
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Software-pipelined 3x3 stride-1 variant (the 40 % of a training step): with 144 accumulator registers there is ONE wave
+// per SIMD, so nothing but the wave's own instruction order can overlap the staging work with the matrix pipe. The LDS
+// tiles are double-buffered and the staging of the following tiles is cut into 16 pieces that ride behind the 16 MFMA
+// groups of the current tile (an MFMA group = 18 MFMAs = 1152 pipe cycles, a piece ~60 instructions):
+//   groups 0..7  : registers of tile t+1 -> LDS buffer (t+1) & 1   (dy transposed, GroupNorm + SiLU on the patch)
+//   groups 8..15 : global loads of tile t+2 -> the registers just freed (half a tile ~ 4 us ahead of their use)
+// One barrier per tile. Launcher guarantees the fast-path conditions: no upsample fold, C1 % 32 == 0, Ct % 32 == 0,
+// Cout % 128 == 0, patch of a 64-pixel tile <= 128 elements per channel.
+__global__ void __launch_bounds__(256, 1) conv_wgrad_sp_kernel(const WgradParams p) {
+  // fixed tile geometry (launcher: Wo % 16 == 0 handled by TW = 16, TH = 4, one image per 64-pixel tile): every LDS address
+  // of the MFMA loop is then a lane term plus a compile-time offset — with runtime geometry the fully unrolled loop kept
+  // ~64 hoisted address registers alive and spilled
+  constexpr int NT = 9, CB = 32, NPX = 16, DLD = 129;
+  constexpr int TW = 16, TH = 4, NI = 1, IW = 18, IHW = 108, PE = 108, PS = 109;
+  constexpr int PBUF = 64 * DLD + CB * PS;        // floats per LDS buffer: dy tile + patch
+  ADM_DYN_SMEM(float, smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  int b = blockIdx.x;
+  const int sp = b % p.split; b /= p.split;
+  const int chunk = b % p.n_chunks, ct = b / p.n_chunks;
+  const int m0 = ct * 128, c0 = chunk * CB;
+  const int Ct = p.C1 + p.C2;
+  const int planeS = p.Hs * p.Ws;
+  const long planeO = (long)p.Ho * p.Wo;
+  const int n_el = CB * PE;
+
+  f32x16 acc[NT];
+  ADM_UNROLL
+  for (int t = 0; t < NT; ++t)
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // tile-invariant roles
+  const int pp_d = tid & 63, co_d0 = tid >> 6;
+  const int dpx = pp_d & (TW - 1), dpy = pp_d >> 4, dimg = 0;
+  const float* xsrc = c0 < p.C1 ? p.x1 + (long)c0 * planeS : p.x2 + (long)(c0 - p.C1) * planeS;
+  const long xbs = c0 < p.C1 ? p.x1_bs : p.x2_bs;
+  int eoff[NPX], epk[NPX];
+  ADM_UNROLL
+  for (int j = 0; j < NPX; ++j) {
+    const int e = tid + 256 * j;
+    const bool en = e < n_el;
+    const int ec = en ? e : 0;
+    const int c = ec / PE, q = ec - c * PE;
+    const int img = 0, r2 = q;
+    const int ly = r2 / IW, lx = r2 - ly * IW;
+    eoff[j] = (int)(img * xbs) + c * planeS + (ly - p.pad_lo) * p.Ws + (lx - p.pad_lo);
+    epk[j] = lx | (ly << 8) | (img << 16) | (c << 24) | (en ? (int)0x80000000 : 0);
+  }
+  float dyr[32], xr[NPX];
+  int n0s = 0;             // first image of the tile held in xr (GroupNorm rows are read at stash time: the latency hides
+                           // behind the running MFMA group, and 32 prefetch registers fewer keep the kernel spill-free)
+  unsigned xvalid = 0;
+  // tile-uniform state of the tile being loaded
+  const float *xt = xsrc, *dsrc = p.dy;
+  int gy0 = 0, gx0 = 0, n0l = 0, back = 0;
+  bool dok = false;
+  auto load_begin = [&](int pt) __attribute__((always_inline)) {
+    const int ig = p.n_ptiles < 65536 ? fdiv(pt, p.mTXY) : pt / (p.tiles_x * p.tiles_y);
+    const int rem = pt - ig * (p.tiles_x * p.tiles_y);
+    const int ty = fdiv(rem, p.mTX), tx = rem - ty * p.tiles_x;
+    n0l = ig * NI;
+    n0s = n0l;
+    const int oy = ty * TH + dpy, ox = tx * TW + dpx, n = n0l + dimg;
+    dok = (n < p.N) & (oy < p.Ho) & (ox < p.Wo);
+    dsrc = p.dy + ((long)(dok ? n : 0) * p.Cout + m0 + co_d0) * planeO + (dok ? (long)oy * p.Wo + ox : 0);
+    back = (ty * TH) * p.Ws + tx * TW;
+    xt = xsrc + (long)n0l * xbs + back;
+    gy0 = ty * TH - p.pad_lo; gx0 = tx * TW - p.pad_lo;
+    xvalid = 0;
+  };
+  auto load_dy = [&](int i) __attribute__((always_inline)) {
+    const float v = dsrc[(long)(4 * i) * planeO];
+    dyr[i] = dok ? v : 0.f;
+  };
+  auto load_x = [&](int j) __attribute__((always_inline)) {
+    const int lx = epk[j] & 255, ly = (epk[j] >> 8) & 255, img = (epk[j] >> 16) & 255, c = (epk[j] >> 24) & 127;
+    const int gy = gy0 + ly, gx = gx0 + lx;
+    const bool ok = (epk[j] < 0) & (n0l + img < p.N) & ((unsigned)gy < (unsigned)p.Hi) & ((unsigned)gx < (unsigned)p.Wi);
+    xr[j] = xt[ok ? eoff[j] : -back];
+    xvalid |= ok ? 1u << j : 0u;
+  };
+  auto stash_dy = [&](float* buf, int i) __attribute__((always_inline)) { buf[pp_d * DLD + co_d0 + 4 * i] = dyr[i]; };
+  auto stash_x = [&](float* buf, int j) __attribute__((always_inline)) {
+    const int lx = epk[j] & 255, ly = (epk[j] >> 8) & 255, img = (epk[j] >> 16) & 255, c = (epk[j] >> 24) & 127;
+    const bool ok = (xvalid >> j) & 1u;
+    float v = xr[j];
+    if (p.gn_scale) {
+      const long gi = ok ? (long)(n0s + img) * Ct + c0 + c : 0;
+      v = v * p.gn_scale[gi] + p.gn_shift[gi];
+    }
+    const float sv = silu_g(v);
+    v = p.act ? sv : v;
+    float* dst = epk[j] < 0 ? buf + 64 * DLD + c * PS + img * IHW + ly * IW + lx
+                            : smem + 2 * PBUF + tid;                       // disabled elements: private dummy word
+    *dst = ok ? v : 0.f;
+  };
+
+  const int t_begin = sp * p.tiles_per_block;
+  int t_end = t_begin + p.tiles_per_block;
+  if (t_end > p.n_ptiles) t_end = p.n_ptiles;
+  if (t_begin < t_end) {
+    // prologue: tile t_begin -> buffer 0, tile t_begin + 1 -> registers
+    load_begin(t_begin);
+    ADM_UNROLL
+    for (int i = 0; i < 32; ++i) load_dy(i);
+    ADM_UNROLL
+    for (int j = 0; j < NPX; ++j) load_x(j);
+    ADM_UNROLL
+    for (int i = 0; i < 32; ++i) stash_dy(smem, i);
+    ADM_UNROLL
+    for (int j = 0; j < NPX; ++j) stash_x(smem, j);
+    if (t_begin + 1 < t_end) {
+      load_begin(t_begin + 1);
+      ADM_UNROLL
+      for (int i = 0; i < 32; ++i) load_dy(i);
+      ADM_UNROLL
+      for (int j = 0; j < NPX; ++j) load_x(j);
+    }
+    __syncthreads();
+  }
+  for (int pt = t_begin; pt < t_end; ++pt) {
+    const float* cur = smem + ((pt - t_begin) & 1) * PBUF;
+    float* nxt = smem + (((pt - t_begin) & 1) ^ 1) * PBUF;
+    const float* ldsD = cur;
+    const float* ldsP = cur + 64 * DLD;
+    const bool has1 = pt + 1 < t_end, has2 = pt + 2 < t_end;     // wave-uniform
+    const int dlane = h * DLD + wave * 32 + l31, plane = l31 * PS + h;
+    auto fetch = [&](int s, float& av, float (&bv)[NT]) __attribute__((always_inline)) {
+      // pixel pp = 2 s + h: px = ((2 s) & 15) + h, py = s >> 3  ->  lane term + compile-time offset
+      av = ldsD[dlane + s * (2 * DLD)];
+      ADM_UNROLL
+      for (int t = 0; t < NT; ++t) bv[t] = ldsP[plane + (s >> 3) * IW + ((2 * s) & 15) + (t / 3) * IW + (t % 3)];
+    };
+    float a0, a1, b0[NT], b1[NT];
+    fetch(0, a0, b0);
+    ADM_UNROLL
+    for (int g = 0; g < 16; ++g) {
+      const int s = 2 * g;
+      fetch(s + 1, a1, b1);
+      ADM_SCHED_FENCE();
+      ADM_UNROLL
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[t], acc[t], 0, 0, 0);
+      if (g < 15) fetch(s + 2, a0, b0);
+      ADM_SCHED_FENCE();
+      ADM_UNROLL
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc[t], 0, 0, 0);
+      // ---- side work of this group, issued while the 18 MFMAs above run -------------------------------------------
+      if (g < 8) {
+        if (has1) {
+          ADM_UNROLL
+          for (int i = 4 * g; i < 4 * g + 4; ++i) stash_dy(nxt, i);
+          stash_x(nxt, 2 * g);
+          stash_x(nxt, 2 * g + 1);
+        }
+      } else {
+        if (has2) {
+          if (g == 8) load_begin(pt + 2);
+          ADM_UNROLL
+          for (int i = 4 * (g - 8); i < 4 * (g - 8) + 4; ++i) load_dy(i);
+          load_x(2 * (g - 8));
+          load_x(2 * (g - 8) + 1);
+        }
+      }
+      ADM_SCHED_FENCE();
+    }
+    __syncthreads();
+  }
+  float* out = p.part + (long)sp * p.Cout * Ct * 9;
+  ADM_UNROLL
+  for (int t = 0; t < NT; ++t) {
+    const int cc = c0 + l31;
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      out[((long)co * Ct + cc) * 9 + t] = acc[t][r];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int split, long numel,
                                                            float* dW, int accumulate) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long)gridDim.x * blockDim.x) {
@@ -355,6 +538,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 static inline int ilog2w(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 // workspace floats needed by launch_conv_wgrad for this shape
+static int g_wgrad_max_split = 0;   // 0 = no cap; adm_set_option("wgrad_max_split", n) caps the split-K factor (tests use it
+void set_wgrad_max_split(int v) { g_wgrad_max_split = v; }   // to put several pixel tiles on one workgroup)
+
 long conv_wgrad_workspace(const adm_conv_args& a, int* split_out) {
   const int C2 = a.x2 ? a.C2 : 0, Ct = a.C1 + C2;
   int Ho, Wo;
@@ -365,6 +551,7 @@ long conv_wgrad_workspace(const adm_conv_args& a, int* split_out) {
   const int CB = a.ks == 3 ? 32 : 128;
   const int pairs = ceil_div(a.Cout, 128) * ceil_div(Ct, CB);
   int split = ceil_div(768, pairs);
+  if (g_wgrad_max_split > 0 && split > g_wgrad_max_split) split = g_wgrad_max_split;
   if (split > n_ptiles) split = n_ptiles;
   if (split < 1) split = 1;
   if (split_out) *split_out = split;
@@ -423,7 +610,18 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
   const int PE = NI * p.IH * p.IW;
   // tile-invariant prefetch path: no upsample fold, every channel chunk inside one source tensor, full cout tiles
   const bool fast = a.up == 0 && a.C1 % CB == 0 && Ct % CB == 0 && a.Cout % 128 == 0;
-  if (use_pf && a.stride == 1 && a.ks == 3 && PE <= 128) {
+  static const int use_sp = [] { const char* e = getenv("ADM_WGRAD_SP"); return e ? atoi(e) : 1; }();
+  if (use_pf && use_sp && fast && a.stride == 1 && a.ks == 3 && TW == 16 && TH == 4) {
+    const size_t smem_sp = sizeof(float) * (2 * ((size_t)64 * 129 + (size_t)CB * 109) + 256);
+#if !defined(ADM_EMU)
+    static bool once_sp = [] {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+      return true;
+    }();
+    (void)once_sp;
+#endif
+    ADM_LAUNCH(conv_wgrad_sp_kernel, grid, block, smem_sp, st, p);
+  } else if (use_pf && a.stride == 1 && a.ks == 3 && PE <= 128) {
     if (fast) ADM_LAUNCH((conv_wgrad_pf_kernel<3, true>), grid, block, smem, st, p);
     else ADM_LAUNCH((conv_wgrad_pf_kernel<3, false>), grid, block, smem, st, p);
   } else if (use_pf && a.ks == 1) {

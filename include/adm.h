@@ -25,7 +25,9 @@ const char* adm_last_error(void);
 /* 1 if built for the device (hipcc, gfx950), 0 for the CPU-emulation test build. */
 int adm_is_device_build(void);
 /* Runtime options: "conv_wino" = 0 (direct MFMA kernel only) | 1 (Winograd F(2x2,3x3) v1) | 2 (wave-specialised v2) |
- * 3 (persistent wave-specialised v3, the default) | -1 (back to the default / ADM_CONV_WINO environment variable). */
+ * 3 (persistent wave-specialised v3, the default) | -1 (back to the default / ADM_CONV_WINO environment variable);
+ * "wgrad_max_split" = n caps the split-K factor of adm_conv2d_wgrad (0 = heuristic; tests use it to put several pixel
+ * tiles on one workgroup). */
 int adm_set_option(const char* name, int value);
 /* Kernel variant the last adm_conv2d on this thread dispatched to (see adm_op_profile.variant; 4311 = Winograd). */
 int adm_last_conv_variant(void);

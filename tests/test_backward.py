@@ -56,9 +56,21 @@ WG_CASES = [
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("max_split", [0, 2], ids=["split-auto", "split2"])
 @pytest.mark.parametrize("case", WG_CASES, ids=[str(i) for i in range(len(WG_CASES))])
-def test_conv_wgrad(backend, case):
+def test_conv_wgrad(backend, case, max_split):
+    """max_split = 2 puts many pixel tiles on one workgroup: the software-pipelined kernels' steady state (LDS double
+    buffer, loads two tiles ahead) instead of prologue/epilogue only."""
     dev = select(backend)
+    from audiodiffusion import _native
+    _native.check(_native.lib().adm_set_option(b"wgrad_max_split", max_split))
+    try:
+        _wgrad_case(dev, case)
+    finally:
+        _native.check(_native.lib().adm_set_option(b"wgrad_max_split", 0))
+
+
+def _wgrad_case(dev, case):
     from audiodiffusion import ops
     Nn, C1, C2, H, W, Cout, ks, stride, up, use_gn, act = case
     x1 = _rand((Nn, C1, H, W), 1, dev)
