@@ -54,12 +54,24 @@ __global__ void __launch_bounds__(256) sumpool2x2_kernel(const float* __restrict
 // dst[n][c][p] (+)= src[n][c][p] with independent batch strides (dst may be a channel slice of a wider tensor)
 __global__ void __launch_bounds__(256) accumulate_kernel(float* dst, long dst_bs, const float* __restrict__ src,
                                                          long src_bs, long per_sample, int N, int accumulate) {
-  const long total = per_sample * N;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long n = i / per_sample, r = i - n * per_sample;
-    const float v = src[n * src_bs + r];
-    float* d = dst + n * dst_bs + r;
-    *d = accumulate ? *d + v : v;
+  // one sample per blockIdx.y: no 64-bit division per element; float4 when everything is 16-byte aligned
+  const int n = blockIdx.y;
+  const float* s = src + (long)n * src_bs;
+  float* d = dst + (long)n * dst_bs;
+  const long stride = (long)gridDim.x * blockDim.x;
+  if (((per_sample | src_bs | dst_bs) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    float4* d4 = reinterpret_cast<float4*>(d);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (per_sample >> 2); i += stride) {
+      float4 v = s4[i];
+      if (accumulate) { const float4 o = d4[i]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      d4[i] = v;
+    }
+    return;
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += stride) {
+    const float v = s[i];
+    d[i] = accumulate ? d[i] + v : v;
   }
 }
 
@@ -71,7 +83,15 @@ __global__ void __launch_bounds__(256) chan_sums_kernel(const float* __restrict_
   const int c = blockIdx.x, n = blockIdx.y;
   const float* p = dy + ((long)n * C + c) * HW;
   double s = 0.0, z = 0.0;
-  for (int i = threadIdx.x; i < HW; i += 256) s += (double)p[i];
+  if ((HW & 3) == 0) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+      const float4 v = p4[i];
+      s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += 256) s += (double)p[i];
+  }
   block_sum2(s, z, red);
   if (threadIdx.x == 0) {
     if (out_nc) {
@@ -430,7 +450,7 @@ int launch_sumpool2x2(const float* in, float* out, int H, int W, long planes, in
 }
 int launch_accumulate(float* dst, long dst_bs, const float* src, long src_bs, long per_sample, int N, int accumulate,
                       hipStream_t st) {
-  ADM_LAUNCH(accumulate_kernel, dim3(bgrid(per_sample * N)), dim3(256), 0, st, dst, dst_bs, src, src_bs, per_sample, N,
+  ADM_LAUNCH(accumulate_kernel, dim3(bgrid((per_sample + 3) / 4), N), dim3(256), 0, st, dst, dst_bs, src, src_bs, per_sample, N,
              accumulate);
   return ADM_CHECK_LAUNCH();
 }
