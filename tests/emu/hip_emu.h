@@ -85,6 +85,11 @@ struct Wave {
   float a[64], b[64];
 };
 struct State {
+  // per worker thread; launch() creates its workers anew, so the fiber stacks must die with the thread
+  // (they used to leak: ~256 MiB per launch of a 512-thread kernel, tens of GiB over a test session)
+  ~State() {
+    for (Fiber& f : fibers) free(f.stack);
+  }
   dim3 grid, block, bid;
   std::vector<Fiber> fibers;
   std::vector<Wave> waves;
