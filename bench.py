@@ -267,7 +267,7 @@ def main():
                            "hbm_frac_fused_min_bytes": round(fwd_per_s / world * (A1_GB + W_GB / B) / 1e3 / PEAK_HBM_TBS, 4)},
         }
         res["roofline"] = roofline(unet, noise, B)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (torchrun pins OMP_NUM_THREADS=1 per rank)
             res["cpu_baseline"] = cpu_baseline(unet.state_dict(), torch.get_num_threads())
         print(json.dumps(res), flush=True)
     if world > 1:
