@@ -526,6 +526,188 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_sp_kernel(const WgradParams
   }
 }
 
+// Eight-wave form of the kernel above: TWO waves per SIMD. Waves w and w + 4 land on the same SIMD, own the same 32 cout
+// rows and split the nine taps 5 / 4 (80 / 64 accumulator registers instead of 144), so while one of them walks through its
+// staging piece the other one's MFMAs keep the matrix pipe busy — the overlap a single in-order wave per SIMD cannot have.
+// Staging per thread halves (512 threads): 16 dy words and 7 patch elements per tile.
+template <int T0, int NT>
+__device__ __forceinline__ void wgrad_sp8_body(const WgradParams& p, float* smem) {
+  // fixed tile geometry (launcher: Wo % 16 == 0 handled by TW = 16, TH = 4, one image per 64-pixel tile): every LDS address
+  // of the MFMA loop is then a lane term plus a compile-time offset — with runtime geometry the fully unrolled loop kept
+  // ~64 hoisted address registers alive and spilled
+  constexpr int CB = 32, NPX = 7, DLD = 129, NDY = 16;
+  constexpr int TW = 16, TH = 4, NI = 1, IW = 18, IHW = 108, PE = 108, PS = 109;
+  constexpr int PBUF = 64 * DLD + CB * PS;        // floats per LDS buffer: dy tile + patch
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+  const int l31 = lane & 31, h = lane >> 5;
+  int b = blockIdx.x;
+  const int sp = b % p.split; b /= p.split;
+  const int chunk = b % p.n_chunks, ct = b / p.n_chunks;
+  const int m0 = ct * 128, c0 = chunk * CB;
+  const int Ct = p.C1 + p.C2;
+  const int planeS = p.Hs * p.Ws;
+  const long planeO = (long)p.Ho * p.Wo;
+  const int n_el = CB * PE;
+
+  f32x16 acc[NT];
+  ADM_UNROLL
+  for (int t = 0; t < NT; ++t)
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // tile-invariant roles
+  const int pp_d = tid & 63, co_d0 = tid >> 6;
+  const int dpx = pp_d & (TW - 1), dpy = pp_d >> 4, dimg = 0;
+  const float* xsrc = c0 < p.C1 ? p.x1 + (long)c0 * planeS : p.x2 + (long)(c0 - p.C1) * planeS;
+  const long xbs = c0 < p.C1 ? p.x1_bs : p.x2_bs;
+  int eoff[NPX], epk[NPX];
+  ADM_UNROLL
+  for (int j = 0; j < NPX; ++j) {
+    const int e = tid + 512 * j;
+    const bool en = e < n_el;
+    const int ec = en ? e : 0;
+    const int c = ec / PE, q = ec - c * PE;
+    const int img = 0, r2 = q;
+    const int ly = r2 / IW, lx = r2 - ly * IW;
+    eoff[j] = (int)(img * xbs) + c * planeS + (ly - p.pad_lo) * p.Ws + (lx - p.pad_lo);
+    epk[j] = lx | (ly << 8) | (img << 16) | (c << 24) | (en ? (int)0x80000000 : 0);
+  }
+  float dyr[NDY], xr[NPX];
+  int n0s = 0;             // first image of the tile held in xr (GroupNorm rows are read at stash time: the latency hides
+                           // behind the running MFMA group, and 32 prefetch registers fewer keep the kernel spill-free)
+  unsigned xvalid = 0;
+  // tile-uniform state of the tile being loaded
+  const float *xt = xsrc, *dsrc = p.dy;
+  int gy0 = 0, gx0 = 0, n0l = 0, back = 0;
+  bool dok = false;
+  auto load_begin = [&](int pt) __attribute__((always_inline)) {
+    const int ig = p.n_ptiles < 65536 ? fdiv(pt, p.mTXY) : pt / (p.tiles_x * p.tiles_y);
+    const int rem = pt - ig * (p.tiles_x * p.tiles_y);
+    const int ty = fdiv(rem, p.mTX), tx = rem - ty * p.tiles_x;
+    n0l = ig * NI;
+    n0s = n0l;
+    const int oy = ty * TH + dpy, ox = tx * TW + dpx, n = n0l + dimg;
+    dok = (n < p.N) & (oy < p.Ho) & (ox < p.Wo);
+    dsrc = p.dy + ((long)(dok ? n : 0) * p.Cout + m0 + co_d0) * planeO + (dok ? (long)oy * p.Wo + ox : 0);   // co_d0 = tid >> 6 in 0..7
+    back = (ty * TH) * p.Ws + tx * TW;
+    xt = xsrc + (long)n0l * xbs + back;
+    gy0 = ty * TH - p.pad_lo; gx0 = tx * TW - p.pad_lo;
+    xvalid = 0;
+  };
+  auto load_dy = [&](int i) __attribute__((always_inline)) {
+    const float v = dsrc[(long)(8 * i) * planeO];
+    dyr[i] = dok ? v : 0.f;
+  };
+  auto load_x = [&](int j) __attribute__((always_inline)) {
+    const int lx = epk[j] & 255, ly = (epk[j] >> 8) & 255, img = (epk[j] >> 16) & 255, c = (epk[j] >> 24) & 127;
+    const int gy = gy0 + ly, gx = gx0 + lx;
+    const bool ok = (epk[j] < 0) & (n0l + img < p.N) & ((unsigned)gy < (unsigned)p.Hi) & ((unsigned)gx < (unsigned)p.Wi);
+    xr[j] = xt[ok ? eoff[j] : -back];
+    xvalid |= ok ? 1u << j : 0u;
+  };
+  auto stash_dy = [&](float* buf, int i) __attribute__((always_inline)) { buf[pp_d * DLD + co_d0 + 8 * i] = dyr[i]; };
+  auto stash_x = [&](float* buf, int j) __attribute__((always_inline)) {
+    const int lx = epk[j] & 255, ly = (epk[j] >> 8) & 255, img = (epk[j] >> 16) & 255, c = (epk[j] >> 24) & 127;
+    const bool ok = (xvalid >> j) & 1u;
+    float v = xr[j];
+    if (p.gn_scale) {
+      const long gi = ok ? (long)(n0s + img) * Ct + c0 + c : 0;
+      v = v * p.gn_scale[gi] + p.gn_shift[gi];
+    }
+    const float sv = silu_g(v);
+    v = p.act ? sv : v;
+    float* dst = epk[j] < 0 ? buf + 64 * DLD + c * PS + img * IHW + ly * IW + lx
+                            : smem + 2 * PBUF + tid;                       // disabled elements: private dummy word (512)
+    *dst = ok ? v : 0.f;
+  };
+
+  const int t_begin = sp * p.tiles_per_block;
+  int t_end = t_begin + p.tiles_per_block;
+  if (t_end > p.n_ptiles) t_end = p.n_ptiles;
+  if (t_begin < t_end) {
+    // prologue: tile t_begin -> buffer 0, tile t_begin + 1 -> registers
+    load_begin(t_begin);
+    ADM_UNROLL
+    for (int i = 0; i < NDY; ++i) load_dy(i);
+    ADM_UNROLL
+    for (int j = 0; j < NPX; ++j) load_x(j);
+    ADM_UNROLL
+    for (int i = 0; i < NDY; ++i) stash_dy(smem, i);
+    ADM_UNROLL
+    for (int j = 0; j < NPX; ++j) stash_x(smem, j);
+    if (t_begin + 1 < t_end) {
+      load_begin(t_begin + 1);
+      ADM_UNROLL
+      for (int i = 0; i < NDY; ++i) load_dy(i);
+      ADM_UNROLL
+      for (int j = 0; j < NPX; ++j) load_x(j);
+    }
+    __syncthreads();
+  }
+  for (int pt = t_begin; pt < t_end; ++pt) {
+    const float* cur = smem + ((pt - t_begin) & 1) * PBUF;
+    float* nxt = smem + (((pt - t_begin) & 1) ^ 1) * PBUF;
+    const float* ldsD = cur;
+    const float* ldsP = cur + 64 * DLD;
+    const bool has1 = pt + 1 < t_end, has2 = pt + 2 < t_end;     // wave-uniform
+    const int dlane = h * DLD + wave * 32 + l31, plane = l31 * PS + h;
+    auto fetch = [&](int s, float& av, float (&bv)[NT]) __attribute__((always_inline)) {
+      // pixel pp = 2 s + h: px = ((2 s) & 15) + h, py = s >> 3  ->  lane term + compile-time offset
+      av = ldsD[dlane + s * (2 * DLD)];
+      ADM_UNROLL
+      for (int t = 0; t < NT; ++t) bv[t] = ldsP[plane + (s >> 3) * IW + ((2 * s) & 15) + ((T0 + t) / 3) * IW + ((T0 + t) % 3)];
+    };
+    float a0, a1, b0[NT], b1[NT];
+    fetch(0, a0, b0);
+    ADM_UNROLL
+    for (int g = 0; g < 16; ++g) {
+      const int s = 2 * g;
+      fetch(s + 1, a1, b1);
+      ADM_SCHED_FENCE();
+      ADM_UNROLL
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[t], acc[t], 0, 0, 0);
+      if (g < 15) fetch(s + 2, a0, b0);
+      ADM_SCHED_FENCE();
+      ADM_UNROLL
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[t], acc[t], 0, 0, 0);
+      // ---- side work of this group; the partner wave on this SIMD issues MFMAs meanwhile -------------------------------------------
+      if (g < 8) {
+        if (has1) {
+          stash_dy(nxt, 2 * g);
+          stash_dy(nxt, 2 * g + 1);
+          if (g < NPX) stash_x(nxt, g);
+        }
+      } else {
+        if (has2) {
+          if (g == 8) load_begin(pt + 2);
+          load_dy(2 * (g - 8));
+          load_dy(2 * (g - 8) + 1);
+          if (g - 8 < NPX) load_x(g - 8);
+        }
+      }
+      ADM_SCHED_FENCE();
+    }
+    __syncthreads();
+  }
+  float* out = p.part + (long)sp * p.Cout * Ct * 9;
+  ADM_UNROLL
+  for (int t = 0; t < NT; ++t) {
+    const int cc = c0 + l31;
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      out[((long)co * Ct + cc) * 9 + T0 + t] = acc[t][r];
+    }
+  }
+}
+
+
+__global__ void __launch_bounds__(512, 1) conv_wgrad_sp8_kernel(const WgradParams p) {
+  ADM_DYN_SMEM(float, smem);
+  if ((threadIdx.x >> 8) == 0) wgrad_sp8_body<0, 5>(p, smem);   // waves 0..3: taps 0..4
+  else wgrad_sp8_body<5, 4>(p, smem);                           // waves 4..7: taps 5..8
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int split, long numel,
                                                            float* dW, int accumulate) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long)gridDim.x * blockDim.x) {
@@ -620,7 +802,19 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
     }();
     (void)once_sp;
 #endif
-    ADM_LAUNCH(conv_wgrad_sp_kernel, grid, block, smem_sp, st, p);
+    static const int use_sp8 = [] { const char* e = getenv("ADM_WGRAD_SP8"); return e ? atoi(e) : 1; }();
+    if (use_sp8) {
+#if !defined(ADM_EMU)
+      static bool once_sp8 = [] {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_sp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+        return true;
+      }();
+      (void)once_sp8;
+#endif
+      ADM_LAUNCH(conv_wgrad_sp8_kernel, grid, dim3(512), smem_sp + sizeof(float) * 256, st, p);
+    } else {
+      ADM_LAUNCH(conv_wgrad_sp_kernel, grid, block, smem_sp, st, p);
+    }
   } else if (use_pf && a.stride == 1 && a.ks == 3 && PE <= 128) {
     if (fast) ADM_LAUNCH((conv_wgrad_pf_kernel<3, true>), grid, block, smem, st, p);
     else ADM_LAUNCH((conv_wgrad_pf_kernel<3, false>), grid, block, smem, st, p);
