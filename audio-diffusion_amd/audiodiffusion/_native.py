@@ -89,6 +89,7 @@ _OPTIONAL_SIGS = {
     "adm_unet_refresh_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adm_unet_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_int, C.c_void_p]),
+    "adm_unet_set_grad_bucket_hook": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_long), C.c_void_p, C.c_void_p]),
     "adm_groupnorm_stats_ex": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "adm_groupnorm_backward": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "adm_conv_wgrad_workspace": (_l, [C.POINTER(ConvArgs)]),
@@ -119,6 +120,9 @@ _OPTIONAL_SIGS = {
 
 _lib = None
 _lib_path = None
+
+
+BUCKET_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int)   # include/adm.h: adm_bucket_fn
 
 
 class NativeError(RuntimeError):

@@ -179,16 +179,53 @@ class GradAllReducer:
         self.bounds = [(i, min(i + per, flat_grads.numel())) for i in range(0, flat_grads.numel(), per)]
         self.pending = []
 
+        self.launched = set()
+        self.enabled = True          # set False on gradient-accumulation micro-steps (DDP no_sync)
+        self.overlapped = 0          # buckets whose all-reduce was queued from inside the backward pass (last step)
+        self._cb = None
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _launch(self, b):
+        lo, hi = self.bounds[b]
+        self.launched.add(b)
+        self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def attach(self, model):
+        """Overlap with the backward pass, as DDP does: the native reverse pass calls back as soon as the last kernel
+        writing into a bucket is enqueued; the bucket's asynchronous all-reduce is queued right then (RCCL orders it after
+        the work already on the current stream) and runs while the remaining layers are still being differentiated."""
+        bounds = (C.c_long * (len(self.bounds) + 1))(*([lo for lo, _ in self.bounds] + [self.bounds[-1][1]]))
+
+        def on_bucket(_user, b):
+            if self.enabled and self._active():
+                self._launch(b)
+                self.overlapped += 1
+
+        self._cb = N.BUCKET_FN(on_bucket)            # keep the trampoline alive as long as the hook is installed
+        N.check(N.lib().adm_unet_set_grad_bucket_hook(model._handle, len(self.bounds), bounds,
+                                                      C.cast(self._cb, C.c_void_p), None))
+        return self
+
     def start(self):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        """Queue every bucket the backward pass has not queued already (all of them without `attach`)."""
+        if not self._active():
             return
-        for lo, hi in self.bounds:
-            self.pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for b in range(len(self.bounds)):
+            if b not in self.launched:
+                self._launch(b)
 
     def finish(self):
         if not self.pending:
+            self.launched = set()
             return
         for w in self.pending:
             w.wait()
         self.pending = []
+        self.launched = set()
         self.g.div_(dist.get_world_size(self.group))
+
+    def begin_step(self):
+        """Call before the forward/backward of a synchronising step."""
+        self.overlapped = 0

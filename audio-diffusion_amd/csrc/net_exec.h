@@ -128,6 +128,16 @@ struct Net {
   // gradients into grads_base (+ offset of the master parameter) and dtemb_all (B, temb_stride) when non-NULL.
   int run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st);
   float* grad_of(const float* master_param) const { return grads_base + (master_param - params_base); }
+  // training, data-parallel overlap: the flat gradient buffer is cut into buckets [bk_lo[b], bk_lo[b+1]); as soon as the
+  // reverse pass has ENQUEUED the last kernel that writes into a bucket, bk_fn(bk_user, b) is called on the host thread so
+  // the caller can queue that bucket's all-reduce behind it while the rest of the backward pass is still running
+  std::vector<long> bk_lo;
+  std::vector<int> bk_total, bk_pending;
+  void (*bk_fn)(void*, int) = nullptr;
+  void* bk_user = nullptr;
+  int set_bucket_hook(int n_buckets, const long* bounds, void (*fn)(void*, int), void* user);
+  void bucket_reset() { bk_pending = bk_total; }
+  void mark_ready(const float* master_param, size_t numel);
   void destroy();
 };
 

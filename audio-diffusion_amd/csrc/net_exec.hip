@@ -154,6 +154,30 @@ int Net::make_conv(const std::string& p, int co, int ci, int ks, const ConvW** o
   return 0;
 }
 
+int Net::set_bucket_hook(int n_buckets, const long* bounds, void (*fn)(void*, int), void* user) {
+  bk_fn = nullptr; bk_lo.clear(); bk_total.clear(); bk_pending.clear();
+  if (n_buckets <= 0 || fn == nullptr) return 0;
+  ADM_REQUIRE(params_base != nullptr && bounds != nullptr, "set_bucket_hook: parameters are not bound to a flat buffer");
+  bk_lo.assign(bounds, bounds + n_buckets + 1);
+  for (int b = 0; b < n_buckets; ++b) ADM_REQUIRE(bk_lo[b] < bk_lo[b + 1], "set_bucket_hook: bounds must ascend");
+  bk_total.assign(n_buckets, 0);
+  for (auto& kv : ps->params) {
+    const long lo = kv.second.dev - params_base, hi = lo + (long)kv.second.numel;
+    for (int b = 0; b < n_buckets; ++b)
+      if (lo < bk_lo[b + 1] && hi > bk_lo[b]) ++bk_total[b];
+  }
+  bk_fn = fn; bk_user = user;
+  bucket_reset();
+  return 0;
+}
+
+void Net::mark_ready(const float* master_param, size_t numel) {
+  if (bk_fn == nullptr) return;
+  const long lo = master_param - params_base, hi = lo + (long)numel;
+  for (size_t b = 0; b + 1 < bk_lo.size(); ++b)
+    if (lo < bk_lo[b + 1] && hi > bk_lo[b] && --bk_pending[b] == 0) bk_fn(bk_user, (int)b);
+}
+
 int Net::refresh_weights(hipStream_t st) {
   for (ConvW& w : convs) ADM_TRY(pack_one(this, w, st));
   return 0;
@@ -476,7 +500,12 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
         ADM_TRY(copy_d2d(grad_of(ps->P(o.w->qkv_prefix + names[k] + ".weight")), tmp_w + (size_t)k * C * C,
                          sizeof(float) * (size_t)C * C, st));
         ADM_TRY(copy_d2d(grad_of(ps->P(o.w->qkv_prefix + names[k] + ".bias")), dbias + (size_t)k * C, sizeof(float) * C, st));
+        mark_ready(ps->P(o.w->qkv_prefix + names[k] + ".weight"), (size_t)C * C);
+        mark_ready(ps->P(o.w->qkv_prefix + names[k] + ".bias"), (size_t)C);
       }
+    } else {
+      mark_ready(ps->P(o.w->key + ".weight"), (size_t)Cout * Ct * o.ks * o.ks);
+      mark_ready(ps->P(o.w->key + ".bias"), (size_t)Cout);
     }
     // ---- data gradient ---------------------------------------------------------------------------------------
     if (o.in1 == t_in) continue;  // the network input needs no gradient
@@ -507,6 +536,8 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       ADM_TRY(launch_gn_backward(t1.ptr, C1, x2, C2, tmp_da, B, (int)plane_i, groups, gb.mean_rstd, gb.g->gamma, gb.g->beta,
                                  o.act, s12, grad_of(gb.g->gamma), grad_of(gb.g->beta), t1.grad, t1.ginit ? 1 : 0,
                                  t2 ? t2->grad : nullptr, (t2 && t2->ginit) ? 1 : 0, st));
+      mark_ready(gb.g->gamma, (size_t)gb.g->C);
+      mark_ready(gb.g->beta, (size_t)gb.g->C);
       t1.ginit = true;
       if (t2) t2->ginit = true;
     } else if (o.up) {

@@ -441,6 +441,7 @@ int adm_unet_forward_backward(adm_unet_t* h, const float* x, const float* timest
   const long n_out = (long)B * c.out_channels * c.sample_h * c.sample_w;
   ADM_TRY(adm_mse_loss(h->eps_buf, target, n_out, loss_dev, net.tensors[net.t_out].grad, h->scratch_d, st));
   net.grads_base = grads_base;
+  net.bucket_reset();
   ADM_TRY(dmemset(grads_base, 0, sizeof(float) * (size_t)h->params_numel, st));
   ADM_TRY(net.run_backward(B, h->dtemb_all, h->temb_rows, st));
   // ---- time-embedding path: time_emb_proj (per resnet), then the 2-layer MLP ---------------------------------
@@ -449,6 +450,8 @@ int adm_unet_forward_backward(adm_unet_t* h, const float* x, const float* timest
   for (auto& r : net.temb_rows) {
     ADM_TRY(launch_linear_bwd(h->dtemb_all + off, R, h->emb, nullptr, B, r.second, K, 1,
                               net.grad_of(P(h, r.first + ".weight")), net.grad_of(P(h, r.first + ".bias")), nullptr, st));
+    net.mark_ready(P(h, r.first + ".weight"), (size_t)r.second * K);
+    net.mark_ready(P(h, r.first + ".bias"), (size_t)r.second);
     off += r.second;
   }
   ADM_TRY(launch_linear_bwd(h->dtemb_all, R, h->emb, h->temb_w, B, R, K, 1, nullptr, nullptr, h->demb, st));
@@ -458,7 +461,21 @@ int adm_unet_forward_backward(adm_unet_t* h, const float* x, const float* timest
   ADM_TRY(launch_linear_bwd(h->dz, K, h->save_sinus, nullptr, B, K, dim_in, 0,
                             net.grad_of(P(h, "time_embedding.linear_1.weight")),
                             net.grad_of(P(h, "time_embedding.linear_1.bias")), nullptr, st));
+  net.mark_ready(P(h, "time_embedding.linear_2.weight"), (size_t)K * K);
+  net.mark_ready(P(h, "time_embedding.linear_2.bias"), (size_t)K);
+  net.mark_ready(P(h, "time_embedding.linear_1.weight"), (size_t)K * dim_in);
+  net.mark_ready(P(h, "time_embedding.linear_1.bias"), (size_t)K);
   return 0;
+}
+
+// Data-parallel overlap (scripts/train_unet.py:259: DDP all-reduces gradient buckets while autograd is still running):
+// fn(user, b) fires on the calling thread, during adm_unet_forward_backward, right after the last kernel writing into
+// bucket b = [bounds[b], bounds[b+1]) of the flat gradient buffer has been enqueued. n_buckets = 0 removes the hook.
+int adm_unet_set_grad_bucket_hook(adm_unet_t* h, int n_buckets, const long* bounds, adm_bucket_fn fn, void* user) {
+  ADM_REQUIRE(h, "unet_set_grad_bucket_hook: null handle");
+  ADM_REQUIRE(n_buckets == 0 || h->training, "unet_set_grad_bucket_hook: call adm_unet_enable_training first");
+  if (n_buckets > 0) ADM_TRY(finalize(h));   // the op list (and its parameter table) must exist to count a bucket's writers
+  return h->net.set_bucket_hook(n_buckets, bounds, fn, user);
 }
 
 size_t adm_unet_workspace_bytes(adm_unet_t* h) { return h ? h->net.arena_bytes : 0; }

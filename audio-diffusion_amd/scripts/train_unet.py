@@ -88,6 +88,8 @@ def main(args):
                               if args.lr_scheduler == "cosine" else (lambda s: 1.0))
     ema = T.EMAModel(flat, inv_gamma=args.ema_inv_gamma, power=args.ema_power, max_value=args.ema_max_decay) if args.use_ema else None
     reducer = T.GradAllReducer(grads)
+    if world > 1 and args.gradient_accumulation_steps == 1:
+        reducer.attach(model)        # DDP overlap: buckets are all-reduced while the reverse pass is still running
     accum = T.GradAccumulator(grads, args.gradient_accumulation_steps)     # accelerator.accumulate(model), :252
 
     global_step = 0
@@ -108,6 +110,7 @@ def main(args):
             noise = torch.randn(clean.shape).to(dev)                          # CPU RNG then H2D, as :238
             timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (clean.shape[0],)).long()
             noisy = noise_scheduler.add_noise(clean.contiguous(), noise, timesteps)
+            reducer.begin_step()
             loss = model.train_step(noisy, timesteps, noise)
             if accum.add(last_batch=(it == steps_per_epoch - 1)):          # accelerator.sync_gradients
                 reducer.start()

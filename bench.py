@@ -62,6 +62,8 @@ def train_main(a, world, rank, dev):
     unet = UNet2DModel(**CFG256).init_random(0)
     flat, grads = unet.enable_training()
     opt, ema, red = T.AdamW(flat), T.EMAModel(flat), T.GradAllReducer(grads)
+    if world > 1:
+        red.attach(unet)          # gradient buckets are all-reduced (RCCL) from inside the reverse pass
     sched = DDPMScheduler()
     g = torch.Generator().manual_seed(7 + rank)
     clean = (torch.rand(B, 1, 256, 256, generator=g) * 2 - 1).to(dev)
@@ -70,6 +72,7 @@ def train_main(a, world, rank, dev):
 
     def step():
         noisy = sched.add_noise(clean, noise, ts)
+        red.begin_step()
         loss = unet.train_step(noisy, ts, noise)
         red.start(), red.finish()
         opt.step(grads, clip=T.clip_grad_norm_(grads, 1.0), ema=ema, ema_decay=ema.next_decay())

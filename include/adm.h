@@ -156,6 +156,14 @@ int adm_unet_refresh_weights(adm_unet_t* h, void* stream);
  * Every activation is kept for the reverse pass; GroupNorm/SiLU are recomputed in the weight-gradient load path. */
 int adm_unet_forward_backward(adm_unet_t* h, const float* x, const float* timesteps_host, int n_timesteps,
                               const float* target, float* loss_dev, float* grads_base, int B, void* stream);
+/* Data-parallel overlap (DistributedDataParallel's bucketed all-reduce running under autograd, train_unet.py:259): cut the
+ * flat gradient buffer into n_buckets ranges [bounds[b], bounds[b+1]) (elements, ascending, n_buckets + 1 values);
+ * fn(user, b) is called on the calling thread during adm_unet_forward_backward as soon as the last kernel writing into
+ * bucket b has been ENQUEUED on the stream — queue the bucket's all-reduce behind it (RCCL orders after the stream) while
+ * the rest of the reverse pass runs. Buckets holding a parameter the pass never touches do not fire: reduce those after
+ * the call returns. n_buckets = 0 removes the hook. */
+typedef void (*adm_bucket_fn)(void* user, int bucket);
+int adm_unet_set_grad_bucket_hook(adm_unet_t* h, int n_buckets, const long* bounds, adm_bucket_fn fn, void* user);
 
 /* ---------------------------------------------------------------- whole denoising loop (row P4; hipGraph)
  * Runs n_steps x {UNet forward, scheduler epilogue, mask} on `x` in place and (optionally) the final u8 image.

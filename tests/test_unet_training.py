@@ -68,7 +68,7 @@ def test_forward_backward_matches_autograd(backend, cfg, B):
 
 
 # ---------------------------------------------------------------- data-parallel equivalence
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, port, q, overlap=False):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -89,17 +89,35 @@ def _ddp_worker(rank, world, port, q):
     x, tgt = torch.randn(4, 1, 16, 16, generator=g), torch.randn(4, 1, 16, 16, generator=g)
     ts = torch.tensor([5, 500, 999, 250])
     sl = slice(rank * 2, rank * 2 + 2)
-    m.train_step(x[sl].contiguous(), ts[sl], tgt[sl].contiguous())
     r = T.GradAllReducer(grads, bucket_mb=0.05)
+    if overlap:                                   # all-reduce buckets are queued from inside the reverse pass (DDP overlap)
+        r.attach(m)
+    r.begin_step()
+    m.train_step(x[sl].contiguous(), ts[sl], tgt[sl].contiguous())
+    n_over = r.overlapped
     r.start(), r.finish()
+    if overlap:
+        assert n_over == len(r.bounds), (n_over, len(r.bounds))     # every bucket fired during the backward pass
+        # a second step re-arms the hook; a no_sync micro-step must not touch the network
+        r.begin_step()
+        r.enabled = False
+        m.train_step(x[sl].contiguous(), ts[sl], tgt[sl].contiguous())
+        assert r.overlapped == 0 and not r.pending
+        r.enabled = True
+        r.begin_step()
+        m.train_step(x[sl].contiguous(), ts[sl], tgt[sl].contiguous())
+        assert r.overlapped == len(r.bounds)
+        r.start(), r.finish()
     if rank == 0:
         q.put(grads.cpu().numpy().copy())  # by value: the producer may exit before the parent reads
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_data_parallel_gradients_equal_full_batch():
-    """2 ranks x (B/2) with the bucketed all-reduce == 1 rank x B, to fp32 tolerance (DDP semantics, train_unet.py:259)."""
+@pytest.mark.parametrize("overlap", [False, True], ids=["after-backward", "overlapped"])
+def test_data_parallel_gradients_equal_full_batch(overlap):
+    """2 ranks x (B/2) with the bucketed all-reduce == 1 rank x B, to fp32 tolerance (DDP semantics, train_unet.py:259);
+    `overlapped`: the buckets are queued by the native reverse pass's bucket hook while it is still running."""
     import os
     import torch.multiprocessing as mp
     select("emu")
@@ -113,10 +131,10 @@ def test_data_parallel_gradients_equal_full_batch():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29900 + os.getpid() % 2000
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port + (7 if overlap else 0), q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
-    got = torch.from_numpy(q.get(timeout=600))
+    got = torch.from_numpy(q.get(timeout=240))
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
