@@ -143,7 +143,7 @@ def main(args):
         dist.destroy_process_group()
 
 
-if __name__ == "__main__":
+def parse_args(argv=None):
     parser = argparse.ArgumentParser(description="MI355X-native training script (reference: scripts/train_unet.py).")
     parser.add_argument("--local_rank", type=int, default=-1)
     parser.add_argument("--dataset_name", type=str, default="synthetic")
@@ -183,4 +183,8 @@ if __name__ == "__main__":
     parser.add_argument("--synthetic_size", type=int, default=2048)
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--log_every", type=int, default=10)
-    main(parser.parse_args())
+    return parser.parse_args(argv)
+
+
+if __name__ == "__main__":
+    main(parse_args())
