@@ -141,6 +141,7 @@ def main(args):
             dist.barrier()
     if world > 1:
         dist.destroy_process_group()
+    return model
 
 
 def parse_args(argv=None):
