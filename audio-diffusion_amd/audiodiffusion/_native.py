@@ -34,6 +34,7 @@ class ConvArgs(C.Structure):
         ("out", C.c_void_p),
         ("x1_bstride", C.c_long), ("x2_bstride", C.c_long), ("w_bstride", C.c_long),
         ("wino_packed", C.c_void_p),
+        ("bf16_packed", C.c_void_p),
     ]
 
 
@@ -67,6 +68,7 @@ _SIGS = {
     "adm_pack_conv_weight_T": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "adm_pack_winograd_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "adm_pack_winograd_weight_T": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "adm_pack_bf16_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "adm_conv_out_dims": (None, [C.c_int] * 6 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "adm_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "adm_unet_create": (C.c_int, [C.POINTER(UNetConfig), C.POINTER(C.c_void_p)]),

@@ -109,8 +109,18 @@ def pack_winograd_weight_T(w):
     return wu
 
 
+def pack_bf16_weight(w, transposed=False):
+    """(Cout,Cin,3,3) fp32 -> bf16 MFMA operand layout [tap][Cin/8][Cout][8] (transposed: the data-gradient filters)."""
+    _f32(w)
+    co, ci = w.shape[:2]
+    shape = (9, co // 8, ci, 8) if transposed else (9, ci // 8, co, 8)
+    wb = torch.empty(shape, dtype=torch.bfloat16, device=w.device)
+    N.check(N.lib().adm_pack_bf16_weight(N.ptr(w), C.c_void_p(wb.data_ptr()), co, ci, int(transposed), N.stream_for(w)))
+    return wb
+
+
 def conv2d(x1, wpacked, bias, ks, x2=None, up=False, stride=1, pad_lo=1, gn=None, act=False, chan_add=None,
-           residual=None, wino=None):
+           residual=None, wino=None, bf16=None):
     """Fused convolution (see include/adm.h adm_conv_args)."""
     _f32(x1)
     Nn, C1, H, W = x1.shape
@@ -132,6 +142,7 @@ def conv2d(x1, wpacked, bias, ks, x2=None, up=False, stride=1, pad_lo=1, gn=None
         a.chan_add, a.chan_add_stride = C.c_void_p(chan_add.data_ptr()), chan_add.stride(0)
     a.residual = N.ptr(residual)
     a.wino_packed = N.ptr(wino)
+    a.bf16_packed = C.c_void_p(bf16.data_ptr()) if bf16 is not None else None
     a.out = N.ptr(out)
     N.check(N.lib().adm_conv2d(C.byref(a), N.stream_for(x1)))
     return out

@@ -46,6 +46,16 @@ void set_winograd_mode(int m);  // 0 off, 1 v1, 2 wave-specialised v2, 3 persist
 bool winograd_eligible(const adm_conv_args& a);
 int launch_conv_winograd(const adm_conv_args& a, hipStream_t st);
 
+// k_conv_bf16.hip (mixed-precision training: bf16 MFMA operands, fp32 accumulate)
+int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transposed, hipStream_t st);
+void set_conv_bf16(int m);   // 0 off (default), 1 on, -1 = ADM_CONV_BF16 from the environment
+bool conv_bf16_enabled();
+bool conv_bf16_eligible(const adm_conv_args& a);
+int launch_conv_bf16(const adm_conv_args& a, hipStream_t st);
+bool conv_wgrad_bf16_eligible(const adm_conv_args& a);
+int launch_conv_wgrad_bf16(const adm_conv_args& a, const float* dy, float* dW, int accumulate, float* workspace, int split,
+                           hipStream_t st);
+
 // k_backward.hip / k_conv_wgrad.hip (training)
 int launch_sumpool2x2(const float* in, float* out, int H, int W, long planes, int accumulate, hipStream_t st);
 int launch_accumulate(float* dst, long dst_bs, const float* src, long src_bs, long per_sample, int N, int accumulate,

@@ -23,10 +23,25 @@
 #define ADM_SCHED_FENCE() ((void)0)
 #define ADM_RCP(x) (1.0f / (x))
 #define ADM_UNIFORM(x) (x)
+// bf16 operand plumbing (k_conv_bf16.hip): two floats -> one dword of 2 x bf16 (round-to-nearest-even, low half = a),
+// v_mfma_f32_32x32x16_bf16 on 4-dword operands, v_alignbit_b32
+#define ADM_PK_BF16(a, b) adm_emu::pk_bf16((a), (b))
+#define ADM_MFMA_BF16(a, b, c) adm_emu::mfma_f32_32x32x16_bf16((a), (b), (c))
+#define ADM_ALIGNBIT(hi, lo, sh) ((unsigned)((((uint64_t)(hi) << 32) | (uint64_t)(lo)) >> (sh)))
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 adm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 adm_bf16x2 __attribute__((ext_vector_type(2)));
+// two floats -> one dword of 2 x bf16 (v_cvt_pk_bf16_f32: round-to-nearest-even; low half = a)
+#define ADM_PK_BF16(a, b) __builtin_bit_cast(unsigned, adm_bf16x2{(__bf16)(a), (__bf16)(b)})
+// v_mfma_f32_32x32x16_bf16 on 4-dword operands: lane l holds A[i = l & 31][k = 8 (l >> 5) + 0..7] (B likewise with j);
+// any k assignment is valid as long as A and B use the same one. C/D: col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+#define ADM_MFMA_BF16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(adm_bf16x8, (a)), __builtin_bit_cast(adm_bf16x8, (b)), (c), 0, 0, 0)
+#define ADM_ALIGNBIT(hi, lo, sh) __builtin_amdgcn_alignbit((hi), (lo), (sh))
 #define ADM_LAUNCH(kern, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), (shmem), (stream), __VA_ARGS__)
 #define ADM_DYN_SMEM(type, name)                                              \

@@ -18,6 +18,7 @@ int adm_set_option(const char* name, int value) {
   ADM_REQUIRE(name, "set_option: null name");
   if (std::string(name) == "conv_wino") { adm::set_winograd_mode(value); return 0; }
   if (std::string(name) == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
+  if (std::string(name) == "conv_bf16") { adm::set_conv_bf16(value); return 0; }
   ADM_FAIL(std::string("set_option: unknown option ") + name);
 }
 int adm_last_conv_variant(void) { return adm::last_conv_variant(); }
@@ -77,6 +78,11 @@ int adm_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, void*
 int adm_pack_winograd_weight_T(const float* w, float* wuT, int Cout, int Cin, void* stream) {
   ADM_REQUIRE(w && wuT, "pack_winograd_weight_T: null argument");
   return launch_pack_winograd_weight_T(w, wuT, Cout, Cin, (hipStream_t)stream);
+}
+
+int adm_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transposed, void* stream) {
+  ADM_REQUIRE(w && wb, "pack_bf16_weight: null argument");
+  return launch_pack_bf16_weight(w, wb, Cout, Cin, transposed, (hipStream_t)stream);
 }
 
 void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo) {

@@ -27,7 +27,9 @@ int adm_is_device_build(void);
 /* Runtime options: "conv_wino" = 0 (direct MFMA kernel only) | 1 (Winograd F(2x2,3x3) v1) | 2 (wave-specialised v2) |
  * 3 (persistent wave-specialised v3, the default) | -1 (back to the default / ADM_CONV_WINO environment variable);
  * "wgrad_max_split" = n caps the split-K factor of adm_conv2d_wgrad (0 = heuristic; tests use it to put several pixel
- * tiles on one workgroup). */
+ * tiles on one workgroup); "conv_bf16" = 1 runs eligible 3x3 stride-1 convolutions (forward, data gradient and weight
+ * gradient) on bf16 MFMA operands with fp32 accumulation (`--mixed_precision bf16`, scripts/train_unet.py:391-401),
+ * 0 = fp32 everywhere (default), -1 = back to the ADM_CONV_BF16 environment variable. */
 int adm_set_option(const char* name, int value);
 /* Kernel variant the last adm_conv2d on this thread dispatched to (see adm_op_profile.variant; 4311 = Winograd). */
 int adm_last_conv_variant(void);
@@ -91,6 +93,9 @@ typedef struct adm_conv_args {
   /* optional: the same 3x3 weights pre-transformed by adm_pack_winograd_weight ([Cin][16][Cout]); when present and the
    * shape is eligible (stride 1, output >= 8x16) the Winograd F(2x2,3x3) kernel may be used (ADM_CONV_WINO=1). */
   const float* wino_packed;
+  /* optional: the same 3x3 weights as bf16 MFMA operands (adm_pack_bf16_weight: [tap][Cin/8][Cout][8] bf16); used when
+   * option "conv_bf16" is on and the shape is eligible (stride 1, output a multiple of 16x16, Cout % 128 == 0). */
+  const void* bf16_packed;
 } adm_conv_args;
 int adm_conv2d(const adm_conv_args* a, void* stream);
 /* (Cout,Cin,ks,ks) -> [Cin][ks*ks][Cout]; both device pointers. */
@@ -105,6 +110,9 @@ int adm_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, void*
  * Pass it as `wino_packed` together with adm_pack_conv_weight_T's packing to run the backward-data pass of a 3x3
  * stride-1 Conv2d (what torch autograd does for scripts/train_unet.py:262 `accelerator.backward(loss)`). */
 int adm_pack_winograd_weight_T(const float* w, float* wuT, int Cout, int Cin, void* stream);
+/* (Cout,Cin,3,3) fp32 -> bf16 (round-to-nearest-even) MFMA operand layout [tap][Cin/8][Cout][8]; transposed != 0 packs
+ * the data-gradient filters instead ([flipped tap][Cout/8][Cin][8]). 2 bytes per weight; both device pointers. */
+int adm_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transposed, void* stream);
 void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);
 
 /* Self-attention core (row U6): qkv is (N, 3*C, T) with channels [q | k | v], head h = channels

@@ -83,6 +83,7 @@ struct Wave {
   unsigned gen = 0;
   uint64_t xch[64];
   float a[64], b[64];
+  uint32_t a8[64][4], b8[64][4];   // bf16 MFMA operands (8 x bf16 per lane)
 };
 struct State {
   // per worker thread; launch() creates its workers anew, so the fiber stacks must die with the thread
@@ -280,6 +281,36 @@ static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4
   wave_sync();
   return d;
 }
+
+typedef unsigned u32x4 __attribute__((vector_size(16)));
+namespace adm_emu {
+static inline uint32_t bf16_bits(float f) {        // round-to-nearest-even, NaN kept quiet (v_cvt_pk_bf16_f32)
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+static inline unsigned pk_bf16(float a, float b) { return bf16_bits(a) | (bf16_bits(b) << 16); }
+static inline float bf16_val(uint32_t dword, int hi) { uint32_t u = hi ? (dword & 0xffff0000u) : (dword << 16); float f; memcpy(&f, &u, 4); return f; }
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8(l>>5)+e], B[k][j=l&31]; exact products, fp32 accumulation in k order
+static inline f32x16 mfma_f32_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  int lane = flat_tid() & 63;
+  Wave& w = S().waves[flat_tid() >> 6];
+  for (int q = 0; q < 4; ++q) { w.a8[lane][q] = a[q]; w.b8[lane][q] = b[q]; }
+  wave_sync();
+  f32x16 d;
+  int j = lane & 31;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    float acc = c[r];
+    for (int h = 0; h < 2; ++h)
+      for (int e = 0; e < 8; ++e)
+        acc = fmaf(bf16_val(w.a8[i + 32 * h][e >> 1], e & 1), bf16_val(w.b8[j + 32 * h][e >> 1], e & 1), acc);
+    d[r] = acc;
+  }
+  wave_sync();
+  return d;
+}
+}  // namespace adm_emu
 
 static inline float adm_emu_expf(float x) { return expf(x); }
 #define __expf adm_emu_expf

@@ -1,0 +1,111 @@
+"""Mixed-precision 3x3 convolution (`--mixed_precision bf16`, scripts/train_unet.py:391-401): bf16 MFMA operands, fp32
+accumulation and epilogue.  Two bars per case: (tight) against a float64 convolution of the SAME bf16-rounded operands —
+what the kernel is meant to compute, only the accumulation order differs; (loose) against the plain fp32 convolution —
+the error the mixed-precision mode introduces, bounded by bf16's 2^-9 relative rounding of each operand."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from native_backend import BACKENDS, select
+from test_kernels import _rand, _relerr
+
+CASES = [
+    # (N, C1, C2, H, W, Cout, up, gn, act, temb, res)
+    (1, 16, 0, 16, 16, 128, 0, 0, 0, 0, 0),     # bare convolution: operands exactly representable after rounding
+    (2, 32, 0, 16, 32, 128, 0, 1, 1, 1, 1),     # GroupNorm + SiLU load path, all epilogue terms, two column tiles
+    (1, 32, 16, 32, 16, 256, 0, 1, 1, 0, 1),    # virtual concat (seam on a chunk boundary), two cout tiles, two row tiles
+    (1, 32, 0, 8, 8, 128, 1, 1, 1, 1, 0),       # nearest x2 folded into the load path
+    (3, 48, 0, 16, 16, 128, 0, 1, 0, 0, 0),     # odd chunk count (3), GroupNorm without activation
+]
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def _refs(x1, x2, w, b, up, gn, act, temb, res):
+    x = torch.cat([x1, x2], 1) if x2 is not None else x1
+    if gn is not None:
+        x = F.group_norm(x, 32, gn[0], gn[1], 1e-5)
+    if act:
+        x = F.silu(x)
+    if up:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    tail = b.double()[None, :, None, None]
+    if temb is not None:
+        tail = tail + temb.double()[:, :, None, None]
+    if res is not None:
+        tail = tail + res.double()
+    exact = F.conv2d(_bf(x), _bf(w), None, padding=1) + tail
+    full = F.conv2d(x.double(), w.double(), None, padding=1) + tail
+    return exact, full
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
+def test_conv_bf16_forward(backend, case):
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, C1, C2, H, W, Cout, up, use_gn, act, use_temb, use_res = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    w = _rand((Cout, Ct, 3, 3), 3, dev, scale=(Ct * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32 if Ct % 32 == 0 else 16, 1e-5, x2=x2) if use_gn else None
+    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
+    _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
+    try:
+        out = ops.conv2d(x1, ops.pack_conv_weight(w), b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb,
+                         residual=res, wino=ops.pack_winograd_weight(w), bf16=ops.pack_bf16_weight(w))
+        assert _native.lib().adm_last_conv_variant() == 5316, "the bf16 kernel was not selected"
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+    c = lambda t: None if t is None else t.cpu()  # noqa: E731
+    if use_gn:   # the reference normalises with the same group count
+        groups = 32 if Ct % 32 == 0 else 16
+        xg = torch.cat([c(x1), c(x2)], 1) if C2 else c(x1)
+        xn = F.group_norm(xg, groups, c(gamma), c(beta), 1e-5)
+        exact, full = _refs(xn, None, c(w), c(b), up, None, act, c(temb), c(res))
+    else:
+        exact, full = _refs(c(x1), c(x2), c(w), c(b), up, None, act, c(temb), c(res))
+    assert out.shape == exact.shape
+    # tight: identical operands. Without GroupNorm/SiLU the rounding points coincide exactly; with them an fp32 last-bit
+    # difference of the activation can flip a bf16 rounding (2^-9 of one operand among Cin*9 products)
+    tight = 2e-6 if not (use_gn or act) else 3e-4
+    assert _relerr(out.double(), exact) < tight, _relerr(out.double(), exact)
+    # loose: the mixed-precision error itself
+    assert _relerr(out.double(), full) < 8e-3, _relerr(out.double(), full)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv_bf16_data_gradient(backend):
+    """Backward-data pass of a 3x3 stride-1 Conv2d as the same kernel on dy with transposed, flipped bf16 filters."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, Cin, Cout, H, W = 2, 128, 32, 16, 32
+    w = _rand((Cout, Cin, 3, 3), 11, dev, scale=(Cin * 9) ** -0.5)
+    dy = _rand((Nn, Cout, H, W), 12, dev)
+    acc = _rand((Nn, Cin, H, W), 13, dev)          # gradient already accumulated in dx (residual fan-in)
+    _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
+    try:
+        dx = ops.conv2d(dy, ops.pack_conv_weight_T(w), None, 3, residual=acc, wino=ops.pack_winograd_weight_T(w),
+                        bf16=ops.pack_bf16_weight(w, transposed=True))
+        assert _native.lib().adm_last_conv_variant() == 5316
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+    exact = torch.nn.grad.conv2d_input((Nn, Cin, H, W), _bf(w.cpu()), _bf(dy.cpu()), padding=1) + acc.cpu().double()
+    assert _relerr(dx.double(), exact) < 2e-6, _relerr(dx.double(), exact)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_bf16_option_off_keeps_fp32(backend):
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    x = _rand((1, 16, 16, 16), 1, dev)
+    w = _rand((128, 16, 3, 3), 2, dev, scale=0.1)
+    ops.conv2d(x, ops.pack_conv_weight(w), None, 3, wino=ops.pack_winograd_weight(w), bf16=ops.pack_bf16_weight(w))
+    assert _native.lib().adm_last_conv_variant() != 5316
