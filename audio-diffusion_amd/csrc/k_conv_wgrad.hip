@@ -790,6 +790,14 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
 #endif
   static const int use_pf = [] { const char* e = getenv("ADM_WGRAD_PF"); return e ? atoi(e) : 1; }();
   const int PE = NI * p.IH * p.IW;
+  if (conv_bf16_enabled() && conv_wgrad_bf16_eligible(a)) {   // mixed precision: bf16 operands, fp32 partial sums
+    ADM_TRY(launch_conv_wgrad_bf16(a, dy, dW, accumulate, workspace, p.split, st));
+    long gb = (numel + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, st, (const float*)workspace, p.split, numel, dW,
+               accumulate);
+    return ADM_CHECK_LAUNCH();
+  }
   // tile-invariant prefetch path: no upsample fold, every channel chunk inside one source tensor, full cout tiles
   const bool fast = a.up == 0 && a.C1 % CB == 0 && Ct % CB == 0 && a.Cout % 128 == 0;
   static const int use_sp = [] { const char* e = getenv("ADM_WGRAD_SP"); return e ? atoi(e) : 1; }();

@@ -109,3 +109,48 @@ def test_bf16_option_off_keeps_fp32(backend):
     w = _rand((128, 16, 3, 3), 2, dev, scale=0.1)
     ops.conv2d(x, ops.pack_conv_weight(w), None, 3, wino=ops.pack_winograd_weight(w), bf16=ops.pack_bf16_weight(w))
     assert _native.lib().adm_last_conv_variant() != 5316
+
+
+WGRAD_CASES = [
+    # (N, C1, C2, H, W, Cout, up, gn, act, max_split)
+    (1, 32, 0, 4, 16, 128, 0, 0, 0, 0),       # one tile, bare: rounding points coincide exactly
+    (2, 32, 0, 8, 32, 128, 0, 1, 1, 0),       # GroupNorm + SiLU recomputed on the load path, 8 tiles
+    (1, 32, 32, 16, 16, 256, 0, 1, 1, 2),     # virtual concat, two cout tiles, several tiles per workgroup (split-K 2)
+    (1, 64, 0, 8, 8, 128, 1, 1, 1, 0),        # nearest x2 folded
+    (3, 32, 0, 4, 16, 128, 0, 0, 0, 1),       # one workgroup walks three images
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[str(i) for i in range(len(WGRAD_CASES))])
+def test_conv_bf16_weight_gradient(backend, case):
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, C1, C2, H, W, Cout, up, use_gn, act, max_split = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    a = torch.cat([x1, x2], 1).cpu() if C2 else x1.cpu()
+    if use_gn:
+        a = F.group_norm(a, 32, gamma.cpu(), beta.cpu(), 1e-5)
+    if act:
+        a = F.silu(a)
+    if up:
+        a = F.interpolate(a, scale_factor=2.0, mode="nearest")
+    dy = _rand((Nn, Cout) + tuple(a.shape[2:]), 7, "cpu")
+    exact = torch.nn.grad.conv2d_weight(_bf(a), (Cout, Ct, 3, 3), _bf(dy), padding=1)
+    full = torch.nn.grad.conv2d_weight(a.double(), (Cout, Ct, 3, 3), dy.double(), padding=1)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
+    _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
+    _native.check(_native.lib().adm_set_option(b"wgrad_max_split", max_split))
+    try:
+        dW = ops.conv2d_wgrad(x1, dy.to(dev), Cout, 3, x2=x2, up=bool(up), gn=gn, act=bool(act))
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+        _native.check(_native.lib().adm_set_option(b"wgrad_max_split", 0))
+    tight = 2e-6 if not (use_gn or act) else 3e-4
+    assert _relerr(dW.double(), exact) < tight, _relerr(dW.double(), exact)
+    assert _relerr(dW.double(), full) < 8e-3, _relerr(dW.double(), full)
+    # and it really was the bf16 kernel: the fp32 path would match `full` to 1e-5 but not `exact`
+    assert _relerr(dW.double(), full) > 1e-5
