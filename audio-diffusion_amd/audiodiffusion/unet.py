@@ -259,11 +259,19 @@ class UNet2DModel:
     __call__ = forward
 
     # ---- training (scripts/train_unet.py:257-267) ---------------------------------------------------------------
-    def enable_training(self, sample_hw=None):
+    def enable_training(self, sample_hw=None, mixed_precision="no"):
         """Moves the master parameters into ONE flat device buffer (so the fused AdamW/EMA kernel updates them in a single
         launch) and switches the native executor to training mode (activations kept, gradient buffers, wgrad/dgrad
-        weight packings). Returns (flat_params, flat_grads) — torch views the optimizer side works on."""
+        weight packings). Returns (flat_params, flat_grads) — torch views the optimizer side works on.
+        mixed_precision="bf16" (scripts/train_unet.py:391-401): the 3x3 stride-1 convolutions of the training passes take
+        bf16 MFMA operands (activations rounded on the load path, filters re-rounded from the fp32 masters after every
+        optimizer step) with fp32 accumulation; everything stored — weights, activations, gradients, optimizer state —
+        stays fp32, so checkpoints and the fp32 sampling path are unaffected."""
         from .training import FlatBuffer
+        if mixed_precision not in ("no", "bf16"):
+            raise ValueError(f"mixed_precision must be 'no' or 'bf16', got {mixed_precision!r}")
+        N.check(N.lib().adm_set_option(b"conv_bf16", 1 if mixed_precision == "bf16" else 0))
+        self.mixed_precision = mixed_precision
         if sample_hw is not None:
             self.sample_size = tuple(sample_hw)
         self._free()

@@ -40,6 +40,8 @@ struct ConvW {
   float* wpT = nullptr;   // backward-data packing [Cout][tap][Cin] (training only)
   float* wu = nullptr;    // Winograd-domain weights [Cin][16][Cout] (3x3 convs, when a Winograd mode is selected)
   float* wuT = nullptr;   // ... of the data-gradient convolution [Cout][16][Cin] (training only)
+  void* wb = nullptr;     // bf16 MFMA operands [tap][Cin/8][Cout][8] (training nets under option conv_bf16)
+  void* wbT = nullptr;    // ... of the data-gradient convolution
   float* bias = nullptr;  // master bias (for q|k|v: the stacked copy)
   int Cin = 0, Cout = 0, ks = 3;
   std::string key;        // diffusers prefix of the master parameter ("" for derived weights)

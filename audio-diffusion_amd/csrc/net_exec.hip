@@ -140,6 +140,14 @@ static int pack_one(Net* net, ConvW& w, hipStream_t st) {
       if (!w.wuT) ADM_TRY(net->dalloc((void**)&w.wuT, sizeof(float) * (size_t)w.Cout * w.Cin * 16));
       ADM_TRY(launch_pack_winograd_weight_T(src, w.wuT, w.Cout, w.Cin, st));
     }
+    // mixed precision (`--mixed_precision bf16`): the filters as bf16 MFMA operands, re-rounded from the fp32 masters after
+    // every optimizer step; only training nets carry them, so sampling stays fp32 whatever the option says
+    if (w.ks == 3 && w.qkv_prefix.empty() && conv_bf16_enabled() && w.Cin % 16 == 0 && w.Cout % 16 == 0) {
+      if (!w.wb) ADM_TRY(net->dalloc(&w.wb, 2 * (size_t)w.Cout * w.Cin * 9));
+      if (!w.wbT) ADM_TRY(net->dalloc(&w.wbT, 2 * (size_t)w.Cout * w.Cin * 9));
+      ADM_TRY(launch_pack_bf16_weight(src, w.wb, w.Cout, w.Cin, 0, st));
+      ADM_TRY(launch_pack_bf16_weight(src, w.wbT, w.Cout, w.Cin, 1, st));
+    }
   }
   return 0;
 }
@@ -395,7 +403,7 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
         a.Cout = o.dyn_cout;
       } else {
         a.wpacked = o.w->wp; a.bias = o.w->bias; a.Cout = o.w->Cout;
-        if (o.stride == 1) a.wino_packed = o.w->wu;   // eligibility (shape, mode) is decided by the launcher
+        if (o.stride == 1) { a.wino_packed = o.w->wu; a.bf16_packed = o.w->wb; }   // eligibility (shape, mode): the launcher
       }
       if (o.temb_off >= 0 && temb_all) { a.chan_add = temb_all + o.temb_off; a.chan_add_stride = temb_stride; }
       if (o.res >= 0) a.residual = tensors[o.res].ptr;
@@ -517,7 +525,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       a.x1 = dy; a.C1 = Cout; a.N = B; a.H = to.H; a.W = to.W;
       a.up = o.stride == 2 ? 2 : 0; a.stride = 1; a.ks = o.ks; a.pad_lo = o.ks == 3 ? 1 : 0;
       a.wpacked = o.w->wpT; a.bias = nullptr; a.Cout = Ct;
-      if (o.stride == 1) a.wino_packed = o.w->wuT;   // 3x3 stride-1: the data gradient is a Winograd-eligible convolution too
+      if (o.stride == 1) { a.wino_packed = o.w->wuT; a.bf16_packed = o.w->wbT; }   // 3x3 stride-1: the data gradient is a Winograd-/bf16-eligible convolution too
       if (direct) {
         a.out = t1.grad;
         if (t1.ginit) a.residual = t1.grad;   // accumulate in the epilogue (same thread reads then writes)

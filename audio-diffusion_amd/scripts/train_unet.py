@@ -51,8 +51,9 @@ def load_images(args, resolution):
 def main(args):
     if args.encodings is not None or args.vae is not None:
         raise NotImplementedError("conditional / latent training is outside this path")
-    if args.mixed_precision != "no":
-        raise NotImplementedError("only fp32 training is implemented (mixed_precision='no', the reference default)")
+    if args.mixed_precision == "fp16":
+        raise NotImplementedError("mixed_precision: 'no' (fp32, the reference default) and 'bf16' are implemented; fp16 "
+                                  "would need loss scaling, which gfx950's bf16 MFMA path makes pointless")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -79,7 +80,9 @@ def main(args):
                   n_fft=args.n_fft)
     noise_scheduler = (DDPMScheduler if args.scheduler == "ddpm" else DDIMScheduler)(num_train_timesteps=args.num_train_steps)
 
-    flat, grads = model.enable_training(resolution)              # identical init on every rank (same seed / checkpoint)
+    # identical init on every rank (same seed / checkpoint). bf16: eligible 3x3 convolutions (forward, data and weight
+    # gradient) run on bf16 MFMA operands with fp32 accumulation; master weights, optimizer state and gradients stay fp32
+    flat, grads = model.enable_training(resolution, mixed_precision=args.mixed_precision)
     optimizer = T.AdamW(flat, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
                         weight_decay=args.adam_weight_decay, eps=args.adam_epsilon)
     n_local = len(images) // world

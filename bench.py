@@ -50,6 +50,8 @@ def parse():
     p.add_argument("--mode", choices=["sample", "train"], default="sample",
                    help="sample (default): BASELINE.json's metric. train: config 5 (scripts/train_unet.py step, fp32).")
     p.add_argument("--train-batch-per-gpu", type=int, default=16)
+    p.add_argument("--mixed-precision", choices=["no", "bf16"], default="no",
+                   help="train mode only: bf16 = BASELINE.json config 5 as written (bf16 MFMA operands, fp32 accumulate)")
     return p.parse_args()
 
 
@@ -60,7 +62,7 @@ def train_main(a, world, rank, dev):
     from audiodiffusion import training as T
     B = a.train_batch_per_gpu
     unet = UNet2DModel(**CFG256).init_random(0)
-    flat, grads = unet.enable_training()
+    flat, grads = unet.enable_training(mixed_precision=a.mixed_precision)
     opt, ema, red = T.AdamW(flat), T.EMAModel(flat), T.GradAllReducer(grads)
     if world > 1:
         red.attach(unet)          # gradient buckets are all-reduced (RCCL) from inside the reverse pass
@@ -102,10 +104,12 @@ def train_main(a, world, rank, dev):
             "metric": "training samples/sec (256x256 UNet2D, fwd+bwd+AdamW+EMA)", "value": round(value, 3),
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"scripts/train_unet.py step, 256x256, batch {B}/GPU, fp32 (reference default mixed_precision=no)",
+            "vs_baseline": None, "dtype": "bf16" if a.mixed_precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"scripts/train_unet.py step, 256x256, batch {B}/GPU, " +
+                                   ("--mixed_precision bf16 (bf16 MFMA operands on the 3x3 convolutions, fp32 accumulate/storage)"
+                                    if a.mixed_precision == "bf16" else "fp32 (reference default mixed_precision=no)"),
                        "global_batch": world * B, "parallelism": f"data parallel x{world}, bucketed RCCL all-reduce"},
-            "fp32_TFLOPs_3x_fwd": round(value * 3 * F1_TFLOP / world, 2), "final_loss": float(loss)}), flush=True)
+            "TFLOPs_3x_fwd": round(value * 3 * F1_TFLOP / world, 2), "final_loss": float(loss)}), flush=True)
 
 
 def cpu_baseline(sd, n_threads):

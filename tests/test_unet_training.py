@@ -175,3 +175,81 @@ def test_gradient_accumulation_equals_one_large_batch(backend):
     d = ema.step(flat)
     assert 0.0 < d < 1.0
     assert torch.allclose(ema.shadow, shadow0 - (1 - d) * (shadow0 - flat), atol=1e-7)
+
+
+# ---------------------------------------------------------------- --mixed_precision bf16 (train_unet.py:391-401, config 5)
+BF16CFG = dict(sample_size=16, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(128, 128),
+               down_block_types=("DownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "UpBlock2D"))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_mixed_precision_bf16_training_step(backend):
+    """bf16 MFMA operands / fp32 accumulation for the eligible 3x3 convolutions of forward, data gradient and weight
+    gradient. Bars: (1) within bf16 tolerance of the fp32 autograd oracle, per parameter tensor; (2) no less accurate than
+    the reference's own mixed-precision mode (torch.autocast(bf16) on the oracle, what accelerate applies); (3) the bf16
+    kernels really ran (the result differs from the fp32 native path); (4) the loss still goes down after an optimizer
+    step that re-rounds the bf16 filters from the fp32 masters."""
+    dev = select(backend)
+    from audiodiffusion import _native
+    from audiodiffusion import training as T
+    from audiodiffusion.unet import UNet2DModel
+    torch.manual_seed(0)
+    ref = OracleUNet(**BF16CFG)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "norm" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(1)
+    x, tgt = torch.randn((2, 1, 16, 16), generator=g), torch.randn((2, 1, 16, 16), generator=g)
+    ts = torch.tensor([5, 700])
+    loss_ref = F.mse_loss(ref(x, ts)["sample"], tgt)
+    loss_ref.backward()
+    g32 = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    ref.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        loss_ac = F.mse_loss(ref(x, ts)["sample"].float(), tgt)
+    loss_ac.backward()
+    gac = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    ref.zero_grad()
+
+    def native(mp):
+        m = UNet2DModel(**BF16CFG).load_state_dict(ref.state_dict())
+        flat, grads = m.enable_training(mixed_precision=mp)
+        loss = float(m.train_step(x.to(dev), ts, tgt.to(dev)))
+        return m, flat, grads, loss
+
+    try:
+        m, flat, grads, loss = native("bf16")
+        gmax = max(float(v.abs().max()) for v in g32.values())
+
+        def errs(get):
+            """(global relative L2 error of the whole gradient, worst per-tensor max error relative to the larger of the
+            tensor's own scale and a tenth of the global one — a lone scalar such as conv_out.bias is a cancelling sum and
+            carries percent-level noise relative to itself under ANY bf16 scheme, the reference's autocast included)"""
+            num = den = 0.0
+            worst = 0.0
+            for n, p in ref.named_parameters():
+                d = get(n) - g32[n]
+                num += float(d.double().pow(2).sum())
+                den += float(g32[n].double().pow(2).sum())
+                worst = max(worst, float(d.abs().max()) / max(float(g32[n].abs().max()), 0.1 * gmax))
+            return (num / den) ** 0.5, worst
+
+        mine = errs(lambda n: grads[m.flat.offsets[n][0]:m.flat.offsets[n][0] + g32[n].numel()].view(g32[n].shape).cpu())
+        auto = errs(lambda n: gac[n].float())
+        assert abs(loss - float(loss_ref.detach())) <= 5e-3 * float(loss_ref.detach()), (loss, float(loss_ref.detach()))
+        assert mine[0] < 1.5e-2 and mine[1] < 2e-2, mine                                   # (1)
+        assert mine[0] <= auto[0], (mine, auto)                                            # (2)
+        assert mine[0] > 1e-4                                                              # (3) bf16 rounding is visible
+        opt = T.AdamW(flat, lr=1e-4)        # Adam's first step moves every weight by lr: 1e-3 overshoots at this width in fp32 too
+        opt.step(grads, clip=T.clip_grad_norm_(grads, 1.0))
+        m.refresh_weights()
+        loss2 = float(m.train_step(x.to(dev), ts, tgt.to(dev)))
+        assert loss2 < loss                                                                # (4)
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+    # the option is per training setup: a model enabled with "no" afterwards is fp32 again
+    m32, _, grads32, loss32 = native("no")
+    e32 = max(float((grads32[m32.flat.offsets[n][0]:m32.flat.offsets[n][0] + g32[n].numel()].view(g32[n].shape).cpu()
+                     - g32[n]).abs().max()) / max(float(g32[n].abs().max()), 1e-2 * gmax) for n in g32)
+    assert e32 < 2e-4 and abs(loss32 - float(loss_ref.detach())) <= 1e-5 * float(loss_ref.detach())
