@@ -213,11 +213,11 @@ if __name__ == "__main__" and "train" in sys.argv[1:]:
 
 
 def trainstep_probe():
-    """Full-size training step (config 5 shape, fp32): forward+backward+clip+AdamW+EMA, B per GPU from PROBE_B."""
+    """Full-size training step (config 5 shape; PROBE_MP=bf16 for mixed precision): forward+backward+clip+AdamW+EMA, B per GPU from PROBE_B."""
     from audiodiffusion import training as T
     B = int(os.environ.get("PROBE_B", "8"))
     m = UNet2DModel(**CFG256).init_random(0)
-    flat, grads = m.enable_training()
+    flat, grads = m.enable_training(mixed_precision=os.environ.get("PROBE_MP", "no"))
     opt, ema = T.AdamW(flat), T.EMAModel(flat)
     x = torch.randn(B, 1, 256, 256, device=dev)
     tgt = torch.randn(B, 1, 256, 256, device=dev)

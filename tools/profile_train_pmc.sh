@@ -4,7 +4,7 @@ OUT=${1:-train_pmc}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/${OUT}
 cd /tmp && export TMPDIR=/tmp
-PROBE_CHECK=0 PROBE_B=16 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/${OUT}/p -- python $R/tools/gpu_probe.py trainstep > $R/gpurun_out/${OUT}/p.log 2>&1
+PROBE_CHECK=0 PROBE_B=16 PROBE_MP=${PROBE_MP:-no} timeout ${PROBE_TIMEOUT:-300} rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/${OUT}/p -- python $R/tools/gpu_probe.py trainstep > $R/gpurun_out/${OUT}/p.log 2>&1
 python - <<PY
 import csv,glob,collections
 f=glob.glob("$R/gpurun_out/${OUT}/p/*/*counter_collection.csv")[0]
