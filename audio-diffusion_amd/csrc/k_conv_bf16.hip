@@ -36,9 +36,16 @@ constexpr int BPW = 18, BPP = BPW * BPW;   // input patch of a 16x16 output tile
 
 __device__ __forceinline__ float silu_b(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
 
+struct Bf16Stage { float v[3][8]; };                 // raw fp32 prefetch of one 16-channel chunk (three 8-channel rounds)
+struct Bf16Filt { u32x4 a[9][2]; };                    // the wave's A fragments of one chunk: 9 taps x 2 cout sub-tiles
+
 template <bool UP, bool ACT>
-__global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const Bf16ConvParams p) {
-  ADM_DYN_SMEM(u32x4, lds);                 // [2 buffers][2 channel groups][324 pixels]
+__global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams p) {
+  // One workgroup per CU (up to 512 registers per lane) so that everything that comes from memory is requested a full
+  // chunk (filters, L2) or two chunks (input patch, HBM) before it is used: the first version requested the next tap's
+  // filters 8 MFMAs ahead and queued them behind the patch loads of the in-order vector-memory counter — 17k cycles per
+  // chunk against 2.3k of MFMA work (profiles/r01_train_bf16_v1_kernel_stats.md).
+  ADM_DYN_SMEM(u32x4, lds);                 // [2 buffers][2 channel groups][324 pixels] + GroupNorm rows [2][Ct] floats
   const int tid = threadIdx.x, lane = tid & 63, wave = ADM_UNIFORM(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave & 1, wn = wave >> 1;
@@ -66,34 +73,53 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const Bf16ConvParams 
     const bool ok = (q < BPP) & (gy >= 0) & (gy < p.Hi) & (gx >= 0) & (gx < p.Wi);
     soff[r] = ok ? (UP ? (gy >> 1) * p.Ws + (gx >> 1) : gy * p.Ws + gx) : -1;
   }
+  float* gnS = reinterpret_cast<float*>(lds + 4 * BPP);     // [Ct] scale, then [Ct] shift of image n
+  float* gnB = gnS + Ct;
+  for (int c = tid; c < Ct; c += 256) {
+    gnS[c] = p.gn_scale[(long)n * p.gn_nstride + c];
+    gnB[c] = p.gn_shift[(long)n * p.gn_nstride + c];
+  }
   const int q2 = 256 + 64 * (wave & 1) + lane;
   const int kg2 = wave >> 1;
   const bool has2 = q2 < BPP;
+  const int n_chunks = Ct >> 4;
 
-  float xr[3][8];
-  auto issue = [&](int c0) __attribute__((always_inline)) {      // raw fp32 loads of chunk [c0, c0 + 16)
+  // every global address is a wave-uniform 64-bit base (SGPR pair, scalar arithmetic) plus a per-lane 32-bit offset that
+  // never changes: per-load 64-bit VGPR addresses (24 patch + 18 filter loads, hoisted out of the loop) cost 130 registers
+  const unsigned so0 = soff[0] < 0 ? 0u : (unsigned)soff[0], so1 = soff[1] < 0 ? 0u : (unsigned)soff[1];
+  auto issue = [&](Bf16Stage& s, int ch) __attribute__((always_inline)) {      // raw fp32 loads of chunk ch
+    const int c0 = 16 * (ch < n_chunks ? ch : n_chunks - 1);     // past the end: harmless re-request, no branch
     const float* xc = c0 < p.C1 ? p.x1 + (long)n * p.x1_bs + (long)c0 * planeS
                                 : p.x2 + (long)n * p.x2_bs + (long)(c0 - p.C1) * planeS;
     ADM_UNROLL
     for (int r = 0; r < 3; ++r) {
       const int kg = r < 2 ? r : kg2;
-      const int so = soff[r < 2 ? 0 : 1];
-      const float* src = xc + (long)(kg * 8) * planeS + (so < 0 ? 0 : so);
+      const unsigned so = r < 2 ? so0 : so1;
       ADM_UNROLL
-      for (int e = 0; e < 8; ++e) xr[r][e] = src[(long)e * planeS];
+      for (int e = 0; e < 8; ++e) {
+        const float* pe = xc + (long)(kg * 8 + e) * planeS;       // uniform
+        s.v[r][e] = pe[so];
+      }
     }
   };
-  auto stash = [&](u32x4* buf, int c0) __attribute__((always_inline)) {   // affine + SiLU, round to bf16, one 16-B LDS store
+  auto stash = [&](const Bf16Stage& s, u32x4* buf, int ch) __attribute__((always_inline)) {   // affine + SiLU -> bf16 -> LDS
+    if (ch >= n_chunks) return;
+    const int c0 = 16 * ch;
     ADM_UNROLL
     for (int r = 0; r < 3; ++r) {
       const int kg = r < 2 ? r : kg2;
       const int so = soff[r < 2 ? 0 : 1];
-      const float* gs = p.gn_scale + (long)n * p.gn_nstride + c0 + kg * 8;
-      const float* gb = p.gn_shift + (long)n * p.gn_nstride + c0 + kg * 8;
+      // GroupNorm rows of this image from LDS (copied once at kernel start): read straight from global memory they are
+      // VECTOR loads (the compiler cannot prove the rows are not aliased by `out`, so no s_load), and waiting for them —
+      // the youngest entries of the in-order vector-memory counter — drained the whole filter/patch prefetch (vmcnt(0))
+      const float4 s0 = *reinterpret_cast<const float4*>(gnS + c0 + kg * 8), s1 = *reinterpret_cast<const float4*>(gnS + c0 + kg * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(gnB + c0 + kg * 8), b1 = *reinterpret_cast<const float4*>(gnB + c0 + kg * 8 + 4);
+      const float gs[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float gb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       float v[8];
       ADM_UNROLL
       for (int e = 0; e < 8; ++e) {
-        float t = xr[r][e] * gs[e] + gb[e];
+        float t = s.v[r][e] * gs[e] + gb[e];
         if (ACT) t = silu_b(t);
         v[e] = so < 0 ? 0.f : t;                                   // zero padding applies to the activated tensor
       }
@@ -102,9 +128,17 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const Bf16ConvParams 
       w[2] = ADM_PK_BF16(v[4], v[5]); w[3] = ADM_PK_BF16(v[6], v[7]);
       if (r < 2) buf[kg * BPP + 64 * wave + lane] = w;
       else if (has2) buf[kg * BPP + q2] = w;
+      ADM_SCHED_FENCE();      // one round at a time: 24 interleaved SiLU chains cost ~70 temporaries
     }
   };
-
+  const unsigned wlane = (unsigned)(h * p.Cout + l31);             // per-lane part of the filter address (16-B units)
+  // filters: ONE register set, refilled in place — as soon as the MFMAs of tap t are issued, the same registers receive
+  // tap t of the next chunk, so every filter fragment is requested a full chunk (72 MFMAs) before its use at a cost of
+  // 72 registers instead of 144
+  auto fetch_tap = [&](Bf16Filt& f, int ch, int t) __attribute__((always_inline)) {
+    const u32x4* wt = p.wb + m0 + ((long)(2 * ch) + (long)t * KG) * p.Cout;     // uniform
+    f.a[t][0] = wt[wlane]; f.a[t][1] = (wt + 32)[wlane];
+  };
   f32x16 acc[2][4];
   ADM_UNROLL
   for (int a = 0; a < 2; ++a)
@@ -115,37 +149,56 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const Bf16ConvParams 
 
   // B fragment of pixel tile t (2 rows x 16 columns), tap (dy, dx): LDS slot (8 wn + 2 t + (l31 >> 4) + dy) * 18 + (l31 & 15) + dx
   const int bbase = h * BPP + (8 * wn + (l31 >> 4)) * BPW + (l31 & 15);
-  const u32x4* wrow = p.wb + (long)h * p.Cout + m0 + l31;          // + (tap * KG + 2 chunk) * Cout + 32 a
-
-  const int n_chunks = Ct >> 4;
-  issue(0);
-  stash(lds, 0);
-  if (n_chunks > 1) issue(16);
-  __syncthreads();
-  for (int ch = 0; ch < n_chunks; ++ch) {
-    const u32x4* cur = lds + (ch & 1) * (2 * BPP);
-    u32x4* nxt = lds + ((ch & 1) ^ 1) * (2 * BPP);
-    const u32x4* wch = wrow + (long)(2 * ch) * p.Cout;
-    u32x4 A[2], An[2];
-    A[0] = wch[0]; A[1] = wch[32];
+  Bf16Filt F;
+  auto mfma_chunk = [&](const u32x4* cur, int ch) __attribute__((always_inline)) {
+    // B fragments one tap ahead, fenced: left alone, the scheduler hoists all 36 LDS reads of the chunk above the first
+    // MFMA (144 registers) and the kernel spills
+    const int chn = ch + 1 < n_chunks ? ch + 1 : ch;   // past the end: re-request the last chunk (no branch in the tap loop)
+    u32x4 Bc[4], Bn[4];
+    ADM_UNROLL
+    for (int pt = 0; pt < 4; ++pt) Bc[pt] = cur[bbase + (2 * pt) * BPW];
     ADM_UNROLL
     for (int t = 0; t < 9; ++t) {
       if (t < 8) {
-        const u32x4* wt = wch + (long)(t + 1) * KG * p.Cout;
-        An[0] = wt[0]; An[1] = wt[32];
+        ADM_UNROLL
+        for (int pt = 0; pt < 4; ++pt) Bn[pt] = cur[bbase + (2 * pt + (t + 1) / 3) * BPW + ((t + 1) % 3)];
       }
+      ADM_SCHED_FENCE();
       ADM_UNROLL
       for (int pt = 0; pt < 4; ++pt) {
-        const u32x4 B = cur[bbase + (2 * pt + t / 3) * BPW + (t % 3)];
-        acc[0][pt] = ADM_MFMA_BF16(A[0], B, acc[0][pt]);
-        acc[1][pt] = ADM_MFMA_BF16(A[1], B, acc[1][pt]);
+        acc[0][pt] = ADM_MFMA_BF16(F.a[t][0], Bc[pt], acc[0][pt]);
+        acc[1][pt] = ADM_MFMA_BF16(F.a[t][1], Bc[pt], acc[1][pt]);
       }
-      A[0] = An[0]; A[1] = An[1];
+      ADM_SCHED_FENCE();
+      fetch_tap(F, chn, t);
+      ADM_UNROLL
+      for (int pt = 0; pt < 4; ++pt) Bc[pt] = Bn[pt];
     }
-    if (ch + 1 < n_chunks) {
-      stash(nxt, 16 * (ch + 1));
-      if (ch + 2 < n_chunks) issue(16 * (ch + 2));
-    }
+  };
+
+  // Pipeline: while chunk c multiplies out of LDS buffer c & 1, the filters of chunk c + 1 (rolling, above) and the raw
+  // patch of chunk c + 2 are in flight, and the patch of chunk c + 1 (requested one iteration earlier) is converted into
+  // the other buffer.  Two patch register sets alternate (X/Y): the loop body is written for an even/odd pair, and the
+  // launcher only takes even chunk counts (Cin % 32 == 0) — an exit between the halves made the register allocator keep
+  // two copies of the 128 accumulators and spill into the loop.
+  Bf16Stage X, Y;
+  u32x4* buf0 = lds;
+  u32x4* buf1 = lds + 2 * BPP;
+  issue(X, 0);
+  ADM_UNROLL
+  for (int t = 0; t < 9; ++t) fetch_tap(F, 0, t);
+  issue(Y, 1);
+  __syncthreads();                        // GroupNorm rows are in LDS
+  stash(X, buf0, 0);
+  __syncthreads();
+  for (int ch = 0; ch < n_chunks; ch += 2) {
+    issue(X, ch + 2);                     // even chunk: LDS buffer 0; patch set Y holds chunk ch + 1, X is free
+    mfma_chunk(buf0, ch);
+    stash(Y, buf1, ch + 1);
+    __syncthreads();
+    issue(Y, ch + 3);                     // odd chunk: LDS buffer 1; patch set X holds chunk ch + 2, Y is free
+    mfma_chunk(buf1, ch + 1);
+    stash(X, buf0, ch + 2);
     __syncthreads();
   }
 
@@ -199,14 +252,29 @@ struct Bf16WgradParams {
   float* part;
   int tiles_x, tiles_y, n_ptiles, n_ct, n_chunks, split, tiles_per_block, nblk;
   long x1_bs, x2_bs;
+  unsigned mTX, mTXY;       // floor(2^32 / d) + 1 for d = tiles_x, tiles_x * tiles_y (0: d == 1 or tile count >= 2^16)
 };
 
+__device__ __forceinline__ int bdiv(int n, int d, unsigned magic) {   // n / d; exact via umulhi for n, d < 2^16
+  return magic ? (int)(((unsigned long long)(unsigned)n * magic) >> 32) : n / d;
+}
+
+// raw fp32 prefetch of one 16x4-pixel tile: 4 dy items (8 pixels each), 7 patch pixel pairs, their in-bounds bits, image
+struct Bf16WgStage { float4 d[4][2]; float xa[7], xb[7]; unsigned ok; int n; };
+
 template <bool UP, bool ACT>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const Bf16WgradParams p) {
+__global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16WgradParams p) {
+  // One workgroup per CU, everything from memory requested two tiles ahead (two register sets P/Q), converted into the
+  // LDS buffer the MFMAs are not reading, one barrier per tile.  The first version loaded, converted and multiplied tile
+  // by tile: 13k cycles per tile against 1.2k of MFMA work (profiles/r01_train_bf16_v1_kernel_stats.md).
   constexpr int XROW = 12;                       // dwords per (row, cin) of the patch
+  constexpr int DFR = 8 * 128;                   // dy fragments (u32x4) per buffer
+  constexpr int XDW = 6 * 32 * XROW;             // patch dwords per buffer
+  constexpr int BUF4 = DFR + XDW / 4;            // u32x4 per buffer
   ADM_DYN_SMEM(u32x4, lds4);
-  u32x4* ldsD = lds4;                            // 8 * 128 fragments
-  unsigned* ldsX = reinterpret_cast<unsigned*>(lds4 + 8 * 128);   // 6 * 32 * 12 dwords
+  unsigned* dummy = reinterpret_cast<unsigned*>(lds4 + 2 * BUF4);          // 256 dwords: disabled lanes store here
+  float* gnS = reinterpret_cast<float*>(dummy + 256);                       // [N][32] scale, then [N][32] shift
+  float* gnB = gnS + p.N * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = ADM_UNIFORM(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   int lid;
@@ -222,6 +290,15 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const Bf16Wgrad
   const long planeO = (long)p.Hi * p.Wi;
   const float* xsrc = c0 < p.C1 ? p.x1 + (long)c0 * planeS : p.x2 + (long)(c0 - p.C1) * planeS;
   const long xbs = c0 < p.C1 ? p.x1_bs : p.x2_bs;
+  const int t_begin = sp * p.tiles_per_block;
+  int t_end = t_begin + p.tiles_per_block;
+  if (t_end > p.n_ptiles) t_end = p.n_ptiles;
+
+  for (int i = tid; i < p.N * 32; i += 256) {          // GroupNorm rows of this channel chunk, every image
+    const long gi = (long)(i >> 5) * p.gn_nstride + c0 + (i & 31);
+    gnS[i] = p.gn_scale[gi];
+    gnB[i] = p.gn_shift[gi];
+  }
 
   f32x16 acc[9];
   ADM_UNROLL
@@ -229,63 +306,83 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const Bf16Wgrad
     ADM_UNROLL
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // tile-invariant staging roles
-  // dy: item = (cout, row, half): 4 per thread, 8 pixels (two float4) each
-  // patch: item = (row, cin, pixel pair): 1728 items, 7 rounds
-  int xcin[7], xrow[7], xq[7];
+  // tile-invariant staging roles.  dy: item = (cout, row, half), 4 per thread, 8 pixels (two float4) each.
+  // patch: item = (row, cin, pixel pair), 1728 items in 7 rounds (the last one partial).
+  unsigned dyo[4]; int ldsd[4];
+  ADM_UNROLL
+  for (int j = 0; j < 4; ++j) {
+    const int id = tid + 256 * j;
+    const int hh = id & 1, r = (id >> 1) & 3, co = id >> 3;
+    dyo[j] = (unsigned)(co * (int)planeO + r * p.Wi + 8 * hh);
+    ldsd[j] = (r * 2 + hh) * 128 + co;
+  }
+  int xcin[7], xrow[7], xq[7], ldsx[7];
   ADM_UNROLL
   for (int j = 0; j < 7; ++j) {
     const int id = tid + 256 * j;
     const int rc = id / 9;
-    xq[j] = id - rc * 9; xrow[j] = rc >> 5; xcin[j] = rc & 31;     // rows >= 6: past the end (round 6 is partial)
+    xq[j] = id - rc * 9; xrow[j] = rc >> 5; xcin[j] = rc & 31;
+    ldsx[j] = xrow[j] < 6 ? (xrow[j] * 32 + xcin[j]) * XROW + xq[j] : -1;       // -1: past the end -> dummy word
   }
 
-  const int t_begin = sp * p.tiles_per_block;
-  int t_end = t_begin + p.tiles_per_block;
-  if (t_end > p.n_ptiles) t_end = p.n_ptiles;
-  for (int pt = t_begin; pt < t_end; ++pt) {
-    const int tx = pt % p.tiles_x;
-    const int ty = (pt / p.tiles_x) % p.tiles_y, n = pt / (p.tiles_x * p.tiles_y);
-    // ---- dy tile -> bf16 A fragments
+  auto load_tile = [&](Bf16WgStage& s, int pt_raw) __attribute__((always_inline)) {
+    const int pt = pt_raw < t_end ? pt_raw : t_end - 1;        // past the end: re-request the last tile (no branch)
+    const int n = bdiv(pt, p.tiles_x * p.tiles_y, p.mTXY);
+    const int rem = pt - n * (p.tiles_x * p.tiles_y);
+    const int ty = bdiv(rem, p.tiles_x, p.mTX), tx = rem - ty * p.tiles_x;
+    s.n = n;
+    const float* dbase = p.dy + ((long)n * p.Cout + m0) * planeO + (long)(ty * 4) * p.Wi + tx * 16;   // uniform
     ADM_UNROLL
     for (int j = 0; j < 4; ++j) {
-      const int id = tid + 256 * j;
-      const int hh = id & 1, r = (id >> 1) & 3, co = id >> 3;
-      const float* src = p.dy + ((long)n * p.Cout + m0 + co) * planeO + (long)(ty * 4 + r) * p.Wi + tx * 16 + 8 * hh;
-      const float4 v0 = *reinterpret_cast<const float4*>(src);
-      const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+      s.d[j][0] = *reinterpret_cast<const float4*>(dbase + dyo[j]);
+      s.d[j][1] = *reinterpret_cast<const float4*>(dbase + dyo[j] + 4);
+    }
+    const float* xt = xsrc + (long)n * xbs;                                                            // uniform
+    const int gy0 = ty * 4 - 1, gx0 = tx * 16 - 1;
+    unsigned ok = 0;
+    ADM_UNROLL
+    for (int j = 0; j < 7; ++j) {
+      const int gy = gy0 + xrow[j], gx = gx0 + 2 * xq[j];
+      const bool oky = (gy >= 0) & (gy < p.Hi) & (ldsx[j] >= 0);
+      const bool ok0 = oky & (gx >= 0) & (gx < p.Wi), ok1 = oky & (gx + 1 < p.Wi);      // gx + 1 >= 0 always
+      const int rowoff = xcin[j] * planeS + (UP ? (gy >> 1) : gy) * p.Ws;
+      const unsigned o0 = ok0 ? (unsigned)(rowoff + (UP ? (gx >> 1) : gx)) : 0u;
+      const unsigned o1 = ok1 ? (unsigned)(rowoff + (UP ? ((gx + 1) >> 1) : gx + 1)) : 0u;
+      s.xa[j] = xt[o0]; s.xb[j] = xt[o1];
+      ok |= ((ok0 ? 1u : 0u) | (ok1 ? 2u : 0u)) << (2 * j);
+    }
+    s.ok = ok;
+  };
+  auto stash_tile = [&](const Bf16WgStage& s, u32x4* buf) __attribute__((always_inline)) {
+    unsigned* bufX = reinterpret_cast<unsigned*>(buf + DFR);
+    ADM_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      const float4 v0 = s.d[j][0], v1 = s.d[j][1];
       u32x4 w;
       w[0] = ADM_PK_BF16(v0.x, v0.y); w[1] = ADM_PK_BF16(v0.z, v0.w);
       w[2] = ADM_PK_BF16(v1.x, v1.y); w[3] = ADM_PK_BF16(v1.z, v1.w);
-      ldsD[(r * 2 + hh) * 128 + co] = w;
+      buf[ldsd[j]] = w;
     }
-    // ---- activated input patch -> bf16 pixel pairs
-    const float* xt = xsrc + (long)n * xbs;
     ADM_UNROLL
     for (int j = 0; j < 7; ++j) {
-      if (j == 6 && xrow[j] >= 6) continue;
-      const int gy = ty * 4 - 1 + xrow[j], gx = tx * 16 - 1 + 2 * xq[j];
-      const bool oky = (gy >= 0) & (gy < p.Hi);
-      const bool ok0 = oky & (gx >= 0) & (gx < p.Wi), ok1 = oky & (gx + 1 < p.Wi);      // gx + 1 >= 0 always
-      const int sy = UP ? (gy >> 1) : gy;
-      const float* row = xt + (long)xcin[j] * planeS + (long)(oky ? sy : 0) * p.Ws;
-      const int sx0 = ok0 ? (UP ? (gx >> 1) : gx) : 0, sx1 = ok1 ? (UP ? ((gx + 1) >> 1) : gx + 1) : 0;
-      float a = row[sx0], b = row[sx1];
-      const long gi = (long)n * p.gn_nstride + c0 + xcin[j];
-      const float sc = p.gn_scale[gi], sh = p.gn_shift[gi];
-      a = a * sc + sh; b = b * sc + sh;
+      const float sc = gnS[s.n * 32 + xcin[j]], sh = gnB[s.n * 32 + xcin[j]];
+      float a = s.xa[j] * sc + sh, b = s.xb[j] * sc + sh;
       if (ACT) { a = silu_b(a); b = silu_b(b); }
-      a = ok0 ? a : 0.f; b = ok1 ? b : 0.f;
-      ldsX[(xrow[j] * 32 + xcin[j]) * XROW + xq[j]] = ADM_PK_BF16(a, b);
+      a = (s.ok >> (2 * j)) & 1u ? a : 0.f;          // zero padding applies to the activated tensor
+      b = (s.ok >> (2 * j)) & 2u ? b : 0.f;
+      unsigned* dst = ldsx[j] >= 0 ? bufX + ldsx[j] : dummy + tid;
+      *dst = ADM_PK_BF16(a, b);
     }
-    __syncthreads();
-    // ---- 4 k-steps x 9 taps
+  };
+  auto mfma_tile = [&](const u32x4* buf, bool valid) __attribute__((always_inline)) {
+    const unsigned* bufX = reinterpret_cast<const unsigned*>(buf + DFR);
     ADM_UNROLL
     for (int r = 0; r < 4; ++r) {
-      const u32x4 A = ldsD[(r * 2 + h) * 128 + 32 * wave + l31];
+      u32x4 A = buf[(r * 2 + h) * 128 + 32 * wave + l31];
+      if (!valid) { A[0] = 0u; A[1] = 0u; A[2] = 0u; A[3] = 0u; }       // tile past the end of an odd range: contributes zero
       ADM_UNROLL
       for (int dy3 = 0; dy3 < 3; ++dy3) {
-        const unsigned* xr = ldsX + ((r + dy3) * 32 + l31) * XROW + 4 * h;
+        const unsigned* xr = bufX + ((r + dy3) * 32 + l31) * XROW + 4 * h;
         const u32x4 d = *reinterpret_cast<const u32x4*>(xr);
         const unsigned d4 = xr[4];
         u32x4 s1, s2;
@@ -297,6 +394,25 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const Bf16Wgrad
         acc[dy3 * 3 + 2] = ADM_MFMA_BF16(A, s2, acc[dy3 * 3 + 2]);
       }
     }
+  };
+
+  Bf16WgStage P, Q;
+  u32x4* buf0 = lds4;
+  u32x4* buf1 = lds4 + BUF4;
+  load_tile(P, t_begin);
+  load_tile(Q, t_begin + 1);
+  __syncthreads();                         // GroupNorm rows are in LDS
+  stash_tile(P, buf0);
+  load_tile(P, t_begin + 2);
+  __syncthreads();
+  for (int pt = t_begin; pt < t_end; pt += 2) {
+    mfma_tile(buf0, true);                 // tile pt; Q holds pt + 1, P (in flight) pt + 2
+    stash_tile(Q, buf1);
+    load_tile(Q, pt + 3);
+    __syncthreads();
+    mfma_tile(buf1, pt + 1 < t_end);       // tile pt + 1; P holds pt + 2, Q (in flight) pt + 3
+    stash_tile(P, buf0);
+    load_tile(P, pt + 4);
     __syncthreads();
   }
   float* out = p.part + (long)sp * p.Cout * Ct * 9;
@@ -353,12 +469,13 @@ bool conv_bf16_enabled() {
   return g_bf16_mode != 0;
 }
 
-// 3x3 stride 1 "same", output a multiple of 16x16, channel chunks of 16 that do not straddle the concat seam, Cout % 128.
+// 3x3 stride 1 "same", output a multiple of 16x16, an even number of 16-channel chunks none of which straddles the
+// concat seam, Cout % 128.
 bool conv_bf16_eligible(const adm_conv_args& a) {
   if (a.ks != 3 || a.stride != 1 || a.pad_lo != 1 || a.w_bstride != 0 || a.bf16_packed == nullptr || a.up > 1) return false;
   const int C2 = a.x2 ? a.C2 : 0;
   const int Hi = a.up ? 2 * a.H : a.H, Wi = a.up ? 2 * a.W : a.W;
-  return Wi % 16 == 0 && Hi % 16 == 0 && (a.C1 + C2) % 16 == 0 && a.C1 % 16 == 0 && a.Cout % 128 == 0 &&
+  return Wi % 16 == 0 && Hi % 16 == 0 && (a.C1 + C2) % 32 == 0 && a.C1 % 16 == 0 && a.Cout % 128 == 0 &&
          (a.gn_scale != nullptr || !a.act);
 }
 
@@ -382,7 +499,8 @@ int launch_conv_bf16(const adm_conv_args& a, hipStream_t st) {
   p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
-  const size_t smem = sizeof(u32x4) * 2 * 2 * BPP;
+  const size_t smem = sizeof(u32x4) * 2 * 2 * BPP + sizeof(float) * 2 * Ct;
+  ADM_REQUIRE(smem <= 64 * 1024, "conv_bf16: too many input channels for the LDS GroupNorm rows");
   set_last_conv_variant(5000 + 316);
   if (a.up) {
     if (a.act) ADM_LAUNCH((conv_bf16_kernel<true, true>), dim3(p.nblk), dim3(256), smem, st, p);
@@ -427,7 +545,11 @@ int launch_conv_wgrad_bf16(const adm_conv_args& a, const float* dy, float* dW, i
   p.nblk = p.n_ct * p.n_chunks * p.split;
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
-  const size_t smem = sizeof(u32x4) * 8 * 128 + sizeof(unsigned) * 6 * 32 * 12;
+  auto magic = [&](long d) { return (d <= 1 || p.n_ptiles >= 65536) ? 0u : (unsigned)((1ULL << 32) / (unsigned long long)d + 1ULL); };
+  p.mTX = magic(p.tiles_x); p.mTXY = magic((long)p.tiles_x * p.tiles_y);
+  const size_t smem = 2 * (sizeof(u32x4) * 8 * 128 + sizeof(unsigned) * 6 * 32 * 12) + sizeof(unsigned) * 256 +
+                      sizeof(float) * 64 * (size_t)a.N;
+  ADM_REQUIRE(smem <= 64 * 1024, "conv_wgrad_bf16: batch too large for the LDS GroupNorm rows");
   if (a.up) {
     if (a.act) ADM_LAUNCH((conv_wgrad_bf16_kernel<true, true>), dim3(p.nblk), dim3(256), smem, st, p);
     else ADM_LAUNCH((conv_wgrad_bf16_kernel<true, false>), dim3(p.nblk), dim3(256), smem, st, p);

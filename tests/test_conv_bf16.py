@@ -11,11 +11,11 @@ from test_kernels import _rand, _relerr
 
 CASES = [
     # (N, C1, C2, H, W, Cout, up, gn, act, temb, res)
-    (1, 16, 0, 16, 16, 128, 0, 0, 0, 0, 0),     # bare convolution: operands exactly representable after rounding
+    (1, 32, 0, 16, 16, 128, 0, 0, 0, 0, 0),     # bare convolution: operands exactly representable after rounding
     (2, 32, 0, 16, 32, 128, 0, 1, 1, 1, 1),     # GroupNorm + SiLU load path, all epilogue terms, two column tiles
-    (1, 32, 16, 32, 16, 256, 0, 1, 1, 0, 1),    # virtual concat (seam on a chunk boundary), two cout tiles, two row tiles
+    (1, 48, 16, 32, 16, 256, 0, 1, 1, 0, 1),    # virtual concat (seam on an odd chunk boundary), two cout tiles, two row tiles
     (1, 32, 0, 8, 8, 128, 1, 1, 1, 1, 0),       # nearest x2 folded into the load path
-    (3, 48, 0, 16, 16, 128, 0, 1, 0, 0, 0),     # odd chunk count (3), GroupNorm without activation
+    (3, 96, 0, 16, 16, 128, 0, 1, 0, 0, 0),     # six chunks, GroupNorm without activation
 ]
 
 
@@ -105,8 +105,8 @@ def test_conv_bf16_data_gradient(backend):
 def test_bf16_option_off_keeps_fp32(backend):
     dev = select(backend)
     from audiodiffusion import _native, ops
-    x = _rand((1, 16, 16, 16), 1, dev)
-    w = _rand((128, 16, 3, 3), 2, dev, scale=0.1)
+    x = _rand((1, 32, 16, 16), 1, dev)
+    w = _rand((128, 32, 3, 3), 2, dev, scale=0.1)
     ops.conv2d(x, ops.pack_conv_weight(w), None, 3, wino=ops.pack_winograd_weight(w), bf16=ops.pack_bf16_weight(w))
     assert _native.lib().adm_last_conv_variant() != 5316
 
