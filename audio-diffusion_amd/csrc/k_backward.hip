@@ -321,17 +321,29 @@ __global__ void __launch_bounds__(256) linear_bwd_weight_kernel(const float* __r
   }
 }
 // dX[b][k] = sum_j dY[b][j] W[j][k]  (then * silu'(X[b][k]) when x_silu: gradient w.r.t. the pre-activation input)
+// One workgroup per (16 columns k, sample b): 16 lanes read 64 contiguous bytes of a W row, the 16 lane groups of the
+// workgroup stride over the rows j and their partial sums meet in LDS.  (One thread per output with a serial loop over
+// all J rows — 9.4k for the stacked time_emb_proj matrix — took 1.8 ms per call: 32 workgroups, pure latency.)
 __global__ void __launch_bounds__(256) linear_bwd_input_kernel(const float* __restrict__ dY, int ldy,
                                                                const float* __restrict__ W, const float* __restrict__ X,
                                                                int B, int J, int K, int x_silu,
                                                                float* __restrict__ dX) {
-  const int total = B * K;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int b = e / K, k = e - b * K;
-    float acc = 0.f;
-    for (int j = 0; j < J; ++j) acc = fmaf(dY[(long)b * ldy + j], W[(long)j * K + k], acc);
-    if (x_silu) acc *= silu_grad(X[(long)b * K + k]);
-    dX[e] = acc;
+  __shared__ float red[16][17];
+  const int kk = threadIdx.x & 15, js = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + kk, b = blockIdx.y;
+  float acc = 0.f;
+  if (k < K) {
+    const float* dyb = dY + (long)b * ldy;
+    for (int j = js; j < J; j += 16) acc = fmaf(dyb[j], W[(long)j * K + k], acc);
+  }
+  red[js][kk] = acc;
+  __syncthreads();
+  if (threadIdx.x < 16 && k < K) {
+    float s = 0.f;
+    ADM_UNROLL
+    for (int q = 0; q < 16; ++q) s += red[q][kk];
+    if (x_silu) s *= silu_grad(X[(long)b * K + k]);
+    dX[(long)b * K + k] = s;
   }
 }
 
@@ -491,7 +503,7 @@ int launch_attention_bwd(const float* qkv, const float* dout, float* dqkv, int N
 int launch_linear_bwd(const float* dY, int ldy, const float* X, const float* W, int B, int J, int K, int x_silu, float* dW,
                       float* db, float* dX, hipStream_t st) {
   if (dW) ADM_LAUNCH(linear_bwd_weight_kernel, dim3(bgrid((long)J * K)), dim3(256), 0, st, dY, ldy, X, B, J, K, x_silu, dW, db);
-  if (dX) ADM_LAUNCH(linear_bwd_input_kernel, dim3(bgrid((long)B * K)), dim3(256), 0, st, dY, ldy, W, X, B, J, K, x_silu, dX);
+  if (dX) ADM_LAUNCH(linear_bwd_input_kernel, dim3((K + 15) / 16, B), dim3(256), 0, st, dY, ldy, W, X, B, J, K, x_silu, dX);
   return ADM_CHECK_LAUNCH();
 }
 int launch_conv_small_cin_wgrad(const float* x, int Cin, int N, int H, int W, const float* dy, int Cout, float* dW,

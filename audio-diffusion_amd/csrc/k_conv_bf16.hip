@@ -184,21 +184,26 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams 
   Bf16Stage X, Y;
   u32x4* buf0 = lds;
   u32x4* buf1 = lds + 2 * BPP;
+  // Order matters: vector memory returns in order, so a filter fragment (L2) requested after a patch load (HBM) cannot
+  // arrive before it. The patch loads are therefore issued at the END of a chunk — after that chunk's rolling filter
+  // requests, which the next chunk's MFMAs wait for — and only the conversion (stash), two chunks later, waits for them.
+  // (Issued ahead of the MFMA phase they cost 9.5k cycles per chunk: every tap-0 wait inherited the HBM latency.)
   issue(X, 0);
   ADM_UNROLL
   for (int t = 0; t < 9; ++t) fetch_tap(F, 0, t);
   issue(Y, 1);
   __syncthreads();                        // GroupNorm rows are in LDS
   stash(X, buf0, 0);
+  issue(X, 2);
   __syncthreads();
   for (int ch = 0; ch < n_chunks; ch += 2) {
-    issue(X, ch + 2);                     // even chunk: LDS buffer 0; patch set Y holds chunk ch + 1, X is free
-    mfma_chunk(buf0, ch);
+    mfma_chunk(buf0, ch);                 // even chunk: LDS buffer 0; Y holds chunk ch + 1, X (in flight) ch + 2
     stash(Y, buf1, ch + 1);
+    issue(Y, ch + 3);
     __syncthreads();
-    issue(Y, ch + 3);                     // odd chunk: LDS buffer 1; patch set X holds chunk ch + 2, Y is free
-    mfma_chunk(buf1, ch + 1);
+    mfma_chunk(buf1, ch + 1);             // odd chunk: LDS buffer 1; X holds chunk ch + 2, Y (in flight) ch + 3
     stash(X, buf0, ch + 2);
+    issue(X, ch + 4);
     __syncthreads();
   }
 
@@ -268,7 +273,9 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
   // LDS buffer the MFMAs are not reading, one barrier per tile.  The first version loaded, converted and multiplied tile
   // by tile: 13k cycles per tile against 1.2k of MFMA work (profiles/r01_train_bf16_v1_kernel_stats.md).
   constexpr int XROW = 12;                       // dwords per (row, cin) of the patch
-  constexpr int DFR = 8 * 128;                   // dy fragments (u32x4) per buffer
+  constexpr int DLD = 130;                       // fragment stride of a (row, half) line of 128 couts: 130 makes the 16 lanes of a
+                                                 // b128 store group (2 couts x 8 (row, half)) hit 16 distinct 16-B slots (128: 8-way)
+  constexpr int DFR = 8 * DLD;                   // dy fragments (u32x4) per buffer
   constexpr int XDW = 6 * 32 * XROW;             // patch dwords per buffer
   constexpr int BUF4 = DFR + XDW / 4;            // u32x4 per buffer
   ADM_DYN_SMEM(u32x4, lds4);
@@ -314,7 +321,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
     const int id = tid + 256 * j;
     const int hh = id & 1, r = (id >> 1) & 3, co = id >> 3;
     dyo[j] = (unsigned)(co * (int)planeO + r * p.Wi + 8 * hh);
-    ldsd[j] = (r * 2 + hh) * 128 + co;
+    ldsd[j] = (r * 2 + hh) * DLD + co;
   }
   int xcin[7], xrow[7], xq[7], ldsx[7];
   ADM_UNROLL
@@ -378,7 +385,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
     const unsigned* bufX = reinterpret_cast<const unsigned*>(buf + DFR);
     ADM_UNROLL
     for (int r = 0; r < 4; ++r) {
-      u32x4 A = buf[(r * 2 + h) * 128 + 32 * wave + l31];
+      u32x4 A = buf[(r * 2 + h) * DLD + 32 * wave + l31];
       if (!valid) { A[0] = 0u; A[1] = 0u; A[2] = 0u; A[3] = 0u; }       // tile past the end of an odd range: contributes zero
       ADM_UNROLL
       for (int dy3 = 0; dy3 < 3; ++dy3) {
@@ -547,7 +554,7 @@ int launch_conv_wgrad_bf16(const adm_conv_args& a, const float* dy, float* dW, i
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
   auto magic = [&](long d) { return (d <= 1 || p.n_ptiles >= 65536) ? 0u : (unsigned)((1ULL << 32) / (unsigned long long)d + 1ULL); };
   p.mTX = magic(p.tiles_x); p.mTXY = magic((long)p.tiles_x * p.tiles_y);
-  const size_t smem = 2 * (sizeof(u32x4) * 8 * 128 + sizeof(unsigned) * 6 * 32 * 12) + sizeof(unsigned) * 256 +
+  const size_t smem = 2 * (sizeof(u32x4) * 8 * 130 + sizeof(unsigned) * 6 * 32 * 12) + sizeof(unsigned) * 256 +
                       sizeof(float) * 64 * (size_t)a.N;
   ADM_REQUIRE(smem <= 64 * 1024, "conv_wgrad_bf16: batch too large for the LDS GroupNorm rows");
   if (a.up) {
