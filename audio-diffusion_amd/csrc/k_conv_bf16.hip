@@ -37,10 +37,14 @@ constexpr int BPW = 18, BPP = BPW * BPW;   // input patch of a 16x16 output tile
 __device__ __forceinline__ float silu_b(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
 
 struct Bf16Stage { float v[3][8]; };                 // raw fp32 prefetch of one 16-channel chunk (three 8-channel rounds)
-struct Bf16Filt { u32x4 a[9][2]; };                    // the wave's A fragments of one chunk: 9 taps x 2 cout sub-tiles
+template <int NA> struct Bf16Filt { u32x4 a[9][NA]; };  // the wave's A fragments of one chunk: 9 taps x NA cout sub-tiles
 
-template <bool UP, bool ACT>
+// WIDE = false: waves as 2 (64 couts) x 2 (8 pixel rows), 2 x 4 accumulator tiles, the two waves of a cout half fetch the
+// same filter fragments.  WIDE = true: waves as 4 (32 couts) x 1, 1 x 8 accumulator tiles: every filter fragment is
+// fetched once per workgroup (half the L2 requests, 36 registers less) at one LDS read per MFMA instead of one per two.
+template <bool UP, bool ACT, bool WIDE>
 __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams p) {
+  constexpr int NA = WIDE ? 1 : 2, NP = WIDE ? 8 : 4;
   // One workgroup per CU (up to 512 registers per lane) so that everything that comes from memory is requested a full
   // chunk (filters, L2) or two chunks (input patch, HBM) before it is used: the first version requested the next tap's
   // filters 8 MFMAs ahead and queued them behind the patch loads of the in-order vector-memory counter — 17k cycles per
@@ -48,7 +52,7 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams 
   ADM_DYN_SMEM(u32x4, lds);                 // [2 buffers][2 channel groups][324 pixels] + GroupNorm rows [2][Ct] floats
   const int tid = threadIdx.x, lane = tid & 63, wave = ADM_UNIFORM(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = WIDE ? wave : (wave & 1), wn = WIDE ? 0 : (wave >> 1);
   int lid;
   {   // consecutive logical tiles (all cout tiles of a pixel tile, then the neighbouring pixel tile) share an XCD's L2
     const int b = blockIdx.x, q = p.nblk >> 3, r = p.nblk & 7, xcd = b & 7;
@@ -57,7 +61,7 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams 
   const int ct = lid % p.n_ct; lid /= p.n_ct;
   const int tx = lid % p.tiles_x; lid /= p.tiles_x;
   const int ty = lid % p.tiles_y, n = lid / p.tiles_y;
-  const int m0 = ct * 128 + wm * 64;
+  const int m0 = ct * 128 + wm * (32 * NA);
   const int Ct = p.C1 + p.C2, KG = Ct >> 3;
   const int planeS = p.Hs * p.Ws;
 
@@ -135,44 +139,45 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams 
   // filters: ONE register set, refilled in place — as soon as the MFMAs of tap t are issued, the same registers receive
   // tap t of the next chunk, so every filter fragment is requested a full chunk (72 MFMAs) before its use at a cost of
   // 72 registers instead of 144
-  auto fetch_tap = [&](Bf16Filt& f, int ch, int t) __attribute__((always_inline)) {
+  auto fetch_tap = [&](Bf16Filt<NA>& f, int ch, int t) __attribute__((always_inline)) {
     const u32x4* wt = p.wb + m0 + ((long)(2 * ch) + (long)t * KG) * p.Cout;     // uniform
-    f.a[t][0] = wt[wlane]; f.a[t][1] = (wt + 32)[wlane];
-  };
-  f32x16 acc[2][4];
-  ADM_UNROLL
-  for (int a = 0; a < 2; ++a)
     ADM_UNROLL
-    for (int t = 0; t < 4; ++t)
+    for (int a = 0; a < NA; ++a) f.a[t][a] = (wt + 32 * a)[wlane];
+  };
+  f32x16 acc[NA][NP];
+  ADM_UNROLL
+  for (int a = 0; a < NA; ++a)
+    ADM_UNROLL
+    for (int t = 0; t < NP; ++t)
       ADM_UNROLL
       for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
 
   // B fragment of pixel tile t (2 rows x 16 columns), tap (dy, dx): LDS slot (8 wn + 2 t + (l31 >> 4) + dy) * 18 + (l31 & 15) + dx
   const int bbase = h * BPP + (8 * wn + (l31 >> 4)) * BPW + (l31 & 15);
-  Bf16Filt F;
+  Bf16Filt<NA> F;
   auto mfma_chunk = [&](const u32x4* cur, int ch) __attribute__((always_inline)) {
     // B fragments one tap ahead, fenced: left alone, the scheduler hoists all 36 LDS reads of the chunk above the first
     // MFMA (144 registers) and the kernel spills
     const int chn = ch + 1 < n_chunks ? ch + 1 : ch;   // past the end: re-request the last chunk (no branch in the tap loop)
-    u32x4 Bc[4], Bn[4];
+    u32x4 Bc[NP], Bn[NP];
     ADM_UNROLL
-    for (int pt = 0; pt < 4; ++pt) Bc[pt] = cur[bbase + (2 * pt) * BPW];
+    for (int pt = 0; pt < NP; ++pt) Bc[pt] = cur[bbase + (2 * pt) * BPW];
     ADM_UNROLL
     for (int t = 0; t < 9; ++t) {
       if (t < 8) {
         ADM_UNROLL
-        for (int pt = 0; pt < 4; ++pt) Bn[pt] = cur[bbase + (2 * pt + (t + 1) / 3) * BPW + ((t + 1) % 3)];
+        for (int pt = 0; pt < NP; ++pt) Bn[pt] = cur[bbase + (2 * pt + (t + 1) / 3) * BPW + ((t + 1) % 3)];
       }
       ADM_SCHED_FENCE();
       ADM_UNROLL
-      for (int pt = 0; pt < 4; ++pt) {
-        acc[0][pt] = ADM_MFMA_BF16(F.a[t][0], Bc[pt], acc[0][pt]);
-        acc[1][pt] = ADM_MFMA_BF16(F.a[t][1], Bc[pt], acc[1][pt]);
+      for (int pt = 0; pt < NP; ++pt) {
+        ADM_UNROLL
+        for (int a = 0; a < NA; ++a) acc[a][pt] = ADM_MFMA_BF16(F.a[t][a], Bc[pt], acc[a][pt]);
       }
       ADM_SCHED_FENCE();
       fetch_tap(F, chn, t);
       ADM_UNROLL
-      for (int pt = 0; pt < 4; ++pt) Bc[pt] = Bn[pt];
+      for (int pt = 0; pt < NP; ++pt) Bc[pt] = Bn[pt];
     }
   };
 
@@ -210,7 +215,7 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams 
   // epilogue: D row = output channel, column = pixel; fp32 bias + per-(n, channel) term + residual
   const long planeO = (long)p.Hi * p.Wi;
   ADM_UNROLL
-  for (int a = 0; a < 2; ++a) {
+  for (int a = 0; a < NA; ++a) {
     float bv[16];
     ADM_UNROLL
     for (int r = 0; r < 16; ++r) {
@@ -218,7 +223,7 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams 
       bv[r] = p.bias[co] + p.chan_add[(long)n * p.chan_add_stride + co];
     }
     ADM_UNROLL
-    for (int pt = 0; pt < 4; ++pt) {
+    for (int pt = 0; pt < NP; ++pt) {
       const int oy = ty * 16 + 8 * wn + 2 * pt + (l31 >> 4), ox = tx * 16 + (l31 & 15);
       const long pix = (long)oy * p.Wi + ox;
       float rv[16];
@@ -509,13 +514,20 @@ int launch_conv_bf16(const adm_conv_args& a, hipStream_t st) {
   const size_t smem = sizeof(u32x4) * 2 * 2 * BPP + sizeof(float) * 2 * Ct;
   ADM_REQUIRE(smem <= 64 * 1024, "conv_bf16: too many input channels for the LDS GroupNorm rows");
   set_last_conv_variant(5000 + 316);
+  static const int wide = [] { const char* e = getenv("ADM_BF16_WIDE"); return e ? atoi(e) : 0; }();
+#define ADM_BF16_LAUNCH(UP_, ACT_)                                                                              \
+  do {                                                                                                          \
+    if (wide) ADM_LAUNCH((conv_bf16_kernel<UP_, ACT_, true>), dim3(p.nblk), dim3(256), smem, st, p);             \
+    else ADM_LAUNCH((conv_bf16_kernel<UP_, ACT_, false>), dim3(p.nblk), dim3(256), smem, st, p);                 \
+  } while (0)
   if (a.up) {
-    if (a.act) ADM_LAUNCH((conv_bf16_kernel<true, true>), dim3(p.nblk), dim3(256), smem, st, p);
-    else ADM_LAUNCH((conv_bf16_kernel<true, false>), dim3(p.nblk), dim3(256), smem, st, p);
+    if (a.act) ADM_BF16_LAUNCH(true, true);
+    else ADM_BF16_LAUNCH(true, false);
   } else {
-    if (a.act) ADM_LAUNCH((conv_bf16_kernel<false, true>), dim3(p.nblk), dim3(256), smem, st, p);
-    else ADM_LAUNCH((conv_bf16_kernel<false, false>), dim3(p.nblk), dim3(256), smem, st, p);
+    if (a.act) ADM_BF16_LAUNCH(false, true);
+    else ADM_BF16_LAUNCH(false, false);
   }
+#undef ADM_BF16_LAUNCH
   return ADM_CHECK_LAUNCH();
 }
 
