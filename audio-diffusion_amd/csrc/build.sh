@@ -20,7 +20,12 @@ if [ "${1:-hip}" = "emu" ]; then
     objs+=("$o")
   done
   wait
-  g++ -shared -o "$out" "${objs[@]}" -lpthread
+  relink=0
+  for o in "${objs[@]}"; do if [ ! -f "$out" ] || [ "$o" -nt "$out" ]; then relink=1; fi; done
+  if [ "$relink" = 1 ]; then   # link to a temporary name and rename: a concurrent loader never sees a half-written file
+    g++ -shared -o "$out.tmp.$$" "${objs[@]}" -lpthread
+    mv -f "$out.tmp.$$" "$out"
+  fi
   echo "built $out"
 else
   out="$root/audio-diffusion_amd/audiodiffusion/libadm_hip.so"
@@ -34,6 +39,11 @@ else
     objs+=("$o")
   done
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+  relink=0
+  for o in "${objs[@]}"; do if [ ! -f "$out" ] || [ "$o" -nt "$out" ]; then relink=1; fi; done
+  if [ "$relink" = 1 ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out.tmp.$$" "${objs[@]}"
+    mv -f "$out.tmp.$$" "$out"
+  fi
   echo "built $out"
 fi

@@ -19,9 +19,10 @@ _built = False
 
 def ensure_emu_built():
     global _built
-    if not _built:
+    if not _built and os.environ.get("ADM_EMU_NOBUILD") != "1":    # spawned rank workers: the parent has built it already
         subprocess.run(["bash", BUILD, "emu"], check=True, capture_output=True)
-        _built = True
+        os.environ["ADM_EMU_NOBUILD"] = "1"                         # inherited by multiprocessing children
+    _built = True
     return EMU_LIB
 
 
