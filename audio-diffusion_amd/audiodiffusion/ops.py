@@ -157,6 +157,45 @@ def attention(qkv, head_dim):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- Transformer2DModel pieces
+def layernorm_nct(x, gamma, beta, eps=1e-5):
+    """LayerNorm over the channel axis of (N,C,H,W) for every token (BasicTransformerBlock.norm1/2/3)."""
+    _f32(x)
+    Nn, Cc = x.shape[:2]
+    y = torch.empty_like(x)
+    N.check(N.lib().adm_layernorm_nct(N.ptr(x), N.ptr(gamma), N.ptr(beta), N.ptr(y), Nn, Cc, x[0, 0].numel(), eps,
+                                      N.stream_for(x)))
+    return y
+
+
+def geglu(x):
+    """(N,2*C4,H,W) = [h | gate] -> (N,C4,H,W) = h * gelu(gate)."""
+    _f32(x)
+    Nn, C2 = x.shape[:2]
+    out = torch.empty((Nn, C2 // 2) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    N.check(N.lib().adm_geglu(N.ptr(x), N.ptr(out), Nn, C2 // 2, x[0, 0].numel(), N.stream_for(x)))
+    return out
+
+
+def cross_attention(q, ctx, wk, wv, head_dim):
+    """q (N,C,H,W), ctx (N,S,Dc), to_k/to_v weights (C,Dc) -> (N,C,H,W)."""
+    _f32(q), _f32(ctx)
+    Nn, Cc = q.shape[:2]
+    out = torch.empty_like(q)
+    N.check(N.lib().adm_cross_attention(N.ptr(q), N.ptr(ctx), N.ptr(wk), N.ptr(wv), N.ptr(out), Nn, Cc, q[0, 0].numel(),
+                                        ctx.shape[1], ctx.shape[2], head_dim, N.stream_for(q)))
+    return out
+
+
+def attention_blocked(qkv, head_dim, key_block=0):
+    """adm_attention with keys processed in blocks (online softmax): qkv (N,3C,H,W) -> (N,C,H,W)."""
+    _f32(qkv)
+    Nn, C3, H, W = qkv.shape
+    out = torch.empty((Nn, C3 // 3, H, W), dtype=torch.float32, device=qkv.device)
+    N.check(N.lib().adm_attention_blocked(N.ptr(qkv), N.ptr(out), Nn, C3 // 3, H * W, head_dim, key_block, N.stream_for(qkv)))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- backward ops (training)
 def _conv_args(x1, wpacked, bias, ks, x2, up, stride, pad_lo, gn, act, Cout):
     Nn, C1, H, W = x1.shape

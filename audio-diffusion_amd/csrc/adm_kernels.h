@@ -79,6 +79,14 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
 // k_attention.hip
 int launch_attention(const float* qkv, float* out, int N, int C, int T, int head_dim, hipStream_t st);
 
+// k_transformer.hip (UNet2DConditionModel: Transformer2DModel blocks)
+int launch_layernorm_nct(const float* x, const float* gamma, const float* beta, float* y, int N, int C, long T, float eps,
+                         hipStream_t st);
+int launch_geglu(const float* in, float* out, int N, int C4, long T, hipStream_t st);
+int launch_cross_attention(const float* q, const float* ctx, const float* Wk, const float* Wv, float* out, int N, int C,
+                           int T, int S, int Dc, int head_dim, hipStream_t st);
+int launch_attention_blocked(const float* qkv, float* out, int N, int C, int T, int head_dim, int key_block, hipStream_t st);
+
 // k_vae.hip
 int launch_softmax_channels(float* s, int N, int J, int T, float scale, hipStream_t st);
 int launch_transpose_ct(const float* in, long in_bs, float* out, int N, int C, int T, hipStream_t st);

@@ -94,4 +94,23 @@ int adm_attention(const float* qkv, float* out, int N, int C, int T, int head_di
   return launch_attention(qkv, out, N, C, T, head_dim, (hipStream_t)stream);
 }
 
+int adm_layernorm_nct(const float* x, const float* gamma, const float* beta, float* y, int N, int C, long T, float eps,
+                      void* stream) {
+  ADM_REQUIRE(x && gamma && beta && y, "layernorm_nct: null argument");
+  return launch_layernorm_nct(x, gamma, beta, y, N, C, T, eps, (hipStream_t)stream);
+}
+int adm_geglu(const float* in, float* out, int N, int C4, long T, void* stream) {
+  ADM_REQUIRE(in && out, "geglu: null argument");
+  return launch_geglu(in, out, N, C4, T, (hipStream_t)stream);
+}
+int adm_cross_attention(const float* q, const float* ctx, const float* Wk, const float* Wv, float* out, int N, int C, int T,
+                        int S, int Dc, int head_dim, void* stream) {
+  ADM_REQUIRE(q && ctx && Wk && Wv && out, "cross_attention: null argument");
+  return launch_cross_attention(q, ctx, Wk, Wv, out, N, C, T, S, Dc, head_dim, (hipStream_t)stream);
+}
+int adm_attention_blocked(const float* qkv, float* out, int N, int C, int T, int head_dim, int key_block, void* stream) {
+  ADM_REQUIRE(qkv && out, "attention_blocked: null argument");
+  return launch_attention_blocked(qkv, out, N, C, T, head_dim, key_block, (hipStream_t)stream);
+}
+
 }  // extern "C"

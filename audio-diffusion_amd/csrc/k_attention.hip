@@ -66,7 +66,8 @@ int launch_attention(const float* qkv, float* out, int N, int C, int T, int head
   const int bs = T >= 256 ? 256 : ((T + 63) / 64) * 64;
   dim3 grid(ceil_div(T, bs), heads, N), block(bs);
   const size_t smem = sizeof(float) * 2 * (size_t)T * head_dim;
-  ADM_REQUIRE(smem <= 160 * 1024, "attention: K/V slab exceeds LDS (this kernel serves the UNet's small-head attention)");
+  if (smem > 64 * 1024)   // K/V of a head no longer fit the default LDS window: key-blocked online-softmax kernel
+    return launch_attention_blocked(qkv, out, N, C, T, head_dim, 0, st);
   const float scale = 1.0f / sqrtf((float)head_dim);
 #define ADM_ATT_CASE(DD)                                                                  \
   if (head_dim == DD) {                                                                   \

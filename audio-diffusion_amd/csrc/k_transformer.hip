@@ -1,0 +1,203 @@
+// k_transformer.hip — the pieces of diffusers' Transformer2DModel / BasicTransformerBlock that UNet2DConditionModel adds
+// to the UNet (scripts/train_unet.py:139-159; called at pipeline_audio_diffusion.py:160-161 with `encoding`):
+//   LayerNorm over channels per token, GEGLU gate, cross-attention on the (batch, seq, dim) audio encoding, and
+//   self-attention for token counts whose K/V no longer fit LDS (64x64 latents of the 512-resolution latent model).
+// Activations stay in the UNet's (N, C, T = H*W) layout, so every Linear of the block is a 1x1 convolution on the MFMA
+// kernel (k_conv_mfma.hip) with its bias / residual epilogue; only the four operations here are new. All HBM-bound
+// elementwise / small-GEMM work: lanes run along T (coalesced), no MFMA.
+#include "adm_kernels.h"
+
+namespace adm {
+
+// y[n][c][t] = (x[n][c][t] - mean_t) * rstd_t * gamma[c] + beta[c], statistics over c for every token (n, t).
+// One lane per token, channel loop strided by T (coalesced across lanes); mean then centred variance (two passes, as
+// ATen's LayerNorm kernel), then the write pass: 3 reads + 1 write of 4 B per element.
+__global__ void __launch_bounds__(256) layernorm_nct_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y, int C,
+                                                            long T, float eps) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const float* xp = x + (long)blockIdx.y * C * T + t;
+  float* yp = y + (long)blockIdx.y * C * T + t;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += xp[(long)c * T];
+  const float mean = s / (float)C;
+  float v = 0.f;
+  for (int c = 0; c < C; ++c) { const float d = xp[(long)c * T] - mean; v = fmaf(d, d, v); }
+  const float rstd = rsqrtf(v / (float)C + eps);
+  for (int c = 0; c < C; ++c) yp[(long)c * T] = (xp[(long)c * T] - mean) * rstd * gamma[c] + beta[c];
+}
+
+int launch_layernorm_nct(const float* x, const float* gamma, const float* beta, float* y, int N, int C, long T, float eps,
+                         hipStream_t st) {
+  ADM_LAUNCH(layernorm_nct_kernel, dim3((unsigned)((T + 255) / 256), N), dim3(256), 0, st, x, gamma, beta, y, C, T, eps);
+  return ADM_CHECK_LAUNCH();
+}
+
+// GEGLU (diffusers attention.GEGLU): in (N, 2*C4, T) = [h | gate] on the channel axis -> out (N, C4, T) = h * gelu(gate),
+// exact (erf) GELU as F.gelu's default.
+__global__ void __launch_bounds__(256) geglu_kernel(const float* __restrict__ in, float* __restrict__ out, long per_sample) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_sample) return;
+  const float* ip = in + (long)blockIdx.y * 2 * per_sample;
+  const float h = ip[i], g = ip[per_sample + i];
+  out[(long)blockIdx.y * per_sample + i] = h * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f)));
+}
+
+int launch_geglu(const float* in, float* out, int N, int C4, long T, hipStream_t st) {
+  const long per = (long)C4 * T;
+  ADM_LAUNCH(geglu_kernel, dim3((unsigned)((per + 255) / 256), N), dim3(256), 0, st, in, out, per);
+  return ADM_CHECK_LAUNCH();
+}
+
+// Cross-attention of every token on the encoding: q (N, C, T) (already projected), ctx (N, S, Dc), Wk / Wv (C, Dc) the
+// to_k / to_v Linear weights (no bias) -> out (N, C, T) = softmax_s(q_t . k_s * d^-0.5) v_s per head (d = C / heads).
+// One workgroup per (256 tokens, head, sample): the head's K and V rows (S x d each) are computed from the encoding into
+// LDS first (S * d * Dc MACs per matrix — S = 1 in the reference's use, where the result is just V broadcast), then each
+// lane owns one query token.
+template <int D>
+__global__ void __launch_bounds__(256) cross_attention_kernel(const float* __restrict__ q, const float* __restrict__ ctx,
+                                                              const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                                              float* __restrict__ out, int C, int T, int S, int Dc,
+                                                              float scale) {
+  ADM_DYN_SMEM(float, smem);
+  float* Ks = smem;           // [S][D]
+  float* Vs = smem + S * D;   // [S][D]
+  const int head = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
+  for (int e = tid; e < 2 * S * D; e += blockDim.x) {
+    const int which = e / (S * D), r = e - which * S * D;
+    const int s = r / D, d = r - s * D;
+    const float* w = (which ? Wv : Wk) + (long)(head * D + d) * Dc;
+    const float* cx = ctx + ((long)n * S + s) * Dc;
+    float acc = 0.f;
+    for (int k = 0; k < Dc; ++k) acc = fmaf(cx[k], w[k], acc);
+    smem[e] = acc;
+  }
+  __syncthreads();
+  const int t = blockIdx.x * blockDim.x + tid;
+  if (t >= T) return;
+  const float* qb = q + ((long)n * C + head * D) * T;
+  float qv[D];
+  ADM_UNROLL
+  for (int d = 0; d < D; ++d) qv[d] = qb[(long)d * T + t];
+  float m = -3.0e38f;
+  for (int s = 0; s < S; ++s) {
+    float a = 0.f;
+    ADM_UNROLL
+    for (int d = 0; d < D; ++d) a = fmaf(qv[d], Ks[s * D + d], a);
+    m = fmaxf(m, a * scale);
+  }
+  float l = 0.f, o[D];
+  ADM_UNROLL
+  for (int d = 0; d < D; ++d) o[d] = 0.f;
+  for (int s = 0; s < S; ++s) {
+    float a = 0.f;
+    ADM_UNROLL
+    for (int d = 0; d < D; ++d) a = fmaf(qv[d], Ks[s * D + d], a);
+    const float p = __expf(a * scale - m);
+    l += p;
+    ADM_UNROLL
+    for (int d = 0; d < D; ++d) o[d] = fmaf(p, Vs[s * D + d], o[d]);
+  }
+  const float inv = 1.0f / l;
+  float* ob = out + ((long)n * C + head * D) * T;
+  ADM_UNROLL
+  for (int d = 0; d < D; ++d) ob[(long)d * T + t] = o[d] * inv;
+}
+
+int launch_cross_attention(const float* q, const float* ctx, const float* Wk, const float* Wv, float* out, int N, int C,
+                           int T, int S, int Dc, int head_dim, hipStream_t st) {
+  ADM_REQUIRE(C % head_dim == 0 && S >= 1, "cross_attention: bad shape");
+  const int heads = C / head_dim;
+  const int bs = T >= 256 ? 256 : ((T + 63) / 64) * 64;
+  dim3 grid(ceil_div(T, bs), heads, N), block(bs);
+  const size_t smem = sizeof(float) * 2 * (size_t)S * head_dim;
+  ADM_REQUIRE(smem <= 64 * 1024, "cross_attention: encoding sequence too long for the LDS K/V slab");
+  const float scale = 1.0f / sqrtf((float)head_dim);
+#define ADM_XATT_CASE(DD)                                                                                         \
+  if (head_dim == DD) {                                                                                           \
+    ADM_LAUNCH((cross_attention_kernel<DD>), grid, block, smem, st, q, ctx, Wk, Wv, out, C, T, S, Dc, scale);     \
+    return ADM_CHECK_LAUNCH();                                                                                    \
+  }
+  ADM_XATT_CASE(4) ADM_XATT_CASE(8) ADM_XATT_CASE(16) ADM_XATT_CASE(32) ADM_XATT_CASE(64)
+#undef ADM_XATT_CASE
+  ADM_FAIL("cross_attention: unsupported head_dim (4/8/16/32/64)");
+}
+
+// Self-attention for long token counts: the same per-head math as attention_kernel (k_attention.hip) with the keys
+// processed in LDS-sized blocks and an online softmax (running maximum m, denominator l and output o rescaled by
+// exp(m_old - m_new) per block).  qkv (N, 3C, T) -> out (N, C, T).
+template <int D>
+__global__ void __launch_bounds__(256) attention_blocked_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C,
+                                                                int T, int KB, float scale) {
+  ADM_DYN_SMEM(float, smem);
+  float* Ks = smem;            // [KB][D]
+  float* Vs = smem + KB * D;   // [KB][D]
+  const int head = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
+  const float* qb = qkv + ((long)n * 3 * C + head * D) * T;
+  const float* kb = qb + (long)C * T;
+  const float* vb = kb + (long)C * T;
+  const int t = blockIdx.x * blockDim.x + tid;
+  const bool live = t < T;
+  float qv[D], o[D];
+  ADM_UNROLL
+  for (int d = 0; d < D; ++d) { qv[d] = live ? qb[(long)d * T + t] : 0.f; o[d] = 0.f; }
+  float m = -3.0e38f, l = 0.f;
+  for (int j0 = 0; j0 < T; j0 += KB) {
+    const int nb = T - j0 < KB ? T - j0 : KB;
+    __syncthreads();                                  // previous block fully consumed
+    for (int e = tid; e < D * nb; e += blockDim.x) {
+      const int d = e / nb, j = e - d * nb;
+      Ks[j * D + d] = kb[(long)d * T + j0 + j];
+      Vs[j * D + d] = vb[(long)d * T + j0 + j];
+    }
+    __syncthreads();
+    float bm = m;
+    for (int j = 0; j < nb; ++j) {
+      float s = 0.f;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) s = fmaf(qv[d], Ks[j * D + d], s);
+      bm = fmaxf(bm, s * scale);
+    }
+    const float corr = __expf(m - bm);
+    l *= corr;
+    ADM_UNROLL
+    for (int d = 0; d < D; ++d) o[d] *= corr;
+    m = bm;
+    for (int j = 0; j < nb; ++j) {
+      float s = 0.f;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) s = fmaf(qv[d], Ks[j * D + d], s);
+      const float pj = __expf(s * scale - m);
+      l += pj;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) o[d] = fmaf(pj, Vs[j * D + d], o[d]);
+    }
+  }
+  if (!live) return;
+  const float inv = 1.0f / l;
+  float* ob = out + ((long)n * C + head * D) * T;
+  ADM_UNROLL
+  for (int d = 0; d < D; ++d) ob[(long)d * T + t] = o[d] * inv;
+}
+
+int launch_attention_blocked(const float* qkv, float* out, int N, int C, int T, int head_dim, int key_block, hipStream_t st) {
+  ADM_REQUIRE(C % head_dim == 0, "attention: C not divisible by head_dim");
+  const int heads = C / head_dim;
+  const int bs = T >= 256 ? 256 : ((T + 63) / 64) * 64;
+  int KB = key_block > 0 ? key_block : (int)(64 * 1024 / (2 * sizeof(float) * head_dim));   // 64 KiB of K + V per block
+  if (KB > T) KB = T;
+  dim3 grid(ceil_div(T, bs), heads, N), block(bs);
+  const size_t smem = sizeof(float) * 2 * (size_t)KB * head_dim;
+  const float scale = 1.0f / sqrtf((float)head_dim);
+#define ADM_ATTB_CASE(DD)                                                                          \
+  if (head_dim == DD) {                                                                            \
+    ADM_LAUNCH((attention_blocked_kernel<DD>), grid, block, smem, st, qkv, out, C, T, KB, scale);  \
+    return ADM_CHECK_LAUNCH();                                                                     \
+  }
+  ADM_ATTB_CASE(4) ADM_ATTB_CASE(8) ADM_ATTB_CASE(16) ADM_ATTB_CASE(32) ADM_ATTB_CASE(64)
+#undef ADM_ATTB_CASE
+  ADM_FAIL("attention: unsupported head_dim (4/8/16/32/64)");
+}
+
+}  // namespace adm

@@ -119,6 +119,20 @@ void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int
  * [h*d, (h+1)*d); out (N, C, T) = softmax(q^T k * d^-0.5) v per head, fp32 softmax. */
 int adm_attention(const float* qkv, float* out, int N, int C, int T, int head_dim, void* stream);
 
+/* Transformer2DModel pieces of UNet2DConditionModel (scripts/train_unet.py:139-159; diffusers transformer_2d.py /
+ * attention.py), all on (N, C, T) activations:
+ *   adm_layernorm_nct: LayerNorm over the channel axis for every token (norm1/2/3 of BasicTransformerBlock).
+ *   adm_geglu: (N, 2*C4, T) = [h | gate] -> (N, C4, T) = h * gelu(gate) (exact erf GELU).
+ *   adm_cross_attention: tokens attend to the encoding ctx (N, S, Dc) through to_k / to_v weights (C, Dc), q given.
+ *   adm_attention_blocked: adm_attention with the keys in blocks of `key_block` (0 = 64 KiB of K+V) and an online
+ *   softmax; adm_attention switches to it by itself when a head's K/V exceed 64 KiB. */
+int adm_layernorm_nct(const float* x, const float* gamma, const float* beta, float* y, int N, int C, long T, float eps,
+                      void* stream);
+int adm_geglu(const float* in, float* out, int N, int C4, long T, void* stream);
+int adm_cross_attention(const float* q, const float* ctx, const float* Wk, const float* Wv, float* out, int N, int C, int T,
+                        int S, int Dc, int head_dim, void* stream);
+int adm_attention_blocked(const float* qkv, float* out, int N, int C, int T, int head_dim, int key_block, void* stream);
+
 /* ---------------------------------------------------------------- UNet2DModel executor (rows U1-U8)
  * Replaces `self.unet(images, t)["sample"]` (pipeline_audio_diffusion.py:163,237; train_unet.py:257). */
 typedef struct adm_unet adm_unet_t;

@@ -1,0 +1,74 @@
+"""Transformer2DModel pieces of UNet2DConditionModel (scripts/train_unet.py:139-159) vs plain torch fp32."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from native_backend import BACKENDS, select
+from test_kernels import _rand, _relerr
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape", [(2, 32, 4, 8), (1, 96, 16, 16), (3, 64, 1, 5)])
+def test_layernorm_over_channels(backend, shape):
+    dev = select(backend)
+    from audiodiffusion import ops
+    x = _rand(shape, 1, dev) * 2 + 0.3
+    g, b = _rand((shape[1],), 2, dev) + 1, _rand((shape[1],), 3, dev)
+    y = ops.layernorm_nct(x, g, b)
+    ref = F.layer_norm(x.cpu().permute(0, 2, 3, 1), (shape[1],), g.cpu(), b.cpu(), 1e-5).permute(0, 3, 1, 2)
+    assert _relerr(y, ref) < 2e-6
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_geglu(backend):
+    dev = select(backend)
+    from audiodiffusion import ops
+    x = _rand((2, 64, 4, 8), 1, dev) * 3
+    h, gate = x.cpu().chunk(2, dim=1)
+    assert _relerr(ops.geglu(x), h * F.gelu(gate)) < 2e-6
+
+
+def _mha(q, k, v, heads):
+    """q (N,C,Tq), k/v (N,C,Tk) channel-major -> (N,C,Tq): heads of C/heads consecutive channels."""
+    Nn, Cc, Tq = q.shape
+    d = Cc // heads
+
+    def sp(t):
+        return t.view(Nn, heads, d, -1).transpose(2, 3)             # (N, heads, T, d)
+
+    p = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * d ** -0.5, dim=-1)
+    return (p @ sp(v)).transpose(2, 3).reshape(Nn, Cc, Tq)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("C,heads,S", [(32, 8, 1), (64, 8, 3), (128, 8, 5), (32, 2, 2)])
+def test_cross_attention_on_encoding(backend, C, heads, S):
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn, H, W, Dc = 2, 4, 8, 12
+    q = _rand((Nn, C, H, W), 1, dev)
+    ctx = _rand((Nn, S, Dc), 2, dev)
+    wk, wv = _rand((C, Dc), 3, dev, scale=Dc ** -0.5), _rand((C, Dc), 4, dev, scale=Dc ** -0.5)
+    out = ops.cross_attention(q, ctx, wk, wv, C // heads)
+    k = (ctx.cpu() @ wk.cpu().T).transpose(1, 2)                     # (N, C, S)
+    v = (ctx.cpu() @ wv.cpu().T).transpose(1, 2)
+    ref = _mha(q.cpu().reshape(Nn, C, H * W), k, v, heads).reshape(Nn, C, H, W)
+    assert _relerr(out, ref) < 5e-6
+    if S == 1:       # one key: the softmax is 1 and every token receives V (what the reference's seq_length-1 encoding does)
+        assert _relerr(out, v.reshape(Nn, C, 1, 1).expand(Nn, C, H, W)) < 2e-6
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("C,heads,HW,key_block", [(32, 2, (8, 8), 16), (64, 8, (4, 24), 32), (32, 8, (8, 8), 0)])
+def test_self_attention_key_blocks_match_one_pass(backend, C, heads, HW, key_block):
+    """Online softmax over key blocks (needed at 64x64 latents: 4096 tokens) == the one-pass kernel == torch."""
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn = 2
+    qkv = _rand((Nn, 3 * C) + HW, 1, dev) * 1.5
+    out = ops.attention_blocked(qkv, C // heads, key_block)
+    T = HW[0] * HW[1]
+    q, k, v = qkv.cpu().reshape(Nn, 3, C, T).unbind(1)
+    ref = _mha(q, k, v, heads).reshape(Nn, C, *HW)
+    assert _relerr(out, ref) < 5e-6
+    assert _relerr(out, ops.attention(qkv, C // heads)) < 5e-6
