@@ -48,6 +48,7 @@ class UNetConfig(C.Structure):
         ("block_out_channels", C.c_int * 8), ("down_attn", C.c_int * 8), ("up_attn", C.c_int * 8),
         ("attention_head_dim", C.c_int), ("norm_num_groups", C.c_int), ("norm_eps", C.c_float),
         ("flip_sin_to_cos", C.c_int), ("freq_shift", C.c_float), ("sample_h", C.c_int), ("sample_w", C.c_int),
+        ("cross_attention_dim", C.c_int),
     ]
 
 
@@ -78,6 +79,7 @@ _SIGS = {
     "adm_unet_create": (C.c_int, [C.POINTER(UNetConfig), C.POINTER(C.c_void_p)]),
     "adm_unet_destroy": (None, [C.c_void_p]),
     "adm_unet_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "adm_unet_set_encoding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "adm_unet_missing_params": (C.c_int, [C.c_void_p]),
     "adm_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, c_float_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "adm_unet_workspace_bytes": (C.c_size_t, [C.c_void_p]),

@@ -39,6 +39,7 @@ def param_specs(cfg):
     nb, L = len(boc), cfg["layers_per_block"]
     temb = boc[0] * 4
     out = []
+    cross = cfg.get("cross_attention_dim") or 0
 
     def conv(p, co, ci, ks):
         out.append((p + ".weight", (co, ci, ks, ks), ci * ks * ks))
@@ -59,6 +60,22 @@ def param_specs(cfg):
             conv(p + ".conv_shortcut", co, ci, 1)
 
     def attn(p, c):
+        if cross:            # diffusers Transformer2DModel with one BasicTransformerBlock (UNet2DConditionModel)
+            tb = p + ".transformer_blocks.0"
+            gn(p + ".norm", c), conv(p + ".proj_in", c, c, 1)
+            gn(tb + ".norm1", c)
+            for n in ("attn1.to_q", "attn1.to_k", "attn1.to_v"):
+                out.append((f"{tb}.{n}.weight", (c, c), c))
+            lin(tb + ".attn1.to_out.0", c, c)
+            gn(tb + ".norm2", c)
+            out.append((tb + ".attn2.to_q.weight", (c, c), c))
+            out.append((tb + ".attn2.to_k.weight", (c, cross), cross))
+            out.append((tb + ".attn2.to_v.weight", (c, cross), cross))
+            lin(tb + ".attn2.to_out.0", c, c)
+            gn(tb + ".norm3", c)
+            lin(tb + ".ff.net.0.proj", 8 * c, c), lin(tb + ".ff.net.2", c, 4 * c)
+            conv(p + ".proj_out", c, c, 1)
+            return
         gn(p + ".group_norm", c)
         for n in ("to_q", "to_k", "to_v", "to_out.0"):
             lin(p + "." + n, c, c)
@@ -70,7 +87,7 @@ def param_specs(cfg):
         ci, o = o, boc[i]
         for j in range(L):
             resnet(f"down_blocks.{i}.resnets.{j}", ci if j == 0 else o, o)
-        if t.startswith("Attn"):
+        if "Attn" in t:
             for j in range(L):
                 attn(f"down_blocks.{i}.attentions.{j}", o)
         if i != nb - 1:
@@ -84,7 +101,7 @@ def param_specs(cfg):
         ci = rev[min(i + 1, nb - 1)]
         for j in range(L + 1):
             resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else o) + (ci if j == L else o), o)
-        if t.startswith("Attn"):
+        if "Attn" in t:
             for j in range(L + 1):
                 attn(f"up_blocks.{i}.attentions.{j}", o)
         if i != nb - 1:
@@ -106,8 +123,10 @@ def _canon_key(k):
 class UNet2DModel:
     config_name = "config.json"
 
+    _defaults = _DEFAULTS
+
     def __init__(self, **kwargs):
-        cfg = dict(_DEFAULTS)
+        cfg = dict(self._defaults)
         cfg.update({k: v for k, v in kwargs.items() if not k.startswith("_")})
         for k in ("down_block_types", "up_block_types", "block_out_channels"):
             cfg[k] = tuple(cfg[k])
@@ -159,8 +178,9 @@ class UNet2DModel:
         nc.layers_per_block, nc.n_blocks = c.layers_per_block, len(c.block_out_channels)
         for i, v in enumerate(c.block_out_channels):
             nc.block_out_channels[i] = v
-            nc.down_attn[i] = int(c.down_block_types[i].startswith("Attn"))
-            nc.up_attn[i] = int(c.up_block_types[i].startswith("Attn"))
+            nc.down_attn[i] = 2 if c.down_block_types[i].startswith("CrossAttn") else int(c.down_block_types[i].startswith("Attn"))
+            nc.up_attn[i] = 2 if c.up_block_types[i].startswith("CrossAttn") else int(c.up_block_types[i].startswith("Attn"))
+        nc.cross_attention_dim = int(c.get("cross_attention_dim") or 0)
         nc.attention_head_dim = c.attention_head_dim if c.attention_head_dim is not None else 0
         nc.norm_num_groups, nc.norm_eps = c.norm_num_groups, c.norm_eps
         nc.flip_sin_to_cos, nc.freq_shift = int(c.flip_sin_to_cos), float(c.freq_shift)
@@ -336,3 +356,72 @@ class UNet2DModel:
             save_file(self._sd, os.path.join(path, "diffusion_pytorch_model.safetensors"))
         else:
             torch.save(self._sd, os.path.join(path, "diffusion_pytorch_model.bin"))
+
+
+# ---------------------------------------------------------------------------------------------- conditional model
+_COND_DEFAULTS = dict(
+    sample_size=None, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
+    down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    mid_block_type="UNetMidBlock2DCrossAttn",
+    up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    only_cross_attention=False, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, downsample_padding=1,
+    mid_block_scale_factor=1, dropout=0.0, act_fn="silu", norm_num_groups=32, norm_eps=1e-5, cross_attention_dim=1280,
+    transformer_layers_per_block=1, encoder_hid_dim=None, encoder_hid_dim_type=None, attention_head_dim=8,
+    num_attention_heads=None, dual_cross_attention=False, use_linear_projection=False, class_embed_type=None,
+    addition_embed_type=None, num_class_embeds=None, upcast_attention=False, resnet_time_scale_shift="default",
+    time_embedding_type="positional", time_embedding_dim=None, time_embedding_act_fn=None, timestep_post_act=None,
+    time_cond_proj_dim=None, conv_in_kernel=3, conv_out_kernel=3, class_embeddings_concat=False,
+)
+
+
+class UNet2DConditionModel(UNet2DModel):
+    """diffusers' UNet2DConditionModel as the reference builds it (`scripts/train_unet.py:139-159`): CrossAttn down / up
+    blocks and a cross-attention mid block whose Transformer2DModel attends to `encoding` (batch, seq_length,
+    cross_attention_dim) — `self.unet(images, t, encoding)["sample"]` (`pipeline_audio_diffusion.py:160-161`).
+    `attention_head_dim` is the number of heads, as in diffusers 0.24 (`num_attention_heads or attention_head_dim`).
+    Inference only this round: `enable_training` raises."""
+
+    _defaults = _COND_DEFAULTS
+
+    @staticmethod
+    def _validate(cfg):
+        ok_down, ok_up = {"DownBlock2D", "CrossAttnDownBlock2D"}, {"UpBlock2D", "CrossAttnUpBlock2D"}
+        bad = [t for t in cfg["down_block_types"] if t not in ok_down] + [t for t in cfg["up_block_types"] if t not in ok_up]
+        if bad:
+            raise NotImplementedError(f"block types {bad} are not implemented (Down/CrossAttnDown/Up/CrossAttnUp)")
+        for k, want in (("time_embedding_type", "positional"), ("act_fn", "silu"), ("resnet_time_scale_shift", "default"),
+                        ("center_input_sample", False), ("class_embed_type", None), ("downsample_padding", 1),
+                        ("mid_block_scale_factor", 1), ("mid_block_type", "UNetMidBlock2DCrossAttn"),
+                        ("only_cross_attention", False), ("transformer_layers_per_block", 1), ("encoder_hid_dim", None),
+                        ("num_attention_heads", None), ("dual_cross_attention", False), ("use_linear_projection", False),
+                        ("addition_embed_type", None), ("upcast_attention", False), ("time_embedding_dim", None),
+                        ("time_cond_proj_dim", None), ("conv_in_kernel", 3), ("conv_out_kernel", 3)):
+            if cfg.get(k, want) != want:
+                raise NotImplementedError(f"UNet2DConditionModel config {k}={cfg[k]!r} is not implemented (expected {want!r})")
+        if not isinstance(cfg["attention_head_dim"], int) or not isinstance(cfg["cross_attention_dim"], int):
+            raise NotImplementedError("per-block attention_head_dim / cross_attention_dim tuples are not implemented")
+        if len(cfg["block_out_channels"]) > 8:
+            raise NotImplementedError("more than 8 blocks")
+
+    def forward(self, sample, timestep, encoder_hidden_states, return_dict=True):
+        assert sample.dim() == 4 and sample.dtype == torch.float32
+        enc = encoder_hidden_states
+        if enc is None:
+            raise ValueError("UNet2DConditionModel needs `encoding` (batch, seq_length, cross_attention_dim)")
+        enc = enc.to(sample.device, torch.float32)
+        if enc.dim() == 2:
+            enc = enc[:, None, :]
+        B = sample.shape[0]
+        if enc.shape[0] != B or enc.shape[2] != self.config.cross_attention_dim:
+            raise ValueError(f"encoding shape {tuple(enc.shape)} does not match (batch={B}, seq, {self.config.cross_attention_dim})")
+        if tuple(sample.shape[2:]) != self._hw():
+            self.sample_size = tuple(sample.shape[2:])
+        h = self._ensure_handle()
+        self._enc = enc.contiguous()            # kept alive: the native side stores the pointer
+        N.check(N.lib().adm_unet_set_encoding(h, N.ptr(self._enc), self._enc.shape[1]))
+        return UNet2DModel.forward(self, sample, timestep)
+
+    __call__ = forward
+
+    def enable_training(self, *a, **k):
+        raise NotImplementedError("training of the conditional UNet (scripts/train_unet.py --encodings) is not implemented")

@@ -28,6 +28,7 @@ struct ParamStore {
   void declare_gn(const std::string& p, int c);
   void declare_resnet(const std::string& p, int ci, int co, int temb);  // temb <= 0: no time_emb_proj
   void declare_attn(const std::string& p, int c);
+  void declare_transformer(const std::string& p, int c, int cross_dim);   // Transformer2DModel with one BasicTransformerBlock
   int set(const char* key, const float* host_data, size_t numel);       // accepts deprecated attention names
   int bind(const char* key, float* dev_ptr);                            // training: parameter lives in a flat buffer
   int missing(std::string* names) const;
@@ -46,6 +47,7 @@ struct ConvW {
   int Cin = 0, Cout = 0, ks = 3;
   std::string key;        // diffusers prefix of the master parameter ("" for derived weights)
   std::string qkv_prefix; // non-empty: q|k|v stacked from <prefix>.to_q/.to_k/.to_v
+  bool has_bias = true;   // false: Linear(bias=False) (Transformer2DModel's to_q/to_k/to_v); qkv: the stacked bias stays zero
   float* stacked = nullptr;  // (3C, C) stacked master copy of q|k|v
 };
 struct GNW {
@@ -69,7 +71,7 @@ struct GnBuf {
   const GNW* g = nullptr;      // the affine parameters this buffer was computed with
 };
 struct Op {
-  enum Kind { GN, CONV, ATTN, SOFTMAXC, TRANSP } kind = CONV;
+  enum Kind { GN, CONV, ATTN, SOFTMAXC, TRANSP, LN, GEGLU, XATTN } kind = CONV;
   int in1 = -1, in2 = -1, out = -1, res = -1, gn = -1;
   int in1_coff = 0, in1_C = 0;      // channel-slice view of in1 (in1_C == 0: whole tensor)
   int wt = -1, wt_coff = 0;         // CONV with per-sample weights taken from tensor `wt` (channel offset wt_coff)
@@ -80,6 +82,9 @@ struct Op {
   int temb_off = -1;
   int head_dim = 0;
   float scale = 1.f;
+  float eps = 0.f;                  // GN / LN: epsilon of this op (0: the net's norm_eps)
+  const float* wk = nullptr;        // XATTN: to_k / to_v master weights (C, cross_dim), no bias
+  const float* wv = nullptr;
 };
 
 struct OpTimer;  // unet_exec.hip (profiling aid)
@@ -98,6 +103,9 @@ struct Net {
   std::vector<std::pair<std::string, int>> temb_rows;  // (time_emb_proj prefix, Cout) in op order (UNet only)
   int t_in = -1, t_out = -1;
   int planned_B = 0;
+  // conditional UNet: encoder_hidden_states of the current call, device (B, ctx_S, ctx_D) (set by the owner before run)
+  const float* ctx = nullptr;
+  int ctx_S = 0, ctx_D = 0;
   std::vector<void*> arena;
   size_t arena_bytes = 0;
   // training
@@ -109,7 +117,7 @@ struct Net {
 
   // ---- construction -----------------------------------------------------------------------------------
   int dalloc(void** p, size_t bytes);
-  int make_conv(const std::string& p, int co, int ci, int ks, const ConvW** out);
+  int make_conv(const std::string& p, int co, int ci, int ks, const ConvW** out, bool bias = true);
   const GNW* make_gn(const std::string& p, int c);
   int new_tensor(int C, int H, int W, bool ext = false);
   int gn_op(int in1, int in2, const GNW* g);
@@ -117,6 +125,10 @@ struct Net {
               int out_ext = -1);
   int resnet(const std::string& p, int x1, int x2, int ci, int co, bool temb, int* rc);
   int attention(const std::string& p, int x, int C, int head_dim, int* rc);  // head_dim <= 64: fused small-head kernel
+  // diffusers Transformer2DModel (GroupNorm eps 1e-6, 1x1 proj_in/out, one BasicTransformerBlock: self-attention,
+  // cross-attention on `ctx`, GEGLU feed-forward; `heads` heads of C / heads channels)
+  int transformer(const std::string& p, int x, int C, int heads, int cross_dim, int* rc);
+  int stacked_qkv(const std::string& prefix, int C, bool bias, const ConvW** out);
   void finish_liveness();
 
   // ---- execution ----------------------------------------------------------------------------------------

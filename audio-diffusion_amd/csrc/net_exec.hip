@@ -34,6 +34,22 @@ void ParamStore::declare_resnet(const std::string& p, int ci, int co, int temb) 
   declare_conv(p + ".conv2", co, co, 3);
   if (ci != co) declare_conv(p + ".conv_shortcut", co, ci, 1);
 }
+void ParamStore::declare_transformer(const std::string& p, int c, int cross_dim) {
+  declare_gn(p + ".norm", c);
+  declare_conv(p + ".proj_in", c, c, 1);
+  const std::string tb = p + ".transformer_blocks.0";
+  declare_gn(tb + ".norm1", c);
+  for (const char* n : {".attn1.to_q", ".attn1.to_k", ".attn1.to_v", ".attn2.to_q"}) declare(tb + n + ".weight", {c, c});
+  declare_lin(tb + ".attn1.to_out.0", c, c);
+  declare_gn(tb + ".norm2", c);
+  declare(tb + ".attn2.to_k.weight", {c, cross_dim});
+  declare(tb + ".attn2.to_v.weight", {c, cross_dim});
+  declare_lin(tb + ".attn2.to_out.0", c, c);
+  declare_gn(tb + ".norm3", c);
+  declare_lin(tb + ".ff.net.0.proj", 8 * c, c);
+  declare_lin(tb + ".ff.net.2", c, 4 * c);
+  declare_conv(p + ".proj_out", c, c, 1);
+}
 void ParamStore::declare_attn(const std::string& p, int c) {
   declare_gn(p + ".group_norm", c);
   declare_lin(p + ".to_q", c, c);
@@ -122,11 +138,11 @@ static int pack_one(Net* net, ConvW& w, hipStream_t st) {
     const char* names[3] = {".to_q", ".to_k", ".to_v"};
     for (int i = 0; i < 3; ++i) {
       ADM_TRY(copy_d2d(w.stacked + (size_t)i * C * C, net->ps->P(w.qkv_prefix + names[i] + ".weight"), sizeof(float) * (size_t)C * C, st));
-      ADM_TRY(copy_d2d(w.bias + (size_t)i * C, net->ps->P(w.qkv_prefix + names[i] + ".bias"), sizeof(float) * (size_t)C, st));
+      if (w.has_bias) ADM_TRY(copy_d2d(w.bias + (size_t)i * C, net->ps->P(w.qkv_prefix + names[i] + ".bias"), sizeof(float) * (size_t)C, st));
     }
   } else {
     src = net->ps->P(w.key + ".weight");
-    w.bias = net->ps->P(w.key + ".bias");
+    w.bias = w.has_bias ? net->ps->P(w.key + ".bias") : nullptr;
   }
   ADM_TRY(launch_pack_conv_weight(src, w.wp, w.Cout, w.Cin, w.ks, st));
   if (w.ks == 3 && w.qkv_prefix.empty() && winograd_enabled() && w.Cout % 32 == 0 && w.Cin % 8 == 0) {
@@ -152,9 +168,9 @@ static int pack_one(Net* net, ConvW& w, hipStream_t st) {
   return 0;
 }
 
-int Net::make_conv(const std::string& p, int co, int ci, int ks, const ConvW** out) {
+int Net::make_conv(const std::string& p, int co, int ci, int ks, const ConvW** out, bool bias) {
   ConvW w;
-  w.Cin = ci; w.Cout = co; w.ks = ks; w.key = p;
+  w.Cin = ci; w.Cout = co; w.ks = ks; w.key = p; w.has_bias = bias;
   ADM_TRY(dalloc((void**)&w.wp, sizeof(float) * (size_t)co * ci * ks * ks));
   convs.push_back(w);
   ADM_TRY(pack_one(this, convs.back(), nullptr));
@@ -237,15 +253,23 @@ int Net::resnet(const std::string& p, int x1, int x2, int ci, int co, bool temb,
   if (sc) res = conv_op(x1, x2, sc, -1, 0, 0, 1, 0, -1, -1);
   return conv_op(hmid, -1, c2, g2, 1, 0, 1, 1, res, -1);
 }
-int Net::attention(const std::string& p, int x, int C, int head_dim, int* rc) {
-  // q|k|v stacked into one 1x1 conv: weights (3C, C), bias 3C; GroupNorm (no SiLU) folded into its load path
-  ConvW qkv; qkv.Cin = C; qkv.Cout = 3 * C; qkv.ks = 1; qkv.qkv_prefix = p;
-  if ((*rc = dalloc((void**)&qkv.stacked, sizeof(float) * (size_t)3 * C * C))) return -1;
-  if ((*rc = dalloc((void**)&qkv.wp, sizeof(float) * (size_t)3 * C * C))) return -1;
-  if ((*rc = dalloc((void**)&qkv.bias, sizeof(float) * (size_t)3 * C))) return -1;
+int Net::stacked_qkv(const std::string& prefix, int C, bool bias, const ConvW** out) {
+  // q|k|v stacked into one 1x1 conv: weights (3C, C), bias 3C (all-zero for Linear(bias=False) projections)
+  ConvW qkv; qkv.Cin = C; qkv.Cout = 3 * C; qkv.ks = 1; qkv.qkv_prefix = prefix; qkv.has_bias = bias;
+  ADM_TRY(dalloc((void**)&qkv.stacked, sizeof(float) * (size_t)3 * C * C));
+  ADM_TRY(dalloc((void**)&qkv.wp, sizeof(float) * (size_t)3 * C * C));
+  ADM_TRY(dalloc((void**)&qkv.bias, sizeof(float) * (size_t)3 * C));
+  if (!bias) { ADM_TRY(dmemset(qkv.bias, 0, sizeof(float) * (size_t)3 * C, nullptr)); ADM_TRY(stream_sync(nullptr)); }
   convs.push_back(qkv);
-  if ((*rc = pack_one(this, convs.back(), nullptr))) return -1;
-  const ConvW* wqkv = &convs.back();
+  ADM_TRY(pack_one(this, convs.back(), nullptr));
+  *out = &convs.back();
+  return 0;
+}
+int Net::attention(const std::string& p, int x, int C, int head_dim, int* rc) {
+  // GroupNorm (no SiLU) folded into the load path of the stacked q|k|v 1x1 conv
+  const ConvW* wqkv_;
+  if ((*rc = stacked_qkv(p, C, true, &wqkv_))) return -1;
+  const ConvW* wqkv = wqkv_;
   const ConvW* wo;
   if ((*rc = make_conv(p + ".to_out.0", C, C, 1, &wo))) return -1;
   const int g = gn_op(x, -1, make_gn(p + ".group_norm", C));
@@ -274,6 +298,49 @@ int Net::attention(const std::string& p, int x, int C, int head_dim, int* rc) {
   pv.out = new_tensor(C, tx.H, tx.W);
   ops.push_back(pv);
   return conv_op(pv.out, -1, wo, -1, 0, 0, 1, 0, x, -1);
+}
+int Net::transformer(const std::string& p, int x, int C, int heads, int cross_dim, int* rc) {
+  ADM_REQUIRE(heads > 0 && C % heads == 0, "transformer: channels not divisible by the head count");
+  (void)cross_dim;
+  const int hd = C / heads;
+  const std::string tb = p + ".transformer_blocks.0";
+  const Tensor tx = tensors[x];
+  const ConvW *w_in, *w_qkv, *w_o1, *w_q2, *w_o2, *w_ff1, *w_ff2, *w_out;
+  if ((*rc = make_conv(p + ".proj_in", C, C, 1, &w_in))) return -1;
+  if ((*rc = stacked_qkv(tb + ".attn1", C, false, &w_qkv))) return -1;
+  if ((*rc = make_conv(tb + ".attn1.to_out.0", C, C, 1, &w_o1))) return -1;
+  if ((*rc = make_conv(tb + ".attn2.to_q", C, C, 1, &w_q2, false))) return -1;
+  if ((*rc = make_conv(tb + ".attn2.to_out.0", C, C, 1, &w_o2))) return -1;
+  if ((*rc = make_conv(tb + ".ff.net.0.proj", 8 * C, C, 1, &w_ff1))) return -1;
+  if ((*rc = make_conv(tb + ".ff.net.2", C, 4 * C, 1, &w_ff2))) return -1;
+  if ((*rc = make_conv(p + ".proj_out", C, C, 1, &w_out))) return -1;
+  auto ln = [&](int in, const std::string& name) {
+    Op o; o.kind = Op::LN; o.in1 = in; o.g = make_gn(name, C); o.eps = 1e-5f;
+    o.out = new_tensor(C, tx.H, tx.W);
+    ops.push_back(o);
+    return o.out;
+  };
+  // hidden = proj_in(GroupNorm(x)), GroupNorm eps = 1e-6 (transformer_2d.py), folded into the conv's load path
+  const int g = gn_op(x, -1, make_gn(p + ".norm", C));
+  ops.back().eps = 1e-6f;
+  const int h0 = conv_op(x, -1, w_in, g, 0, 0, 1, 0, -1, -1);
+  // self-attention: h1 = to_out(attn(qkv(LN1(h0)))) + h0
+  const int qkv = conv_op(ln(h0, tb + ".norm1"), -1, w_qkv, -1, 0, 0, 1, 0, -1, -1);
+  Op a; a.kind = Op::ATTN; a.in1 = qkv; a.head_dim = hd; a.out = new_tensor(C, tx.H, tx.W);
+  ops.push_back(a);
+  const int h1 = conv_op(a.out, -1, w_o1, -1, 0, 0, 1, 0, h0, -1);
+  // cross-attention on the encoding: h2 = to_out(xattn(to_q(LN2(h1)), ctx)) + h1
+  const int q2 = conv_op(ln(h1, tb + ".norm2"), -1, w_q2, -1, 0, 0, 1, 0, -1, -1);
+  Op xa; xa.kind = Op::XATTN; xa.in1 = q2; xa.head_dim = hd; xa.out = new_tensor(C, tx.H, tx.W);
+  xa.wk = ps->P(tb + ".attn2.to_k.weight"); xa.wv = ps->P(tb + ".attn2.to_v.weight");
+  ops.push_back(xa);
+  const int h2 = conv_op(xa.out, -1, w_o2, -1, 0, 0, 1, 0, h1, -1);
+  // feed-forward: h3 = W2(GEGLU(W1(LN3(h2)))) + h2
+  const int ff = conv_op(ln(h2, tb + ".norm3"), -1, w_ff1, -1, 0, 0, 1, 0, -1, -1);
+  Op ge; ge.kind = Op::GEGLU; ge.in1 = ff; ge.out = new_tensor(4 * C, tx.H, tx.W);
+  ops.push_back(ge);
+  const int h3 = conv_op(ge.out, -1, w_ff2, -1, 0, 0, 1, 0, h2, -1);
+  return conv_op(h3, -1, w_out, -1, 0, 0, 1, 0, x, -1);
 }
 void Net::finish_liveness() {
   for (size_t i = 0; i < ops.size(); ++i) {
@@ -379,8 +446,8 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
       const GnBuf& g = gnbufs[o.gn];
       const float* x2 = o.in2 >= 0 ? tensors[o.in2].ptr : nullptr;
       const int C2 = o.in2 >= 0 ? tensors[o.in2].C : 0;
-      ADM_TRY(launch_groupnorm_stats(t1.ptr, t1.C, x2, C2, B, t1.H * t1.W, groups, eps, o.g->gamma, o.g->beta, g.scale,
-                                     g.shift, st, g.mean_rstd));
+      ADM_TRY(launch_groupnorm_stats(t1.ptr, t1.C, x2, C2, B, t1.H * t1.W, groups, o.eps > 0.f ? o.eps : eps, o.g->gamma,
+                                     o.g->beta, g.scale, g.shift, st, g.mean_rstd));
       tm->end(0, 0, 3.0 * B * (t1.C + C2) * t1.H * t1.W, 4.0 * B * (t1.C + C2) * t1.H * t1.W);
     } else if (o.kind == Op::CONV) {
       adm_conv_args a;
@@ -418,6 +485,19 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
       const int C = t1.C / 3, T = t1.H * t1.W;
       ADM_TRY(launch_attention(t1.ptr, tensors[o.out].ptr, B, C, T, o.head_dim, st));
       tm->end(2, o.head_dim, 4.0 * B * C * (double)T * T, 16.0 * B * C * T);
+    } else if (o.kind == Op::LN) {
+      const long T = (long)t1.H * t1.W;
+      ADM_TRY(launch_layernorm_nct(t1.ptr, o.g->gamma, o.g->beta, tensors[o.out].ptr, B, t1.C, T, o.eps, st));
+      tm->end(7, 0, 8.0 * B * t1.C * T, 16.0 * B * t1.C * T);
+    } else if (o.kind == Op::GEGLU) {
+      const long T = (long)t1.H * t1.W;
+      ADM_TRY(launch_geglu(t1.ptr, tensors[o.out].ptr, B, t1.C / 2, T, st));
+      tm->end(8, 0, 10.0 * B * (t1.C / 2) * T, 6.0 * B * t1.C * T);
+    } else if (o.kind == Op::XATTN) {
+      ADM_REQUIRE(ctx != nullptr && ctx_S > 0, "conditional UNet: no encoding set (adm_unet_set_encoding) before the forward");
+      const int T = t1.H * t1.W;
+      ADM_TRY(launch_cross_attention(t1.ptr, ctx, o.wk, o.wv, tensors[o.out].ptr, B, t1.C, T, ctx_S, ctx_D, o.head_dim, st));
+      tm->end(9, o.head_dim, 4.0 * B * t1.C * (double)T * ctx_S, 8.0 * B * t1.C * T);
     } else if (o.kind == Op::SOFTMAXC) {
       const int T = t1.H * t1.W;
       ADM_TRY(launch_softmax_channels(t1.ptr, B, t1.C, T, o.scale, st));

@@ -70,13 +70,15 @@ static void declare_all(adm_unet* h) {
     const std::string bp = "down_blocks." + std::to_string(i);
     for (int j = 0; j < L; ++j) {
       ps.declare_resnet(bp + ".resnets." + std::to_string(j), j == 0 ? cin : out, out, temb);
-      if (c.down_attn[i]) ps.declare_attn(bp + ".attentions." + std::to_string(j), out);
+      if (c.down_attn[i] == 2) ps.declare_transformer(bp + ".attentions." + std::to_string(j), out, c.cross_attention_dim);
+      else if (c.down_attn[i]) ps.declare_attn(bp + ".attentions." + std::to_string(j), out);
     }
     if (i != nb - 1) ps.declare_conv(bp + ".downsamplers.0.conv", out, out, 3);
   }
   const int mid = boc[nb - 1];
   ps.declare_resnet("mid_block.resnets.0", mid, mid, temb);
-  ps.declare_attn("mid_block.attentions.0", mid);
+  if (c.cross_attention_dim > 0) ps.declare_transformer("mid_block.attentions.0", mid, c.cross_attention_dim);
+  else ps.declare_attn("mid_block.attentions.0", mid);
   ps.declare_resnet("mid_block.resnets.1", mid, mid, temb);
   out = boc[nb - 1];
   for (int i = 0; i < nb; ++i) {
@@ -88,7 +90,8 @@ static void declare_all(adm_unet* h) {
       const int skip = (j == L) ? cin : out;
       const int rin = (j == 0) ? prev : out;
       ps.declare_resnet(bp + ".resnets." + std::to_string(j), rin + skip, out, temb);
-      if (c.up_attn[i]) ps.declare_attn(bp + ".attentions." + std::to_string(j), out);
+      if (c.up_attn[i] == 2) ps.declare_transformer(bp + ".attentions." + std::to_string(j), out, c.cross_attention_dim);
+      else if (c.up_attn[i]) ps.declare_attn(bp + ".attentions." + std::to_string(j), out);
     }
     if (i != nb - 1) ps.declare_conv(bp + ".upsamplers.0.conv", out, out, 3);
   }
@@ -143,7 +146,8 @@ static int finalize(adm_unet* h) {
     for (int j = 0; j < L; ++j) {
       x = b.resnet(bp + ".resnets." + std::to_string(j), x, -1, j == 0 ? cin : out, out, true, &rc);
       ADM_TRY(rc);
-      if (c.down_attn[i]) { x = b.attention(bp + ".attentions." + std::to_string(j), x, out, hd ? hd : out, &rc); ADM_TRY(rc); }
+      if (c.down_attn[i] == 2) { x = b.transformer(bp + ".attentions." + std::to_string(j), x, out, hd, c.cross_attention_dim, &rc); ADM_TRY(rc); }
+      else if (c.down_attn[i]) { x = b.attention(bp + ".attentions." + std::to_string(j), x, out, hd ? hd : out, &rc); ADM_TRY(rc); }
       skips.push_back(x);
     }
     if (i != nb - 1) {
@@ -154,7 +158,9 @@ static int finalize(adm_unet* h) {
   }
   const int mid = boc[nb - 1];
   x = b.resnet("mid_block.resnets.0", x, -1, mid, mid, true, &rc); ADM_TRY(rc);
-  x = b.attention("mid_block.attentions.0", x, mid, hd ? hd : mid, &rc); ADM_TRY(rc);
+  if (c.cross_attention_dim > 0) x = b.transformer("mid_block.attentions.0", x, mid, hd, c.cross_attention_dim, &rc);
+  else x = b.attention("mid_block.attentions.0", x, mid, hd ? hd : mid, &rc);
+  ADM_TRY(rc);
   x = b.resnet("mid_block.resnets.1", x, -1, mid, mid, true, &rc); ADM_TRY(rc);
   out = boc[nb - 1];
   for (int i = 0; i < nb; ++i) {
@@ -170,7 +176,8 @@ static int finalize(adm_unet* h) {
       ADM_REQUIRE(b.tensors[s].C == skip, "unet: skip channel mismatch at " + bp);
       x = b.resnet(bp + ".resnets." + std::to_string(j), x, s, rin + skip, out, true, &rc);
       ADM_TRY(rc);
-      if (c.up_attn[i]) { x = b.attention(bp + ".attentions." + std::to_string(j), x, out, hd ? hd : out, &rc); ADM_TRY(rc); }
+      if (c.up_attn[i] == 2) { x = b.transformer(bp + ".attentions." + std::to_string(j), x, out, hd, c.cross_attention_dim, &rc); ADM_TRY(rc); }
+      else if (c.up_attn[i]) { x = b.attention(bp + ".attentions." + std::to_string(j), x, out, hd ? hd : out, &rc); ADM_TRY(rc); }
     }
     if (i != nb - 1) {
       ADM_TRY(b.make_conv(bp + ".upsamplers.0.conv", out, out, 3, &w));
@@ -316,7 +323,8 @@ static int run_loop(adm_unet* h, const LoopArgs& a, const adm_sched_coef* coef_h
   } else {
     std::vector<uint64_t> key = {(uint64_t)a.x, (uint64_t)a.B, (uint64_t)a.n_steps, (uint64_t)a.step_noise,
                                  (uint64_t)a.mask, (uint64_t)a.mask_start, (uint64_t)a.mask_end, (uint64_t)a.u8,
-                                 (uint64_t)a.encode, (uint64_t)h->coef_dev, (uint64_t)run};
+                                 (uint64_t)a.encode, (uint64_t)h->coef_dev, (uint64_t)run, (uint64_t)h->net.ctx,
+                                 (uint64_t)h->net.ctx_S};
     if (!h->gexec || key != h->gkey) {
       if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
       hipGraph_t graph = nullptr;
@@ -348,6 +356,15 @@ int adm_unet_create(const adm_unet_config* cfg, adm_unet_t** out) {
   ADM_REQUIRE(cfg && out, "unet_create: null argument");
   ADM_REQUIRE(cfg->n_blocks >= 1 && cfg->n_blocks <= 8, "unet_create: n_blocks out of range");
   ADM_REQUIRE(cfg->norm_num_groups > 0 && cfg->layers_per_block >= 1, "unet_create: bad config");
+  ADM_REQUIRE(cfg->cross_attention_dim >= 0, "unet_create: cross_attention_dim < 0");
+  for (int i = 0; i < cfg->n_blocks; ++i)
+    ADM_REQUIRE((cfg->down_attn[i] != 2 && cfg->up_attn[i] != 2) || cfg->cross_attention_dim > 0,
+                "unet_create: CrossAttn blocks need cross_attention_dim > 0");
+  if (cfg->cross_attention_dim > 0) {
+    ADM_REQUIRE(cfg->attention_head_dim > 0, "unet_create: conditional model needs attention_head_dim (= number of heads)");
+    for (int i = 0; i < cfg->n_blocks; ++i)
+      ADM_REQUIRE(cfg->block_out_channels[i] % cfg->attention_head_dim == 0, "unet_create: channels not divisible by the head count");
+  }
   for (int i = 0; i < cfg->n_blocks; ++i)
     ADM_REQUIRE(cfg->block_out_channels[i] % cfg->norm_num_groups == 0 && cfg->block_out_channels[i] % 32 == 0,
                 "unet_create: block_out_channels must be multiples of 32 and of norm_num_groups");
@@ -397,6 +414,14 @@ int adm_unet_forward(adm_unet_t* h, const float* x, const float* timesteps_host,
   return run_forward(h, x, out, B, nullptr, st);
 }
 
+int adm_unet_set_encoding(adm_unet_t* h, const float* encoding_dev, int seq_len) {
+  ADM_REQUIRE(h, "unet_set_encoding: null handle");
+  ADM_REQUIRE(h->cfg.cross_attention_dim > 0, "unet_set_encoding: this model has no cross-attention (UNet2DModel)");
+  ADM_REQUIRE((encoding_dev != nullptr) == (seq_len > 0), "unet_set_encoding: pointer and seq_len must both be given (or both cleared)");
+  h->net.ctx = encoding_dev; h->net.ctx_S = seq_len; h->net.ctx_D = h->cfg.cross_attention_dim;
+  return 0;
+}
+
 int adm_unet_bind_param(adm_unet_t* h, const char* key, float* dev_ptr) {
   ADM_REQUIRE(h && key && dev_ptr, "unet_bind_param: null argument");
   ADM_REQUIRE(!h->finalized, "unet_bind_param: model already finalized");
@@ -406,6 +431,7 @@ int adm_unet_bind_param(adm_unet_t* h, const char* key, float* dev_ptr) {
 int adm_unet_enable_training(adm_unet_t* h, const float* params_base, long numel) {
   ADM_REQUIRE(h && params_base && numel > 0, "unet_enable_training: bad argument");
   ADM_REQUIRE(!h->finalized, "unet_enable_training: must be called before the first forward");
+  ADM_REQUIRE(h->cfg.cross_attention_dim == 0, "unet_enable_training: training of the conditional UNet is not implemented");
   for (auto& kv : h->ps.params)
     ADM_REQUIRE(kv.second.set && kv.second.dev >= params_base && kv.second.dev + kv.second.numel <= params_base + numel,
                 "unet_enable_training: parameter " + kv.first + " is not bound inside the flat buffer");

@@ -139,13 +139,16 @@ typedef struct adm_unet adm_unet_t;
 typedef struct adm_unet_config {
   int in_channels, out_channels, layers_per_block, n_blocks;
   int block_out_channels[8];
-  int down_attn[8]; /* 1 = AttnDownBlock2D */
-  int up_attn[8];   /* 1 = AttnUpBlock2D */
-  int attention_head_dim, norm_num_groups;
+  int down_attn[8]; /* 1 = AttnDownBlock2D, 2 = CrossAttnDownBlock2D (UNet2DConditionModel) */
+  int up_attn[8];   /* 1 = AttnUpBlock2D,   2 = CrossAttnUpBlock2D */
+  int attention_head_dim, norm_num_groups; /* conditional model: attention_head_dim is the NUMBER of heads (diffusers 0.24) */
   float norm_eps;
   int flip_sin_to_cos;
   float freq_shift;
   int sample_h, sample_w;
+  /* > 0: UNet2DConditionModel (scripts/train_unet.py:139-159): width of the encoding; the mid block is then
+   * UNetMidBlock2DCrossAttn and adm_unet_set_encoding must be called before a forward / sample loop. */
+  int cross_attention_dim;
 } adm_unet_config;
 
 int adm_unet_create(const adm_unet_config* cfg, adm_unet_t** out);
@@ -153,6 +156,10 @@ void adm_unet_destroy(adm_unet_t* h);
 /* Upload one parameter by its diffusers state-dict key (host pointer, fp32, `numel` elements).
  * Deprecated attention names (query/key/value/proj_attn, audiodiffusion/utils.py:41-54) are accepted. */
 int adm_unet_set_param(adm_unet_t* h, const char* key, const float* host_data, size_t numel);
+/* Conditional model: encoder_hidden_states for the following forwards / sample loops — device pointer (B, seq_len,
+ * cross_attention_dim) fp32, owned by the caller and kept alive until replaced
+ * (`self.unet(images, t, encoding)`, pipeline_audio_diffusion.py:160-161). */
+int adm_unet_set_encoding(adm_unet_t* h, const float* encoding_dev, int seq_len);
 /* Number of parameters still missing after the set_param calls (0 = ready); names via adm_last_error(). */
 int adm_unet_missing_params(adm_unet_t* h);
 /* eps = unet(x, t): x,out (B,Cin,H,W)/(B,Cout,H,W) device; timesteps: B floats on the HOST (or 1 broadcast). */
