@@ -21,7 +21,7 @@ from PIL import Image  # noqa: E402
 from .mel import Mel  # noqa: E402,F401
 from .pipeline_audio_diffusion import AudioDiffusionPipeline  # noqa: E402
 from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: E402,F401
-from .unet import UNet2DModel  # noqa: E402,F401
+from .unet import UNet2DConditionModel, UNet2DModel  # noqa: E402,F401
 from .vae import AutoencoderKL  # noqa: E402,F401
 
 try:  # progress bars are optional plumbing

@@ -22,7 +22,7 @@ from . import _native as N
 from . import ops
 from .mel import Mel
 from .schedulers import DDIMScheduler, DDPMScheduler, randn_tensor
-from .unet import UNet2DModel
+from .unet import UNet2DConditionModel, UNet2DModel
 from .vae import AutoencoderKL
 
 
@@ -31,12 +31,8 @@ class PipelineOutput(dict):
     __getattr__ = dict.__getitem__
 
 
-class UNet2DConditionModel:  # placeholder type so `isinstance` checks of the reference loop keep their meaning
-    def __init__(self, *a, **k):
-        raise NotImplementedError("conditional generation (UNet2DConditionModel) is outside the hot path (SURVEY.md §8(f))")
-
-
-_CLASSES = {"AutoencoderKL": AutoencoderKL, "UNet2DModel": UNet2DModel, "DDIMScheduler": DDIMScheduler, "DDPMScheduler": DDPMScheduler, "Mel": Mel}
+_CLASSES = {"AutoencoderKL": AutoencoderKL, "UNet2DModel": UNet2DModel, "UNet2DConditionModel": UNet2DConditionModel,
+            "DDIMScheduler": DDIMScheduler, "DDPMScheduler": DDPMScheduler, "Mel": Mel}
 
 
 class DiffusionPipeline:
@@ -142,7 +138,7 @@ class AudioDiffusionPipeline(DiffusionPipeline):
 
     # ---- the native denoising loop (pipeline_audio_diffusion.py:159-185 + :192-194) ----------------------
     def _denoise(self, images, start_step, eta, step_generator, mask, mask_start, mask_end, step_noise=None,
-                 use_graph=True, want_u8=True):
+                 use_graph=True, want_u8=True, encoding=None):
         sched, unet = self.scheduler, self.unet
         rows = sched.coef_rows(eta)[start_step:]
         n = len(rows)
@@ -151,6 +147,8 @@ class AudioDiffusionPipeline(DiffusionPipeline):
         if tuple(unet._hw()) != (H, W):
             unet.sample_size = (H, W)
         h = unet._ensure_handle()
+        if isinstance(unet, UNet2DConditionModel):     # `self.unet(images, t, encoding)` (:160-161): constant over the loop
+            unet._set_encoding(h, encoding, B, x.device)
         u8 = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=x.device) if want_u8 else None
         if Cc != 1 and want_u8:
             u8 = None  # NHWC permute for multi-channel images is done after the loop
@@ -215,8 +213,6 @@ class AudioDiffusionPipeline(DiffusionPipeline):
         Extra keyword-only knobs (not in the reference; defaults reproduce it): `step_noise` injects the
         per-step scheduler noise (parity tests), `audio=False` skips the image->audio conversion,
         `return_float=True` additionally returns the final float images."""
-        if encoding is not None:
-            raise NotImplementedError("conditional generation (`encoding`) is outside the hot path (SURVEY.md §8(f))")
         steps = steps or self.get_default_steps()
         self.scheduler.set_timesteps(steps)
         step_generator = step_generator or generator
@@ -260,7 +256,7 @@ class AudioDiffusionPipeline(DiffusionPipeline):
 
         use_mask = mask if (mask is not None and (mask_start > 0 or mask_end > 0)) else None
         images, u8 = self._denoise(images, start_step, eta, step_generator, use_mask, mask_start, mask_end,
-                                   step_noise=step_noise, want_u8=self.vqvae is None)
+                                   step_noise=step_noise, want_u8=self.vqvae is None, encoding=encoding)
 
         if self.vqvae is not None:
             # 0.18215 was scaling factor used in training to ensure unit variance (pipeline:187-190); the 1/0.18215
@@ -290,6 +286,8 @@ class AudioDiffusionPipeline(DiffusionPipeline):
         """Reverse step process: recover noisy image from generated image (`pipeline_audio_diffusion.py:207-242`)."""
         # Only works with DDIM as this method is deterministic
         assert isinstance(self.scheduler, DDIMScheduler)
+        if isinstance(self.unet, UNet2DConditionModel):   # the reference calls self.unet(sample, t) here (:237): no encoding
+            raise NotImplementedError("encode() is defined for the unconditional UNet2DModel only, as in the reference")
         self.scheduler.set_timesteps(steps)
         sample = np.array(
             [np.frombuffer(image.tobytes(), dtype="uint8").reshape((1, image.height, image.width)) for image in images]

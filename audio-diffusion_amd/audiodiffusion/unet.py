@@ -346,7 +346,7 @@ class UNet2DModel:
 
     def save_pretrained(self, path, safe_serialization=True):
         os.makedirs(path, exist_ok=True)
-        d = {"_class_name": "UNet2DModel", "_diffusers_version": "0.24.0"}
+        d = {"_class_name": type(self).__name__, "_diffusers_version": "0.24.0"}
         d.update({k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()})
         d["sample_size"] = list(self.sample_size) if isinstance(self.sample_size, tuple) else self.sample_size
         with open(os.path.join(path, self.config_name), "w") as f:
@@ -405,21 +405,21 @@ class UNet2DConditionModel(UNet2DModel):
 
     def forward(self, sample, timestep, encoder_hidden_states, return_dict=True):
         assert sample.dim() == 4 and sample.dtype == torch.float32
-        enc = encoder_hidden_states
-        if enc is None:
-            raise ValueError("UNet2DConditionModel needs `encoding` (batch, seq_length, cross_attention_dim)")
-        enc = enc.to(sample.device, torch.float32)
-        if enc.dim() == 2:
-            enc = enc[:, None, :]
-        B = sample.shape[0]
-        if enc.shape[0] != B or enc.shape[2] != self.config.cross_attention_dim:
-            raise ValueError(f"encoding shape {tuple(enc.shape)} does not match (batch={B}, seq, {self.config.cross_attention_dim})")
         if tuple(sample.shape[2:]) != self._hw():
             self.sample_size = tuple(sample.shape[2:])
-        h = self._ensure_handle()
+        self._set_encoding(self._ensure_handle(), encoder_hidden_states, sample.shape[0], sample.device)
+        return UNet2DModel.forward(self, sample, timestep)
+
+    def _set_encoding(self, h, enc, B, device):
+        if enc is None:
+            raise ValueError("UNet2DConditionModel needs `encoding` (batch, seq_length, cross_attention_dim)")
+        enc = enc.to(device, torch.float32)
+        if enc.dim() == 2:
+            enc = enc[:, None, :]
+        if enc.dim() != 3 or enc.shape[0] != B or enc.shape[2] != self.config.cross_attention_dim:
+            raise ValueError(f"encoding shape {tuple(enc.shape)} does not match (batch={B}, seq, {self.config.cross_attention_dim})")
         self._enc = enc.contiguous()            # kept alive: the native side stores the pointer
         N.check(N.lib().adm_unet_set_encoding(h, N.ptr(self._enc), self._enc.shape[1]))
-        return UNet2DModel.forward(self, sample, timestep)
 
     __call__ = forward
 

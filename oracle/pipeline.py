@@ -68,7 +68,10 @@ class AudioDiffusionPipeline:
             mask = self.scheduler.add_noise(input_images, noise, self.scheduler.timesteps[start_step:].clone())
 
         for step, t in enumerate(self.progress_bar(self.scheduler.timesteps[start_step:])):
-            model_output = self.unet(images, t)["sample"]
+            if hasattr(self.unet.config, "get") and self.unet.config.get("cross_attention_dim"):   # :160-161
+                model_output = self.unet(images, t, encoding)["sample"]
+            else:
+                model_output = self.unet(images, t)["sample"]
             vn = None if step_noise is None else step_noise[step]
             if isinstance(self.scheduler, DDIMScheduler):
                 images = self.scheduler.step(

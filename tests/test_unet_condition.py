@@ -81,3 +81,41 @@ def test_conditional_unet_forward_matches_oracle(backend, cfg, B, S):
         mine(x.to(dev), ts, None)
     with pytest.raises(NotImplementedError):
         mine.enable_training()
+
+
+MEL = dict(x_res=16, y_res=16, hop_length=64, n_fft=256, n_iter=2, sample_rate=4000)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conditional_pipeline_sampling_matches_oracle_and_roundtrips(backend, tmp_path):
+    """`pipeline(..., encoding=...)` (pipeline_audio_diffusion.py:86,160-161): native loop with the encoding held constant
+    over the steps vs the oracle loop; then save_pretrained / from_pretrained keep the class (`model_index.json`)."""
+    import numpy as np
+    from oracle import mel as omel
+    from oracle import pipeline as opipe
+    from oracle import schedulers as osched
+    dev = select(backend)
+    from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, Mel, UNet2DConditionModel
+    torch.manual_seed(0)
+    ref_unet = OracleCond(**TINY).eval()
+    unet = UNet2DConditionModel(**TINY).load_state_dict(ref_unet.state_dict())
+    ref = opipe.AudioDiffusionPipeline(None, ref_unet, omel.Mel(**MEL), osched.DDIMScheduler())
+    mine = AudioDiffusionPipeline(None, unet, Mel(**MEL), DDIMScheduler())
+    mine.set_progress_bar_config(disable=True)
+    g = torch.Generator().manual_seed(42)
+    noise = torch.randn(2, 1, 16, 16, generator=g)
+    enc = torch.randn(2, 1, 12, generator=g)
+    ri, rf = ref(batch_size=2, steps=4, noise=noise.clone(), encoding=enc, audio=False, return_float=True)
+    mi, mf = mine(batch_size=2, steps=4, noise=noise.clone().to(dev), encoding=enc.to(dev), audio=False, return_float=True)
+    assert float((mf.cpu() - rf).abs().max()) <= 1e-3
+    a = np.stack([np.asarray(i).astype(int) for i in mi])
+    b = np.stack([np.asarray(i).astype(int) for i in ri])
+    assert np.abs(a - b).max() <= 1 and (a == b).mean() >= 0.995
+    with pytest.raises(ValueError):
+        mine(batch_size=2, steps=2, noise=noise.clone().to(dev), audio=False)         # conditional model, no encoding
+    mine.save_pretrained(str(tmp_path / "cond"))
+    again = AudioDiffusionPipeline.from_pretrained(str(tmp_path / "cond"))
+    assert type(again.unet).__name__ == "UNet2DConditionModel" and again.unet.config.cross_attention_dim == 12
+    again.set_progress_bar_config(disable=True)
+    _, af = again(batch_size=2, steps=4, noise=noise.clone().to(dev), encoding=enc.to(dev), audio=False, return_float=True)
+    assert torch.equal(af.cpu(), mf.cpu())
