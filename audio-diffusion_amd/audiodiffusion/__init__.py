@@ -18,6 +18,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from PIL import Image  # noqa: E402
 
+from .audio_encoder import AudioEncoder  # noqa: E402,F401
 from .mel import Mel  # noqa: E402,F401
 from .pipeline_audio_diffusion import AudioDiffusionPipeline  # noqa: E402
 from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: E402,F401

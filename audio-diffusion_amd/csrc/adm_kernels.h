@@ -87,6 +87,13 @@ int launch_cross_attention(const float* q, const float* ctx, const float* Wk, co
                            int T, int S, int Dc, int head_dim, hipStream_t st);
 int launch_attention_blocked(const float* qkv, float* out, int N, int C, int T, int head_dim, int key_block, hipStream_t st);
 
+// k_audio_encoder.hip (AudioEncoder: audiodiffusion/audio_encoder.py:62-84)
+int launch_sepconv_block(const float* x, const float* dw, const float* pw, const float* pb, const float* bn_scale,
+                         const float* bn_shift, float slope, float* tmp, float* y, int N, int Ci, int Co, int H, int W,
+                         hipStream_t st);
+int launch_dense_act(const float* x, const float* W, const float* b, const float* post_scale, const float* post_shift,
+                     float slope, int leaky, float* y, int N, int K, int J, int hwc_C, hipStream_t st);
+
 // k_vae.hip
 int launch_softmax_channels(float* s, int N, int J, int T, float scale, hipStream_t st);
 int launch_transpose_ct(const float* in, long in_bs, float* out, int N, int C, int T, hipStream_t st);

@@ -113,4 +113,16 @@ int adm_attention_blocked(const float* qkv, float* out, int N, int C, int T, int
   return launch_attention_blocked(qkv, out, N, C, T, head_dim, key_block, (hipStream_t)stream);
 }
 
+int adm_sepconv_block(const float* x, const float* dw, const float* pw, const float* pb, const float* bn_scale,
+                      const float* bn_shift, float slope, float* tmp, float* y, int N, int Ci, int Co, int H, int W,
+                      void* stream) {
+  ADM_REQUIRE(x && dw && pw && pb && bn_scale && bn_shift && tmp && y, "sepconv_block: null argument");
+  return launch_sepconv_block(x, dw, pw, pb, bn_scale, bn_shift, slope, tmp, y, N, Ci, Co, H, W, (hipStream_t)stream);
+}
+int adm_dense_act(const float* x, const float* W, const float* b, const float* post_scale, const float* post_shift,
+                  float slope, int leaky, float* y, int N, int K, int J, int hwc_C, void* stream) {
+  ADM_REQUIRE(x && W && b && y && ((post_scale == nullptr) == (post_shift == nullptr)), "dense_act: bad argument");
+  return launch_dense_act(x, W, b, post_scale, post_shift, slope, leaky, y, N, K, J, hwc_C, (hipStream_t)stream);
+}
+
 }  // extern "C"

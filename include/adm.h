@@ -133,6 +133,18 @@ int adm_cross_attention(const float* q, const float* ctx, const float* Wk, const
                         int S, int Dc, int head_dim, void* stream);
 int adm_attention_blocked(const float* qkv, float* out, int N, int C, int T, int head_dim, int key_block, void* stream);
 
+/* AudioEncoder (audiodiffusion/audio_encoder.py:62-84; produces the `encoding` of the conditional models), eval mode:
+ *   adm_sepconv_block: ConvBlock = depthwise 3x3 (no bias, dw (Ci,1,3,3)) -> pointwise 1x1 (pw (Co,Ci), pb) ->
+ *     LeakyReLU(slope) -> BatchNorm2d folded to bn_scale/bn_shift -> MaxPool 2x2; x (N,Ci,H,W) -> y (N,Co,H/2,W/2);
+ *     tmp: N*Ci*H*W floats of scratch.
+ *   adm_dense_act: y (N,J) = post(b + W x), W (J,K); leaky != 0 applies LeakyReLU(slope), post_scale/shift (NULL ok) a
+ *     folded BatchNorm1d; hwc_C > 0 reads x (N, hwc_C, K/hwc_C) as if flattened in NHWC order (DenseBlock, :55). */
+int adm_sepconv_block(const float* x, const float* dw, const float* pw, const float* pb, const float* bn_scale,
+                      const float* bn_shift, float slope, float* tmp, float* y, int N, int Ci, int Co, int H, int W,
+                      void* stream);
+int adm_dense_act(const float* x, const float* W, const float* b, const float* post_scale, const float* post_shift,
+                  float slope, int leaky, float* y, int N, int K, int J, int hwc_C, void* stream);
+
 /* ---------------------------------------------------------------- UNet2DModel executor (rows U1-U8)
  * Replaces `self.unet(images, t)["sample"]` (pipeline_audio_diffusion.py:163,237; train_unet.py:257). */
 typedef struct adm_unet adm_unet_t;
