@@ -8,7 +8,7 @@ training step (`:226-267`) runs as: fused add_noise kernel -> native UNet forwar
 diffusers layout by `AudioDiffusionPipeline.save_pretrained` every `--save_model_epochs` (`:286-311`).
 
 Launch:  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_unet.py --dataset_name ...
-Not implemented (raise): --encodings (conditional), --vae (latent training), mixed precision, hub push, tensorboard.
+Implemented: fp32 and --mixed_precision bf16, --vae (latent training), gradient accumulation, EMA, DDP. Not implemented (raise): --encodings (conditional training), fp16; hub push and tensorboard are ignored.
 """
 import argparse
 import math
@@ -23,7 +23,8 @@ import torch.distributed as dist
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
-from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, DDPMScheduler, Mel, UNet2DModel  # noqa: E402
+from audiodiffusion import (AudioDiffusionPipeline, AutoencoderKL, DDIMScheduler, DDPMScheduler, Mel,  # noqa: E402
+                            UNet2DModel)
 from audiodiffusion import training as T  # noqa: E402
 
 
@@ -49,8 +50,9 @@ def load_images(args, resolution):
 
 
 def main(args):
-    if args.encodings is not None or args.vae is not None:
-        raise NotImplementedError("conditional / latent training is outside this path")
+    if args.encodings is not None:
+        raise NotImplementedError("training of the conditional UNet (--encodings) is not implemented; inference is "
+                                  "(UNet2DConditionModel + AudioEncoder)")
     if args.mixed_precision == "fp16":
         raise NotImplementedError("mixed_precision: 'no' (fp32, the reference default) and 'bf16' are implemented; fp16 "
                                   "would need loss scaling, which gfx950's bf16 MFMA path makes pointless")
@@ -68,11 +70,24 @@ def main(args):
     resolution = (args.resolution, args.resolution) if isinstance(args.resolution, int) else args.resolution
     images = load_images(args, resolution)                         # (N,1,H,W) uint8
     resolution = tuple(images.shape[2:])
+    # latent diffusion (train_unet.py:95-104): a frozen AutoencoderKL maps every batch to latents the UNet is trained on
+    vqvae, latent_resolution = None, None
+    if args.vae is not None:
+        try:
+            vqvae = AutoencoderKL.from_pretrained(args.vae)
+        except EnvironmentError:
+            vqvae = AudioDiffusionPipeline.from_pretrained(args.vae).vqvae
+        latent_resolution = tuple(vqvae.encode(torch.zeros((1, 1) + resolution, device=dev)).latent_dist.sample().shape[2:])
     if args.from_pretrained is not None:
         pipeline = AudioDiffusionPipeline.from_pretrained(args.from_pretrained)
         mel, model = pipeline.mel, pipeline.unet
+        if getattr(pipeline, "vqvae", None) is not None:            # :110-111
+            vqvae = pipeline.vqvae
+            latent_resolution = tuple(vqvae.encode(torch.zeros((1, 1) + resolution, device=dev)).latent_dist.sample().shape[2:])
     else:
-        model = UNet2DModel(sample_size=resolution, in_channels=1, out_channels=1, layers_per_block=2,
+        lc = 1 if vqvae is None else vqvae.config["latent_channels"]
+        model = UNet2DModel(sample_size=resolution if vqvae is None else latent_resolution, in_channels=lc,
+                            out_channels=lc, layers_per_block=2,
                             block_out_channels=(128, 128, 256, 256, 512, 512),
                             down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
                             up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4).init_random(args.seed)
@@ -82,7 +97,8 @@ def main(args):
 
     # identical init on every rank (same seed / checkpoint). bf16: eligible 3x3 convolutions (forward, data and weight
     # gradient) run on bf16 MFMA operands with fp32 accumulation; master weights, optimizer state and gradients stay fp32
-    flat, grads = model.enable_training(resolution, mixed_precision=args.mixed_precision)
+    flat, grads = model.enable_training(resolution if vqvae is None else latent_resolution,
+                                        mixed_precision=args.mixed_precision)
     optimizer = T.AdamW(flat, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
                         weight_decay=args.adam_weight_decay, eps=args.adam_epsilon)
     n_local = len(images) // world
@@ -110,6 +126,8 @@ def main(args):
         for it in range(steps_per_epoch):
             idx = perm[it * args.train_batch_size:(it + 1) * args.train_batch_size]
             clean = (images[idx].to(dev).float() / 255.0 - 0.5) / 0.5     # ToTensor + Normalize([0.5],[0.5]) (:73-78)
+            if vqvae is not None:        # :231-235: posterior sample, scaled to roughly unit variance
+                clean = vqvae.encode(clean.contiguous()).latent_dist.sample() * 0.18215
             noise = torch.randn(clean.shape).to(dev)                          # CPU RNG then H2D, as :238
             timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (clean.shape[0],)).long()
             noisy = noise_scheduler.add_noise(clean.contiguous(), noise, timesteps)
@@ -137,7 +155,7 @@ def main(args):
                 ema.copy_to(flat)                                   # train_unet.py:292-294: EMA weights go INTO the live model
                 model.refresh_weights()
             model.sync_state_dict_from_flat()
-            AudioDiffusionPipeline(vqvae=None, unet=model, mel=mel, scheduler=noise_scheduler).save_pretrained(output_dir)
+            AudioDiffusionPipeline(vqvae=vqvae, unet=model, mel=mel, scheduler=noise_scheduler).save_pretrained(output_dir)
         if world > 1:
             dist.broadcast(flat, src=0)                             # keep replicas identical after the EMA copy
             model.refresh_weights()

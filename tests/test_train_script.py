@@ -101,3 +101,31 @@ def test_training_script_two_ranks_stay_in_lockstep(tmp_path):
     saved = AudioDiffusionPipeline.from_pretrained(str(tmp_path / "out")).unet.state_dict()
     moved = max(float((saved[k] - v).abs().max()) for k, v in start.state_dict().items())
     assert 0 < moved < 0.1
+
+
+def test_latent_training_with_frozen_vae(tmp_path):
+    """`--vae` (train_unet.py:95-104,231-235): the UNet trains on 0.18215 * posterior samples of a frozen AutoencoderKL, the
+    saved pipeline carries the VAE and samples through encode -> denoise -> decode."""
+    select("emu")
+    from audiodiffusion import AudioDiffusionPipeline, AutoencoderKL
+    vae_cfg = dict(sample_size=(32, 32), in_channels=1, out_channels=1, latent_channels=1, layers_per_block=1,
+                   block_out_channels=(32, 64), down_block_types=("DownEncoderBlock2D",) * 2,
+                   up_block_types=("UpDecoderBlock2D",) * 2)
+    vae = AutoencoderKL(**vae_cfg).init_random(5)
+    vae.save_pretrained(str(tmp_path / "vae"))
+    from audiodiffusion import DDPMScheduler, Mel, UNet2DModel
+    start = UNet2DModel(**dict(TINY, sample_size=16)).init_random(3)
+    AudioDiffusionPipeline(vae, start, Mel(**dict(MEL, x_res=32, y_res=32)), DDPMScheduler()).save_pretrained(str(tmp_path / "start"))
+    tr = _script("train_unet")
+    model = tr.main(tr.parse_args(["--from_pretrained", str(tmp_path / "start"), "--dataset_name", "synthetic", "--resolution", "32",
+                                   "--synthetic_size", "4", "--output_dir", str(tmp_path / "out"), "--train_batch_size", "2",
+                                   "--num_epochs", "1", "--save_model_epochs", "1", "--lr_warmup_steps", "1",
+                                   "--learning_rate", "1e-3", "--hop_length", "64", "--sample_rate", "4000", "--n_fft", "256"]))
+    assert tuple(model._hw()) == (16, 16)                      # trained at the latent resolution (32 / 2)
+    out = AudioDiffusionPipeline.from_pretrained(str(tmp_path / "out"))
+    assert out.vqvae is not None and tuple(out.unet._hw()) == (16, 16)
+    out.set_progress_bar_config(disable=True)
+    images, _ = out(batch_size=1, steps=2, generator=torch.Generator().manual_seed(0), audio=False, return_float=True)
+    assert images[0].size == (32, 32)
+    moved = max(float((out.unet.state_dict()[k] - v).abs().max()) for k, v in start.state_dict().items())
+    assert 0 < moved < 0.1
