@@ -187,6 +187,39 @@ def cross_attention(q, ctx, wk, wv, head_dim):
     return out
 
 
+def layernorm_nct_backward(x, dy, gamma, eps=1e-5):
+    """-> (dx, dgamma, dbeta) of layernorm_nct."""
+    _f32(x), _f32(dy)
+    Nn, Cc = x.shape[:2]
+    T = x[0, 0].numel()
+    dx = torch.empty_like(x)
+    stats = torch.empty(2 * Nn * T, dtype=torch.float32, device=x.device)
+    dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
+    N.check(N.lib().adm_layernorm_nct_backward(N.ptr(x), N.ptr(dy), N.ptr(gamma), N.ptr(dx), 0, N.ptr(stats), N.ptr(dg),
+                                               N.ptr(db), Nn, Cc, T, eps, N.stream_for(x)))
+    return dx, dg, db
+
+
+def geglu_backward(x, dy):
+    _f32(x), _f32(dy)
+    Nn, C2 = x.shape[:2]
+    dx = torch.empty_like(x)
+    N.check(N.lib().adm_geglu_backward(N.ptr(x), N.ptr(dy), N.ptr(dx), Nn, C2 // 2, x[0, 0].numel(), N.stream_for(x)))
+    return dx
+
+
+def cross_attention_backward(q, ctx, wk, wv, dy, head_dim):
+    """-> (dq, dWk, dWv) of cross_attention."""
+    _f32(q), _f32(dy)
+    Nn, Cc = q.shape[:2]
+    dq = torch.empty_like(q)
+    dwk, dwv = torch.zeros_like(wk), torch.zeros_like(wv)
+    N.check(N.lib().adm_cross_attention_backward(N.ptr(q), N.ptr(ctx), N.ptr(wk), N.ptr(wv), N.ptr(dy), N.ptr(dq), N.ptr(dwk),
+                                                 N.ptr(dwv), Nn, Cc, q[0, 0].numel(), ctx.shape[1], ctx.shape[2], head_dim,
+                                                 N.stream_for(q)))
+    return dq, dwk, dwv
+
+
 def attention_blocked(qkv, head_dim, key_block=0):
     """adm_attention with keys processed in blocks (online softmax): qkv (N,3C,H,W) -> (N,C,H,W)."""
     _f32(qkv)

@@ -113,6 +113,21 @@ int adm_attention_blocked(const float* qkv, float* out, int N, int C, int T, int
   return launch_attention_blocked(qkv, out, N, C, T, head_dim, key_block, (hipStream_t)stream);
 }
 
+int adm_layernorm_nct_backward(const float* x, const float* dy, const float* gamma, float* dx, int accumulate, float* stats,
+                               float* dgamma, float* dbeta, int N, int C, long T, float eps, void* stream) {
+  ADM_REQUIRE(x && dy && gamma && dx && stats && dgamma && dbeta, "layernorm_nct_backward: null argument");
+  return launch_layernorm_nct_bwd(x, dy, gamma, dx, accumulate, stats, dgamma, dbeta, N, C, T, eps, (hipStream_t)stream);
+}
+int adm_geglu_backward(const float* in, const float* dy, float* din, int N, int C4, long T, void* stream) {
+  ADM_REQUIRE(in && dy && din, "geglu_backward: null argument");
+  return launch_geglu_bwd(in, dy, din, N, C4, T, (hipStream_t)stream);
+}
+int adm_cross_attention_backward(const float* q, const float* ctx, const float* Wk, const float* Wv, const float* dy,
+                                 float* dq, float* dWk, float* dWv, int N, int C, int T, int S, int Dc, int head_dim,
+                                 void* stream) {
+  ADM_REQUIRE(q && ctx && Wk && Wv && dy && dq && dWk && dWv, "cross_attention_backward: null argument");
+  return launch_cross_attention_bwd(q, ctx, Wk, Wv, dy, dq, dWk, dWv, N, C, T, S, Dc, head_dim, (hipStream_t)stream);
+}
 int adm_sepconv_block(const float* x, const float* dw, const float* pw, const float* pb, const float* bn_scale,
                       const float* bn_shift, float slope, float* tmp, float* y, int N, int Ci, int Co, int H, int W,
                       void* stream) {

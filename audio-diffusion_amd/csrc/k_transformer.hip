@@ -200,4 +200,188 @@ int launch_attention_blocked(const float* qkv, float* out, int N, int C, int T, 
   ADM_FAIL("attention: unsupported head_dim (4/8/16/32/64)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward passes (training of the conditional UNet, scripts/train_unet.py:254-259 with --encodings)
+
+// LayerNorm backward, pass 1 (one lane per token): with g_c = dy_c * gamma_c and xh_c = (x_c - mean) * rstd,
+//   dx_c = rstd * (g_c - mean_c(g) - xh_c * mean_c(g * xh));  the token's (mean, rstd) are kept for pass 2.
+__global__ void __launch_bounds__(256) layernorm_nct_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   const float* __restrict__ gamma, float* __restrict__ dx,
+                                                                   int accumulate, float* __restrict__ stats, int C, long T,
+                                                                   float eps) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const long base = (long)blockIdx.y * C * T + t;
+  const float* xp = x + base;
+  const float* gp = dy + base;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += xp[(long)c * T];
+  const float mean = s / (float)C;
+  float v = 0.f;
+  for (int c = 0; c < C; ++c) { const float d = xp[(long)c * T] - mean; v = fmaf(d, d, v); }
+  const float rstd = rsqrtf(v / (float)C + eps);
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float g = gp[(long)c * T] * gamma[c], xh = (xp[(long)c * T] - mean) * rstd;
+    s1 += g; s2 = fmaf(g, xh, s2);
+  }
+  s1 /= (float)C; s2 /= (float)C;
+  float* dp = dx + base;
+  for (int c = 0; c < C; ++c) {
+    const float g = gp[(long)c * T] * gamma[c], xh = (xp[(long)c * T] - mean) * rstd;
+    const float r = rstd * (g - s1 - xh * s2);
+    dp[(long)c * T] = accumulate ? dp[(long)c * T] + r : r;
+  }
+  stats[2 * ((long)blockIdx.y * T + t)] = mean;
+  stats[2 * ((long)blockIdx.y * T + t) + 1] = rstd;
+}
+// pass 2 (one workgroup per channel): dgamma_c += sum_{n,t} dy * xh, dbeta_c += sum_{n,t} dy
+__global__ void __launch_bounds__(256) layernorm_nct_bwd_affine_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                       const float* __restrict__ stats, float* dgamma,
+                                                                       float* dbeta, int N, int C, long T) {
+  __shared__ float red[2][256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  float a = 0.f, b = 0.f;
+  for (long i = tid; i < (long)N * T; i += 256) {
+    const long n = i / T, t = i - n * T;
+    const long e = (n * C + c) * T + t;
+    const float g = dy[e];
+    a = fmaf(g, (x[e] - stats[2 * i]) * stats[2 * i + 1], a);
+    b += g;
+  }
+  red[0][tid] = a; red[1][tid] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) { dgamma[c] += red[0][0]; dbeta[c] += red[1][0]; }
+}
+
+int launch_layernorm_nct_bwd(const float* x, const float* dy, const float* gamma, float* dx, int accumulate, float* stats,
+                             float* dgamma, float* dbeta, int N, int C, long T, float eps, hipStream_t st) {
+  ADM_LAUNCH(layernorm_nct_bwd_dx_kernel, dim3((unsigned)((T + 255) / 256), N), dim3(256), 0, st, x, dy, gamma, dx, accumulate,
+             stats, C, T, eps);
+  ADM_LAUNCH(layernorm_nct_bwd_affine_kernel, dim3(C), dim3(256), 0, st, x, dy, (const float*)stats, dgamma, dbeta, N, C, T);
+  return ADM_CHECK_LAUNCH();
+}
+
+// GEGLU backward: out = h * gelu(g)  ->  dh = dy * gelu(g),  dg = dy * h * gelu'(g),
+// gelu'(g) = Phi(g) + g * phi(g) (exact form: Phi = 0.5 (1 + erf(g / sqrt 2)), phi = exp(-g^2 / 2) / sqrt(2 pi)).
+__global__ void __launch_bounds__(256) geglu_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dy,
+                                                        float* __restrict__ din, long per_sample) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per_sample) return;
+  const float* ip = in + (long)blockIdx.y * 2 * per_sample;
+  float* dp = din + (long)blockIdx.y * 2 * per_sample;
+  const float h = ip[i], g = ip[per_sample + i], d = dy[(long)blockIdx.y * per_sample + i];
+  const float Phi = 0.5f * (1.0f + erff(g * 0.70710678118654752f));
+  const float phi = 0.39894228040143268f * __expf(-0.5f * g * g);
+  dp[i] = d * g * Phi;
+  dp[per_sample + i] = d * h * (Phi + g * phi);
+}
+
+int launch_geglu_bwd(const float* in, const float* dy, float* din, int N, int C4, long T, hipStream_t st) {
+  const long per = (long)C4 * T;
+  ADM_LAUNCH(geglu_bwd_kernel, dim3((unsigned)((per + 255) / 256), N), dim3(256), 0, st, in, dy, din, per);
+  return ADM_CHECK_LAUNCH();
+}
+
+// Cross-attention backward: dq (N, C, T) and the gradients of to_k / to_v (C, Dc) (accumulated with atomics: every
+// (sample, head) workgroup owns D rows of each, the batch sums over samples). The encoding itself is data (no gradient).
+// One workgroup per (head, sample); K, V recomputed into LDS; lanes stride over the tokens; dK / dV of the head
+// (S x D each) are reduced in LDS, then folded with the encoding into dWk / dWv.
+template <int D>
+__global__ void __launch_bounds__(256) cross_attention_bwd_kernel(const float* __restrict__ q, const float* __restrict__ ctx,
+                                                                  const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                                                  const float* __restrict__ dy, float* __restrict__ dq,
+                                                                  float* dWk, float* dWv, int C, int T, int S, int Dc,
+                                                                  float scale) {
+  ADM_DYN_SMEM(float, smem);
+  float* Ks = smem;            // [S][D]
+  float* Vs = Ks + S * D;
+  float* dKs = Vs + S * D;
+  float* dVs = dKs + S * D;
+  const int head = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  for (int e = tid; e < 2 * S * D; e += blockDim.x) {
+    const int which = e / (S * D), r = e - which * S * D;
+    const int s = r / D, d = r - s * D;
+    const float* w = (which ? Wv : Wk) + (long)(head * D + d) * Dc;
+    const float* cx = ctx + ((long)n * S + s) * Dc;
+    float acc = 0.f;
+    for (int k = 0; k < Dc; ++k) acc = fmaf(cx[k], w[k], acc);
+    smem[e] = acc;
+    smem[2 * S * D + e] = 0.f;
+  }
+  __syncthreads();
+  const float* qb = q + ((long)n * C + head * D) * T;
+  const float* gb = dy + ((long)n * C + head * D) * T;
+  float* dqb = dq + ((long)n * C + head * D) * T;
+  for (int t = tid; t < T; t += blockDim.x) {
+    float qv[D], go[D], dqv[D];
+    ADM_UNROLL
+    for (int d = 0; d < D; ++d) { qv[d] = qb[(long)d * T + t]; go[d] = gb[(long)d * T + t]; dqv[d] = 0.f; }
+    float m = -3.0e38f;
+    for (int s = 0; s < S; ++s) {
+      float a = 0.f;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) a = fmaf(qv[d], Ks[s * D + d], a);
+      m = fmaxf(m, a * scale);
+    }
+    float l = 0.f, dsum = 0.f;
+    for (int s = 0; s < S; ++s) {
+      float a = 0.f, gv = 0.f;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) { a = fmaf(qv[d], Ks[s * D + d], a); gv = fmaf(go[d], Vs[s * D + d], gv); }
+      const float p = __expf(a * scale - m);
+      l += p; dsum = fmaf(p, gv, dsum);
+    }
+    const float inv = 1.0f / l, Di = dsum * inv;
+    for (int s = 0; s < S; ++s) {
+      float a = 0.f, gv = 0.f;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) { a = fmaf(qv[d], Ks[s * D + d], a); gv = fmaf(go[d], Vs[s * D + d], gv); }
+      const float p = __expf(a * scale - m) * inv;
+      const float ds = p * (gv - Di) * scale;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) {
+        dqv[d] = fmaf(ds, Ks[s * D + d], dqv[d]);
+        atomicAdd(&dKs[s * D + d], ds * qv[d]);
+        atomicAdd(&dVs[s * D + d], p * go[d]);
+      }
+    }
+    ADM_UNROLL
+    for (int d = 0; d < D; ++d) dqb[(long)d * T + t] = dqv[d];
+  }
+  __syncthreads();
+  // dW[(head*D + d)][k] += sum_s dK[s][d] * ctx[n][s][k]
+  for (int e = tid; e < 2 * D * Dc; e += blockDim.x) {
+    const int which = e / (D * Dc), r = e - which * D * Dc;
+    const int d = r / Dc, k = r - d * Dc;
+    const float* g = which ? dVs : dKs;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc = fmaf(g[s * D + d], ctx[((long)n * S + s) * Dc + k], acc);
+    atomicAdd((which ? dWv : dWk) + (long)(head * D + d) * Dc + k, acc);
+  }
+}
+
+int launch_cross_attention_bwd(const float* q, const float* ctx, const float* Wk, const float* Wv, const float* dy, float* dq,
+                               float* dWk, float* dWv, int N, int C, int T, int S, int Dc, int head_dim, hipStream_t st) {
+  ADM_REQUIRE(C % head_dim == 0 && S >= 1, "cross_attention_bwd: bad shape");
+  const int heads = C / head_dim;
+  const int bs = T >= 256 ? 256 : ((T + 63) / 64) * 64;
+  const size_t smem = sizeof(float) * 4 * (size_t)S * head_dim;
+  ADM_REQUIRE(smem <= 64 * 1024, "cross_attention_bwd: encoding sequence too long for the LDS K/V slab");
+  const float scale = 1.0f / sqrtf((float)head_dim);
+#define ADM_XATTB_CASE(DD)                                                                                              \
+  if (head_dim == DD) {                                                                                                 \
+    ADM_LAUNCH((cross_attention_bwd_kernel<DD>), dim3(heads, N), dim3(bs), smem, st, q, ctx, Wk, Wv, dy, dq, dWk, dWv, C, \
+               T, S, Dc, scale);                                                                                        \
+    return ADM_CHECK_LAUNCH();                                                                                          \
+  }
+  ADM_XATTB_CASE(4) ADM_XATTB_CASE(8) ADM_XATTB_CASE(16) ADM_XATTB_CASE(32) ADM_XATTB_CASE(64)
+#undef ADM_XATTB_CASE
+  ADM_FAIL("cross_attention_bwd: unsupported head_dim (4/8/16/32/64)");
+}
+
 }  // namespace adm

@@ -132,6 +132,16 @@ int adm_geglu(const float* in, float* out, int N, int C4, long T, void* stream);
 int adm_cross_attention(const float* q, const float* ctx, const float* Wk, const float* Wv, float* out, int N, int C, int T,
                         int S, int Dc, int head_dim, void* stream);
 int adm_attention_blocked(const float* qkv, float* out, int N, int C, int T, int head_dim, int key_block, void* stream);
+/* Backward passes of the three (training of the conditional UNet, scripts/train_unet.py:254-259 with --encodings):
+ *   adm_layernorm_nct_backward: dx (accumulate != 0: +=), dgamma += , dbeta += ; stats: 2*N*T floats of scratch.
+ *   adm_geglu_backward: d(in) (N, 2*C4, T) from dy (N, C4, T).
+ *   adm_cross_attention_backward: dq (N, C, T); dWk, dWv (C, Dc) += (atomics). The encoding receives no gradient. */
+int adm_layernorm_nct_backward(const float* x, const float* dy, const float* gamma, float* dx, int accumulate, float* stats,
+                               float* dgamma, float* dbeta, int N, int C, long T, float eps, void* stream);
+int adm_geglu_backward(const float* in, const float* dy, float* din, int N, int C4, long T, void* stream);
+int adm_cross_attention_backward(const float* q, const float* ctx, const float* Wk, const float* Wv, const float* dy,
+                                 float* dq, float* dWk, float* dWv, int N, int C, int T, int S, int Dc, int head_dim,
+                                 void* stream);
 
 /* AudioEncoder (audiodiffusion/audio_encoder.py:62-84; produces the `encoding` of the conditional models), eval mode:
  *   adm_sepconv_block: ConvBlock = depthwise 3x3 (no bias, dw (Ci,1,3,3)) -> pointwise 1x1 (pw (Co,Ci), pb) ->

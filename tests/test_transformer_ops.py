@@ -72,3 +72,51 @@ def test_self_attention_key_blocks_match_one_pass(backend, C, heads, HW, key_blo
     ref = _mha(q, k, v, heads).reshape(Nn, C, *HW)
     assert _relerr(out, ref) < 5e-6
     assert _relerr(out, ops.attention(qkv, C // heads)) < 5e-6
+
+
+# ---------------------------------------------------------------- backward passes vs torch autograd
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape", [(2, 32, 4, 8), (1, 96, 16, 16)])
+def test_layernorm_backward(backend, shape):
+    dev = select(backend)
+    from audiodiffusion import ops
+    x = (_rand(shape, 1, "cpu") * 2 + 0.3).requires_grad_(True)
+    g, b = (_rand((shape[1],), 2, "cpu") + 1).requires_grad_(True), _rand((shape[1],), 3, "cpu").requires_grad_(True)
+    y = F.layer_norm(x.permute(0, 2, 3, 1), (shape[1],), g, b, 1e-5).permute(0, 3, 1, 2)
+    dy = _rand(shape, 4, "cpu")
+    y.backward(dy)
+    dx, dg, db = ops.layernorm_nct_backward(x.detach().to(dev), dy.to(dev), g.detach().to(dev))
+    assert _relerr(dx, x.grad) < 1e-5 and _relerr(dg, g.grad) < 1e-5 and _relerr(db, b.grad) < 1e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_geglu_backward(backend):
+    dev = select(backend)
+    from audiodiffusion import ops
+    x = (_rand((2, 64, 4, 8), 1, "cpu") * 3).requires_grad_(True)
+    h, gate = x.chunk(2, dim=1)
+    dy = _rand((2, 32, 4, 8), 2, "cpu")
+    (h * F.gelu(gate)).backward(dy)
+    assert _relerr(ops.geglu_backward(x.detach().to(dev), dy.to(dev)), x.grad) < 2e-6
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("C,heads,S", [(32, 8, 1), (64, 8, 3), (32, 2, 2)])
+def test_cross_attention_backward(backend, C, heads, S):
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn, H, W, Dc = 2, 4, 8, 12
+    q = _rand((Nn, C, H, W), 1, "cpu").requires_grad_(True)
+    ctx = _rand((Nn, S, Dc), 2, "cpu")
+    wk = _rand((C, Dc), 3, "cpu", scale=Dc ** -0.5).requires_grad_(True)
+    wv = _rand((C, Dc), 4, "cpu", scale=Dc ** -0.5).requires_grad_(True)
+    out = _mha(q.reshape(Nn, C, H * W), (ctx @ wk.T).transpose(1, 2), (ctx @ wv.T).transpose(1, 2), heads).reshape(Nn, C, H, W)
+    dy = _rand((Nn, C, H, W), 5, "cpu")
+    out.backward(dy)
+    dq, dwk, dwv = ops.cross_attention_backward(q.detach().to(dev), ctx.to(dev), wk.detach().to(dev), wv.detach().to(dev),
+                                                dy.to(dev), C // heads)
+    assert _relerr(dwv, wv.grad) < 1e-5
+    if S == 1:       # a softmax over one key has no gradient: dq = 0, dWk = 0
+        assert float(dq.abs().max()) == 0 and float(dwk.abs().max()) < 1e-6 * float(wv.grad.abs().max())
+    else:
+        assert _relerr(dq, q.grad) < 1e-5 and _relerr(dwk, wk.grad) < 2e-5
