@@ -220,6 +220,16 @@ def cross_attention_backward(q, ctx, wk, wv, dy, head_dim):
     return dq, dwk, dwv
 
 
+def attention_backward_blocked(qkv, dout, head_dim, block=0):
+    _f32(qkv), _f32(dout)
+    Nn, C3, H, W = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    stats = torch.empty(3 * Nn * (C3 // 3 // head_dim) * H * W, dtype=torch.float32, device=qkv.device)
+    N.check(N.lib().adm_attention_backward_blocked(N.ptr(qkv), N.ptr(dout), N.ptr(dqkv), N.ptr(stats), Nn, C3 // 3, H * W,
+                                                   head_dim, block, N.stream_for(qkv)))
+    return dqkv
+
+
 def attention_blocked(qkv, head_dim, key_block=0):
     """adm_attention with keys processed in blocks (online softmax): qkv (N,3C,H,W) -> (N,C,H,W)."""
     _f32(qkv)

@@ -379,7 +379,7 @@ class UNet2DConditionModel(UNet2DModel):
     blocks and a cross-attention mid block whose Transformer2DModel attends to `encoding` (batch, seq_length,
     cross_attention_dim) — `self.unet(images, t, encoding)["sample"]` (`pipeline_audio_diffusion.py:160-161`).
     `attention_head_dim` is the number of heads, as in diffusers 0.24 (`num_attention_heads or attention_head_dim`).
-    Inference only this round: `enable_training` raises."""
+    Training: `enable_training()` + `train_step(noisy, t, target, encoding)`."""
 
     _defaults = _COND_DEFAULTS
 
@@ -423,5 +423,8 @@ class UNet2DConditionModel(UNet2DModel):
 
     __call__ = forward
 
-    def enable_training(self, *a, **k):
-        raise NotImplementedError("training of the conditional UNet (scripts/train_unet.py --encodings) is not implemented")
+    def train_step(self, noisy, timesteps, target, encoder_hidden_states):
+        """`model(noisy_images, timesteps, batch["encoding"])` + mse + backward (scripts/train_unet.py:254-259)."""
+        assert getattr(self, "_training", False), "call enable_training() first"
+        self._set_encoding(self._handle, encoder_hidden_states, noisy.shape[0], noisy.device)
+        return UNet2DModel.train_step(self, noisy, timesteps, target)

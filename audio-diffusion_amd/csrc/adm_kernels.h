@@ -90,6 +90,8 @@ int launch_layernorm_nct_bwd(const float* x, const float* dy, const float* gamma
 int launch_geglu_bwd(const float* in, const float* dy, float* din, int N, int C4, long T, hipStream_t st);
 int launch_cross_attention_bwd(const float* q, const float* ctx, const float* Wk, const float* Wv, const float* dy, float* dq,
                                float* dWk, float* dWv, int N, int C, int T, int S, int Dc, int head_dim, hipStream_t st);
+int launch_attention_bwd_blocked(const float* qkv, const float* dout, float* dqkv, float* stats, int N, int C, int T,
+                                 int head_dim, int block, hipStream_t st);
 int launch_attention_blocked(const float* qkv, float* out, int N, int C, int T, int head_dim, int key_block, hipStream_t st);
 
 // k_audio_encoder.hip (AudioEncoder: audiodiffusion/audio_encoder.py:62-84)

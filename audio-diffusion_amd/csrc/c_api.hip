@@ -128,6 +128,11 @@ int adm_cross_attention_backward(const float* q, const float* ctx, const float* 
   ADM_REQUIRE(q && ctx && Wk && Wv && dy && dq && dWk && dWv, "cross_attention_backward: null argument");
   return launch_cross_attention_bwd(q, ctx, Wk, Wv, dy, dq, dWk, dWv, N, C, T, S, Dc, head_dim, (hipStream_t)stream);
 }
+int adm_attention_backward_blocked(const float* qkv, const float* dout, float* dqkv, float* stats, int N, int C, int T,
+                                   int head_dim, int block, void* stream) {
+  ADM_REQUIRE(qkv && dout && dqkv && stats, "attention_backward_blocked: null argument");
+  return launch_attention_bwd_blocked(qkv, dout, dqkv, stats, N, C, T, head_dim, block, (hipStream_t)stream);
+}
 int adm_sepconv_block(const float* x, const float* dw, const float* pw, const float* pb, const float* bn_scale,
                       const float* bn_shift, float slope, float* tmp, float* y, int N, int Ci, int Co, int H, int W,
                       void* stream) {

@@ -384,4 +384,144 @@ int launch_cross_attention_bwd(const float* q, const float* ctx, const float* Wk
   ADM_FAIL("cross_attention_bwd: unsupported head_dim (4/8/16/32/64)");
 }
 
+// Self-attention backward for token counts whose head slab does not fit LDS (k_backward.hip: attn_bwd_kernel keeps
+// Q, K, V and dout of a head resident). Flash-attention backward in two kernels, probabilities recomputed:
+//   dq kernel  (lane = query i): key blocks through LDS; pass 1 online softmax gives m_i, 1/l_i and D_i = dout_i . out_i
+//                                (kept in `stats` for the second kernel), pass 2 accumulates dq_i.
+//   dkv kernel (lane = key j)  : query blocks (q, dout, stats) through LDS; dk_j, dv_j.
+template <int D>
+__global__ void __launch_bounds__(256) attn_bwd_blocked_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                  float* __restrict__ dqkv, float* __restrict__ stats, int C,
+                                                                  int T, int KB, float scale) {
+  ADM_DYN_SMEM(float, smem);
+  float* Ks = smem;
+  float* Vs = smem + KB * D;
+  const int head = blockIdx.y, n = blockIdx.z, tid = threadIdx.x, heads = C / D;
+  const float* qb = qkv + ((long)n * 3 * C + head * D) * T;
+  const float* kb = qb + (long)C * T;
+  const float* vb = kb + (long)C * T;
+  const float* ob = dout + ((long)n * C + head * D) * T;
+  const int i = blockIdx.x * blockDim.x + tid;
+  const bool live = i < T;
+  float q[D], go[D], dq[D];
+  ADM_UNROLL
+  for (int d = 0; d < D; ++d) { q[d] = live ? qb[(long)d * T + i] : 0.f; go[d] = live ? ob[(long)d * T + i] : 0.f; dq[d] = 0.f; }
+  float m = -3.0e38f, l = 0.f, dsum = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float inv = pass ? 1.0f / l : 0.f, Di = pass ? dsum * inv : 0.f;
+    for (int j0 = 0; j0 < T; j0 += KB) {
+      const int nb = T - j0 < KB ? T - j0 : KB;
+      __syncthreads();
+      for (int e = tid; e < D * nb; e += blockDim.x) {
+        const int d = e / nb, j = e - d * nb;
+        Ks[j * D + d] = kb[(long)d * T + j0 + j];
+        Vs[j * D + d] = vb[(long)d * T + j0 + j];
+      }
+      __syncthreads();
+      if (pass == 0) {
+        float bm = m;
+        for (int j = 0; j < nb; ++j) {
+          float s = 0.f;
+          ADM_UNROLL
+          for (int d = 0; d < D; ++d) s = fmaf(q[d], Ks[j * D + d], s);
+          bm = fmaxf(bm, s * scale);
+        }
+        const float corr = __expf(m - bm);
+        l *= corr; dsum *= corr; m = bm;
+        for (int j = 0; j < nb; ++j) {
+          float s = 0.f, gv = 0.f;
+          ADM_UNROLL
+          for (int d = 0; d < D; ++d) { s = fmaf(q[d], Ks[j * D + d], s); gv = fmaf(go[d], Vs[j * D + d], gv); }
+          const float pj = __expf(s * scale - m);
+          l += pj; dsum = fmaf(pj, gv, dsum);
+        }
+      } else {
+        for (int j = 0; j < nb; ++j) {
+          float s = 0.f, gv = 0.f;
+          ADM_UNROLL
+          for (int d = 0; d < D; ++d) { s = fmaf(q[d], Ks[j * D + d], s); gv = fmaf(go[d], Vs[j * D + d], gv); }
+          const float ds = __expf(s * scale - m) * inv * (gv - Di) * scale;
+          ADM_UNROLL
+          for (int d = 0; d < D; ++d) dq[d] = fmaf(ds, Ks[j * D + d], dq[d]);
+        }
+      }
+    }
+  }
+  if (!live) return;
+  float* dqb = dqkv + ((long)n * 3 * C + head * D) * T;
+  ADM_UNROLL
+  for (int d = 0; d < D; ++d) dqb[(long)d * T + i] = dq[d];
+  float* sp = stats + 3 * (((long)n * heads + head) * T + i);
+  sp[0] = m; sp[1] = 1.0f / l; sp[2] = dsum / l;
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) attn_bwd_blocked_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                   float* __restrict__ dqkv, const float* __restrict__ stats,
+                                                                   int C, int T, int QB, float scale) {
+  ADM_DYN_SMEM(float, smem);
+  float* Qs = smem;                 // [QB][D]
+  float* Os = Qs + QB * D;          // dout [QB][D]
+  float* Ss = Os + QB * D;          // [QB][3]: m, 1/l, D
+  const int head = blockIdx.y, n = blockIdx.z, tid = threadIdx.x, heads = C / D;
+  const float* qb = qkv + ((long)n * 3 * C + head * D) * T;
+  const float* kb = qb + (long)C * T;
+  const float* vb = kb + (long)C * T;
+  const float* ob = dout + ((long)n * C + head * D) * T;
+  const float* sb = stats + 3 * ((long)n * heads + head) * T;
+  const int j = blockIdx.x * blockDim.x + tid;
+  const bool live = j < T;
+  float k[D], v[D], dk[D], dv[D];
+  ADM_UNROLL
+  for (int d = 0; d < D; ++d) { k[d] = live ? kb[(long)d * T + j] : 0.f; v[d] = live ? vb[(long)d * T + j] : 0.f; dk[d] = 0.f; dv[d] = 0.f; }
+  for (int i0 = 0; i0 < T; i0 += QB) {
+    const int nb = T - i0 < QB ? T - i0 : QB;
+    __syncthreads();
+    for (int e = tid; e < D * nb; e += blockDim.x) {
+      const int d = e / nb, i = e - d * nb;
+      Qs[i * D + d] = qb[(long)d * T + i0 + i];
+      Os[i * D + d] = ob[(long)d * T + i0 + i];
+    }
+    for (int e = tid; e < 3 * nb; e += blockDim.x) Ss[e] = sb[3 * (long)i0 + e];
+    __syncthreads();
+    for (int i = 0; i < nb; ++i) {
+      float s = 0.f, gv = 0.f;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) { s = fmaf(Qs[i * D + d], k[d], s); gv = fmaf(Os[i * D + d], v[d], gv); }
+      const float p = __expf(s * scale - Ss[3 * i]) * Ss[3 * i + 1];
+      const float ds = p * (gv - Ss[3 * i + 2]) * scale;
+      ADM_UNROLL
+      for (int d = 0; d < D; ++d) { dk[d] = fmaf(ds, Qs[i * D + d], dk[d]); dv[d] = fmaf(p, Os[i * D + d], dv[d]); }
+    }
+  }
+  if (!live) return;
+  float* dkb = dqkv + ((long)n * 3 * C + C + head * D) * T;
+  float* dvb = dkb + (long)C * T;
+  ADM_UNROLL
+  for (int d = 0; d < D; ++d) { dkb[(long)d * T + j] = dk[d]; dvb[(long)d * T + j] = dv[d]; }
+}
+
+// stats: 3 * N * (C / head_dim) * T floats of scratch
+int launch_attention_bwd_blocked(const float* qkv, const float* dout, float* dqkv, float* stats, int N, int C, int T,
+                                 int head_dim, int block, hipStream_t st) {
+  ADM_REQUIRE(C % head_dim == 0 && stats != nullptr, "attention_bwd: bad argument");
+  const int heads = C / head_dim;
+  const int bs = T >= 256 ? 256 : ((T + 63) / 64) * 64;
+  int KB = block > 0 ? block : (int)(64 * 1024 / (sizeof(float) * (2 * head_dim + 3)));
+  if (KB > T) KB = T;
+  dim3 grid(ceil_div(T, bs), heads, N);
+  const size_t smem = sizeof(float) * (size_t)KB * (2 * head_dim + 3);
+  const float scale = 1.0f / sqrtf((float)head_dim);
+#define ADM_ATTBB_CASE(DD)                                                                                                  \
+  if (head_dim == DD) {                                                                                                     \
+    ADM_LAUNCH((attn_bwd_blocked_dq_kernel<DD>), grid, dim3(bs), smem, st, qkv, dout, dqkv, stats, C, T, KB, scale);          \
+    ADM_LAUNCH((attn_bwd_blocked_dkv_kernel<DD>), grid, dim3(bs), smem, st, qkv, dout, dqkv, (const float*)stats, C, T, KB,   \
+               scale);                                                                                                      \
+    return ADM_CHECK_LAUNCH();                                                                                              \
+  }
+  ADM_ATTBB_CASE(4) ADM_ATTBB_CASE(8) ADM_ATTBB_CASE(16) ADM_ATTBB_CASE(32) ADM_ATTBB_CASE(64)
+#undef ADM_ATTBB_CASE
+  ADM_FAIL("attention_bwd: unsupported head_dim (4/8/16/32/64)");
+}
+
 }  // namespace adm

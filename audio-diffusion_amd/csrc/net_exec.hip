@@ -540,7 +540,43 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
     if (o.kind == Op::ATTN) {
       Tensor& to = tensors[o.out];
       ADM_REQUIRE(to.ginit && !t1.ginit, "run_backward: attention gradient state");
-      ADM_TRY(launch_attention_bwd(t1.ptr, to.grad, t1.grad, B, t1.C / 3, t1.H * t1.W, o.head_dim, st));
+      const int C = t1.C / 3, T = t1.H * t1.W;
+      if (o.head_dim <= 32 && sizeof(float) * ((size_t)4 * T * o.head_dim + 3 * T) <= 64 * 1024) {
+        ADM_TRY(launch_attention_bwd(t1.ptr, to.grad, t1.grad, B, C, T, o.head_dim, st));
+      } else {   // head slab too large for LDS (transformer blocks at 32x32 / 64x64 latents): key / query blocks
+        ADM_REQUIRE(tmp_da_floats >= (size_t)3 * B * (C / o.head_dim) * T, "run_backward: scratch too small");
+        ADM_TRY(launch_attention_bwd_blocked(t1.ptr, to.grad, t1.grad, tmp_da, B, C, T, o.head_dim, 0, st));
+      }
+      t1.ginit = true;
+      continue;
+    }
+    if (o.kind == Op::LN) {
+      Tensor& to = tensors[o.out];
+      const long T = (long)t1.H * t1.W;
+      ADM_REQUIRE(to.ginit, "run_backward: LayerNorm output gradient missing");
+      ADM_REQUIRE(tmp_da_floats >= (size_t)2 * B * T, "run_backward: scratch too small");
+      ADM_TRY(launch_layernorm_nct_bwd(t1.ptr, to.grad, o.g->gamma, t1.grad, t1.ginit ? 1 : 0, tmp_da, grad_of(o.g->gamma),
+                                       grad_of(o.g->beta), B, t1.C, T, o.eps, st));
+      mark_ready(o.g->gamma, (size_t)t1.C);
+      mark_ready(o.g->beta, (size_t)t1.C);
+      t1.ginit = true;
+      continue;
+    }
+    if (o.kind == Op::GEGLU) {
+      Tensor& to = tensors[o.out];
+      ADM_REQUIRE(to.ginit && !t1.ginit, "run_backward: GEGLU gradient state");
+      ADM_TRY(launch_geglu_bwd(t1.ptr, to.grad, t1.grad, B, t1.C / 2, (long)t1.H * t1.W, st));
+      t1.ginit = true;
+      continue;
+    }
+    if (o.kind == Op::XATTN) {
+      Tensor& to = tensors[o.out];
+      ADM_REQUIRE(to.ginit && !t1.ginit, "run_backward: cross-attention gradient state");
+      ADM_REQUIRE(ctx != nullptr && ctx_S > 0, "run_backward: no encoding set");
+      ADM_TRY(launch_cross_attention_bwd(t1.ptr, ctx, o.wk, o.wv, to.grad, t1.grad, grad_of(o.wk), grad_of(o.wv), B, t1.C,
+                                         t1.H * t1.W, ctx_S, ctx_D, o.head_dim, st));
+      mark_ready(o.wk, (size_t)t1.C * ctx_D);
+      mark_ready(o.wv, (size_t)t1.C * ctx_D);
       t1.ginit = true;
       continue;
     }
@@ -557,7 +593,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
     if (o.res >= 0) ADM_TRY(contribute(o.res, dy, (long)Cout * plane_o, Cout));
     // ---- bias (+ time-embedding bias) gradients ------------------------------------------------------------
     float* dW = qkv ? tmp_w : grad_of(ps->P(o.w->key + ".weight"));
-    float* dbias = qkv ? tmp_w + (size_t)Cout * Ct : grad_of(ps->P(o.w->key + ".bias"));
+    float* dbias = qkv ? tmp_w + (size_t)Cout * Ct : (o.w->has_bias ? grad_of(ps->P(o.w->key + ".bias")) : nullptr);
     if (qkv) ADM_TRY(dmemset(dbias, 0, sizeof(float) * Cout, st));
     ADM_TRY(launch_chan_sums(dy, B, Cout, (int)plane_o, (o.temb_off >= 0 && dtemb_all) ? dtemb_all + o.temb_off : nullptr,
                              temb_stride, 0, dbias, st));
@@ -587,13 +623,14 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       for (int k = 0; k < 3; ++k) {
         ADM_TRY(copy_d2d(grad_of(ps->P(o.w->qkv_prefix + names[k] + ".weight")), tmp_w + (size_t)k * C * C,
                          sizeof(float) * (size_t)C * C, st));
-        ADM_TRY(copy_d2d(grad_of(ps->P(o.w->qkv_prefix + names[k] + ".bias")), dbias + (size_t)k * C, sizeof(float) * C, st));
         mark_ready(ps->P(o.w->qkv_prefix + names[k] + ".weight"), (size_t)C * C);
+        if (!o.w->has_bias) continue;
+        ADM_TRY(copy_d2d(grad_of(ps->P(o.w->qkv_prefix + names[k] + ".bias")), dbias + (size_t)k * C, sizeof(float) * C, st));
         mark_ready(ps->P(o.w->qkv_prefix + names[k] + ".bias"), (size_t)C);
       }
     } else {
       mark_ready(ps->P(o.w->key + ".weight"), (size_t)Cout * Ct * o.ks * o.ks);
-      mark_ready(ps->P(o.w->key + ".bias"), (size_t)Cout);
+      if (o.w->has_bias) mark_ready(ps->P(o.w->key + ".bias"), (size_t)Cout);
     }
     // ---- data gradient ---------------------------------------------------------------------------------------
     if (o.in1 == t_in) continue;  // the network input needs no gradient

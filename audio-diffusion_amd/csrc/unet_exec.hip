@@ -431,7 +431,6 @@ int adm_unet_bind_param(adm_unet_t* h, const char* key, float* dev_ptr) {
 int adm_unet_enable_training(adm_unet_t* h, const float* params_base, long numel) {
   ADM_REQUIRE(h && params_base && numel > 0, "unet_enable_training: bad argument");
   ADM_REQUIRE(!h->finalized, "unet_enable_training: must be called before the first forward");
-  ADM_REQUIRE(h->cfg.cross_attention_dim == 0, "unet_enable_training: training of the conditional UNet is not implemented");
   for (auto& kv : h->ps.params)
     ADM_REQUIRE(kv.second.set && kv.second.dev >= params_base && kv.second.dev + kv.second.numel <= params_base + numel,
                 "unet_enable_training: parameter " + kv.first + " is not bound inside the flat buffer");

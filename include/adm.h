@@ -139,6 +139,10 @@ int adm_attention_blocked(const float* qkv, float* out, int N, int C, int T, int
 int adm_layernorm_nct_backward(const float* x, const float* dy, const float* gamma, float* dx, int accumulate, float* stats,
                                float* dgamma, float* dbeta, int N, int C, long T, float eps, void* stream);
 int adm_geglu_backward(const float* in, const float* dy, float* din, int N, int C4, long T, void* stream);
+/* adm_attention_backward for any token count: keys / queries in LDS blocks of `block` (0 = 64 KiB), probabilities
+ * recomputed; stats: 3 * N * (C / head_dim) * T floats of scratch. */
+int adm_attention_backward_blocked(const float* qkv, const float* dout, float* dqkv, float* stats, int N, int C, int T,
+                                   int head_dim, int block, void* stream);
 int adm_cross_attention_backward(const float* q, const float* ctx, const float* Wk, const float* Wv, const float* dy,
                                  float* dq, float* dWk, float* dWv, int N, int C, int T, int S, int Dc, int head_dim,
                                  void* stream);

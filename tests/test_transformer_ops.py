@@ -120,3 +120,19 @@ def test_cross_attention_backward(backend, C, heads, S):
         assert float(dq.abs().max()) == 0 and float(dwk.abs().max()) < 1e-6 * float(wv.grad.abs().max())
     else:
         assert _relerr(dq, q.grad) < 1e-5 and _relerr(dwk, wk.grad) < 2e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("C,heads,HW,block", [(32, 2, (8, 8), 16), (64, 8, (4, 24), 32), (64, 4, (8, 8), 0)])
+def test_self_attention_backward_in_blocks(backend, C, heads, HW, block):
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn, T = 2, HW[0] * HW[1]
+    qkv = (_rand((Nn, 3 * C) + HW, 1, "cpu") * 1.5).requires_grad_(True)
+    q, k, v = qkv.reshape(Nn, 3, C, T).unbind(1)
+    dout = _rand((Nn, C) + HW, 2, "cpu")
+    _mha(q, k, v, heads).reshape(Nn, C, *HW).backward(dout)
+    got = ops.attention_backward_blocked(qkv.detach().to(dev), dout.to(dev), C // heads, block)
+    assert _relerr(got, qkv.grad) < 2e-5
+    if C // heads <= 32:
+        assert _relerr(got, ops.attention_backward(qkv.detach().to(dev), dout.to(dev), C // heads)) < 2e-5

@@ -79,8 +79,6 @@ def test_conditional_unet_forward_matches_oracle(backend, cfg, B, S):
     assert float((got2 - want2).abs().max()) <= 1e-4 * float(want2.abs().max())
     with pytest.raises(ValueError):
         mine(x.to(dev), ts, None)
-    with pytest.raises(NotImplementedError):
-        mine.enable_training()
 
 
 MEL = dict(x_res=16, y_res=16, hop_length=64, n_fft=256, n_iter=2, sample_rate=4000)
@@ -119,3 +117,46 @@ def test_conditional_pipeline_sampling_matches_oracle_and_roundtrips(backend, tm
     again.set_progress_bar_config(disable=True)
     _, af = again(batch_size=2, steps=4, noise=noise.clone().to(dev), encoding=enc.to(dev), audio=False, return_float=True)
     assert torch.equal(af.cpu(), mf.cpu())
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("cfg,B,S", [(TINY, 2, 1), (TINY3, 3, 4)], ids=["tiny-seq1", "tiny3-seq4"])
+def test_conditional_unet_gradients_match_autograd(backend, cfg, B, S):
+    """`model(noisy, t, batch["encoding"])`, mse_loss, backward (scripts/train_unet.py:254-259): loss and every parameter
+    gradient of the native forward+backward vs torch autograd on the oracle; then one optimizer step."""
+    import torch.nn.functional as F
+    dev = select(backend)
+    from audiodiffusion import training as T
+    from audiodiffusion.unet import UNet2DConditionModel
+    torch.manual_seed(0)
+    ref = OracleCond(**cfg)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "norm" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    mine = UNet2DConditionModel(**cfg).load_state_dict(ref.state_dict())
+    flat, grads = mine.enable_training()
+    ss = cfg["sample_size"]
+    hw = (ss, ss) if isinstance(ss, int) else ss
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((B, cfg["in_channels"]) + tuple(hw), generator=g)
+    tgt = torch.randn((B, cfg["out_channels"]) + tuple(hw), generator=g)
+    enc = torch.randn((B, S, cfg["cross_attention_dim"]), generator=g)
+    ts = torch.tensor([5, 500, 999][:B])
+    loss_ref = F.mse_loss(ref(x, ts, enc)["sample"], tgt)
+    loss_ref.backward()
+    loss = mine.train_step(x.to(dev), ts, tgt.to(dev), enc.to(dev))
+    assert abs(float(loss) - float(loss_ref.detach())) <= 1e-5 * float(loss_ref.detach())
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters())
+    worst = ("", 0.0)
+    for name, p in ref.named_parameters():
+        off = mine.flat.offsets[name][0]
+        got = grads[off:off + p.numel()].view(p.shape).cpu()
+        err = float((got - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-3 * gmax)
+        if err > worst[1]:
+            worst = (name, err)
+    assert worst[1] < 3e-4, worst
+    opt = T.AdamW(flat, lr=1e-4)
+    opt.step(grads, clip=T.clip_grad_norm_(grads, 1.0))
+    mine.refresh_weights()
+    assert float(mine.train_step(x.to(dev), ts, tgt.to(dev), enc.to(dev))) < float(loss)
