@@ -8,9 +8,11 @@ training step (`:226-267`) runs as: fused add_noise kernel -> native UNet forwar
 diffusers layout by `AudioDiffusionPipeline.save_pretrained` every `--save_model_epochs` (`:286-311`).
 
 Launch:  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_unet.py --dataset_name ...
-Implemented: fp32 and --mixed_precision bf16, --vae (latent training), gradient accumulation, EMA, DDP. Not implemented (raise): --encodings (conditional training), fp16; hub push and tensorboard are ignored.
+Implemented: fp32 and --mixed_precision bf16, --vae (latent training), --encodings (conditional training), gradient
+accumulation, EMA, DDP. Not implemented (raise): fp16; hub push and tensorboard are ignored.
 """
 import argparse
+import pickle
 import math
 import os
 import sys
@@ -24,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
 from audiodiffusion import (AudioDiffusionPipeline, AutoencoderKL, DDIMScheduler, DDPMScheduler, Mel,  # noqa: E402
-                            UNet2DModel)
+                            UNet2DConditionModel, UNet2DModel)
 from audiodiffusion import training as T  # noqa: E402
 
 
@@ -38,21 +40,20 @@ def synthetic_dataset(n, resolution, seed=7):
 
 
 def load_images(args, resolution):
+    """-> ((N,1,H,W) uint8 images, audio_file per image) — the two dataset columns the reference's transform reads (:80-87)."""
     if args.dataset_name == "synthetic":
-        return synthetic_dataset(args.synthetic_size, resolution)
+        return synthetic_dataset(args.synthetic_size, resolution), [f"synthetic_{i % 4}" for i in range(args.synthetic_size)]
     from datasets import load_dataset, load_from_disk
     if os.path.exists(args.dataset_name):
         ds = load_from_disk(args.dataset_name)["train"]
     else:
         ds = load_dataset(args.dataset_name, args.dataset_config_name, cache_dir=args.cache_dir, split="train")
     imgs = [np.frombuffer(im.tobytes(), dtype="uint8").reshape(im.height, im.width) for im in ds["image"]]
-    return torch.from_numpy(np.stack(imgs))[:, None]
+    files = list(ds["audio_file"]) if "audio_file" in ds.column_names else [None] * len(imgs)
+    return torch.from_numpy(np.stack(imgs))[:, None], files
 
 
 def main(args):
-    if args.encodings is not None:
-        raise NotImplementedError("training of the conditional UNet (--encodings) is not implemented; inference is "
-                                  "(UNet2DConditionModel + AudioEncoder)")
     if args.mixed_precision == "fp16":
         raise NotImplementedError("mixed_precision: 'no' (fp32, the reference default) and 'bf16' are implemented; fp16 "
                                   "would need loss scaling, which gfx950's bf16 MFMA path makes pointless")
@@ -68,8 +69,18 @@ def main(args):
     output_dir = os.environ.get("SM_MODEL_DIR", None) or args.output_dir
 
     resolution = (args.resolution, args.resolution) if isinstance(args.resolution, int) else args.resolution
-    images = load_images(args, resolution)                         # (N,1,H,W) uint8
+    images, audio_files = load_images(args, resolution)            # (N,1,H,W) uint8
     resolution = tuple(images.shape[2:])
+    # conditional training (:93-94): pickled {audio_file: encoding} as written by scripts/encode_audio.py of the reference
+    enc_table = None
+    if args.encodings is not None:
+        with open(args.encodings, "rb") as f:
+            encodings = pickle.load(f)
+        missing = sorted({a for a in audio_files if a not in encodings})
+        if missing:
+            raise KeyError(f"--encodings has no entry for {missing[:3]}{'...' if len(missing) > 3 else ''}")
+        enc_table = torch.stack([torch.as_tensor(np.asarray(encodings[a]), dtype=torch.float32).reshape(-1, np.asarray(
+            encodings[a]).shape[-1]) for a in audio_files])           # (N, seq_length, cross_attention_dim)
     # latent diffusion (train_unet.py:95-104): a frozen AutoencoderKL maps every batch to latents the UNet is trained on
     vqvae, latent_resolution = None, None
     if args.vae is not None:
@@ -86,6 +97,15 @@ def main(args):
             latent_resolution = tuple(vqvae.encode(torch.zeros((1, 1) + resolution, device=dev)).latent_dist.sample().shape[2:])
     else:
         lc = 1 if vqvae is None else vqvae.config["latent_channels"]
+    if args.from_pretrained is None and enc_table is not None:       # :139-159
+        model = UNet2DConditionModel(sample_size=resolution if vqvae is None else latent_resolution, in_channels=lc,
+                                     out_channels=lc, layers_per_block=2, block_out_channels=(128, 256, 512, 512),
+                                     down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",),
+                                     up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3,
+                                     cross_attention_dim=int(enc_table.shape[-1])).init_random(args.seed)
+        mel = Mel(x_res=resolution[1], y_res=resolution[0], hop_length=args.hop_length, sample_rate=args.sample_rate,
+                  n_fft=args.n_fft)
+    elif args.from_pretrained is None:
         model = UNet2DModel(sample_size=resolution if vqvae is None else latent_resolution, in_channels=lc,
                             out_channels=lc, layers_per_block=2,
                             block_out_channels=(128, 128, 256, 256, 512, 512),
@@ -132,7 +152,10 @@ def main(args):
             timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (clean.shape[0],)).long()
             noisy = noise_scheduler.add_noise(clean.contiguous(), noise, timesteps)
             reducer.begin_step()
-            loss = model.train_step(noisy, timesteps, noise)
+            if enc_table is not None:                                      # :254-255
+                loss = model.train_step(noisy, timesteps, noise, enc_table[idx].to(dev))
+            else:
+                loss = model.train_step(noisy, timesteps, noise)
             if accum.add(last_batch=(it == steps_per_epoch - 1)):          # accelerator.sync_gradients
                 reducer.start()
                 reducer.finish()

@@ -129,3 +129,49 @@ def test_latent_training_with_frozen_vae(tmp_path):
     assert images[0].size == (32, 32)
     moved = max(float((out.unet.state_dict()[k] - v).abs().max()) for k, v in start.state_dict().items())
     assert 0 < moved < 0.1
+
+
+def test_conditional_training_from_encodings(tmp_path):
+    """encode_audio.py -> pickled {audio_file: (1, 100) encoding} -> train_unet.py --encodings (scripts/encode_audio.py:27-30,
+    scripts/train_unet.py:85-87,93-94,254-255) -> saved conditional pipeline samples with `encoding=`."""
+    import pickle
+    select("emu")
+    from audiodiffusion import AudioDiffusionPipeline, AudioEncoder, DDPMScheduler, Mel, UNet2DConditionModel
+    from oracle import audio_encoder as oenc
+    rng = np.random.default_rng(0)
+    os.makedirs(tmp_path / "wav")
+    slice_size = MEL["x_res"] * MEL["hop_length"] - 1
+    for k in range(2):
+        y = (0.3 * rng.standard_normal(slice_size * 3 + 5)).astype(np.float32)
+        scipy.io.wavfile.write(tmp_path / "wav" / f"{k}.wav", MEL["sample_rate"], y)
+    a2i = _script("audio_to_images")
+    a2i.main(a2i.parse_args(["--input_dir", str(tmp_path / "wav"), "--output_dir", str(tmp_path / "data"), "--resolution", "16",
+                             "--hop_length", "64", "--sample_rate", "4000", "--n_fft", "256"]))
+    # encodings: the reference's AudioEncoder architecture on a small mel geometry
+    enc = AudioEncoder()
+    enc.mel = Mel(x_res=24, y_res=16, sample_rate=4000, n_fft=256, hop_length=64, top_db=80)
+    enc.load_state_dict(oenc.random_state_dict(3, y_res=16, x_res=24))
+    ea = _script("encode_audio")
+    table = ea.main(ea.parse_args(["--dataset_name", str(tmp_path / "data"), "--output_file", str(tmp_path / "enc.p")]), enc)
+    assert len(table) == 2 and all(tuple(v.shape) == (1, 100) for v in table.values())
+    with open(tmp_path / "enc.p", "rb") as f:
+        assert set(pickle.load(f)) == set(table)
+    cfg = dict(sample_size=(16, 16), in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(32, 64),
+               down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
+               cross_attention_dim=100, attention_head_dim=4)
+    start = UNet2DConditionModel(**cfg).init_random(3)
+    AudioDiffusionPipeline(None, start, Mel(**MEL), DDPMScheduler()).save_pretrained(str(tmp_path / "start"))
+    tr = _script("train_unet")
+    tr.main(tr.parse_args(["--from_pretrained", str(tmp_path / "start"), "--dataset_name", str(tmp_path / "data"),
+                           "--encodings", str(tmp_path / "enc.p"), "--output_dir", str(tmp_path / "out"),
+                           "--train_batch_size", "2", "--num_epochs", "1", "--save_model_epochs", "1", "--lr_warmup_steps", "1",
+                           "--learning_rate", "1e-3", "--hop_length", "64", "--sample_rate", "4000", "--n_fft", "256"]))
+    pipe = AudioDiffusionPipeline.from_pretrained(str(tmp_path / "out"))
+    assert type(pipe.unet).__name__ == "UNet2DConditionModel"
+    moved = sum(float((pipe.unet.state_dict()[k] - v).abs().max()) > 0 for k, v in start.state_dict().items())
+    assert moved >= 0.85 * len(start.state_dict())      # to_k of a 1-token encoding has no gradient, everything else moves
+    pipe.set_progress_bar_config(disable=True)
+    e = next(iter(table.values()))[:, None, :]
+    images, _ = pipe(batch_size=1, steps=2, generator=torch.Generator().manual_seed(0), encoding=e, audio=False,
+                     return_float=True)
+    assert images[0].size == (16, 16)
