@@ -32,84 +32,44 @@ except Exception:  # pragma: no cover
 
 
 class AudioDiffusion:
-    def __init__(
-        self,
-        model_id: str = "teticio/audio-diffusion-256",
-        cuda: bool = torch.cuda.is_available(),
-        progress_bar: Iterable = tqdm,
-    ):
-        """Class for generating audio using De-noising Diffusion Probabilistic Models
-        (`audiodiffusion/__init__.py:15-33`).
+    """One-sample convenience front end of the pipeline — the reference's `AudioDiffusion` (`audiodiffusion/__init__.py:15-140`):
+    same constructor and method signatures, defaults and return shapes (`(PIL image, (sample_rate, audio))`), every call
+    forwarded to `AudioDiffusionPipeline.__call__` with `batch_size=1, return_dict=False`.  `model_id` is a local
+    directory in the diffusers layout (no hub access); the MI355X is torch's "cuda" device and there is no CPU mode."""
 
-        Args:
-            model_id (String): name of model (local directory in the diffusers layout; no hub access here)
-            cuda (bool): use CUDA? (the MI355X is torch's "cuda" device on ROCm; this path has no CPU mode)
-            progress_bar (iterable): iterable callback for progress updates or None
-        """
+    def __init__(self, model_id: str = "teticio/audio-diffusion-256", cuda: bool = torch.cuda.is_available(),
+                 progress_bar: Iterable = tqdm):
         self.model_id = model_id
-        self.pipe = AudioDiffusionPipeline.from_pretrained(self.model_id)
+        self.pipe = AudioDiffusionPipeline.from_pretrained(model_id)
         if cuda:
             self.pipe.to("cuda")
-        self.progress_bar = progress_bar or (lambda _: _)
+        self.progress_bar = progress_bar if progress_bar is not None else (lambda it: it)
 
-    def generate_spectrogram_and_audio(
-        self,
-        steps: int = None,
-        generator: torch.Generator = None,
-        step_generator: torch.Generator = None,
-        eta: float = 0,
-        noise: torch.Tensor = None,
-        encoding: torch.Tensor = None,
-    ) -> Tuple[Image.Image, Tuple[int, np.ndarray]]:
-        """Generate random mel spectrogram and convert to audio (`__init__.py:35-68`)."""
-        images, (sample_rate, audios) = self.pipe(
-            batch_size=1,
-            steps=steps,
-            generator=generator,
-            step_generator=step_generator,
-            eta=eta,
-            noise=noise,
-            encoding=encoding,
-            return_dict=False,
-        )
+    def _one(self, **call) -> Tuple[Image.Image, Tuple[int, np.ndarray]]:
+        images, (sample_rate, audios) = self.pipe(batch_size=1, return_dict=False, **call)
         return images[0], (sample_rate, audios[0])
 
-    def generate_spectrogram_and_audio_from_audio(
-        self,
-        audio_file: str = None,
-        raw_audio: np.ndarray = None,
-        slice: int = 0,
-        start_step: int = 0,
-        steps: int = None,
-        generator: torch.Generator = None,
-        mask_start_secs: float = 0,
-        mask_end_secs: float = 0,
-        step_generator: torch.Generator = None,
-        eta: float = 0,
-        encoding: torch.Tensor = None,
-        noise: torch.Tensor = None,
-    ) -> Tuple[Image.Image, Tuple[int, np.ndarray]]:
-        """Generate random mel spectrogram from audio input and convert to audio (`__init__.py:70-122`)."""
-        images, (sample_rate, audios) = self.pipe(
-            batch_size=1,
-            audio_file=audio_file,
-            raw_audio=raw_audio,
-            slice=slice,
-            start_step=start_step,
-            steps=steps,
-            generator=generator,
-            mask_start_secs=mask_start_secs,
-            mask_end_secs=mask_end_secs,
-            step_generator=step_generator,
-            eta=eta,
-            noise=noise,
-            encoding=encoding,
-            return_dict=False,
-        )
-        return images[0], (sample_rate, audios[0])
+    def generate_spectrogram_and_audio(self, steps: int = None, generator: torch.Generator = None,
+                                       step_generator: torch.Generator = None, eta: float = 0, noise: torch.Tensor = None,
+                                       encoding: torch.Tensor = None) -> Tuple[Image.Image, Tuple[int, np.ndarray]]:
+        """Unconditional (or `encoding`-conditioned) sample from noise (`__init__.py:35-68`)."""
+        return self._one(steps=steps, generator=generator, step_generator=step_generator, eta=eta, noise=noise,
+                         encoding=encoding)
+
+    def generate_spectrogram_and_audio_from_audio(self, audio_file: str = None, raw_audio: np.ndarray = None, slice: int = 0,
+                                                  start_step: int = 0, steps: int = None, generator: torch.Generator = None,
+                                                  mask_start_secs: float = 0, mask_end_secs: float = 0,
+                                                  step_generator: torch.Generator = None, eta: float = 0,
+                                                  encoding: torch.Tensor = None, noise: torch.Tensor = None
+                                                  ) -> Tuple[Image.Image, Tuple[int, np.ndarray]]:
+        """Variation / in- and out-painting of one slice of an audio input (`__init__.py:70-122`): `start_step` keeps the
+        input noised to that step, `mask_*_secs` pin the start / end of the spectrogram to the input."""
+        return self._one(audio_file=audio_file, raw_audio=raw_audio, slice=slice, start_step=start_step, steps=steps,
+                         generator=generator, mask_start_secs=mask_start_secs, mask_end_secs=mask_end_secs,
+                         step_generator=step_generator, eta=eta, noise=noise, encoding=encoding)
 
     @staticmethod
     def loop_it(audio: np.ndarray, sample_rate: int, loops: int = 12) -> np.ndarray:
-        """Loop audio on bar boundaries (`__init__.py:124-140`). The reference delegates to librosa's beat
-        tracker, a post-hoc CPU nicety that SURVEY.md §2.1 #3 places outside the hot path."""
+        """Loop audio on bar boundaries (`__init__.py:124-140`). The reference delegates to librosa's beat tracker, a post-hoc
+        CPU nicety that SURVEY.md §2.1 #3 places outside the hot path."""
         raise NotImplementedError("loop_it needs librosa.beat.beat_track, which is outside the MI355X hot path")

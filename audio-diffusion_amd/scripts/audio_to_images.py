@@ -47,59 +47,78 @@ def file_examples(mel, audio_file, batch_slices):
     return out
 
 
-def main(args):
-    mel = Mel(x_res=args.resolution[0], y_res=args.resolution[1], hop_length=args.hop_length,
-              sample_rate=args.sample_rate, n_fft=args.n_fft)
-    os.makedirs(args.output_dir, exist_ok=True)
-    audio_files = sorted(os.path.join(root, file) for root, _, files in os.walk(args.input_dir) for file in files
-                         if re.search(r"\.(mp3|wav|m4a)$", file, re.IGNORECASE))
-    examples = []
-    for audio_file in audio_files:
-        try:
-            examples.extend(file_examples(mel, audio_file, args.batch_slices))
-        except KeyboardInterrupt:
-            raise
-        except Exception as e:                           # unreadable / unsupported file: report and continue (`:36-42`)
-            print(f"{audio_file}: {e}")
-            continue
-    if len(examples) == 0:
-        logger.warning("No valid audio files were found.")
-        return None
+AUDIO_SUFFIX = re.compile(r"\.(mp3|wav|m4a)$", re.IGNORECASE)      # the extensions the reference walks for (`:24-30`)
+
+
+def find_audio(input_dir):
+    return sorted(os.path.join(d, f) for d, _, names in os.walk(input_dir) for f in names if AUDIO_SUFFIX.search(f))
+
+
+def write_dataset(examples, output_dir):
+    """Rows -> HF DatasetDict{"train"} on disk with the reference's schema (`:67-78`)."""
     import pandas as pd
     from datasets import Dataset, DatasetDict, Features, Image, Value
-    ds = Dataset.from_pandas(pd.DataFrame(examples),
-                             features=Features({"image": Image(), "audio_file": Value(dtype="string"),
-                                                "slice": Value(dtype="int16")}))
-    dsd = DatasetDict({"train": ds})
-    dsd.save_to_disk(os.path.join(args.output_dir))
+    schema = Features({"image": Image(), "audio_file": Value(dtype="string"), "slice": Value(dtype="int16")})
+    dsd = DatasetDict({"train": Dataset.from_pandas(pd.DataFrame(examples), features=schema)})
+    dsd.save_to_disk(os.path.join(output_dir))
+    return dsd
+
+
+def main(args):
+    width, height = args.resolution
+    mel = Mel(x_res=width, y_res=height, hop_length=args.hop_length, sample_rate=args.sample_rate, n_fft=args.n_fft)
+    os.makedirs(args.output_dir, exist_ok=True)
+    examples = []
+    for audio_file in find_audio(args.input_dir):
+        try:
+            examples += file_examples(mel, audio_file, args.batch_slices)
+        except KeyboardInterrupt:
+            raise
+        except Exception as e:                           # unreadable / unsupported file: report and go on (`:36-42`)
+            print(f"{audio_file}: {e}")
+    if not examples:
+        logger.warning("No valid audio files were found.")
+        return None
+    dsd = write_dataset(examples, args.output_dir)
     if args.push_to_hub:
         raise NotImplementedError("--push_to_hub needs network access; copy the saved dataset instead")
     return dsd
 
 
+def _resolution(text):
+    """"256" -> (256, 256); "216,96" -> (216, 96) = (width, height), as the reference's --resolution (`:97-110`)."""
+    parts = [p for p in str(text).split(",")]
+    try:
+        nums = [int(p) for p in parts]
+    except ValueError:
+        nums = []
+    if len(nums) == 1:
+        return (nums[0], nums[0])
+    if len(nums) == 2:
+        return (nums[0], nums[1])
+    raise ValueError("Resolution must be a tuple of two integers or a single integer.")
+
+
+FLAGS = (   # the reference's CLI (`:83-95`) plus --batch_slices
+    ("--input_dir", dict(type=str)),
+    ("--output_dir", dict(type=str, default="data")),
+    ("--resolution", dict(type=str, default="256", help="Either square resolution or width,height.")),
+    ("--hop_length", dict(type=int, default=512)),
+    ("--push_to_hub", dict(type=str, default=None)),
+    ("--sample_rate", dict(type=int, default=22050)),
+    ("--n_fft", dict(type=int, default=2048)),
+    ("--batch_slices", dict(type=int, default=256, help="slices per Mel kernel launch (not in the reference)")),
+)
+
+
 def parse_args(argv=None):
     parser = argparse.ArgumentParser(description="Create dataset of Mel spectrograms from directory of audio files.")
-    parser.add_argument("--input_dir", type=str)
-    parser.add_argument("--output_dir", type=str, default="data")
-    parser.add_argument("--resolution", type=str, default="256", help="Either square resolution or width,height.")
-    parser.add_argument("--hop_length", type=int, default=512)
-    parser.add_argument("--push_to_hub", type=str, default=None)
-    parser.add_argument("--sample_rate", type=int, default=22050)
-    parser.add_argument("--n_fft", type=int, default=2048)
-    parser.add_argument("--batch_slices", type=int, default=256, help="slices per Mel kernel launch (not in the reference)")
+    for flag, kw in FLAGS:
+        parser.add_argument(flag, **kw)
     args = parser.parse_args(argv)
     if args.input_dir is None:
         raise ValueError("You must specify an input directory for the audio files.")
-    try:
-        args.resolution = (int(args.resolution), int(args.resolution))
-    except ValueError:
-        try:
-            args.resolution = tuple(int(x) for x in args.resolution.split(","))
-            if len(args.resolution) != 2:
-                raise ValueError
-        except ValueError:
-            raise ValueError("Resolution must be a tuple of two integers or a single integer.")
-    assert isinstance(args.resolution, tuple)
+    args.resolution = _resolution(args.resolution)
     return args
 
 
