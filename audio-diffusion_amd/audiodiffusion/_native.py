@@ -70,6 +70,7 @@ _SIGS = {
     "adm_pack_winograd_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "adm_pack_winograd_weight_T": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "adm_pack_bf16_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "adm_pack_bf16_weight_ks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "adm_conv_out_dims": (None, [C.c_int] * 6 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "adm_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "adm_layernorm_nct": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_long, C.c_float, C.c_void_p]),

@@ -113,9 +113,10 @@ def pack_bf16_weight(w, transposed=False):
     """(Cout,Cin,3,3) fp32 -> bf16 MFMA operand layout [tap][Cin/8][Cout][8] (transposed: the data-gradient filters)."""
     _f32(w)
     co, ci = w.shape[:2]
-    shape = (9, co // 8, ci, 8) if transposed else (9, ci // 8, co, 8)
+    ks = w.shape[2] if w.dim() == 4 else 1
+    shape = (ks * ks, co // 8, ci, 8) if transposed else (ks * ks, ci // 8, co, 8)
     wb = torch.empty(shape, dtype=torch.bfloat16, device=w.device)
-    N.check(N.lib().adm_pack_bf16_weight(N.ptr(w), C.c_void_p(wb.data_ptr()), co, ci, int(transposed), N.stream_for(w)))
+    N.check(N.lib().adm_pack_bf16_weight_ks(N.ptr(w), C.c_void_p(wb.data_ptr()), co, ci, ks, int(transposed), N.stream_for(w)))
     return wb
 
 

@@ -290,7 +290,9 @@ class UNet2DModel:
         from .training import FlatBuffer
         if mixed_precision not in ("no", "bf16"):
             raise ValueError(f"mixed_precision must be 'no' or 'bf16', got {mixed_precision!r}")
-        N.check(N.lib().adm_set_option(b"conv_bf16", 1 if mixed_precision == "bf16" else 0))
+        # ADM_BF16_LEVEL=2 additionally puts the 1x1 convolutions on bf16 operands (opt-in: emulator-verified, not yet timed)
+        level = int(os.environ.get("ADM_BF16_LEVEL", "1")) if mixed_precision == "bf16" else 0
+        N.check(N.lib().adm_set_option(b"conv_bf16", level))
         self.mixed_precision = mixed_precision
         if sample_hw is not None:
             self.sample_size = tuple(sample_hw)

@@ -47,9 +47,15 @@ bool winograd_eligible(const adm_conv_args& a);
 int launch_conv_winograd(const adm_conv_args& a, hipStream_t st);
 
 // k_conv_bf16.hip (mixed-precision training: bf16 MFMA operands, fp32 accumulate)
-int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transposed, hipStream_t st);
-void set_conv_bf16(int m);   // 0 off (default), 1 on, -1 = ADM_CONV_BF16 from the environment
+int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transposed, hipStream_t st, int ks = 3);
+void set_conv_bf16(int m);   // 0 off (default), 1 = 3x3 convs, 2 = 3x3 and 1x1 convs (opt-in), -1 = ADM_CONV_BF16
 bool conv_bf16_enabled();
+int conv_bf16_mode();
+// k_conv1x1_bf16.hip (mode 2)
+bool conv1x1_bf16_eligible(const adm_conv_args& a);
+int launch_conv1x1_bf16(const adm_conv_args& a, hipStream_t st);
+bool conv1x1_wgrad_bf16_eligible(const adm_conv_args& a);
+int launch_conv1x1_wgrad_bf16(const adm_conv_args& a, const float* dy, float* workspace, int split, hipStream_t st);
 bool conv_bf16_eligible(const adm_conv_args& a);
 int launch_conv_bf16(const adm_conv_args& a, hipStream_t st);
 bool conv_wgrad_bf16_eligible(const adm_conv_args& a);

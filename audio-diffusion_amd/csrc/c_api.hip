@@ -85,6 +85,11 @@ int adm_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transp
   return launch_pack_bf16_weight(w, wb, Cout, Cin, transposed, (hipStream_t)stream);
 }
 
+int adm_pack_bf16_weight_ks(const float* w, void* wb, int Cout, int Cin, int ks, int transposed, void* stream) {
+  ADM_REQUIRE(w && wb, "pack_bf16_weight: null argument");
+  return launch_pack_bf16_weight(w, wb, Cout, Cin, transposed, (hipStream_t)stream, ks);
+}
+
 void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo) {
   conv_out_dims(H, W, up, stride, ks, pad_lo, Ho, Wo);
 }

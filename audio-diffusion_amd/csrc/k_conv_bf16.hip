@@ -439,13 +439,16 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
   }
 }
 
+static int g_bf16_mode = -1;   // -1: ADM_CONV_BF16 from the environment (default 0 = fp32 everywhere; 2 = 1x1 convs too)
+bool conv_bf16_enabled();
+
 // ---------------------------------------------------------------- filters: fp32 (Cout,Cin,3,3) -> bf16 [tap][Cin/8][Cout][8]
 __global__ void pack_bf16_weight_kernel(const float* __restrict__ w, unsigned* __restrict__ wb, int Cout, int Cin,
-                                        int transposed) {
+                                        int transposed, int taps) {
   // one thread per bf16 PAIR of the packed tensor. transposed: the data-gradient filters (roles of Cout/Cin swapped, taps
   // flipped), i.e. packed "Cout" = Cin and packed "Cin" = Cout.
   const int Co = transposed ? Cin : Cout, Ci = transposed ? Cout : Cin;
-  const long total = (long)9 * Ci * Co / 2;
+  const long total = (long)taps * Ci * Co / 2;       // taps = 9 (3x3) or 1 (1x1: [Cin/8][Cout][8])
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int e2 = (int)(i & 3);
@@ -456,25 +459,30 @@ __global__ void pack_bf16_weight_kernel(const float* __restrict__ w, unsigned* _
   const int ci = kg * 8 + 2 * e2;
   float a, b;
   if (!transposed) {
-    a = w[((long)co * Cin + ci) * 9 + t];
-    b = w[((long)co * Cin + ci + 1) * 9 + t];
+    a = w[((long)co * Cin + ci) * taps + t];
+    b = w[((long)co * Cin + ci + 1) * taps + t];
   } else {
-    a = w[((long)ci * Cin + co) * 9 + (8 - t)];
-    b = w[((long)(ci + 1) * Cin + co) * 9 + (8 - t)];
+    a = w[((long)ci * Cin + co) * taps + (taps - 1 - t)];
+    b = w[((long)(ci + 1) * Cin + co) * taps + (taps - 1 - t)];
   }
   wb[i] = ADM_PK_BF16(a, b);
 }
 
-int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transposed, hipStream_t st) {
+int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transposed, hipStream_t st, int ks) {
   ADM_REQUIRE(Cout % 8 == 0 && Cin % 8 == 0, "pack_bf16_weight: channel counts must be multiples of 8");
-  const long total = (long)9 * Cin * Cout / 2;
+  ADM_REQUIRE(ks == 3 || ks == 1, "pack_bf16_weight: ks must be 1 or 3");
+  const int taps = ks * ks;
+  const long total = (long)taps * Cin * Cout / 2;
   ADM_LAUNCH(pack_bf16_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (unsigned*)wb, Cout, Cin,
-             transposed);
+             transposed, taps);
   return ADM_CHECK_LAUNCH();
+}
+int conv_bf16_mode() {
+  conv_bf16_enabled();
+  return g_bf16_mode;
 }
 
 // ---------------------------------------------------------------- dispatch
-static int g_bf16_mode = -1;   // -1: ADM_CONV_BF16 from the environment (default 0 = fp32 everywhere)
 void set_conv_bf16(int m) { g_bf16_mode = m; }
 bool conv_bf16_enabled() {
   if (g_bf16_mode < 0) { const char* e = getenv("ADM_CONV_BF16"); g_bf16_mode = e ? atoi(e) : 0; }

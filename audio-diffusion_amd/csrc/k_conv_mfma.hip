@@ -498,6 +498,7 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
     return launch_conv_small(a, st);  // conv_in / conv_out class (tiny Cin or Cout): direct kernel
   ADM_REQUIRE(!(a.ks == 1 && (a.stride != 1 || a.up)), "conv2d: 1x1 supports stride 1, no upsample");
   if (conv_bf16_enabled() && conv_bf16_eligible(a)) return launch_conv_bf16(a, st);
+  if (conv_bf16_mode() >= 2 && conv1x1_bf16_eligible(a)) return launch_conv1x1_bf16(a, st);
   if (winograd_enabled() && winograd_eligible(a)) return launch_conv_winograd(a, st);
   ConvParams p;
   p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2;

@@ -29,7 +29,8 @@ int adm_is_device_build(void);
  * "wgrad_max_split" = n caps the split-K factor of adm_conv2d_wgrad (0 = heuristic; tests use it to put several pixel
  * tiles on one workgroup); "conv_bf16" = 1 runs eligible 3x3 stride-1 convolutions (forward, data gradient and weight
  * gradient) on bf16 MFMA operands with fp32 accumulation (`--mixed_precision bf16`, scripts/train_unet.py:391-401),
- * 0 = fp32 everywhere (default), -1 = back to the ADM_CONV_BF16 environment variable. */
+ * 2 = additionally the eligible 1x1 convolutions (opt-in: emulator-verified, not yet timed), 0 = fp32 everywhere
+ * (default), -1 = back to the ADM_CONV_BF16 environment variable. */
 int adm_set_option(const char* name, int value);
 /* Kernel variant the last adm_conv2d on this thread dispatched to (see adm_op_profile.variant; 4311 = Winograd). */
 int adm_last_conv_variant(void);
@@ -113,6 +114,9 @@ int adm_pack_winograd_weight_T(const float* w, float* wuT, int Cout, int Cin, vo
 /* (Cout,Cin,3,3) fp32 -> bf16 (round-to-nearest-even) MFMA operand layout [tap][Cin/8][Cout][8]; transposed != 0 packs
  * the data-gradient filters instead ([flipped tap][Cout/8][Cin][8]). 2 bytes per weight; both device pointers. */
 int adm_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transposed, void* stream);
+/* the same for (Cout,Cin,ks,ks), ks = 3 or 1 (1x1: [Cin/8][Cout][8]; used when option "conv_bf16" = 2 also puts the
+ * 1x1 convolutions on bf16 operands — opt-in, see k_conv1x1_bf16.hip). */
+int adm_pack_bf16_weight_ks(const float* w, void* wb, int Cout, int Cin, int ks, int transposed, void* stream);
 void adm_conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);
 
 /* Self-attention core (row U6): qkv is (N, 3*C, T) with channels [q | k | v], head h = channels

@@ -154,3 +154,113 @@ def test_conv_bf16_weight_gradient(backend, case):
     assert _relerr(dW.double(), full) < 8e-3, _relerr(dW.double(), full)
     # and it really was the bf16 kernel: the fp32 path would match `full` to 1e-5 but not `exact`
     assert _relerr(dW.double(), full) > 1e-5
+
+
+# ---------------------------------------------------------------- 1x1 convolutions on bf16 operands (option conv_bf16 = 2)
+PW_CASES = [
+    # (N, C1, C2, H, W, Cout, gn, act, temb, res)
+    (1, 32, 0, 16, 16, 128, 0, 0, 0, 0),      # bare shortcut convolution
+    (2, 64, 32, 16, 32, 128, 0, 0, 0, 1),     # shortcut on a virtual concat (seam on a chunk boundary) + residual, 2 tiles
+    (2, 64, 0, 16, 16, 256, 1, 0, 0, 0),      # attention projection: GroupNorm (no SiLU) on the load path, two cout tiles
+    (1, 32, 0, 16, 16, 128, 1, 1, 1, 1),      # all load-path and epilogue terms
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", PW_CASES, ids=[str(i) for i in range(len(PW_CASES))])
+def test_conv1x1_bf16_forward(backend, case):
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, C1, C2, H, W, Cout, use_gn, act, use_temb, use_res = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    w = _rand((Cout, Ct, 1, 1), 3, dev, scale=Ct ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
+    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
+    res = _rand((Nn, Cout, H, W), 8, dev) if use_res else None
+    _native.check(_native.lib().adm_set_option(b"conv_bf16", 2))
+    try:
+        out = ops.conv2d(x1, ops.pack_conv_weight(w), b, 1, x2=x2, pad_lo=0, gn=gn, act=bool(act), chan_add=temb,
+                         residual=res, bf16=ops.pack_bf16_weight(w))
+        assert _native.lib().adm_last_conv_variant() == 5116, "the 1x1 bf16 kernel was not selected"
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))     # mode 1 keeps 1x1 convolutions in fp32
+        ops.conv2d(x1, ops.pack_conv_weight(w), b, 1, x2=x2, pad_lo=0, gn=gn, act=bool(act), chan_add=temb,
+                   residual=res, bf16=ops.pack_bf16_weight(w))
+        assert _native.lib().adm_last_conv_variant() != 5116
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+    c = lambda t: None if t is None else t.cpu()  # noqa: E731
+    x = torch.cat([c(x1), c(x2)], 1) if C2 else c(x1)
+    if use_gn:
+        x = F.group_norm(x, 32, c(gamma), c(beta), 1e-5)
+    if act:
+        x = F.silu(x)
+    tail = c(b).double()[None, :, None, None]
+    if use_temb:
+        tail = tail + c(temb).double()[:, :, None, None]
+    if use_res:
+        tail = tail + c(res).double()
+    exact = F.conv2d(_bf(x), _bf(c(w))) + tail
+    full = F.conv2d(x.double(), c(w).double()) + tail
+    tight = 2e-6 if not (use_gn or act) else 3e-4
+    assert _relerr(out.double(), exact) < tight, _relerr(out.double(), exact)
+    assert _relerr(out.double(), full) < 8e-3
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv1x1_bf16_data_gradient(backend):
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, Cin, Cout, H, W = 2, 128, 64, 16, 16
+    w = _rand((Cout, Cin, 1, 1), 11, dev, scale=Cin ** -0.5)
+    dy = _rand((Nn, Cout, H, W), 12, dev)
+    _native.check(_native.lib().adm_set_option(b"conv_bf16", 2))
+    try:
+        dx = ops.conv2d(dy, ops.pack_conv_weight_T(w), None, 1, pad_lo=0, bf16=ops.pack_bf16_weight(w, transposed=True))
+        assert _native.lib().adm_last_conv_variant() == 5116
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+    exact = torch.nn.grad.conv2d_input((Nn, Cin, H, W), _bf(w.cpu()), _bf(dy.cpu()))
+    assert _relerr(dx.double(), exact) < 2e-6
+
+
+PW_WGRAD_CASES = [
+    # (N, C1, C2, H, W, Cout, gn, act, max_split)
+    (1, 128, 0, 8, 8, 128, 0, 0, 0),       # one stage, bare
+    (2, 128, 128, 8, 16, 128, 0, 0, 2),    # shortcut on a virtual concat, several stages per workgroup
+    (3, 128, 0, 8, 8, 256, 1, 1, 1),       # GroupNorm + SiLU recomputed on the load path, odd stage count, two cout tiles
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", PW_WGRAD_CASES, ids=[str(i) for i in range(len(PW_WGRAD_CASES))])
+def test_conv1x1_bf16_weight_gradient(backend, case):
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, C1, C2, H, W, Cout, use_gn, act, max_split = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    a = torch.cat([x1, x2], 1).cpu() if C2 else x1.cpu()
+    if use_gn:
+        a = F.group_norm(a, 32, gamma.cpu(), beta.cpu(), 1e-5)
+    if act:
+        a = F.silu(a)
+    dy = _rand((Nn, Cout, H, W), 7, "cpu")
+    exact = torch.nn.grad.conv2d_weight(_bf(a), (Cout, Ct, 1, 1), _bf(dy))
+    full = torch.nn.grad.conv2d_weight(a.double(), (Cout, Ct, 1, 1), dy.double())
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
+    _native.check(_native.lib().adm_set_option(b"conv_bf16", 2))
+    _native.check(_native.lib().adm_set_option(b"wgrad_max_split", max_split))
+    try:
+        dW = ops.conv2d_wgrad(x1, dy.to(dev), Cout, 1, x2=x2, pad_lo=0, gn=gn, act=bool(act))
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+        _native.check(_native.lib().adm_set_option(b"wgrad_max_split", 0))
+    tight = 2e-6 if not (use_gn or act) else 3e-4
+    assert _relerr(dW.double(), exact) < tight, _relerr(dW.double(), exact)
+    assert 1e-5 < _relerr(dW.double(), full) < 8e-3
