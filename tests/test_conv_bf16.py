@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from native_backend import BACKENDS, select
+from native_backend import BACKENDS, BACKENDS_FIRST_CONTACT, select
 from test_kernels import _rand, _relerr
 
 CASES = [
@@ -166,7 +166,7 @@ PW_CASES = [
 ]
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
 @pytest.mark.parametrize("case", PW_CASES, ids=[str(i) for i in range(len(PW_CASES))])
 def test_conv1x1_bf16_forward(backend, case):
     dev = select(backend)
@@ -210,7 +210,7 @@ def test_conv1x1_bf16_forward(backend, case):
     assert _relerr(out.double(), full) < 8e-3
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
 def test_conv1x1_bf16_data_gradient(backend):
     dev = select(backend)
     from audiodiffusion import _native, ops
@@ -235,7 +235,7 @@ PW_WGRAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
 @pytest.mark.parametrize("case", PW_WGRAD_CASES, ids=[str(i) for i in range(len(PW_WGRAD_CASES))])
 def test_conv1x1_bf16_weight_gradient(backend, case):
     dev = select(backend)
