@@ -41,7 +41,7 @@ def _mha(q, k, v, heads):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("C,heads,S", [(32, 8, 1), (64, 8, 3), (128, 8, 5), (32, 2, 2)])
+@pytest.mark.parametrize("C,heads,S", [(32, 8, 1), (64, 8, 3), (128, 8, 5), (32, 2, 2), (64, 2, 2), (128, 2, 3)])
 def test_cross_attention_on_encoding(backend, C, heads, S):
     dev = select(backend)
     from audiodiffusion import ops
@@ -59,7 +59,8 @@ def test_cross_attention_on_encoding(backend, C, heads, S):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("C,heads,HW,key_block", [(32, 2, (8, 8), 16), (64, 8, (4, 24), 32), (32, 8, (8, 8), 0)])
+@pytest.mark.parametrize("C,heads,HW,key_block", [(32, 2, (8, 8), 16), (64, 8, (4, 24), 32), (32, 8, (8, 8), 0),
+                                                   (64, 2, (8, 8), 24), (128, 2, (4, 8), 16)])
 def test_self_attention_key_blocks_match_one_pass(backend, C, heads, HW, key_block):
     """Online softmax over key blocks (needed at 64x64 latents: 4096 tokens) == the one-pass kernel == torch."""
     dev = select(backend)
@@ -101,7 +102,7 @@ def test_geglu_backward(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
-@pytest.mark.parametrize("C,heads,S", [(32, 8, 1), (64, 8, 3), (32, 2, 2)])
+@pytest.mark.parametrize("C,heads,S", [(32, 8, 1), (64, 8, 3), (32, 2, 2), (64, 2, 2), (128, 2, 3)])
 def test_cross_attention_backward(backend, C, heads, S):
     dev = select(backend)
     from audiodiffusion import ops
@@ -123,7 +124,8 @@ def test_cross_attention_backward(backend, C, heads, S):
 
 
 @pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
-@pytest.mark.parametrize("C,heads,HW,block", [(32, 2, (8, 8), 16), (64, 8, (4, 24), 32), (64, 4, (8, 8), 0)])
+@pytest.mark.parametrize("C,heads,HW,block", [(32, 2, (8, 8), 16), (64, 8, (4, 24), 32), (64, 4, (8, 8), 0),
+                                               (64, 2, (8, 8), 24), (128, 2, (4, 8), 16)])
 def test_self_attention_backward_in_blocks(backend, C, heads, HW, block):
     dev = select(backend)
     from audiodiffusion import ops
