@@ -203,16 +203,23 @@ class Mel:
 
     # ---- reference API -------------------------------------------------------------------------------------
     def load_audio(self, audio_file: str = None, raw_audio: np.ndarray = None):
-        """Load audio (`mel.py:92-106`). Files: WAV via scipy only (librosa's decoders/resampler are out of scope)."""
+        """Load audio (`mel.py:92-106`). Files: WAV via scipy (other rates are resampled with scipy's polyphase filter,
+        not librosa's soxr_hq: decoding is outside the parity scope)."""
         if audio_file is not None:
             import scipy.io.wavfile
             sr, data = scipy.io.wavfile.read(audio_file)
-            if sr != self.sr:
-                raise NotImplementedError(f"resampling {sr} -> {self.sr} Hz is not implemented; pass raw_audio at {self.sr} Hz")
             if data.dtype.kind in "iu":
                 data = data.astype(np.float32) / np.iinfo(data.dtype).max
             if data.ndim > 1:
                 data = data.mean(axis=1)
+            if sr != self.sr:
+                # librosa.load resamples with soxr_hq (`mel.py:100`); soxr is not available here, so a file at another
+                # rate goes through scipy's polyphase (Kaiser-windowed) resampler: band-limited and length-consistent, but
+                # NOT sample-identical to the reference — file decoding is outside the parity scope (SURVEY §8(a) M1)
+                import math
+                import scipy.signal
+                g = math.gcd(int(sr), int(self.sr))
+                data = scipy.signal.resample_poly(data.astype(np.float64), self.sr // g, sr // g)
             self.audio = data.astype(np.float32)
         else:
             self.audio = raw_audio

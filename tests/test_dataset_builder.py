@@ -59,3 +59,18 @@ def test_audio_to_images_matches_the_oracle_slice_by_slice(backend, tmp_path):
         assert got.shape == (y_res, x_res) and got.dtype == np.uint8
         d = np.abs(got.astype(int) - ref.astype(int))       # same bar as tests/test_mel.py
         assert d.max() <= 1 and (d == 0).mean() >= 0.999, f"{r['audio_file']} slice {r['slice']}: {d.max()} {(d == 0).mean()}"
+
+
+def test_wav_at_another_rate_is_resampled(tmp_path):
+    """`librosa.load(file, sr=...)` (mel.py:100) resamples; here scipy's polyphase filter stands in (not sample-identical,
+    decoding is outside the parity scope): the length scales with the rate ratio and a tone keeps its frequency."""
+    import scipy.io.wavfile
+    select("emu")
+    from audiodiffusion import Mel
+    mel = Mel(x_res=16, y_res=16, hop_length=64, n_fft=256, sample_rate=4000)
+    t = np.arange(12000) / 12000.0
+    scipy.io.wavfile.write(tmp_path / "a.wav", 12000, (0.4 * np.sin(2 * np.pi * 500 * t)).astype(np.float32))
+    mel.load_audio(str(tmp_path / "a.wav"))
+    assert len(mel.audio) == 4000 and mel.audio.dtype == np.float32
+    spec = np.abs(np.fft.rfft(mel.audio))
+    assert abs(int(spec.argmax()) - 500) <= 1            # 1 Hz per bin over one second
