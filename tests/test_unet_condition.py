@@ -159,4 +159,17 @@ def test_conditional_unet_gradients_match_autograd(backend, cfg, B, S):
     opt = T.AdamW(flat, lr=1e-4)
     opt.step(grads, clip=T.clip_grad_norm_(grads, 1.0))
     mine.refresh_weights()
-    assert float(mine.train_step(x.to(dev), ts, tgt.to(dev), enc.to(dev))) < float(loss)
+    # data-parallel overlap: every bucket of the flat gradient buffer is reported ready exactly once by the reverse pass
+    # (LayerNorm affine, to_k / to_v, bias-free projections included), so no bucket waits for the end of the backward
+    import ctypes as C
+    from audiodiffusion import _native as N
+    per = 4096
+    lows = list(range(0, grads.numel(), per)) + [grads.numel()]
+    fired = []
+    cb = N.BUCKET_FN(lambda _u, b: fired.append(b))
+    N.check(N.lib().adm_unet_set_grad_bucket_hook(mine._handle, len(lows) - 1, (C.c_long * len(lows))(*lows),
+                                                  C.cast(cb, C.c_void_p), None))
+    loss2 = float(mine.train_step(x.to(dev), ts, tgt.to(dev), enc.to(dev)))
+    N.check(N.lib().adm_unet_set_grad_bucket_hook(mine._handle, 0, None, None, None))
+    assert sorted(fired) == list(range(len(lows) - 1))
+    assert loss2 < float(loss)
