@@ -70,6 +70,12 @@ class AudioDiffusion:
 
     @staticmethod
     def loop_it(audio: np.ndarray, sample_rate: int, loops: int = 12) -> np.ndarray:
-        """Loop audio on bar boundaries (`__init__.py:124-140`). The reference delegates to librosa's beat tracker, a post-hoc
-        CPU nicety that SURVEY.md §2.1 #3 places outside the hot path."""
-        raise NotImplementedError("loop_it needs librosa.beat.beat_track, which is outside the MI355X hot path")
+        """Loop audio on bar boundaries (`__init__.py:124-140`): the stretch from the first tracked beat to the last whole
+        bar of four beats, tiled `loops` times; None when no full bar was found.  The beat tracker is `beat.beat_track`, a
+        host-side restatement of `librosa.beat.beat_track` (post-processing on the CPU, as in the reference)."""
+        from .beat import beat_track
+        _, beats = beat_track(y=audio, sr=sample_rate, units="samples")
+        beats_in_bar = (len(beats) - 1) // 4 * 4
+        if beats_in_bar > 0:
+            return np.tile(audio[beats[0]:beats[beats_in_bar]], loops)
+        return None
