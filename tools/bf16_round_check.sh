@@ -13,7 +13,3 @@ export ADM_BF16_WIDE=$W
 timeout 30 python -m pytest tests/test_conv_bf16.py tests/test_backward.py -m gpu -q -k "bf16 or linear" 2>&1 | tail -2
 PROBE_MP=bf16 PROBE_TIMEOUT=40 bash tools/profile_train_trace.sh r01s 2>&1 | head -8 | cut -c1-140
 grep "train step" $O/tr.log
-# opt-in level 2 (1x1 convolutions on bf16 operands too; emulator-verified at the end of round 1, never timed): A/B
-ADM_BF16_LEVEL=2 PROBE_CHECK=0 PROBE_B=16 PROBE_MP=bf16 timeout 60 python tools/gpu_probe.py trainstep 2>&1 | grep "train step" | sed 's/^/level2: /'
-ADM_TEST_UNTIMED=1 ADM_BF16_LEVEL=2 timeout 60 python -m pytest tests/test_conv_bf16.py tests/test_unet_training.py tests/test_transformer_ops.py tests/test_unet_condition.py -m gpu -q 2>&1 | tail -3
-timeout 90 python tools/cond_probe.py 2>&1 | tail -3

@@ -1,0 +1,17 @@
+# First GPU command of the next round: run everything that was written after round 1's GPU budget was spent and has
+# therefore only ever run on the emulator.   gpurun --timeout 400 -- 'bash tools/first_contact.sh r02a'
+#   1. the hardware variants of the first-contact tests (transformer-block backward kernels, conditional-UNet gradients,
+#      opt-in bf16 1x1 convolutions) — ADM_TEST_UNTIMED=1 un-skips them
+#   2. bf16 training step, level 1 (measured: 114.8 ms at B = 16) against level 2 (1x1 convolutions on bf16 operands too)
+#   3. the conditional UNet at the reference configuration, 64x64 latents: timing + parity against the oracle
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/${1:-first_contact}; mkdir -p $O
+cd $R
+ADM_TEST_UNTIMED=1 timeout 150 python -m pytest tests/test_conv_bf16.py tests/test_transformer_ops.py tests/test_unet_condition.py \
+    -m gpu -q 2>&1 | tail -15 > $O/first_contact_pytest.txt
+tail -3 $O/first_contact_pytest.txt
+for L in 1 2; do
+  ADM_BF16_LEVEL=$L PROBE_CHECK=0 PROBE_B=16 PROBE_MP=bf16 timeout 90 python tools/gpu_probe.py trainstep 2>&1 | grep "train step" | sed "s/^/bf16 level $L: /" | tee -a $O/train_levels.txt
+done
+ADM_TEST_UNTIMED=1 ADM_BF16_LEVEL=2 timeout 90 python -m pytest tests/test_unet_training.py -m gpu -q -k mixed_precision 2>&1 | tail -2 | tee $O/level2_parity.txt
+timeout 120 python tools/cond_probe.py 2>&1 | tail -3 | tee $O/cond_probe.txt
