@@ -51,6 +51,10 @@ int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int tra
 void set_conv_bf16(int m);   // 0 off (default), 1 = 3x3 convs, 2 = 3x3 and 1x1 convs (opt-in), -1 = ADM_CONV_BF16
 bool conv_bf16_enabled();
 int conv_bf16_mode();
+// k_conv_bf16_persist.hip (opt-in ADM_BF16_PERSIST=1: persistent chunk-stream variant of the 3x3 bf16 kernel)
+bool conv_bf16_persist_enabled();
+void set_conv_bf16_persist(int v);
+int launch_conv_bf16_persist(const adm_conv_args& a, hipStream_t st);
 // k_conv1x1_bf16.hip (mode 2)
 bool conv1x1_bf16_eligible(const adm_conv_args& a);
 int launch_conv1x1_bf16(const adm_conv_args& a, hipStream_t st);

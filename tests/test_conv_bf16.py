@@ -264,3 +264,57 @@ def test_conv1x1_bf16_weight_gradient(backend, case):
     tight = 2e-6 if not (use_gn or act) else 3e-4
     assert _relerr(dW.double(), exact) < tight, _relerr(dW.double(), exact)
     assert 1e-5 < _relerr(dW.double(), full) < 8e-3
+
+
+# ---------------------------------------------------------------- persistent chunk-stream variant (option conv_bf16_persist)
+PERSIST_CASES = [
+    # (N, C1, C2, H, W, Cout, up, gn, act, temb, res)
+    (2, 64, 0, 16, 32, 128, 0, 1, 1, 1, 1),      # 4 tiles on a 3-workgroup grid: tile boundaries inside a workgroup, 4 chunks
+    (3, 48, 16, 32, 16, 256, 0, 1, 1, 0, 1),     # two cout tiles per pixel tile (filters change across the boundary), 3 images
+    (2, 128, 0, 16, 16, 128, 0, 0, 0, 0, 0),     # one tile per image: the GroupNorm row set flips at every boundary, 8 chunks
+    (1, 64, 0, 16, 16, 128, 1, 1, 1, 0, 0),      # nearest x2 folded: 32x32 output, image borders on every tile
+    (5, 64, 0, 16, 16, 128, 0, 1, 0, 1, 0),      # 5 tiles on 3 workgroups: ranges of 2, 2 and 1 tiles
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("case", PERSIST_CASES, ids=[str(i) for i in range(len(PERSIST_CASES))])
+def test_conv_bf16_persistent_stream_matches_one_tile_per_workgroup(backend, case):
+    """The chunk stream that runs across tile boundaries must produce exactly what the one-tile-per-workgroup kernel does
+    (same operands, same accumulation order inside a tile: bit-identical), and both match the rounded-operand reference."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, C1, C2, H, W, Cout, up, use_gn, act, use_temb, use_res = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    w = _rand((Cout, Ct, 3, 3), 3, dev, scale=(Ct * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
+    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
+
+    def run():
+        return ops.conv2d(x1, ops.pack_conv_weight(w), b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb,
+                          residual=res, bf16=ops.pack_bf16_weight(w))
+
+    _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
+    try:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", 0))
+        one = run()
+        assert _native.lib().adm_last_conv_variant() == 5316
+        _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", 1))
+        stream = run()
+        assert _native.lib().adm_last_conv_variant() == 5317, "the persistent kernel was not selected"
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", 0))
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+    assert torch.equal(stream.cpu(), one.cpu())
+    c = lambda t: None if t is None else t.cpu()  # noqa: E731
+    xg = torch.cat([c(x1), c(x2)], 1) if C2 else c(x1)
+    if use_gn:
+        xg = F.group_norm(xg, 32, c(gamma), c(beta), 1e-5)
+    exact, _ = _refs(xg, None, c(w), c(b), up, None, act, c(temb), c(res))
+    assert _relerr(stream.double(), exact) < (2e-6 if not (use_gn or act) else 3e-4)

@@ -3,6 +3,7 @@
 #   1. the hardware variants of the first-contact tests (transformer-block backward kernels, conditional-UNet gradients,
 #      opt-in bf16 1x1 convolutions) — ADM_TEST_UNTIMED=1 un-skips them
 #   2. bf16 training step, level 1 (measured: 114.8 ms at B = 16) against level 2 (1x1 convolutions on bf16 operands too)
+#      ... and the persistent chunk-stream forward kernel (ADM_BF16_PERSIST=1), per layer shape and on the whole step
 #   3. the conditional UNet at the reference configuration, 64x64 latents: timing + parity against the oracle
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-first_contact}; mkdir -p $O
@@ -10,6 +11,8 @@ cd $R
 ADM_TEST_UNTIMED=1 timeout 150 python -m pytest tests/test_conv_bf16.py tests/test_transformer_ops.py tests/test_unet_condition.py \
     -m gpu -q 2>&1 | tail -15 > $O/first_contact_pytest.txt
 tail -3 $O/first_contact_pytest.txt
+ADM_BF16_PERSIST=1 PROBE_CHECK=0 PROBE_B=16 PROBE_MP=bf16 timeout 90 python tools/gpu_probe.py trainstep 2>&1 | grep "train step" | sed "s/^/bf16 level 1 + persistent forward kernel: /" | tee -a $O/train_levels.txt
+for V in 0 1; do ADM_BF16_PERSIST=$V ADM_BF16_WIDE=0 timeout 40 python tools/bf16_ab_probe.py 2>&1 | grep -v "^TOTAL" | sed "s/^/persist=$V /" | tee -a $O/persist_ab.txt; done
 for L in 1 2; do
   ADM_BF16_LEVEL=$L PROBE_CHECK=0 PROBE_B=16 PROBE_MP=bf16 timeout 90 python tools/gpu_probe.py trainstep 2>&1 | grep "train step" | sed "s/^/bf16 level $L: /" | tee -a $O/train_levels.txt
 done
