@@ -74,7 +74,7 @@ def test_random_bf16_forward(backend, case):
     assert _relerr(out.double(), ref) < (2e-6 if not (use_gn or act) else 3e-4)
 
 
-WG_CASES = [(rng_n, c1, c2, h, w, co, gn, act, ms) for (rng_n, c1, c2, h, w, co, _up, gn, act, _t, _r, _v), ms in
+WG_CASES = [(rng_n, c1, c2, h, w, co, up, gn, act, ms) for (rng_n, c1, c2, h, w, co, up, gn, act, _t, _r, _v), ms in
             zip(_cases(8, 7), [0, 1, 2, 0, 3, 0, 2, 1])]
 
 
@@ -83,7 +83,7 @@ WG_CASES = [(rng_n, c1, c2, h, w, co, gn, act, ms) for (rng_n, c1, c2, h, w, co,
 def test_random_bf16_weight_gradient(backend, case):
     dev = select(backend)
     from audiodiffusion import _native, ops
-    Nn, C1, C2, H, W, Cout, use_gn, act, max_split = case
+    Nn, C1, C2, H, W, Cout, up, use_gn, act, max_split = case
     x1 = _rand((Nn, C1, H, W), 1, dev)
     x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
     Ct = C1 + C2
@@ -93,13 +93,15 @@ def test_random_bf16_weight_gradient(backend, case):
         a = F.group_norm(a, 32, gamma.cpu(), beta.cpu(), 1e-5)
     if act:
         a = F.silu(a)
-    dy = _rand((Nn, Cout, H, W), 7, "cpu")
+    if up:
+        a = F.interpolate(a, scale_factor=2.0, mode="nearest")
+    dy = _rand((Nn, Cout) + tuple(a.shape[2:]), 7, "cpu")
     ref = torch.nn.grad.conv2d_weight(_bf(a), (Cout, Ct, 3, 3), _bf(dy), padding=1)
     gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
     _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
     _native.check(_native.lib().adm_set_option(b"wgrad_max_split", max_split))
     try:
-        dW = ops.conv2d_wgrad(x1, dy.to(dev), Cout, 3, x2=x2, gn=gn, act=bool(act))
+        dW = ops.conv2d_wgrad(x1, dy.to(dev), Cout, 3, x2=x2, up=bool(up), gn=gn, act=bool(act))
     finally:
         _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
         _native.check(_native.lib().adm_set_option(b"wgrad_max_split", 0))
