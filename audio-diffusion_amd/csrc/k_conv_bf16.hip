@@ -30,6 +30,7 @@ struct Bf16ConvParams {
   const float* residual; float* out;
   int tiles_x, tiles_y, n_ct, nblk;
   long x1_bs, x2_bs;
+  int zins;   // UP kernels: 1 = zero-insertion x2 (data gradient of a stride-2 convolution) instead of nearest x2
 };
 
 constexpr int BPW = 18, BPP = BPW * BPW;   // input patch of a 16x16 output tile
@@ -74,7 +75,8 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams 
     const int q = r == 0 ? 64 * wave + lane : 256 + 64 * (wave & 1) + lane;
     const int ly = q / BPW, lx = q - ly * BPW;
     const int gy = ty * 16 + ly - 1, gx = tx * 16 + lx - 1;
-    const bool ok = (q < BPP) & (gy >= 0) & (gy < p.Hi) & (gx >= 0) & (gx < p.Wi);
+    bool ok = (q < BPP) & (gy >= 0) & (gy < p.Hi) & (gx >= 0) & (gx < p.Wi);
+    if (UP) ok = ok & !(p.zins && ((gy | gx) & 1));          // zero insertion: odd rows / columns are the inserted zeros
     soff[r] = ok ? (UP ? (gy >> 1) * p.Ws + (gx >> 1) : gy * p.Ws + gx) : -1;
   }
   float* gnS = reinterpret_cast<float*>(lds + 4 * BPP);     // [Ct] scale, then [Ct] shift of image n
@@ -492,7 +494,9 @@ bool conv_bf16_enabled() {
 // 3x3 stride 1 "same", output a multiple of 16x16, an even number of 16-channel chunks none of which straddles the
 // concat seam, Cout % 128.
 bool conv_bf16_eligible(const adm_conv_args& a) {
-  if (a.ks != 3 || a.stride != 1 || a.pad_lo != 1 || a.w_bstride != 0 || a.bf16_packed == nullptr || a.up > 1) return false;
+  if (a.ks != 3 || a.stride != 1 || a.pad_lo != 1 || a.w_bstride != 0 || a.bf16_packed == nullptr) return false;
+  // up = 2 (zero insertion: the data gradient of a stride-2 convolution) only at the opt-in level 2: not yet run on hardware
+  if (a.up > (conv_bf16_mode() >= 2 ? 2 : 1)) return false;
   const int C2 = a.x2 ? a.C2 : 0;
   const int Hi = a.up ? 2 * a.H : a.H, Wi = a.up ? 2 * a.W : a.W;
   return Wi % 16 == 0 && Hi % 16 == 0 && (a.C1 + C2) % 32 == 0 && a.C1 % 16 == 0 && a.Cout % 128 == 0 &&
@@ -502,7 +506,7 @@ bool conv_bf16_eligible(const adm_conv_args& a) {
 int launch_conv_bf16(const adm_conv_args& a, hipStream_t st) {
   Bf16ConvParams p;
   const int C2 = a.x2 ? a.C2 : 0, Ct = a.C1 + C2;
-  if (conv_bf16_persist_enabled() && Ct >= 64 && Ct <= 1024) return launch_conv_bf16_persist(a, st);   // opt-in (k_conv_bf16_persist.hip)
+  if (conv_bf16_persist_enabled() && Ct >= 64 && Ct <= 1024 && a.up <= 1) return launch_conv_bf16_persist(a, st);   // opt-in (k_conv_bf16_persist.hip)
   p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2;
   p.N = a.N; p.Hs = a.H; p.Ws = a.W;
   p.Hi = a.up ? 2 * a.H : a.H; p.Wi = a.up ? 2 * a.W : a.W;
@@ -515,7 +519,7 @@ int launch_conv_bf16(const adm_conv_args& a, hipStream_t st) {
   p.chan_add = a.chan_add; p.chan_add_stride = a.chan_add_stride;
   if (p.chan_add == nullptr) { p.chan_add = conv_zero_bias(a.Cout); p.chan_add_stride = 0; }
   ADM_REQUIRE(p.gn_scale && p.gn_shift && p.bias && p.chan_add, "conv_bf16: constant buffers");
-  p.residual = a.residual; p.out = a.out;
+  p.residual = a.residual; p.out = a.out; p.zins = a.up == 2;
   p.tiles_x = p.Wi / 16; p.tiles_y = p.Hi / 16; p.n_ct = a.Cout / 128;
   p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;

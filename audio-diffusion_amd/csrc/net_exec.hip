@@ -645,7 +645,8 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       a.x1 = dy; a.C1 = Cout; a.N = B; a.H = to.H; a.W = to.W;
       a.up = o.stride == 2 ? 2 : 0; a.stride = 1; a.ks = o.ks; a.pad_lo = o.ks == 3 ? 1 : 0;
       a.wpacked = o.w->wpT; a.bias = nullptr; a.Cout = Ct;
-      if (o.stride == 1) { a.wino_packed = o.w->wuT; a.bf16_packed = o.w->wbT; }   // 3x3 stride-1: the data gradient is a Winograd-/bf16-eligible convolution too
+      if (o.stride == 1) a.wino_packed = o.w->wuT;   // 3x3 stride-1: the data gradient is a Winograd-eligible convolution too
+      a.bf16_packed = o.w->wbT;                      // bf16: stride-1, and (opt-in level 2) stride-2 via zero insertion
       if (direct) {
         a.out = t1.grad;
         if (t1.ginit) a.residual = t1.grad;   // accumulate in the epilogue (same thread reads then writes)

@@ -318,3 +318,25 @@ def test_conv_bf16_persistent_stream_matches_one_tile_per_workgroup(backend, cas
         xg = F.group_norm(xg, 32, c(gamma), c(beta), 1e-5)
     exact, _ = _refs(xg, None, c(w), c(b), up, None, act, c(temb), c(res))
     assert _relerr(stream.double(), exact) < (2e-6 if not (use_gn or act) else 3e-4)
+
+
+@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+def test_conv_bf16_stride2_data_gradient_by_zero_insertion(backend):
+    """Backward-data pass of a 3x3 stride-2 Conv2d (Downsample2D) = the bf16 kernel on the zero-inserted dy (up = 2) with
+    transposed, flipped filters; opt-in level 2."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, Cin, Cout, H, W = 2, 128, 64, 32, 32           # forward: (Cin, 32, 32) -> (Cout, 16, 16)
+    w = _rand((Cout, Cin, 3, 3), 11, dev, scale=(Cin * 9) ** -0.5)
+    dy = _rand((Nn, Cout, H // 2, W // 2), 12, dev)
+    _native.check(_native.lib().adm_set_option(b"conv_bf16", 2))
+    try:
+        dx = ops.conv2d(dy, ops.pack_conv_weight_T(w), None, 3, up=2, bf16=ops.pack_bf16_weight(w, transposed=True))
+        assert _native.lib().adm_last_conv_variant() == 5316
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))        # level 1 keeps this one in fp32
+        ops.conv2d(dy, ops.pack_conv_weight_T(w), None, 3, up=2, bf16=ops.pack_bf16_weight(w, transposed=True))
+        assert _native.lib().adm_last_conv_variant() != 5316
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+    exact = torch.nn.grad.conv2d_input((Nn, Cin, H, W), _bf(w.cpu()), _bf(dy.cpu()), stride=2, padding=1)
+    assert _relerr(dx.double(), exact) < 2e-6, _relerr(dx.double(), exact)
