@@ -128,8 +128,8 @@ def test_save_load_roundtrip_and_facade(tmp_path):
     ad.pipe.set_progress_bar_config(disable=True)
     img, (sr, audio) = ad.generate_spectrogram_and_audio(steps=2, noise=noise.clone())
     assert img.size == (16, 16) and sr == 4000 and audio.ndim == 1
-    with pytest.raises(NotImplementedError):
-        AudioDiffusion.loop_it(audio, sr)
+    looped = AudioDiffusion.loop_it(audio, sr)          # a quarter of a second of model output rarely holds a full bar
+    assert looped is None or (looped.ndim == 1 and len(looped) % 12 == 0)
 
 
 # ---------------------------------------------------------------- latent audio diffusion (config 4: AutoencoderKL)
