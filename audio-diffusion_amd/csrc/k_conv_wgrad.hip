@@ -798,6 +798,14 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
     ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, st, (const float*)workspace, slabs, numel, dW, accumulate);
     return ADM_CHECK_LAUNCH();
   }
+  if (conv_bf16_enabled() && conv_wgrad_bf16_eligible(a) && wgrad_bf16_8w_enabled() && p.split >= 2) {   // opt-in 8-wave variant
+    const int slabs = launch_conv_wgrad_bf16w8(a, dy, workspace, p.split, st);
+    ADM_REQUIRE(slabs > 0 && slabs <= p.split, "conv_wgrad_bf16w8: launch failed");
+    long gb = (numel + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, st, (const float*)workspace, slabs, numel, dW, accumulate);
+    return ADM_CHECK_LAUNCH();
+  }
   if (conv_bf16_enabled() && conv_wgrad_bf16_eligible(a)) {   // mixed precision: bf16 operands, fp32 partial sums
     ADM_TRY(launch_conv_wgrad_bf16(a, dy, dW, accumulate, workspace, p.split, st));
     long gb = (numel + 255) / 256;

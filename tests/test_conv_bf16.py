@@ -340,3 +340,42 @@ def test_conv_bf16_stride2_data_gradient_by_zero_insertion(backend):
         _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
     exact = torch.nn.grad.conv2d_input((Nn, Cin, H, W), _bf(w.cpu()), _bf(dy.cpu()), stride=2, padding=1)
     assert _relerr(dx.double(), exact) < 2e-6, _relerr(dx.double(), exact)
+
+
+@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("case", WGRAD_CASES + [(2, 64, 32, 16, 32, 256, 0, 1, 1, 0), (1, 32, 0, 8, 16, 128, 1, 1, 1, 4)],
+                         ids=[str(i) for i in range(len(WGRAD_CASES) + 2)])
+def test_conv_bf16_weight_gradient_8_waves(backend, case):
+    """Opt-in 8-wave variant (option wgrad_bf16_8w): two wave groups share the staged tile, multiply different pixel rows and
+    write separate partial-sum slabs; same operands as the 4-wave kernel, so the same bars."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, C1, C2, H, W, Cout, up, use_gn, act, max_split = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    a = torch.cat([x1, x2], 1).cpu() if C2 else x1.cpu()
+    if use_gn:
+        a = F.group_norm(a, 32, gamma.cpu(), beta.cpu(), 1e-5)
+    if act:
+        a = F.silu(a)
+    if up:
+        a = F.interpolate(a, scale_factor=2.0, mode="nearest")
+    dy = _rand((Nn, Cout) + tuple(a.shape[2:]), 7, "cpu")
+    exact = torch.nn.grad.conv2d_weight(_bf(a), (Cout, Ct, 3, 3), _bf(dy), padding=1)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
+    got = {}
+    for w8 in (0, 1):
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
+        _native.check(_native.lib().adm_set_option(b"wgrad_bf16_8w", w8))
+        _native.check(_native.lib().adm_set_option(b"wgrad_max_split", max_split))
+        try:
+            got[w8] = ops.conv2d_wgrad(x1, dy.to(dev), Cout, 3, x2=x2, up=bool(up), gn=gn, act=bool(act))
+        finally:
+            _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+            _native.check(_native.lib().adm_set_option(b"wgrad_bf16_8w", 0))
+            _native.check(_native.lib().adm_set_option(b"wgrad_max_split", 0))
+    tight = 2e-6 if not (use_gn or act) else 3e-4
+    assert _relerr(got[1].double(), exact) < tight, _relerr(got[1].double(), exact)
+    assert _relerr(got[1].double(), got[0].double()) < 2e-6      # same products, different summation partition
