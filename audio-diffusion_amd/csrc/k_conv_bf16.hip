@@ -506,7 +506,8 @@ bool conv_bf16_eligible(const adm_conv_args& a) {
 int launch_conv_bf16(const adm_conv_args& a, hipStream_t st) {
   Bf16ConvParams p;
   const int C2 = a.x2 ? a.C2 : 0, Ct = a.C1 + C2;
-  if (conv_bf16_persist_enabled() && Ct >= 64 && Ct <= 1024 && a.up <= 1) return launch_conv_bf16_persist(a, st);   // opt-in (k_conv_bf16_persist.hip)
+  if (conv_bf16_persist_enabled() && Ct >= 64 && Ct <= 1024 && a.up <= 1) return launch_conv_bf16_persist(a, st);
+  if (conv_bf16_8w_enabled()) return launch_conv_bf16w8(a, st);                          // opt-in (k_conv_bf16w8.hip)   // opt-in (k_conv_bf16_persist.hip)
   p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2;
   p.N = a.N; p.Hs = a.H; p.Ws = a.W;
   p.Hi = a.up ? 2 * a.H : a.H; p.Wi = a.up ? 2 * a.W : a.W;

@@ -32,7 +32,8 @@ int adm_is_device_build(void);
  * 2 = additionally the eligible 1x1 convolutions (opt-in: emulator-verified, not yet timed), 0 = fp32 everywhere
  * (default), -1 = back to the ADM_CONV_BF16 environment variable; "conv_bf16_persist" = 1 selects the persistent
  * chunk-stream variant of the 3x3 bf16 kernel, "wgrad_bf16_8w" = 1 the 8-wave variant of the bf16 3x3 weight-gradient
- * kernel (both opt-in, ADM_BF16_PERSIST / ADM_WGRAD_BF16_8W; emulator-verified, not yet timed). */
+ * kernel, "conv_bf16_8w" = 1 the 8-wave variant of the forward / data-gradient kernel (all opt-in: ADM_BF16_PERSIST,
+ * ADM_WGRAD_BF16_8W, ADM_BF16_8W; emulator-verified, not yet timed). */
 int adm_set_option(const char* name, int value);
 /* Kernel variant the last adm_conv2d on this thread dispatched to (see adm_op_profile.variant; 4311 = Winograd). */
 int adm_last_conv_variant(void);

@@ -379,3 +379,35 @@ def test_conv_bf16_weight_gradient_8_waves(backend, case):
     tight = 2e-6 if not (use_gn or act) else 3e-4
     assert _relerr(got[1].double(), exact) < tight, _relerr(got[1].double(), exact)
     assert _relerr(got[1].double(), got[0].double()) < 2e-6      # same products, different summation partition
+
+
+@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("case", CASES + PERSIST_CASES, ids=[str(i) for i in range(len(CASES) + len(PERSIST_CASES))])
+def test_conv_bf16_forward_8_waves_matches_4_waves(backend, case):
+    """Opt-in 8-wave forward kernel (option conv_bf16_8w): same operands, same per-tile accumulation order -> bit-identical
+    to the 4-wave kernel."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, C1, C2, H, W, Cout, up, use_gn, act, use_temb, use_res = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    w = _rand((Cout, Ct, 3, 3), 3, dev, scale=(Ct * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32 if Ct % 32 == 0 else 16, 1e-5, x2=x2) if use_gn else None
+    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
+    got = {}
+    _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
+    try:
+        for w8 in (0, 1):
+            _native.check(_native.lib().adm_set_option(b"conv_bf16_8w", w8))
+            got[w8] = ops.conv2d(x1, ops.pack_conv_weight(w), b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb,
+                                 residual=res, bf16=ops.pack_bf16_weight(w))
+            assert _native.lib().adm_last_conv_variant() == (5318 if w8 else 5316)
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16_8w", 0))
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+    assert torch.equal(got[1].cpu(), got[0].cpu())
