@@ -55,6 +55,7 @@ int conv_bf16_mode();
 bool conv_bf16_persist_enabled();
 void set_conv_bf16_persist(int v);
 int launch_conv_bf16_persist(const adm_conv_args& a, hipStream_t st);
+int launch_conv_bf16_persist8(const adm_conv_args& a, hipStream_t st);   // k_conv_bf16_persist8.hip (persist mode 2)
 // k_conv_bf16w8.hip (opt-in ADM_BF16_8W=1: 8-wave variant of the bf16 3x3 forward / data-gradient kernel)
 bool conv_bf16_8w_enabled();
 void set_conv_bf16_8w(int v);

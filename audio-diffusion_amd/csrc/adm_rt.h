@@ -28,6 +28,7 @@
 #define ADM_PK_BF16(a, b) adm_emu::pk_bf16((a), (b))
 #define ADM_MFMA_BF16(a, b, c) adm_emu::mfma_f32_32x32x16_bf16((a), (b), (c))
 #define ADM_ALIGNBIT(hi, lo, sh) ((unsigned)((((uint64_t)(hi) << 32) | (uint64_t)(lo)) >> (sh)))
+#define ADM_OPAQUE_V(x) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -42,6 +43,9 @@ typedef __bf16 adm_bf16x2 __attribute__((ext_vector_type(2)));
 #define ADM_MFMA_BF16(a, b, c) \
   __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(adm_bf16x8, (a)), __builtin_bit_cast(adm_bf16x8, (b)), (c), 0, 0, 0)
 #define ADM_ALIGNBIT(hi, lo, sh) __builtin_amdgcn_alignbit((hi), (lo), (sh))
+// makes a per-lane value opaque to the optimiser (no instruction): stops it from folding a loop-invariant lane offset into
+// dozens of pre-computed 64-bit addresses that then live in registers across the whole loop
+#define ADM_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #define ADM_LAUNCH(kern, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), (shmem), (stream), __VA_ARGS__)
 #define ADM_DYN_SMEM(type, name)                                              \

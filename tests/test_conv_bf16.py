@@ -278,8 +278,9 @@ PERSIST_CASES = [
 
 
 @pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("mode", [1, 2], ids=["4waves", "8waves"])
 @pytest.mark.parametrize("case", PERSIST_CASES, ids=[str(i) for i in range(len(PERSIST_CASES))])
-def test_conv_bf16_persistent_stream_matches_one_tile_per_workgroup(backend, case):
+def test_conv_bf16_persistent_stream_matches_one_tile_per_workgroup(backend, case, mode):
     """The chunk stream that runs across tile boundaries must produce exactly what the one-tile-per-workgroup kernel does
     (same operands, same accumulation order inside a tile: bit-identical), and both match the rounded-operand reference."""
     dev = select(backend)
@@ -305,9 +306,9 @@ def test_conv_bf16_persistent_stream_matches_one_tile_per_workgroup(backend, cas
         _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", 0))
         one = run()
         assert _native.lib().adm_last_conv_variant() == 5316
-        _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", 1))
+        _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", mode))
         stream = run()
-        assert _native.lib().adm_last_conv_variant() == 5317, "the persistent kernel was not selected"
+        assert _native.lib().adm_last_conv_variant() == (5317 if mode == 1 else 5319), "the persistent kernel was not selected"
     finally:
         _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", 0))
         _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
