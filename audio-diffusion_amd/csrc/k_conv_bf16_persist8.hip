@@ -224,27 +224,30 @@ __global__ void __launch_bounds__(512, 1) conv_bf16p8_kernel(const Bf16ConvParam
     // epilogue of `cur`; the next tile's chunk 0 sits in buf0, its chunks 1 / 2 are in flight, its filters requested
     ADM_UNROLL
     for (int a = 0; a < 2; ++a) {
-      float bv[16];
-      ADM_UNROLL
-      for (int r = 0; r < 16; ++r) bv[r] = ebias[64 * wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h];
+      const float* eb = ebias + 64 * wm + 32 * a + 4 * h;          // read per element below: 16 registers fewer live
       ADM_UNROLL
       for (int pt = 0; pt < 2; ++pt) {
         const int oy = cur.ty * 16 + 4 * wn + 2 * pt + (l31 >> 4), ox = cur.tx * 16 + (l31 & 15);
         const long pix = (long)oy * p.Wi + ox;
-        float rv[16];
-        if (RES) {            // batched: a load-or-not decision per element serialises 128 round trips (guide §5 trap (c))
-          ADM_UNROLL
-          for (int r = 0; r < 16; ++r) {
-            const int co = cur.m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-            rv[r] = p.residual[((long)cur.n * p.Cout + co) * planeO + pix];
-          }
-        }
         ADM_UNROLL
-        for (int r = 0; r < 16; ++r) {
-          const int co = cur.m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-          float v = acc[a][pt][r] + bv[r];
-          if (RES) v += rv[r];
-          p.out[((long)cur.n * p.Cout + co) * planeO + pix] = v;
+        for (int half = 0; half < 2; ++half) {      // residual in two batches of 8: the stream's state leaves little room
+          float rv[8];
+          if (RES) {
+            ADM_UNROLL
+            for (int q = 0; q < 8; ++q) {
+              const int r = 8 * half + q;
+              const int co = cur.m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+              rv[q] = p.residual[((long)cur.n * p.Cout + co) * planeO + pix];
+            }
+          }
+          ADM_UNROLL
+          for (int q = 0; q < 8; ++q) {
+            const int r = 8 * half + q;
+            const int co = cur.m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = acc[a][pt][r] + eb[(r & 3) + 8 * (r >> 2)];
+            if (RES) v += rv[q];
+            p.out[((long)cur.n * p.Cout + co) * planeO + pix] = v;
+          }
         }
       }
     }
