@@ -19,5 +19,6 @@ ADM_WGRAD_BF16_8W=1 PROBE_CHECK=0 PROBE_B=16 PROBE_MP=bf16 timeout 90 python too
 for L in 1 2; do
   ADM_BF16_LEVEL=$L PROBE_CHECK=0 PROBE_B=16 PROBE_MP=bf16 timeout 90 python tools/gpu_probe.py trainstep 2>&1 | grep "train step" | sed "s/^/bf16 level $L: /" | tee -a $O/train_levels.txt
 done
+ADM_BF16_LEVEL=2 ADM_BF16_PERSIST=2 ADM_WGRAD_BF16_8W=1 PROBE_CHECK=0 PROBE_B=16 PROBE_MP=bf16 timeout 90 python tools/gpu_probe.py trainstep 2>&1 | grep "train step" | sed "s/^/bf16 level 2 + persistent 8-wave forward + 8-wave weight gradient: /" | tee -a $O/train_levels.txt
 ADM_TEST_UNTIMED=1 ADM_BF16_LEVEL=2 timeout 90 python -m pytest tests/test_unet_training.py -m gpu -q -k mixed_precision 2>&1 | tail -2 | tee $O/level2_parity.txt
 timeout 120 python tools/cond_probe.py 2>&1 | tail -3 | tee $O/cond_probe.txt
