@@ -11,6 +11,10 @@ outputs for this path and neither third-party package can be imported in this
 container, so the oracle is pinned only by the analytic anchors of SURVEY.md
 §8(c) (see tests/test_oracle_anchors.py).
 
+Modules: `unet` (UNet2DModel), `unet_condition` (UNet2DConditionModel: Transformer2DModel blocks, cross-attention on the
+encoding), `schedulers` (DDPM / DDIM), `pipeline` (the sampling procedure, `encode`, `slerp`), `mel` (librosa's
+melspectrogram / NNLS / Griffin-Lim chain), `vae` (AutoencoderKL), `audio_encoder` (the reference's AudioEncoder forward).
+
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg
 may import this package. The product (`audio-diffusion_amd/`) never does.
 """
