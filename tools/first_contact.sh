@@ -22,3 +22,4 @@ done
 ADM_BF16_LEVEL=2 ADM_BF16_PERSIST=2 ADM_WGRAD_BF16_8W=1 PROBE_CHECK=0 PROBE_B=16 PROBE_MP=bf16 timeout 90 python tools/gpu_probe.py trainstep 2>&1 | grep "train step" | sed "s/^/bf16 level 2 + persistent 8-wave forward + 8-wave weight gradient: /" | tee -a $O/train_levels.txt
 ADM_TEST_UNTIMED=1 ADM_BF16_LEVEL=2 timeout 90 python -m pytest tests/test_unet_training.py -m gpu -q -k mixed_precision 2>&1 | tail -2 | tee $O/level2_parity.txt
 timeout 120 python tools/cond_probe.py 2>&1 | tail -3 | tee $O/cond_probe.txt
+timeout 90 python tools/bf16_blocked_probe.py 2>&1 | tail -5 | tee $O/blocked_probe.txt
