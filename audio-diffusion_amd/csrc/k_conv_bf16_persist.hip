@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256, 1) conv_bf16p_kernel(const Bf16ConvParams
   const int Ct = p.C1 + p.C2, KG = Ct >> 3, n_chunks = Ct >> 4;
   const int planeS = p.Hs * p.Ws;
   float* gnrows = reinterpret_cast<float*>(lds + 4 * PPP);          // set s: scale at gnrows + s*2*Ct, shift at + Ct
-  float* ebias = gnrows + 4 * Ct;                                     // [128] epilogue constants of the current tile
+  float* ebias = gnrows + 4 * Ct;                                     // [2][128] epilogue constants of the current tile, by tile parity
   const int t_first = blockIdx.x * p.tiles_per_wg;
   int t_last = t_first + p.tiles_per_wg;
   if (t_last > p.nblk) t_last = p.nblk;
@@ -210,7 +210,8 @@ __global__ void __launch_bounds__(256, 1) conv_bf16p_kernel(const Bf16ConvParams
     for (int ch = 0; ch < n_chunks; ch += 2) {
       mfma_chunk(buf0, ch);
       if (ch == 0) {
-        if (tid < 128) ebias[tid] = eb0 + eb1;
+        if (tid < 128) ebias[(seq & 1) * 128 + tid] = eb0 + eb1;   // two sets by tile parity: a fast wave may be a whole
+                                                                     // MFMA chunk into the next tile while a slow one still reads
         if (nxt.valid) {
           float* gs = gnrows + ((seq + 1) & 1) * 2 * Ct;
           ADM_UNROLL
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(256, 1) conv_bf16p_kernel(const Bf16ConvParams
     for (int a = 0; a < 2; ++a) {
       float bv[16];
       ADM_UNROLL
-      for (int r = 0; r < 16; ++r) bv[r] = ebias[64 * wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h];
+      for (int r = 0; r < 16; ++r) bv[r] = ebias[(seq & 1) * 128 + 64 * wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h];
       ADM_UNROLL
       for (int pt = 0; pt < 4; ++pt) {
         const int oy = cur.ty * 16 + 8 * wn + 2 * pt + (l31 >> 4), ox = cur.tx * 16 + (l31 & 15);
@@ -302,7 +303,7 @@ int launch_conv_bf16_persist(const adm_conv_args& a, hipStream_t st) {
   int grid = p.nblk < n_cu ? p.nblk : n_cu;
   p.tiles_per_wg = ceil_div(p.nblk, grid);
   grid = ceil_div(p.nblk, p.tiles_per_wg);
-  const size_t smem = sizeof(u32x4) * 2 * 2 * PPP + sizeof(float) * (4 * Ct + 128);
+  const size_t smem = sizeof(u32x4) * 2 * 2 * PPP + sizeof(float) * (4 * Ct + 256);
   ADM_REQUIRE(smem <= 64 * 1024 && Ct <= 1024, "conv_bf16: too many input channels for the LDS GroupNorm rows");
   set_last_conv_variant(5000 + 317);
 #define ADM_BF16P_LAUNCH(UP_, ACT_)                                                                            \
