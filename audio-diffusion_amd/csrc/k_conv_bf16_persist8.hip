@@ -1,6 +1,9 @@
 // k_conv_bf16_persist8.hip — the persistent chunk-stream kernel (k_conv_bf16_persist.hip) with 8 waves, two per SIMD
 // (k_conv_bf16w8.hip): both opt-in ideas combined.  OPT-IN (ADM_BF16_PERSIST=2 / option "conv_bf16_persist" = 2), emulator
 // parity only.  With 64 accumulator registers per wave the stream's extra state fits without AGPR spills.
+// CAUTION: the register allocation of this kernel is fragile with ROCm 7.2 — small source changes (a compile-time patch
+// index, a parity-indexed LDS constant set) flip it between 0 and ~125 spilled registers inside the tile loop, which makes
+// every scratch reload a vmcnt(0) drain.  Re-check `-Rpass-analysis=kernel-resource-usage` after ANY edit before timing.
 #include "adm_kernels.h"
 
 namespace adm {
@@ -39,7 +42,7 @@ __global__ void __launch_bounds__(512, 1) conv_bf16p8_kernel(const Bf16ConvParam
   const int Ct = p.C1 + p.C2, KG = Ct >> 3, n_chunks = Ct >> 4;
   const int planeS = p.Hs * p.Ws;
   float* gnrows = reinterpret_cast<float*>(lds + 4 * RPP);          // set s: scale at gnrows + s*2*Ct, shift at + Ct
-  float* ebias = gnrows + 4 * Ct;                                     // [2][128] epilogue constants of the current tile, by tile parity
+  float* ebias = gnrows + 4 * Ct;                                     // [128] epilogue constants of the current tile
   const int t_first = blockIdx.x * p.tiles_per_wg;
   int t_last = t_first + p.tiles_per_wg;
   if (t_last > p.nblk) t_last = p.nblk;
@@ -203,8 +206,8 @@ __global__ void __launch_bounds__(512, 1) conv_bf16p8_kernel(const Bf16ConvParam
     for (int ch = 0; ch < n_chunks; ch += 2) {
       mfma_chunk(buf0, ch);
       if (ch == 0) {
-        if (tid < 128) ebias[(seq & 1) * 128 + tid] = eb0 + eb1;   // two sets by tile parity: a fast wave may be a whole
-                                                                     // MFMA chunk into the next tile while a slow one still reads
+        __syncthreads();          // every wave has left the previous tile's epilogue (which reads ebias) before it is rewritten
+        if (tid < 128) ebias[tid] = eb0 + eb1;
         if (nxt.valid) {
           float* gs = gnrows + ((seq + 1) & 1) * 2 * Ct;
           ADM_UNROLL
@@ -225,7 +228,7 @@ __global__ void __launch_bounds__(512, 1) conv_bf16p8_kernel(const Bf16ConvParam
     // epilogue of `cur`; the next tile's chunk 0 sits in buf0, its chunks 1 / 2 are in flight, its filters requested
     ADM_UNROLL
     for (int a = 0; a < 2; ++a) {
-      const float* eb = ebias + (seq & 1) * 128 + 64 * wm + 32 * a + 4 * h;          // read per element below: 16 registers fewer live
+      const float* eb = ebias + 64 * wm + 32 * a + 4 * h;          // read per element below: 16 registers fewer live
       ADM_UNROLL
       for (int pt = 0; pt < 2; ++pt) {
         const int oy = cur.ty * 16 + 4 * wn + 2 * pt + (l31 >> 4), ox = cur.tx * 16 + (l31 & 15);
