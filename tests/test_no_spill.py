@@ -1,0 +1,47 @@
+"""Static check of the gfx950 code of the bf16 kernels: a register spill inside their loops turns every scratch reload into a
+`s_waitcnt vmcnt(0)` that drains the prefetch pipeline, and the allocator has proved fragile — so the
+measured default kernels must compile spill-free, and the opt-in ones within the bounds written down in DESIGN.md."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "audio-diffusion_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _usage(src):
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", os.devnull,
+                        "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+        m = re.search(r"(ScratchSize \[bytes/lane\]|VGPRs Spill|VGPRs|AGPRs): (\d+)", line)
+        if m and name:
+            out[name][m.group(1).split(" ")[0]] = int(m.group(2))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src,max_scratch", [
+    ("k_conv_bf16.hip", 0),              # measured defaults: forward / data gradient, weight gradient, packing
+    ("k_conv_bf16w8.hip", 0),
+    ("k_conv_wgrad_bf16w8.hip", 0),
+    ("k_conv_bf16_persist.hip", 0),
+    ("k_conv_bf16_persist8.hip", 16),    # residual variants: 3 registers reloaded once per tile, outside the chunk loop
+    ("k_conv1x1_bf16.hip", 0),
+    ("k_conv_bf16_blocked.hip", 0),
+])
+def test_bf16_kernels_compile_without_spills(src, max_scratch):
+    usage = _usage(src)
+    kernels = {k: v for k, v in usage.items() if "kernel" in k}
+    assert kernels, usage
+    worst = max(v.get("ScratchSize", 0) for v in kernels.values())
+    assert worst <= max_scratch, {k: v for k, v in kernels.items() if v.get("ScratchSize", 0) > max_scratch}
