@@ -1,4 +1,4 @@
-"""Static check of the gfx950 code of the bf16 kernels: a register spill inside their loops turns every scratch reload into a
+"""Static check of the gfx950 code of the convolution kernels: a register spill inside their loops turns every scratch reload into a
 `s_waitcnt vmcnt(0)` that drains the prefetch pipeline, and the allocator has proved fragile — so the
 measured default kernels must compile spill-free, and the opt-in ones within the bounds written down in DESIGN.md."""
 import os
@@ -31,6 +31,8 @@ def _usage(src):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("src,max_scratch", [
+    ("k_conv_wino.hip", 0),              # the headline kernel (persistent wave-specialised Winograd) and its predecessors
+    ("k_conv_wgrad.hip", 0),             # fp32 weight gradients incl. the 8-wave software-pipelined kernel
     ("k_conv_bf16.hip", 0),              # measured defaults: forward / data gradient, weight gradient, packing
     ("k_conv_bf16w8.hip", 0),
     ("k_conv_wgrad_bf16w8.hip", 0),
@@ -39,7 +41,7 @@ def _usage(src):
     ("k_conv1x1_bf16.hip", 0),
     ("k_conv_bf16_blocked.hip", 0),
 ])
-def test_bf16_kernels_compile_without_spills(src, max_scratch):
+def test_conv_kernels_compile_without_spills(src, max_scratch):
     usage = _usage(src)
     kernels = {k: v for k, v in usage.items() if "kernel" in k}
     assert kernels, usage
