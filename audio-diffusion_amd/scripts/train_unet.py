@@ -173,12 +173,19 @@ def main(args):
                       flush=True)
         if world > 1:
             dist.barrier()
-        if rank == 0 and ((epoch + 1) % args.save_model_epochs == 0 or epoch == args.num_epochs - 1):
+        save_model = (epoch + 1) % args.save_model_epochs == 0 or epoch == args.num_epochs - 1
+        save_images = (epoch + 1) % args.save_images_epochs == 0
+        if rank == 0 and (save_model or save_images):               # :286-298
             if ema is not None:
-                ema.copy_to(flat)                                   # train_unet.py:292-294: EMA weights go INTO the live model
+                ema.copy_to(flat)                                   # :292-294: EMA weights go INTO the live model
                 model.refresh_weights()
             model.sync_state_dict_from_flat()
-            AudioDiffusionPipeline(vqvae=vqvae, unet=model, mel=mel, scheduler=noise_scheduler).save_pretrained(output_dir)
+            pipeline = AudioDiffusionPipeline(vqvae=vqvae, unet=model, mel=mel, scheduler=noise_scheduler)
+            if save_model:
+                pipeline.save_pretrained(output_dir)
+            if save_images:                                         # :313-348 (the reference logs these to tensorboard)
+                write_samples(pipeline, args, epoch, output_dir, dev,
+                              None if enc_table is None else [enc_table[i] for i in range(len(enc_table))])
         if world > 1:
             dist.broadcast(flat, src=0)                             # keep replicas identical after the EMA copy
             model.refresh_weights()
@@ -186,6 +193,29 @@ def main(args):
     if world > 1:
         dist.destroy_process_group()
     return model
+
+
+def write_samples(pipeline, args, epoch, output_dir, dev, encodings):
+    """`eval_batch_size` samples from the current (EMA) weights with the reference's fixed seeds (generator 42,
+    random.seed(42) for the encodings, :313-329), written as PNG + peak-normalised WAV files under
+    <output_dir>/samples/ — the stand-in for the tensorboard images / audio of :332-347 (no tensorboard here)."""
+    import random
+    import scipy.io.wavfile
+    generator = torch.Generator(device="cpu").manual_seed(42)
+    encoding = None
+    if encodings is not None:
+        random.seed(42)
+        encoding = torch.stack(random.sample(encodings, min(args.eval_batch_size, len(encodings)))).to(dev)
+    n = args.eval_batch_size if encoding is None else encoding.shape[0]
+    pipeline.set_progress_bar_config(disable=True)
+    images, (sample_rate, audios) = pipeline(generator=generator, batch_size=n, return_dict=False, encoding=encoding)
+    d = os.path.join(output_dir, "samples")
+    os.makedirs(d, exist_ok=True)
+    for i, (image, audio) in enumerate(zip(images, audios)):
+        image.save(os.path.join(d, f"epoch{epoch:04d}_{i}.png"))
+        peak = float(np.abs(audio).max())
+        scipy.io.wavfile.write(os.path.join(d, f"epoch{epoch:04d}_{i}.wav"), sample_rate,
+                               (audio / peak if peak > 0 else audio).astype(np.float32))       # librosa.util.normalize
 
 
 def parse_args(argv=None):

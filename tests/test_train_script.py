@@ -175,3 +175,25 @@ def test_conditional_training_from_encodings(tmp_path):
     images, _ = pipe(batch_size=1, steps=2, generator=torch.Generator().manual_seed(0), encoding=e, audio=False,
                      return_float=True)
     assert images[0].size == (16, 16)
+
+
+def test_sample_files_at_save_images_epochs(tmp_path):
+    """`--save_images_epochs` (train_unet.py:313-348): samples from the live (EMA) weights with the fixed seed, here written as
+    PNG / WAV files instead of tensorboard events; the training model itself runs the sampling loop."""
+    select("emu")
+    from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, Mel, UNet2DModel
+    start = UNet2DModel(**TINY).init_random(3)
+    AudioDiffusionPipeline(None, start, Mel(**MEL), DDIMScheduler()).save_pretrained(str(tmp_path / "start"))
+    tr = _script("train_unet")
+    tr.main(tr.parse_args(["--from_pretrained", str(tmp_path / "start"), "--dataset_name", "synthetic", "--resolution", "16",
+                           "--synthetic_size", "4", "--output_dir", str(tmp_path / "out"), "--train_batch_size", "2",
+                           "--num_epochs", "1", "--save_model_epochs", "5", "--save_images_epochs", "1", "--eval_batch_size", "2",
+                           "--scheduler", "ddim", "--lr_warmup_steps", "1", "--hop_length", "64", "--sample_rate", "4000",
+                           "--n_fft", "256"]))
+    files = sorted(os.listdir(tmp_path / "out" / "samples"))
+    assert files == ["epoch0000_0.png", "epoch0000_0.wav", "epoch0000_1.png", "epoch0000_1.wav"]
+    sr, audio = scipy.io.wavfile.read(tmp_path / "out" / "samples" / "epoch0000_1.wav")
+    assert sr == 4000 and audio.dtype == np.float32 and abs(float(np.abs(audio).max()) - 1.0) < 1e-6
+    from PIL import Image
+    assert Image.open(tmp_path / "out" / "samples" / "epoch0000_0.png").size == (16, 16)
+    assert os.path.exists(tmp_path / "out" / "unet" / "config.json")            # last epoch also saves the model
