@@ -124,6 +124,7 @@ _OPTIONAL_SIGS = {
     "adm_grad_norm_clip": (C.c_int, [C.c_void_p, C.c_long, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adm_adamw_ema_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long] + [C.c_float] * 5 +
                            [C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
+    "adm_flat_op": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_void_p]),
     "adm_vae_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "adm_vae_destroy": (None, [C.c_void_p]),
     "adm_vae_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
@@ -175,6 +176,14 @@ def lib():
 
 def is_device_build():
     return bool(lib().adm_is_device_build())
+
+
+def default_device():
+    """Where product objects allocate: the CURRENT HIP device of this process (one process per GPU: train_unet.py and
+    bench.py call torch.cuda.set_device(LOCAL_RANK) before building anything), or the host for the emulation build."""
+    if is_device_build():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
 def check(rc):

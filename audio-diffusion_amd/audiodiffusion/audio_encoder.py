@@ -28,7 +28,7 @@ class AudioEncoder:
         self.mel = Mel(x_res=216, y_res=96, sample_rate=22050, n_fft=2048, hop_length=512, top_db=80)
         self._sd = {}
         self._dev = None
-        self.device = torch.device("cuda:0") if N.is_device_build() else torch.device("cpu")
+        self.device = N.default_device()
 
     # ---- weights -----------------------------------------------------------------------------------------
     def load_state_dict(self, sd):

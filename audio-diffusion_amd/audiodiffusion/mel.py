@@ -150,7 +150,7 @@ class Mel:
             pass
 
     def _device(self):
-        return torch.device("cuda:0") if N.is_device_build() else torch.device("cpu")
+        return N.default_device()
 
     def _ensure_handle(self):
         if self._handle is not None:

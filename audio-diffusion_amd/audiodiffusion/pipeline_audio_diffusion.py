@@ -43,7 +43,7 @@ class DiffusionPipeline:
     def __init__(self):
         self._modules = {}
         self._progress_bar_config = {}
-        self._device = torch.device("cuda:0") if N.is_device_build() else torch.device("cpu")
+        self._device = N.default_device()
 
     def register_modules(self, **kwargs):
         for k, v in kwargs.items():
@@ -220,11 +220,11 @@ class AudioDiffusionPipeline(DiffusionPipeline):
         if type(self.unet.sample_size) == int:
             self.unet.sample_size = (self.unet.sample_size, self.unet.sample_size)
         if noise is None:
-            noise = torch.randn(
+            # the reference's torch.randn(..., generator=generator, device=self.device) (:120-128); going through
+            # randn_tensor additionally accepts a CPU generator on the GPU build (drawn on the host, then moved)
+            noise = randn_tensor(
                 (batch_size, self.unet.in_channels, self.unet.sample_size[0], self.unet.sample_size[1]),
-                generator=generator,
-                device=self.device,
-            )
+                generator, self.device, torch.float32)
         images = noise
         mask = None
         mask_start = mask_end = 0

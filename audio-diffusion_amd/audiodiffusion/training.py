@@ -9,7 +9,9 @@ ema_model.step, and the data-parallel gradient all-reduce that `accelerator.back
 Every per-parameter pass is ONE fused HIP kernel over a flat fp32 buffer (csrc/k_train.hip) instead of ~450 per-tensor
 launches; loss / norm / clip scalars stay on the device (no host sync inside a step). The gradient all-reduce uses
 `torch.distributed` (backend "nccl" == RCCL over xGMI on the MI355X node) in ~25 MB buckets of the flat gradient buffer.
-The UNet backward itself (the kernels that fill the gradient buffer) is the next build step — see DESIGN.md §7.
+The kernels that fill the gradient buffer are `adm_unet_forward_backward` (csrc/net_exec.hip: run_backward), driven by
+`UNet2DModel.train_step`. No torch arithmetic op touches parameters, gradients or optimizer state: the remaining
+elementwise passes (micro-step accumulation, 1/world, EMA on its own) go through `adm_flat_op`.
 """
 import ctypes as C
 import math
@@ -40,6 +42,15 @@ class FlatBuffer:
         for k, v in state_dict.items():
             self.view(k).copy_(v)
         return self
+
+
+FLAT_ADD, FLAT_SCALE_FROM, FLAT_DIV, FLAT_EMA = 0, 1, 2, 3
+
+
+def flat_op(y, x, op, a=0.0):
+    """y (op)= x on flat fp32 buffers (csrc/k_train.hip: flat_op_kernel)."""
+    N.check(N.lib().adm_flat_op(N.ptr(y), N.ptr(x), y.numel(), op, float(a), N.stream_for(y)))
+    return y
 
 
 def mse_loss(pred, target, want_grad=True):
@@ -95,7 +106,7 @@ class EMAModel:
         gradient-accumulation micro-steps, where the reference still calls `ema_model.step(model)` (train_unet.py:265-266)
         although the optimizer does not move the parameters."""
         d = self.next_decay()
-        self.shadow.sub_((self.shadow - flat_params) * (1.0 - d))
+        flat_op(self.shadow, flat_params, FLAT_EMA, 1.0 - d)
         return d
 
 
@@ -115,11 +126,11 @@ class GradAccumulator:
         """Call after each forward/backward; returns True when the optimizer should step (`sync_gradients`)."""
         if self.steps <= 1:
             return True
-        self.acc.add_(self.grads)
+        flat_op(self.acc, self.grads, FLAT_ADD)
         self.count += 1
         if self.count % self.steps != 0 and not last_batch:
             return False
-        torch.mul(self.acc, 1.0 / self.steps, out=self.grads)
+        flat_op(self.grads, self.acc, FLAT_SCALE_FROM, 1.0 / self.steps)
         self.acc.zero_()
         self.count = 0
         return True
@@ -224,7 +235,7 @@ class GradAllReducer:
             w.wait()
         self.pending = []
         self.launched = set()
-        self.g.div_(dist.get_world_size(self.group))
+        flat_op(self.g, None, FLAT_DIV, float(dist.get_world_size(self.group)))
 
     def begin_step(self):
         """Call before the forward/backward of a synchronising step."""

@@ -138,7 +138,7 @@ class UNet2DModel:
         self._handle = None
         self._handle_hw = None
         self._sd = {}
-        self.device = torch.device("cuda:0") if N.is_device_build() else torch.device("cpu")
+        self.device = N.default_device()
 
     @staticmethod
     def _validate(cfg):
@@ -290,14 +290,17 @@ class UNet2DModel:
         from .training import FlatBuffer
         if mixed_precision not in ("no", "bf16"):
             raise ValueError(f"mixed_precision must be 'no' or 'bf16', got {mixed_precision!r}")
-        # ADM_BF16_LEVEL=2 additionally puts the 1x1 convolutions on bf16 operands (opt-in: emulator-verified, not yet timed)
-        level = int(os.environ.get("ADM_BF16_LEVEL", "1")) if mixed_precision == "bf16" else 0
+        # level 2 (default; measured 98.6 vs 113.5 ms per step at level 1, profiles/r02_first_contact.md): the 1x1
+        # convolutions and the stride-2 data gradients take bf16 operands too; ADM_BF16_LEVEL=1 keeps them fp32.
+        # The level is read by adm_unet_enable_training and belongs to THIS model from then on: the process-wide option is
+        # put back to 0 below, and the native sampling entry points always run fp32.
+        level = int(os.environ.get("ADM_BF16_LEVEL", "2")) if mixed_precision == "bf16" else 0
         N.check(N.lib().adm_set_option(b"conv_bf16", level))
         self.mixed_precision = mixed_precision
         if sample_hw is not None:
             self.sample_size = tuple(sample_hw)
         self._free()
-        dev = torch.device("cuda:0") if N.is_device_build() else torch.device("cpu")
+        dev = N.default_device()
         specs = [(k, s) for k, s, _ in param_specs(self.config)]
         self.flat = FlatBuffer(specs, dev).load(self._sd)
         self.flat_grads = torch.zeros_like(self.flat.data)
@@ -305,7 +308,10 @@ class UNet2DModel:
         lib = N.lib()
         for k, _ in specs:
             N.check(lib.adm_unet_bind_param(h, k.encode(), C.c_void_p(self.flat.view(k).data_ptr())))
-        N.check(lib.adm_unet_enable_training(h, N.ptr(self.flat.data), self.flat.numel))
+        try:
+            N.check(lib.adm_unet_enable_training(h, N.ptr(self.flat.data), self.flat.numel))
+        finally:
+            N.check(lib.adm_set_option(b"conv_bf16", 0))
         self._training = True
         return self.flat.data, self.flat_grads
 

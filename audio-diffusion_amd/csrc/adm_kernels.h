@@ -48,22 +48,9 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st);
 
 // k_conv_bf16.hip (mixed-precision training: bf16 MFMA operands, fp32 accumulate)
 int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transposed, hipStream_t st, int ks = 3);
-void set_conv_bf16(int m);   // 0 off (default), 1 = 3x3 convs, 2 = 3x3 and 1x1 convs (opt-in), -1 = ADM_CONV_BF16
+void set_conv_bf16(int m);   // 0 off (default), 1 = 3x3 convs, 2 = 3x3, 1x1 and stride-2 data-gradient convs, -1 = ADM_CONV_BF16
 bool conv_bf16_enabled();
 int conv_bf16_mode();
-// k_conv_bf16_persist.hip (opt-in ADM_BF16_PERSIST=1: persistent chunk-stream variant of the 3x3 bf16 kernel)
-bool conv_bf16_persist_enabled();
-void set_conv_bf16_persist(int v);
-int launch_conv_bf16_persist(const adm_conv_args& a, hipStream_t st);
-int launch_conv_bf16_persist8(const adm_conv_args& a, hipStream_t st);   // k_conv_bf16_persist8.hip (persist mode 2)
-// k_conv_bf16w8.hip (opt-in ADM_BF16_8W=1: 8-wave variant of the bf16 3x3 forward / data-gradient kernel)
-bool conv_bf16_8w_enabled();
-void set_conv_bf16_8w(int v);
-int launch_conv_bf16w8(const adm_conv_args& a, hipStream_t st);
-// k_conv_wgrad_bf16w8.hip (opt-in ADM_WGRAD_BF16_8W=1: 8-wave variant of the bf16 3x3 weight-gradient kernel)
-bool wgrad_bf16_8w_enabled();
-void set_wgrad_bf16_8w(int v);
-int launch_conv_wgrad_bf16w8(const adm_conv_args& a, const float* dy, float* workspace, int split, hipStream_t st);
 // k_conv_bf16_blocked.hip (prototype: blocked bf16 activations, op level only)
 int launch_gn_apply_bf16_blocked(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, const float* gn_scale,
                                  const float* gn_shift, int act, void* xb, hipStream_t st);

@@ -19,9 +19,6 @@ int adm_set_option(const char* name, int value) {
   if (std::string(name) == "conv_wino") { adm::set_winograd_mode(value); return 0; }
   if (std::string(name) == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
   if (std::string(name) == "conv_bf16") { adm::set_conv_bf16(value); return 0; }
-  if (std::string(name) == "conv_bf16_persist") { adm::set_conv_bf16_persist(value); return 0; }
-  if (std::string(name) == "wgrad_bf16_8w") { adm::set_wgrad_bf16_8w(value); return 0; }
-  if (std::string(name) == "conv_bf16_8w") { adm::set_conv_bf16_8w(value); return 0; }
   ADM_FAIL(std::string("set_option: unknown option ") + name);
 }
 int adm_last_conv_variant(void) { return adm::last_conv_variant(); }

@@ -495,7 +495,7 @@ bool conv_bf16_enabled() {
 // concat seam, Cout % 128.
 bool conv_bf16_eligible(const adm_conv_args& a) {
   if (a.ks != 3 || a.stride != 1 || a.pad_lo != 1 || a.w_bstride != 0 || a.bf16_packed == nullptr) return false;
-  // up = 2 (zero insertion: the data gradient of a stride-2 convolution) only at the opt-in level 2: not yet run on hardware
+  // up = 2 (zero insertion: the data gradient of a stride-2 convolution) at level 2
   if (a.up > (conv_bf16_mode() >= 2 ? 2 : 1)) return false;
   const int C2 = a.x2 ? a.C2 : 0;
   const int Hi = a.up ? 2 * a.H : a.H, Wi = a.up ? 2 * a.W : a.W;
@@ -506,8 +506,6 @@ bool conv_bf16_eligible(const adm_conv_args& a) {
 int launch_conv_bf16(const adm_conv_args& a, hipStream_t st) {
   Bf16ConvParams p;
   const int C2 = a.x2 ? a.C2 : 0, Ct = a.C1 + C2;
-  if (conv_bf16_persist_enabled() && Ct >= 64 && Ct <= 1024 && a.up <= 1) return launch_conv_bf16_persist(a, st);
-  if (conv_bf16_8w_enabled()) return launch_conv_bf16w8(a, st);                          // opt-in (k_conv_bf16w8.hip)   // opt-in (k_conv_bf16_persist.hip)
   p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2;
   p.N = a.N; p.Hs = a.H; p.Ws = a.W;
   p.Hi = a.up ? 2 * a.H : a.H; p.Wi = a.up ? 2 * a.W : a.W;
@@ -528,12 +526,8 @@ int launch_conv_bf16(const adm_conv_args& a, hipStream_t st) {
   const size_t smem = sizeof(u32x4) * 2 * 2 * BPP + sizeof(float) * 2 * Ct;
   ADM_REQUIRE(smem <= 64 * 1024, "conv_bf16: too many input channels for the LDS GroupNorm rows");
   set_last_conv_variant(5000 + 316);
-  static const int wide = [] { const char* e = getenv("ADM_BF16_WIDE"); return e ? atoi(e) : 0; }();
-#define ADM_BF16_LAUNCH(UP_, ACT_)                                                                              \
-  do {                                                                                                          \
-    if (wide) ADM_LAUNCH((conv_bf16_kernel<UP_, ACT_, true>), dim3(p.nblk), dim3(256), smem, st, p);             \
-    else ADM_LAUNCH((conv_bf16_kernel<UP_, ACT_, false>), dim3(p.nblk), dim3(256), smem, st, p);                 \
-  } while (0)
+  // WIDE = true (waves 4 x 1) measured 640 vs 634 us on 128->128 @256^2: not instantiated
+#define ADM_BF16_LAUNCH(UP_, ACT_) ADM_LAUNCH((conv_bf16_kernel<UP_, ACT_, false>), dim3(p.nblk), dim3(256), smem, st, p)
   if (a.up) {
     if (a.act) ADM_BF16_LAUNCH(true, true);
     else ADM_BF16_LAUNCH(true, false);

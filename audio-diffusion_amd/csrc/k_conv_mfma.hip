@@ -420,36 +420,47 @@ template <class K> static void allow_big_lds(K, size_t) {}
 // bias is read unconditionally by the epilogue: a NULL bias maps to a shared all-zero device buffer.
 const float* conv_zero_bias(int n);
 static const float* zero_bias(int n) { return conv_zero_bias(n); }
+// Both constant buffers are keyed by the current HIP device (a process normally owns one GPU, but nothing here assumes
+// it) and grown outside any stream capture: the executors call them from finalize()/their uncaptured warm-up forward.
+static int const_dev_slot() {
+  int dev = 0;
+#if !defined(ADM_EMU)
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+#endif
+  return dev;
+}
 const float* conv_zero_bias(int n) {
-  static float* z = nullptr;
-  static int cap = 0;
-  if (n > cap) {
+  static float* z[16] = {};
+  static int cap[16] = {};
+  const int d = const_dev_slot();
+  if (n > cap[d]) {
     void* pz = nullptr;
     const int want = n < 8192 ? 8192 : n;
     if (dmalloc(&pz, sizeof(float) * want) != 0) return nullptr;
     dmemset(pz, 0, sizeof(float) * want, nullptr);
     stream_sync(nullptr);
-    z = (float*)pz;  // the previous (smaller) buffer is intentionally leaked: launches may still read it
-    cap = want;
+    z[d] = (float*)pz;  // the previous (smaller) buffer is intentionally leaked: launches may still read it
+    cap[d] = want;
   }
-  return z;
+  return z[d];
 }
 
 // shared all-ones device buffer (identity GroupNorm scale for convolutions without a normalisation on their input)
 const float* conv_const_ones(int n) {
-  static float* z = nullptr;
-  static int cap = 0;
-  if (n > cap) {
+  static float* z[16] = {};
+  static int cap[16] = {};
+  const int d = const_dev_slot();
+  if (n > cap[d]) {
     const int want = n < 8192 ? 8192 : n;
     std::vector<float> h((size_t)want, 1.0f);
     void* pz = nullptr;
     if (dmalloc(&pz, sizeof(float) * want) != 0) return nullptr;
     if (copy_h2d(pz, h.data(), sizeof(float) * want, nullptr) != 0) return nullptr;
     stream_sync(nullptr);
-    z = (float*)pz;
-    cap = want;
+    z[d] = (float*)pz;
+    cap[d] = want;
   }
-  return z;
+  return z[d];
 }
 
 static bool use_pf() {

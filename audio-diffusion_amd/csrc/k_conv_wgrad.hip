@@ -790,17 +790,9 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
 #endif
   static const int use_pf = [] { const char* e = getenv("ADM_WGRAD_PF"); return e ? atoi(e) : 1; }();
   const int PE = NI * p.IH * p.IW;
-  if (conv_bf16_mode() >= 2 && conv1x1_wgrad_bf16_eligible(a)) {   // opt-in: 1x1 weight gradient on bf16 operands
+  if (conv_bf16_mode() >= 2 && conv1x1_wgrad_bf16_eligible(a)) {   // level 2: 1x1 weight gradient on bf16 operands
     const int slabs = launch_conv1x1_wgrad_bf16(a, dy, workspace, p.split, st);
     ADM_REQUIRE(slabs > 0 && slabs <= p.split, "conv1x1_wgrad_bf16: launch failed");
-    long gb = (numel + 255) / 256;
-    if (gb > 4096) gb = 4096;
-    ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, st, (const float*)workspace, slabs, numel, dW, accumulate);
-    return ADM_CHECK_LAUNCH();
-  }
-  if (conv_bf16_enabled() && conv_wgrad_bf16_eligible(a) && wgrad_bf16_8w_enabled() && p.split >= 2) {   // opt-in 8-wave variant
-    const int slabs = launch_conv_wgrad_bf16w8(a, dy, workspace, p.split, st);
-    ADM_REQUIRE(slabs > 0 && slabs <= p.split, "conv_wgrad_bf16w8: launch failed");
     long gb = (numel + 255) / 256;
     if (gb > 4096) gb = 4096;
     ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, st, (const float*)workspace, slabs, numel, dW, accumulate);

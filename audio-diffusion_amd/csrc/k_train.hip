@@ -89,6 +89,30 @@ __global__ void __launch_bounds__(256) adamw_ema_kernel(float* __restrict__ p, c
   }
 }
 
+// Elementwise passes over a flat buffer that the optimizer side needs besides the fused AdamW kernel (gradient
+// accumulation micro-steps, the DDP 1/world scaling, EMAModel.step on its own): one float4 grid-stride kernel.
+enum { FLAT_ADD = 0, FLAT_SCALE_FROM = 1, FLAT_DIV = 2, FLAT_EMA = 3 };
+template <int OP>
+__device__ __forceinline__ float flat_apply(float y, float x, float a) {
+  if (OP == FLAT_ADD) return y + x;                  // acc.add_(grads)
+  if (OP == FLAT_SCALE_FROM) return x * a;           // torch.mul(acc, 1/k, out=grads)
+  if (OP == FLAT_DIV) return y / a;                  // grads.div_(world)
+  return y - a * (y - x);                            // s_param.sub_((1-decay)*(s_param-param)), a = 1-decay
+}
+template <int OP>
+__global__ void __launch_bounds__(256) flat_op_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float a) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = OP == FLAT_SCALE_FROM ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(y)[i];
+    const float4 u = OP == FLAT_DIV ? v : reinterpret_cast<const float4*>(x)[i];
+    v.x = flat_apply<OP>(v.x, u.x, a); v.y = flat_apply<OP>(v.y, u.y, a);
+    v.z = flat_apply<OP>(v.z, u.z, a); v.w = flat_apply<OP>(v.w, u.w, a);
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long i = n4 << 2; i < n; ++i) y[i] = flat_apply<OP>(y[i], OP == FLAT_DIV ? 0.f : x[i], a);
+}
+
 static inline unsigned tgrid(long n) {
   long g = (n + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -134,6 +158,21 @@ int adm_adamw_ema_step(float* params, const float* grads, float* exp_avg, float*
   a.ema_one_minus_decay = 1.0f - ema_decay;
   ADM_LAUNCH(adamw_ema_kernel, dim3(tgrid(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, ema,
              n, a, clip_coef_dev);
+  return ADM_CHECK_LAUNCH();
+}
+
+// y (op)= x over flat fp32 buffers (16-byte aligned): op 0: y += x; 1: y = x*a; 2: y /= a (x unused); 3: y -= a*(y-x).
+int adm_flat_op(float* y, const float* x, long n, int op, float a, void* stream) {
+  ADM_REQUIRE(y && n > 0 && op >= 0 && op <= 3 && (x || op == FLAT_DIV), "flat_op: bad argument");
+  ADM_REQUIRE(((uintptr_t)y & 15) == 0 && (!x || ((uintptr_t)x & 15) == 0), "flat_op: buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(tgrid(n / 4 + 1)), b(256);
+  switch (op) {
+    case FLAT_ADD: ADM_LAUNCH(flat_op_kernel<FLAT_ADD>, g, b, 0, st, y, x, n, a); break;
+    case FLAT_SCALE_FROM: ADM_LAUNCH(flat_op_kernel<FLAT_SCALE_FROM>, g, b, 0, st, y, x, n, a); break;
+    case FLAT_DIV: ADM_LAUNCH(flat_op_kernel<FLAT_DIV>, g, b, 0, st, y, x, n, a); break;
+    default: ADM_LAUNCH(flat_op_kernel<FLAT_EMA>, g, b, 0, st, y, x, n, a); break;
+  }
   return ADM_CHECK_LAUNCH();
 }
 

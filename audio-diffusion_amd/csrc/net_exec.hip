@@ -159,7 +159,7 @@ static int pack_one(Net* net, ConvW& w, hipStream_t st) {
     // mixed precision (`--mixed_precision bf16`): the filters as bf16 MFMA operands, re-rounded from the fp32 masters after
     // every optimizer step; only training nets carry them, so sampling stays fp32 whatever the option says
     const bool bf3 = w.ks == 3 && w.qkv_prefix.empty() && conv_bf16_enabled();
-    const bool bf1 = w.ks == 1 && conv_bf16_mode() >= 2;          // opt-in: shortcuts and attention projections too
+    const bool bf1 = w.ks == 1 && conv_bf16_mode() >= 2;          // level 2: shortcuts and attention projections too
     if ((bf3 || bf1) && w.Cin % 16 == 0 && w.Cout % 16 == 0) {
       const size_t bytes = 2 * (size_t)w.Cout * w.Cin * w.ks * w.ks;
       if (!w.wb) ADM_TRY(net->dalloc(&w.wb, bytes));

@@ -40,6 +40,8 @@ struct adm_unet {
   int* step_dev = nullptr;
   // training
   bool training = false;
+  int warm_B = 0;         // batch size at which an uncaptured forward has already run (see run_loop)
+  int bf16_level = 0;     // mixed-precision level of THIS model (option conv_bf16 as it stood at adm_unet_enable_training)
   long params_numel = 0;
   float *dtemb_all = nullptr, *demb = nullptr, *dz = nullptr, *save_sinus = nullptr, *save_z = nullptr;
   double* scratch_d = nullptr;
@@ -118,7 +120,17 @@ static int restack_temb(adm_unet* h, hipStream_t st) {
   return 0;
 }
 
+// The conv dispatchers read the process-wide option conv_bf16; a model's own level is put in force only while one of ITS
+// training entry points runs (and while its weights are packed), and every inference entry point runs at level 0 — so the
+// sampling path stays fp32 even through a training handle, and one model's setting never leaks into another's.
+struct Bf16Scope {
+  int prev;
+  explicit Bf16Scope(int level) : prev(conv_bf16_mode()) { set_conv_bf16(level); }
+  ~Bf16Scope() { set_conv_bf16(prev); }
+};
+
 static int finalize(adm_unet* h) {
+  Bf16Scope pack_scope(h->training ? h->bf16_level : 0);
   if (h->finalized) return 0;
   std::string missing;
   const int nmiss = h->ps.missing(&missing);
@@ -327,6 +339,13 @@ static int run_loop(adm_unet* h, const LoopArgs& a, const adm_sched_coef* coef_h
                                  (uint64_t)h->net.ctx_S};
     if (!h->gexec || key != h->gkey) {
       if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+      if (h->warm_B != a.B) {
+        // One UNCAPTURED forward (into eps_buf; the sample is not touched) before the first capture at this batch size:
+        // the launchers' one-time work — constant buffers (hipMalloc + null-stream copy), hipFuncSetAttribute for the
+        // >64 KiB LDS kernels, device-attribute queries — is not legal inside a stream capture.
+        ADM_TRY(run_forward(h, a.x, h->eps_buf, a.B, h->coef_dev, run));
+        h->warm_B = a.B;
+      }
       hipGraph_t graph = nullptr;
       ADM_HIP_OK(hipStreamBeginCapture(run, hipStreamCaptureModeThreadLocal));
       int rc = enqueue_step(h, a, 0, run);
@@ -411,6 +430,7 @@ int adm_unet_forward(adm_unet_t* h, const float* x, const float* timesteps_host,
   for (int i = 0; i < B; ++i) t[i] = timesteps_host[n_timesteps == 1 ? 0 : i];
   ADM_TRY(copy_h2d(h->t_dev, t.data(), sizeof(float) * B, st));
   ADM_TRY(stream_sync(st));  // t is a stack/vector buffer: make the copy complete before returning
+  Bf16Scope fp32(0);
   return run_forward(h, x, out, B, nullptr, st);
 }
 
@@ -435,6 +455,7 @@ int adm_unet_enable_training(adm_unet_t* h, const float* params_base, long numel
     ADM_REQUIRE(kv.second.set && kv.second.dev >= params_base && kv.second.dev + kv.second.numel <= params_base + numel,
                 "unet_enable_training: parameter " + kv.first + " is not bound inside the flat buffer");
   h->training = true;
+  h->bf16_level = conv_bf16_mode();
   h->params_numel = numel;
   h->net.params_base = params_base;
   return 0;
@@ -442,6 +463,7 @@ int adm_unet_enable_training(adm_unet_t* h, const float* params_base, long numel
 
 int adm_unet_refresh_weights(adm_unet_t* h, void* stream) {
   ADM_REQUIRE(h && h->finalized, "unet_refresh_weights: model not finalized");
+  Bf16Scope own(h->bf16_level);
   ADM_TRY(h->net.refresh_weights((hipStream_t)stream));
   return restack_temb(h, (hipStream_t)stream);
 }
@@ -454,6 +476,7 @@ int adm_unet_forward_backward(adm_unet_t* h, const float* x, const float* timest
   ADM_REQUIRE(h->training, "unet_forward_backward: call adm_unet_enable_training first");
   ADM_REQUIRE(n_timesteps == 1 || n_timesteps == B, "unet_forward_backward: need 1 or B timesteps");
   hipStream_t st = (hipStream_t)stream;
+  Bf16Scope own(h->bf16_level);
   ADM_TRY(finalize(h));
   ADM_TRY(plan(h, B));
   std::vector<float> t(B);
@@ -517,6 +540,7 @@ int adm_unet_profile(adm_unet_t* h, const float* x, float timestep, float* out, 
   std::vector<adm_op_profile> v;
   OpTimer tm;
   tm.recs = &v;
+  Bf16Scope fp32(0);
   ADM_TRY(run_forward(h, x, out, B, nullptr, st, &tm));
   *n_out = (int)v.size();
   for (int i = 0; i < (int)v.size() && i < cap; ++i) recs[i] = v[i];
@@ -528,6 +552,7 @@ int adm_sample_loop(adm_unet_t* h, float* x, int B, const adm_sched_coef* coef_h
                     int use_graph, void* stream) {
   ADM_REQUIRE(h && x && coef_host && n_steps > 0, "sample_loop: bad argument");
   LoopArgs a{x, B, n_steps, step_noise, mask, mask_start, mask_end, u8_out, 0};
+  Bf16Scope fp32(0);
   return run_loop(h, a, coef_host, use_graph, (hipStream_t)stream);
 }
 
@@ -535,6 +560,7 @@ int adm_encode_loop(adm_unet_t* h, float* x, int B, const adm_sched_coef* coef_h
                     void* stream) {
   ADM_REQUIRE(h && x && coef_host && n_steps > 0, "encode_loop: bad argument");
   LoopArgs a{x, B, n_steps, nullptr, nullptr, 0, 0, nullptr, 1};
+  Bf16Scope fp32(0);
   return run_loop(h, a, coef_host, use_graph, (hipStream_t)stream);
 }
 

@@ -122,8 +122,13 @@ def main(args):
     optimizer = T.AdamW(flat, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
                         weight_decay=args.adam_weight_decay, eps=args.adam_epsilon)
     n_local = len(images) // world
-    steps_per_epoch = n_local // args.train_batch_size
-    lr_scheduler = T.LambdaLR(optimizer, T.get_cosine_schedule_with_warmup(args.lr_warmup_steps, steps_per_epoch * args.num_epochs)
+    # len(train_dataloader) of the reference (:91, DataLoader default drop_last=False): the last batch may be partial
+    steps_per_epoch = -(-n_local // args.train_batch_size)
+    if steps_per_epoch == 0:
+        raise ValueError(f"dataset of {len(images)} images leaves rank {rank} of {world} without a single sample")
+    # the LR scheduler steps on synchronising steps only (:178): its length is divided by the accumulation factor
+    num_training_steps = (steps_per_epoch * args.num_epochs) // args.gradient_accumulation_steps
+    lr_scheduler = T.LambdaLR(optimizer, T.get_cosine_schedule_with_warmup(args.lr_warmup_steps, num_training_steps)
                               if args.lr_scheduler == "cosine" else (lambda s: 1.0))
     ema = T.EMAModel(flat, inv_gamma=args.ema_inv_gamma, power=args.ema_power, max_value=args.ema_max_decay) if args.use_ema else None
     reducer = T.GradAllReducer(grads)
@@ -141,7 +146,7 @@ def main(args):
                 ema.optimization_step = global_step
             continue
         g = torch.Generator().manual_seed(args.seed + epoch)
-        perm = torch.randperm(len(images), generator=g)[rank::world]   # DataLoader(shuffle=True), sharded by rank
+        perm = torch.randperm(len(images), generator=g)[rank::world][:n_local]   # DataLoader(shuffle=True), sharded by rank
         t0, seen = time.perf_counter(), 0
         for it in range(steps_per_epoch):
             idx = perm[it * args.train_batch_size:(it + 1) * args.train_batch_size]
@@ -201,7 +206,7 @@ def write_samples(pipeline, args, epoch, output_dir, dev, encodings):
     <output_dir>/samples/ — the stand-in for the tensorboard images / audio of :332-347 (no tensorboard here)."""
     import random
     import scipy.io.wavfile
-    generator = torch.Generator(device="cpu").manual_seed(42)
+    generator = torch.Generator(device=dev).manual_seed(42)            # on the training device, as :314
     encoding = None
     if encodings is not None:
         random.seed(42)

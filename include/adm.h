@@ -285,6 +285,10 @@ int adm_grad_norm_clip(const float* grads, long n, float max_norm, float* norm_c
 int adm_adamw_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, long n, float lr,
                        float beta1, float beta2, float eps, float weight_decay, int step, const float* clip_coef_dev,
                        float ema_decay, void* stream);
+/* the remaining optimizer-side passes over a flat buffer, one launch each: op 0: y += x (accelerator.accumulate micro-step
+ * sum, :252); 1: y = x*a (mean of the accumulated micro-gradients); 2: y /= a (DDP's 1/world, :259); 3: y -= a*(y-x)
+ * (EMAModel.step on its own, a = 1-decay, :265-266). Buffers 16-byte aligned. */
+int adm_flat_op(float* y, const float* x, long n, int op, float a, void* stream);
 
 /* ---------------------------------------------------------------- backward ops of the training step (rows T5/T8)
  * What `accelerator.backward(loss)` (scripts/train_unet.py:259-262) asks torch autograd to run for the ops of

@@ -39,12 +39,3 @@ def select(backend):
 
 
 BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
-
-# Kernels written after round 1's GPU budget was spent: parity-green on the emulator, never run on a MI355X.  Their
-# hardware variants are opt-in (ADM_TEST_UNTIMED=1, set by tools/first_contact.sh) so that a first-contact failure cannot
-# stop the `-x` GPU suite in front of everything that HAS been verified on hardware; drop this list once they have run.
-BACKENDS_FIRST_CONTACT = [
-    pytest.param("emu", id="emu"),
-    pytest.param("hip", id="hip", marks=[pytest.mark.gpu, pytest.mark.skipif(
-        os.environ.get("ADM_TEST_UNTIMED") != "1", reason="not yet run on hardware; set ADM_TEST_UNTIMED=1")]),
-]

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from native_backend import BACKENDS, BACKENDS_FIRST_CONTACT, select
+from native_backend import BACKENDS, select
 from test_kernels import _rand, _relerr
 
 CASES = [
@@ -166,7 +166,7 @@ PW_CASES = [
 ]
 
 
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", PW_CASES, ids=[str(i) for i in range(len(PW_CASES))])
 def test_conv1x1_bf16_forward(backend, case):
     dev = select(backend)
@@ -210,7 +210,7 @@ def test_conv1x1_bf16_forward(backend, case):
     assert _relerr(out.double(), full) < 8e-3
 
 
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_conv1x1_bf16_data_gradient(backend):
     dev = select(backend)
     from audiodiffusion import _native, ops
@@ -235,7 +235,7 @@ PW_WGRAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", PW_WGRAD_CASES, ids=[str(i) for i in range(len(PW_WGRAD_CASES))])
 def test_conv1x1_bf16_weight_gradient(backend, case):
     dev = select(backend)
@@ -266,7 +266,7 @@ def test_conv1x1_bf16_weight_gradient(backend, case):
     assert 1e-5 < _relerr(dW.double(), full) < 8e-3
 
 
-# ---------------------------------------------------------------- persistent chunk-stream variant (option conv_bf16_persist)
+# ---------------------------------------------------------------- tile-boundary cases (several pixel / cout tiles, ragged grids)
 PERSIST_CASES = [
     # (N, C1, C2, H, W, Cout, up, gn, act, temb, res)
     (2, 64, 0, 16, 32, 128, 0, 1, 1, 1, 1),      # 4 tiles on a 3-workgroup grid: tile boundaries inside a workgroup, 4 chunks
@@ -277,54 +277,10 @@ PERSIST_CASES = [
 ]
 
 
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
-@pytest.mark.parametrize("mode", [1, 2], ids=["4waves", "8waves"])
-@pytest.mark.parametrize("case", PERSIST_CASES, ids=[str(i) for i in range(len(PERSIST_CASES))])
-def test_conv_bf16_persistent_stream_matches_one_tile_per_workgroup(backend, case, mode):
-    """The chunk stream that runs across tile boundaries must produce exactly what the one-tile-per-workgroup kernel does
-    (same operands, same accumulation order inside a tile: bit-identical), and both match the rounded-operand reference."""
-    dev = select(backend)
-    from audiodiffusion import _native, ops
-    Nn, C1, C2, H, W, Cout, up, use_gn, act, use_temb, use_res = case
-    x1 = _rand((Nn, C1, H, W), 1, dev)
-    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
-    Ct = C1 + C2
-    w = _rand((Cout, Ct, 3, 3), 3, dev, scale=(Ct * 9) ** -0.5)
-    b = _rand((Cout,), 4, dev)
-    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
-    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
-    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
-    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
-    res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
-
-    def run():
-        return ops.conv2d(x1, ops.pack_conv_weight(w), b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb,
-                          residual=res, bf16=ops.pack_bf16_weight(w))
-
-    _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
-    try:
-        _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", 0))
-        one = run()
-        assert _native.lib().adm_last_conv_variant() == 5316
-        _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", mode))
-        stream = run()
-        assert _native.lib().adm_last_conv_variant() == (5317 if mode == 1 else 5319), "the persistent kernel was not selected"
-    finally:
-        _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", 0))
-        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
-    assert torch.equal(stream.cpu(), one.cpu())
-    c = lambda t: None if t is None else t.cpu()  # noqa: E731
-    xg = torch.cat([c(x1), c(x2)], 1) if C2 else c(x1)
-    if use_gn:
-        xg = F.group_norm(xg, 32, c(gamma), c(beta), 1e-5)
-    exact, _ = _refs(xg, None, c(w), c(b), up, None, act, c(temb), c(res))
-    assert _relerr(stream.double(), exact) < (2e-6 if not (use_gn or act) else 3e-4)
-
-
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_conv_bf16_stride2_data_gradient_by_zero_insertion(backend):
     """Backward-data pass of a 3x3 stride-2 Conv2d (Downsample2D) = the bf16 kernel on the zero-inserted dy (up = 2) with
-    transposed, flipped filters; opt-in level 2."""
+    transposed, flipped filters; mixed-precision level 2."""
     dev = select(backend)
     from audiodiffusion import _native, ops
     Nn, Cin, Cout, H, W = 2, 128, 64, 32, 32           # forward: (Cin, 32, 32) -> (Cout, 16, 16)
@@ -343,79 +299,8 @@ def test_conv_bf16_stride2_data_gradient_by_zero_insertion(backend):
     assert _relerr(dx.double(), exact) < 2e-6, _relerr(dx.double(), exact)
 
 
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
-@pytest.mark.parametrize("case", WGRAD_CASES + [(2, 64, 32, 16, 32, 256, 0, 1, 1, 0), (1, 32, 0, 8, 16, 128, 1, 1, 1, 4)],
-                         ids=[str(i) for i in range(len(WGRAD_CASES) + 2)])
-def test_conv_bf16_weight_gradient_8_waves(backend, case):
-    """Opt-in 8-wave variant (option wgrad_bf16_8w): two wave groups share the staged tile, multiply different pixel rows and
-    write separate partial-sum slabs; same operands as the 4-wave kernel, so the same bars."""
-    dev = select(backend)
-    from audiodiffusion import _native, ops
-    Nn, C1, C2, H, W, Cout, up, use_gn, act, max_split = case
-    x1 = _rand((Nn, C1, H, W), 1, dev)
-    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
-    Ct = C1 + C2
-    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
-    a = torch.cat([x1, x2], 1).cpu() if C2 else x1.cpu()
-    if use_gn:
-        a = F.group_norm(a, 32, gamma.cpu(), beta.cpu(), 1e-5)
-    if act:
-        a = F.silu(a)
-    if up:
-        a = F.interpolate(a, scale_factor=2.0, mode="nearest")
-    dy = _rand((Nn, Cout) + tuple(a.shape[2:]), 7, "cpu")
-    exact = torch.nn.grad.conv2d_weight(_bf(a), (Cout, Ct, 3, 3), _bf(dy), padding=1)
-    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
-    got = {}
-    for w8 in (0, 1):
-        _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
-        _native.check(_native.lib().adm_set_option(b"wgrad_bf16_8w", w8))
-        _native.check(_native.lib().adm_set_option(b"wgrad_max_split", max_split))
-        try:
-            got[w8] = ops.conv2d_wgrad(x1, dy.to(dev), Cout, 3, x2=x2, up=bool(up), gn=gn, act=bool(act))
-        finally:
-            _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
-            _native.check(_native.lib().adm_set_option(b"wgrad_bf16_8w", 0))
-            _native.check(_native.lib().adm_set_option(b"wgrad_max_split", 0))
-    tight = 2e-6 if not (use_gn or act) else 3e-4
-    assert _relerr(got[1].double(), exact) < tight, _relerr(got[1].double(), exact)
-    assert _relerr(got[1].double(), got[0].double()) < 2e-6      # same products, different summation partition
-
-
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
-@pytest.mark.parametrize("case", CASES + PERSIST_CASES, ids=[str(i) for i in range(len(CASES) + len(PERSIST_CASES))])
-def test_conv_bf16_forward_8_waves_matches_4_waves(backend, case):
-    """Opt-in 8-wave forward kernel (option conv_bf16_8w): same operands, same per-tile accumulation order -> bit-identical
-    to the 4-wave kernel."""
-    dev = select(backend)
-    from audiodiffusion import _native, ops
-    Nn, C1, C2, H, W, Cout, up, use_gn, act, use_temb, use_res = case
-    x1 = _rand((Nn, C1, H, W), 1, dev)
-    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
-    Ct = C1 + C2
-    w = _rand((Cout, Ct, 3, 3), 3, dev, scale=(Ct * 9) ** -0.5)
-    b = _rand((Cout,), 4, dev)
-    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
-    gn = ops.groupnorm_stats(x1, gamma, beta, 32 if Ct % 32 == 0 else 16, 1e-5, x2=x2) if use_gn else None
-    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
-    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
-    res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
-    got = {}
-    _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
-    try:
-        for w8 in (0, 1):
-            _native.check(_native.lib().adm_set_option(b"conv_bf16_8w", w8))
-            got[w8] = ops.conv2d(x1, ops.pack_conv_weight(w), b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb,
-                                 residual=res, bf16=ops.pack_bf16_weight(w))
-            assert _native.lib().adm_last_conv_variant() == (5318 if w8 else 5316)
-    finally:
-        _native.check(_native.lib().adm_set_option(b"conv_bf16_8w", 0))
-        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
-    assert torch.equal(got[1].cpu(), got[0].cpu())
-
-
 # ---------------------------------------------------------------- prototype: blocked bf16 activations (op level)
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", CASES + PERSIST_CASES, ids=[str(i) for i in range(len(CASES) + len(PERSIST_CASES))])
 def test_blocked_bf16_activation_prototype_matches_fused_load_kernel(backend, case):
     """GroupNorm-apply pass -> xb[n][C/8][H][W][8] bf16 -> convolution with no conversion work: the same rounded operands

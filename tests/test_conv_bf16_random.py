@@ -1,12 +1,11 @@
-"""Seeded random sweep over the shapes the bf16 3x3 kernels accept (forward: one-tile and persistent variants; weight
-gradient), each case against the float64 convolution of the same bf16-rounded operands."""
+"""Seeded random sweep over the shapes the bf16 3x3 kernels accept (forward and weight gradient), each case against the float64 convolution of the same bf16-rounded operands."""
 import random
 
 import pytest
 import torch
 import torch.nn.functional as F
 
-from native_backend import BACKENDS_FIRST_CONTACT, select
+from native_backend import BACKENDS, select
 from test_kernels import _rand, _relerr
 
 
@@ -32,7 +31,7 @@ def _cases(n, seed):
 CASES = _cases(18, 20260924)
 
 
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", CASES, ids=[f"{i}-{c[-1]}" for i, c in enumerate(CASES)])
 def test_random_bf16_forward(backend, case):
     dev = select(backend)
@@ -48,15 +47,12 @@ def test_random_bf16_forward(backend, case):
     temb = _rand((Nn, Cout), 7, dev) if use_temb else None
     Ho, Wo = (2 * H, 2 * W) if up else (H, W)
     res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
-    persist = variant == "persist" and Ct >= 64
     _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
-    _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", int(persist)))
     try:
         out = ops.conv2d(x1, ops.pack_conv_weight(w), b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb,
                          residual=res, bf16=ops.pack_bf16_weight(w))
-        assert _native.lib().adm_last_conv_variant() == (5317 if persist else 5316)
+        assert _native.lib().adm_last_conv_variant() == 5316
     finally:
-        _native.check(_native.lib().adm_set_option(b"conv_bf16_persist", 0))
         _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
     c = lambda t: None if t is None else t.cpu()  # noqa: E731
     x = torch.cat([c(x1), c(x2)], 1) if C2 else c(x1)
@@ -78,7 +74,7 @@ WG_CASES = [(rng_n, c1, c2, h, w, co, up, gn, act, ms) for (rng_n, c1, c2, h, w,
             zip(_cases(8, 7), [0, 1, 2, 0, 3, 0, 2, 1])]
 
 
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", WG_CASES, ids=[str(i) for i in range(len(WG_CASES))])
 def test_random_bf16_weight_gradient(backend, case):
     dev = select(backend)

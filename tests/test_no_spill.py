@@ -35,10 +35,6 @@ def _usage(src):
     ("k_conv_wgrad.hip:sp8|sp_kernel|pf_kernelILi3ELb1|pf_kernelILi1ELb1", 0),   # fp32 weight gradients on the fast paths (the
                                          # generic 1x1 fallback `pf_kernel<1, false>` is known to spill; it serves odd chunkings only)
     ("k_conv_bf16.hip", 0),              # measured defaults: forward / data gradient, weight gradient, packing
-    ("k_conv_bf16w8.hip", 0),
-    ("k_conv_wgrad_bf16w8.hip", 0),
-    ("k_conv_bf16_persist.hip", 0),
-    ("k_conv_bf16_persist8.hip", 16),    # residual variants: 3 registers reloaded once per tile, outside the chunk loop
     ("k_conv1x1_bf16.hip", 0),
     ("k_conv_bf16_blocked.hip", 0),
 ])

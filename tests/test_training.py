@@ -83,6 +83,8 @@ def _worker(rank, world, port, q):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from native_backend import select
+    select("emu")                 # finish() applies the 1/world scaling with the native flat-op kernel
     from audiodiffusion.training import GradAllReducer
     g = torch.arange(100000, dtype=torch.float32) * (rank + 1)
     r = GradAllReducer(g, bucket_mb=1 / 16)  # 16384-float buckets -> several buckets in flight
@@ -105,3 +107,19 @@ def test_grad_allreduce_gloo_world2():
         p.join(timeout=300)
         assert p.exitcode == 0
     assert torch.allclose(out, torch.arange(100000, dtype=torch.float32) * 1.5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_flat_ops_match_the_torch_expressions_they_replace(backend):
+    """adm_flat_op vs the four torch expressions of the reference's optimizer side (accumulate / mean / 1-over-world / EMA)."""
+    dev = select(backend)
+    from audiodiffusion import training as T
+    g = torch.Generator().manual_seed(3)
+    for n in (4, 4099, 65536 + 4):                      # buffers are padded to float4 by FlatBuffer; tails still covered
+        y0, x = torch.randn(n, generator=g), torch.randn(n, generator=g)
+        for op, a, ref in ((T.FLAT_ADD, 0.0, lambda y: y + x), (T.FLAT_SCALE_FROM, 1.0 / 3, lambda y: x * (1.0 / 3)),
+                           (T.FLAT_DIV, 3.0, lambda y: y / 3.0), (T.FLAT_EMA, 1 - 0.9, lambda y: y - (y - x) * (1 - 0.9))):
+            y = y0.clone().to(dev)
+            T.flat_op(y, None if op == T.FLAT_DIV else x.to(dev), op, a)
+            want = ref(y0.clone())
+            assert torch.allclose(y.cpu(), want, rtol=2e-7, atol=1e-9), (n, op, float((y.cpu() - want).abs().max()))

@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from native_backend import BACKENDS, BACKENDS_FIRST_CONTACT, select
+from native_backend import BACKENDS, select
 from test_kernels import _rand, _relerr
 
 
@@ -76,7 +76,7 @@ def test_self_attention_key_blocks_match_one_pass(backend, C, heads, HW, key_blo
 
 
 # ---------------------------------------------------------------- backward passes vs torch autograd
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("shape", [(2, 32, 4, 8), (1, 96, 16, 16)])
 def test_layernorm_backward(backend, shape):
     dev = select(backend)
@@ -90,7 +90,7 @@ def test_layernorm_backward(backend, shape):
     assert _relerr(dx, x.grad) < 1e-5 and _relerr(dg, g.grad) < 1e-5 and _relerr(db, b.grad) < 1e-5
 
 
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_geglu_backward(backend):
     dev = select(backend)
     from audiodiffusion import ops
@@ -101,7 +101,7 @@ def test_geglu_backward(backend):
     assert _relerr(ops.geglu_backward(x.detach().to(dev), dy.to(dev)), x.grad) < 2e-6
 
 
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("C,heads,S", [(32, 8, 1), (64, 8, 3), (32, 2, 2), (64, 2, 2), (128, 2, 3)])
 def test_cross_attention_backward(backend, C, heads, S):
     dev = select(backend)
@@ -123,7 +123,7 @@ def test_cross_attention_backward(backend, C, heads, S):
         assert _relerr(dq, q.grad) < 1e-5 and _relerr(dwk, wk.grad) < 2e-5
 
 
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("C,heads,HW,block", [(32, 2, (8, 8), 16), (64, 8, (4, 24), 32), (64, 4, (8, 8), 0),
                                                (64, 2, (8, 8), 24), (128, 2, (4, 8), 16)])
 def test_self_attention_backward_in_blocks(backend, C, heads, HW, block):

@@ -3,7 +3,7 @@ native executor vs the oracle restatement on identical weights / inputs."""
 import pytest
 import torch
 
-from native_backend import BACKENDS, BACKENDS_FIRST_CONTACT, select
+from native_backend import BACKENDS, select
 from oracle.unet_condition import UNet2DConditionModel as OracleCond
 
 TINY = dict(sample_size=16, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(32, 64),
@@ -119,7 +119,7 @@ def test_conditional_pipeline_sampling_matches_oracle_and_roundtrips(backend, tm
     assert torch.equal(af.cpu(), mf.cpu())
 
 
-@pytest.mark.parametrize("backend", BACKENDS_FIRST_CONTACT)
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("cfg,B,S", [(TINY, 2, 1), (TINY3, 3, 4)], ids=["tiny-seq1", "tiny3-seq4"])
 def test_conditional_unet_gradients_match_autograd(backend, cfg, B, S):
     """`model(noisy, t, batch["encoding"])`, mse_loss, backward (scripts/train_unet.py:254-259): loss and every parameter

@@ -8,9 +8,6 @@
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-first_contact}; mkdir -p $O
 cd $R
-ADM_TEST_UNTIMED=1 timeout 150 python -m pytest tests/test_conv_bf16.py tests/test_conv_bf16_random.py tests/test_transformer_ops.py tests/test_unet_condition.py \
-    -m gpu -q 2>&1 | tail -15 > $O/first_contact_pytest.txt
-tail -3 $O/first_contact_pytest.txt
 ADM_BF16_PERSIST=1 PROBE_CHECK=0 PROBE_B=16 PROBE_MP=bf16 timeout 90 python tools/gpu_probe.py trainstep 2>&1 | grep "train step" | sed "s/^/bf16 level 1 + persistent forward kernel: /" | tee -a $O/train_levels.txt
 for V in 0 1 2; do ADM_BF16_PERSIST=$V ADM_BF16_WIDE=0 timeout 40 python tools/bf16_ab_probe.py 2>&1 | grep -v "^TOTAL" | sed "s/^/persist=$V /" | tee -a $O/persist_ab.txt; done
 ADM_BF16_8W=1 PROBE_CHECK=0 PROBE_B=16 PROBE_MP=bf16 timeout 90 python tools/gpu_probe.py trainstep 2>&1 | grep "train step" | sed "s/^/bf16 level 1 + 8-wave forward kernel: /" | tee -a $O/train_levels.txt
