@@ -26,50 +26,60 @@ class MelConfigStruct(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("x_res", "y_res", "sample_rate", "n_fft", "hop_length", "top_db", "n_iter")]
 
 
-# ---- constant tables (host, fp64; formulas of librosa.filters.mel / scipy.signal.get_window) -----------------
+# ---- constant tables (host, fp64) -------------------------------------------------------------------------------
 
-def _hz_to_mel(f):
-    f = np.asanyarray(f, dtype=float)
-    f_sp = 200.0 / 3
-    mels = f / f_sp
-    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
-    min_log_mel = min_log_hz / f_sp
-    if f.ndim:
-        m = f >= min_log_hz
-        mels[m] = min_log_mel + np.log(f[m] / min_log_hz) / logstep
-    elif f >= min_log_hz:
-        mels = min_log_mel + np.log(f / min_log_hz) / logstep
-    return mels
+def _slaney_hz(mel):
+    """Slaney's auditory scale, mel -> Hz: linear (200/3 Hz per mel) below 1 kHz = 15 mel, then 27 log-spaced steps per
+    factor 6.4 (librosa.mel_to_hz, htk=False)."""
+    mel = np.asarray(mel, dtype=np.float64)
+    lin = (200.0 / 3.0) * mel
+    k = 1000.0 / (200.0 / 3.0)                            # the 1 kHz knee in mel: 15 up to one ulp, as librosa computes it
+    return np.where(mel >= k, 1000.0 * np.exp((np.log(6.4) / 27.0) * (mel - k)), lin)
 
 
-def _mel_to_hz(mels):
-    mels = np.asanyarray(mels, dtype=float)
-    f_sp = 200.0 / 3
-    freqs = f_sp * mels
-    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
-    min_log_mel = min_log_hz / f_sp
-    if mels.ndim:
-        m = mels >= min_log_mel
-        freqs[m] = min_log_hz * np.exp(logstep * (mels[m] - min_log_mel))
-    elif mels >= min_log_mel:
-        freqs = min_log_hz * np.exp(logstep * (mels - min_log_mel))
-    return freqs
+def _slaney_mel(hz):
+    hz = float(hz)
+    return 1000.0 / (200.0 / 3.0) + np.log(hz / 1000.0) / (np.log(6.4) / 27.0) if hz >= 1000.0 else hz / (200.0 / 3.0)
 
 
-def slaney_filterbank(sr, n_fft, n_mels, dtype):
-    """Triangular Slaney-normalised filterbank (htk=False, fmin=0, fmax=sr/2), shape (n_mels, 1+n_fft//2)."""
-    weights = np.zeros((n_mels, 1 + n_fft // 2), dtype=dtype)
-    fftfreqs = np.fft.rfftfreq(n=n_fft, d=1.0 / sr)
-    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(0.0), _hz_to_mel(sr / 2.0), n_mels + 2))
-    fdiff = np.diff(mel_f)
-    ramps = np.subtract.outer(mel_f, fftfreqs)
-    for i in range(n_mels):
-        lower = -ramps[i] / fdiff[i]
-        upper = ramps[i + 2] / fdiff[i + 1]
-        weights[i] = np.maximum(0, np.minimum(lower, upper))
-    enorm = 2.0 / (mel_f[2 : n_mels + 2] - mel_f[:n_mels])
-    weights *= enorm[:, np.newaxis]
-    return weights
+def slaney_filter_taps(sr, n_fft, n_mels):
+    """The Slaney-normalised triangular filterbank librosa.filters.mel(sr, n_fft, n_mels) builds (htk=False, fmin=0,
+    fmax=sr/2), generated SPARSE, filter by filter, from the triangle's corner frequencies instead of a dense
+    (n_mels, n_bins) matrix: filter m rises from lo = edge[m] to its apex edge[m+1] and falls to hi = edge[m+2]; its
+    non-zero taps are the FFT bins strictly inside (lo, hi). Returns (start, count, w32, w64): first bin and number of
+    bins per filter and the concatenated weights as librosa stores them for float32 audio (triangle rounded to float32,
+    THEN scaled by the float64 area normalisation 2/(hi-lo) and rounded again) and for float64 audio."""
+    n_bins = 1 + n_fft // 2
+    edge = _slaney_hz(np.linspace(_slaney_mel(0.0), _slaney_mel(sr / 2.0), n_mels + 2))
+    bin_hz = np.fft.rfftfreq(n=n_fft, d=1.0 / sr)
+    start, count = np.zeros(n_mels, np.int32), np.zeros(n_mels, np.int32)
+    w32, w64 = [], []
+    for m in range(n_mels):
+        lo, apex, hi = edge[m], edge[m + 1], edge[m + 2]
+        first = int(np.searchsorted(bin_hz, lo, side="right"))          # first bin with f > lo
+        last = int(np.searchsorted(bin_hz, hi, side="left")) - 1        # last bin with f < hi
+        f = bin_hz[first:last + 1]
+        tri = np.minimum((f - lo) / (apex - lo), (hi - f) / (hi - apex))
+        keep = np.nonzero(tri > 0)[0]                                   # guards against a bin rounding onto a corner
+        if len(keep) == 0:
+            continue
+        first, f, tri = first + int(keep[0]), f[keep[0]:keep[-1] + 1], tri[keep[0]:keep[-1] + 1]
+        area = 2.0 / (hi - lo)
+        start[m], count[m] = first, len(f)
+        w64.append(tri * area)
+        w32.append((tri.astype(np.float32).astype(np.float64) * area).astype(np.float32))
+    w32 = np.concatenate(w32).astype(np.float32) if w32 else np.zeros(0, np.float32)
+    w64 = np.concatenate(w64).astype(np.float64) if w64 else np.zeros(0, np.float64)
+    return start, count, w32, w64
+
+
+def taps_to_dense(start, count, w, n_bins):
+    out = np.zeros((len(start), n_bins), dtype=w.dtype)
+    o = 0
+    for m, (s0, c) in enumerate(zip(start, count)):
+        out[m, s0:s0 + c] = w[o:o + c]
+        o += c
+    return out
 
 
 def _window_sumsquare(window, n_frames, hop, n_fft):
@@ -163,20 +173,9 @@ class Mel:
         window = scipy.signal.get_window("hann", n_fft, fftbins=True).astype(np.float64)
         q = np.arange(n_fft // 2)
         tw = np.stack([np.cos(2 * np.pi * q / n_fft), -np.sin(2 * np.pi * q / n_fft)], axis=1).astype(np.float64)
-        fb32 = slaney_filterbank(self.sr, n_fft, self.n_mels, np.float32)
-        fb64 = slaney_filterbank(self.sr, n_fft, self.n_mels, np.float64)
-        nz = fb64 > 0
-        start = np.zeros(self.n_mels, np.int32)
-        count = np.zeros(self.n_mels, np.int32)
-        w32, w64 = [], []
-        for m in range(self.n_mels):
-            idx = np.nonzero(nz[m])[0]
-            if len(idx):
-                start[m], count[m] = idx[0], idx[-1] - idx[0] + 1  # contiguous support of a triangle
-                w32.append(fb32[m, idx[0] : idx[-1] + 1]), w64.append(fb64[m, idx[0] : idx[-1] + 1])
-        w32 = np.concatenate(w32).astype(np.float32) if w32 else np.zeros(0, np.float32)
-        w64 = np.concatenate(w64).astype(np.float64) if w64 else np.zeros(0, np.float64)
-        self.filter_taps = (start.copy(), count.copy())  # exposed for the bit-exact mel-bin-index parity test
+        start, count, w32, w64 = slaney_filter_taps(self.sr, n_fft, self.n_mels)
+        fb64 = taps_to_dense(start, count, w64, n_bins)
+        self.filter_taps = (start.copy(), count.copy())
         # CSC (per FFT bin: the mel filters touching it), same tap set
         t_off = np.zeros(n_bins + 1, np.int32)
         t_idx, t_w = [], []
@@ -248,6 +247,19 @@ class Mel:
         frames = 1 + n // self.hop_length
         out = torch.empty((B, self.n_mels, frames), dtype=torch.uint8, device=dev)
         N.check(N.lib().adm_mel_forward(h, N.ptr(t), int(arr.dtype == np.float64), B, n, n, N.ptr(out), N.stream_for(t)))
+        return out.cpu().numpy()
+
+    def audio_slices_to_melspectrograms(self, slices) -> np.ndarray:
+        """librosa.feature.melspectrogram of every slice (`mel.py:140-147`, before the dB conversion):
+        (B, y_res, frames) in the slices' precision."""
+        arr = np.stack([np.asarray(s) for s in slices])
+        if arr.dtype not in (np.float32, np.float64):
+            arr = arr.astype(np.float32 if arr.dtype.itemsize <= 4 else np.float64)
+        h = self._ensure_handle()
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self._device())
+        B, n = t.shape
+        out = torch.empty((B, self.n_mels, 1 + n // self.hop_length), dtype=t.dtype, device=t.device)
+        N.check(N.lib().adm_mel_forward_power(h, N.ptr(t), int(arr.dtype == np.float64), B, n, n, N.ptr(out), N.stream_for(t)))
         return out.cpu().numpy()
 
     def audio_slice_to_image(self, slice: int, ref: Union[float, Callable] = np.max) -> Image.Image:

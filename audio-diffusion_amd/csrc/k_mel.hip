@@ -400,7 +400,29 @@ void adm_mel_destroy(adm_mel_t* h) {
 }
 
 // audio: device, B slices of n_samples (fp32 or fp64), consecutive slices `slice_stride` elements apart.
-// image_out: device (B, n_mels, n_frames) uint8 with n_frames = 1 + n_samples / hop.
+// melspec_out: device (B, n_mels, n_frames) in the audio's precision, n_frames = 1 + n_samples / hop:
+// librosa.feature.melspectrogram (mel.py:140-147) before the dB conversion.
+int adm_mel_forward_power(adm_mel_t* h, const void* audio, int is_f64, int B, long slice_stride, int n_samples,
+                          void* melspec_out, void* stream) {
+  ADM_REQUIRE(h && audio && melspec_out && B > 0 && n_samples > 0, "mel_forward_power: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const adm_mel_config& c = h->cfg;
+  const int n_frames = 1 + n_samples / c.hop_length;
+  dim3 grid(n_frames, B);
+  const size_t smem = fft_smem(h);
+  if (is_f64) {
+    ADM_LAUNCH((mel_stft_power_kernel<double>), grid, dim3(256), smem, st, (const double*)audio, slice_stride, n_samples,
+               c.n_fft, h->log2n, c.hop_length, h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count,
+               h->fb_off, h->fb_w32, h->fb_w64, h->n_mels, n_frames, (double*)melspec_out);
+  } else {
+    ADM_LAUNCH((mel_stft_power_kernel<float>), grid, dim3(256), smem, st, (const float*)audio, slice_stride, n_samples,
+               c.n_fft, h->log2n, c.hop_length, h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count,
+               h->fb_off, h->fb_w32, h->fb_w64, h->n_mels, n_frames, (float*)melspec_out);
+  }
+  return ADM_CHECK_LAUNCH();
+}
+
+// image_out: device (B, n_mels, n_frames) uint8 = the dB conversion + quantisation (mel.py:148-150) of the above.
 int adm_mel_forward(adm_mel_t* h, const void* audio, int is_f64, int B, long slice_stride, int n_samples,
                     uint8_t* image_out, void* stream) {
   ADM_REQUIRE(h && audio && image_out && B > 0, "mel_forward: bad argument");
@@ -409,18 +431,11 @@ int adm_mel_forward(adm_mel_t* h, const void* audio, int is_f64, int B, long sli
   const int n_frames = 1 + n_samples / c.hop_length;
   const size_t need = (size_t)B * h->n_mels * n_frames * 8;
   if (h->cap_fwd < need) { ADM_TRY(stream_sync(st)); ADM_TRY(grow(h, &h->melspec, need)); h->cap_fwd = need; }
-  dim3 grid(n_frames, B);
-  const size_t smem = fft_smem(h);
+  ADM_TRY(adm_mel_forward_power(h, audio, is_f64, B, slice_stride, n_samples, h->melspec, stream));
   if (is_f64) {
-    ADM_LAUNCH((mel_stft_power_kernel<double>), grid, dim3(256), smem, st, (const double*)audio, slice_stride, n_samples,
-               c.n_fft, h->log2n, c.hop_length, h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count,
-               h->fb_off, h->fb_w32, h->fb_w64, h->n_mels, n_frames, (double*)h->melspec);
     ADM_LAUNCH((mel_db_u8_kernel<double>), dim3(B), dim3(256), 0, st, (const double*)h->melspec, h->n_mels * n_frames,
                (float)c.top_db, image_out);
   } else {
-    ADM_LAUNCH((mel_stft_power_kernel<float>), grid, dim3(256), smem, st, (const float*)audio, slice_stride, n_samples,
-               c.n_fft, h->log2n, c.hop_length, h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count,
-               h->fb_off, h->fb_w32, h->fb_w64, h->n_mels, n_frames, (float*)h->melspec);
     ADM_LAUNCH((mel_db_u8_kernel<float>), dim3(B), dim3(256), 0, st, (const float*)h->melspec, h->n_mels * n_frames,
                (float)c.top_db, image_out);
   }

@@ -347,6 +347,10 @@ void adm_mel_destroy(adm_mel_t* h);
  * image_out: device (B, y_res, 1 + n_samples/hop) uint8. */
 int adm_mel_forward(adm_mel_t* h, const void* audio, int is_f64, int B, long slice_stride, int n_samples,
                     uint8_t* image_out, void* stream);
+/* the mel power spectrogram before the dB conversion (librosa.feature.melspectrogram, audiodiffusion/mel.py:140-147):
+ * melspec_out: device (B, y_res, 1 + n_samples/hop) in the audio's precision (fp32 or fp64). */
+int adm_mel_forward_power(adm_mel_t* h, const void* audio, int is_f64, int B, long slice_stride, int n_samples,
+                          void* melspec_out, void* stream);
 /* images: device (B, y_res, n_frames) uint8; init_phase: device (B, n_bins, n_frames) fp64 in [0,1) (Griffin-Lim start
  * phase / 2 pi); audio_out: device (B, hop*(n_frames-1)) fp32; stft_mag_out: NULL or device (B, n_frames, n_bins) fp64;
  * pg_max_host: NULL or receives max |projected gradient| of the NNLS start point (librosa stops there iff <= 1e-5). */

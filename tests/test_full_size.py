@@ -73,6 +73,82 @@ def test_ddim50_loop_is_deterministic_shardable_and_quantises_as_documented(dev,
     assert np.isfinite(flt.cpu().numpy()).all() and float(flt.abs().max()) <= 1.0 + 1e-6      # clip_sample keeps x0 in [-1,1]
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Loop-level parity AT BASELINE SIZES against the CPU oracle driven through the same procedure
+# (`pipeline_audio_diffusion.py:159-199`): same weights, same start noise, same injected per-step scheduler noise.
+# Bars: final float image <= 1e-3 (north_star), uint8 image <= 1 LSB and >= 99.5 % identical.
+def _loop_parity(dev, cfg, sched_name, steps, start_step, B, seed, vae_cfg=None, eta=0.0):
+    import os
+    from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, DDPMScheduler, Mel, UNet2DModel
+    from audiodiffusion.vae import AutoencoderKL
+    from oracle import mel as omel
+    from oracle import pipeline as opipe
+    from oracle import schedulers as osched
+    from oracle.unet import UNet2DModel as OracleUNet
+    from oracle.vae import AutoencoderKL as OracleVAE
+    torch.set_num_threads(min(32, os.cpu_count() or 8))            # the oracle convolutions do not scale past this
+    unet = UNet2DModel(**cfg).init_random(seed)
+    ref_unet = OracleUNet(**cfg).eval()
+    ref_unet.load_state_dict(unet.state_dict())
+    vae = ref_vae = None
+    if vae_cfg is not None:
+        vae = AutoencoderKL(**vae_cfg).init_random(seed + 1)
+        ref_vae = OracleVAE(**vae_cfg).eval()
+        ref_vae.load_state_dict(vae.state_dict())
+    mine = AudioDiffusionPipeline(vae, unet, Mel(), (DDIMScheduler if sched_name == "ddim" else DDPMScheduler)()).to(dev)
+    mine.set_progress_bar_config(disable=True)
+    ref = opipe.AudioDiffusionPipeline(ref_vae, ref_unet, omel.Mel(),
+                                       (osched.DDIMScheduler if sched_name == "ddim" else osched.DDPMScheduler)())
+    g = torch.Generator().manual_seed(1000 + seed)
+    hw = cfg["sample_size"]
+    noise = torch.randn((B, cfg["in_channels"]) + tuple(hw), generator=g)
+    n_run = steps - start_step
+    step_noise = torch.randn((n_run, B, cfg["in_channels"]) + tuple(hw), generator=g)
+    kw = dict(batch_size=B, steps=steps, start_step=start_step, eta=eta, audio=False, return_float=True)
+    ri, rf = ref(noise=noise.clone(), step_noise=step_noise, **kw)
+    mi, mf = mine(noise=noise.clone().to(dev), step_noise=step_noise.to(dev), **kw)
+    err = float((mf.cpu() - rf).abs().max())
+    a = np.stack([np.asarray(i).astype(int) for i in mi])
+    b = np.stack([np.asarray(i).astype(int) for i in ri])
+    assert a.shape == b.shape
+    assert err <= 1e-3, err
+    assert np.abs(a - b).max() <= 1 and (a == b).mean() >= 0.995, (np.abs(a - b).max(), (a == b).mean())
+    return err
+
+
+def test_config1_64x64_ddpm_10_steps_loop_matches_the_oracle(dev):
+    """BASELINE.json configs[0]: audio-diffusion-64 (the train_unet.py architecture at 64x64), DDPM, 1 sample, 10 steps —
+    the noise term of every DDPM step is injected so both sides consume identical draws."""
+    cfg = dict(CFG256, sample_size=(64, 64))
+    _loop_parity(dev, cfg, "ddpm", 10, 0, 1, seed=0)
+
+
+def test_config2_256_ddpm_1000_schedule_last_steps_match_the_oracle(dev):
+    """configs[1]: 256x256 pixel-space DDPM on the 1000-step schedule; the oracle affords the last 4 of them at batch 2
+    (start_step = 996: timesteps 3, 2, 1, 0 — three with the injected variance noise, the last one without)."""
+    _loop_parity(dev, CFG256, "ddpm", 1000, 996, 2, seed=1)
+
+
+def test_config3_256_ddim_10_steps_loop_matches_the_oracle(dev):
+    """configs[2]: 256x256 DDIM (eta = 0), a complete 10-step sampling from pure noise through the captured hipGraph."""
+    _loop_parity(dev, CFG256, "ddim", 10, 0, 1, seed=2)
+
+
+def test_config3_256_ddim_eta_1_uses_the_injected_noise(dev):
+    """DDIM with eta = 1 draws variance noise every step (`pipeline_audio_diffusion.py:165-172`): 4 steps, batch 1."""
+    _loop_parity(dev, CFG256, "ddim", 4, 0, 1, seed=3, eta=1.0)
+
+
+def test_config4_latent_ddpm_10_steps_and_vae_decode_match_the_oracle(dev):
+    """configs[3]: latent audio diffusion — DDPM-10 on 1x32x32 latents with the train_unet.py architecture, then
+    AutoencoderKL.decode(latents / 0.18215) to 256x256 and the uint8 conversion (`pipeline_audio_diffusion.py:187-199`)."""
+    vae_cfg = dict(sample_size=(256, 256), in_channels=1, out_channels=1, latent_channels=1, layers_per_block=2,
+                   block_out_channels=(128, 256, 512, 512), down_block_types=("DownEncoderBlock2D",) * 4,
+                   up_block_types=("UpDecoderBlock2D",) * 4)
+    cfg = dict(CFG256, sample_size=(32, 32))
+    _loop_parity(dev, cfg, "ddpm", 10, 0, 1, seed=4, vae_cfg=vae_cfg)
+
+
 def test_training_step_256_gradients_match_autograd_at_batch_1(dev):
     import torch.nn.functional as F
     from audiodiffusion import UNet2DModel
