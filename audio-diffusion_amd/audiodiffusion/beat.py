@@ -16,7 +16,7 @@ Unpinned against librosa itself (no fixtures in the reference); `tests/test_beat
 import numpy as np
 import scipy.signal
 
-from .mel import slaney_filterbank
+from .mel import slaney_filter_taps, taps_to_dense
 
 HOP, N_FFT, N_MELS = 512, 2048, 128
 
@@ -34,7 +34,8 @@ def onset_strength(y, sr, hop_length=HOP, n_fft=N_FFT):
     idx = np.arange(n_fft)[None, :] + hop_length * np.arange(n_frames)[:, None]
     window = scipy.signal.get_window("hann", n_fft, fftbins=True).astype(np.float32)
     power = np.abs(np.fft.rfft(yp[idx] * window, axis=1)).astype(np.float32) ** 2            # (frames, bins)
-    mel = power @ slaney_filterbank(sr, n_fft, N_MELS, np.float32).T                            # (frames, mels)
+    start, count, w32, _ = slaney_filter_taps(sr, n_fft, N_MELS)
+    mel = power @ taps_to_dense(start, count, w32, 1 + n_fft // 2).T                            # (frames, mels)
     S = _power_to_db(mel.T)                                                                      # (mels, frames)
     flux = np.maximum(0.0, S[:, 1:] - S[:, :-1])
     env = np.median(flux, axis=0)

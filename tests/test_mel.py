@@ -72,7 +72,8 @@ def test_image_to_audio_with_injected_phase(backend):
     ref_audio = omel.griffinlim(ref_mag, ref.n_iter, ref.hop_length, ref.n_fft, init_phase=phase)
     audio, mag = mine.images_to_audios([img], init_phase=phase[None], return_magnitude=True)
     assert mine.last_nnls_pg is not None and mine.last_nnls_pg <= 1e-5
-    assert np.abs(mag[0] - ref_mag).max() <= 1e-9 * max(1.0, np.abs(ref_mag).max())
+    # compared as POWER: untouched rows (DC, Nyquist) hold pseudo-inverse rounding noise around 0 (see tests/test_golden.py)
+    assert np.abs(mag[0] ** 2 - ref_mag ** 2).max() <= 1e-12 * max(1.0, np.abs(ref_mag ** 2).max())
     assert audio.shape == (1, mine.hop_length * (mine.x_res - 1)) and audio.dtype == np.float32
     err = np.abs(audio[0] - ref_audio).max() / np.abs(ref_audio).max()
     assert err <= 1e-3, err
