@@ -45,7 +45,7 @@ def sample_sharded(pipe, global_batch, steps=None, seed=42, eta=0.0, gather=True
         step_noise = [next(it)[lo:hi].to(dev) if r["k_noise"] != 0.0 else None for r in rows]
     _, u8 = pipe._denoise(x[lo:hi].contiguous().to(dev), 0, eta, None, None, 0, 0, step_noise=step_noise)
     u8 = u8.reshape(hi - lo, H, W)
-    if not gather or world == 1:
+    if not gather or not dist.is_initialized():      # a 1-rank group still goes through the collective (RCCL shake-out)
         return u8, (lo, hi)
     per = (global_batch + world - 1) // world
     pad = torch.zeros((per, H, W), dtype=torch.uint8, device=dev)

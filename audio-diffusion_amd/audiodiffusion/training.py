@@ -184,8 +184,9 @@ class GradAllReducer:
     async all-reduce so buckets pipeline over the xGMI links; `finish()` waits and applies the 1/world scaling that DDP
     applies. No collective is issued under gradient accumulation micro-steps (`no_sync`, train_unet.py:252)."""
 
-    def __init__(self, flat_grads, bucket_mb=25, group=None):
+    def __init__(self, flat_grads, bucket_mb=25, group=None, force=False):
         self.g, self.group = flat_grads, group
+        self.force = bool(force)     # issue the collectives even in a 1-rank group (single-GPU shake-out of the RCCL path)
         per = max(1, int(bucket_mb * (1 << 20)) // 4)
         self.bounds = [(i, min(i + per, flat_grads.numel())) for i in range(0, flat_grads.numel(), per)]
         self.pending = []
@@ -196,7 +197,7 @@ class GradAllReducer:
         self._cb = None
 
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
 
     def _launch(self, b):
         lo, hi = self.bounds[b]

@@ -9,13 +9,25 @@ region. N > 1: one process per GPU (torchrun), the global noise batch is generat
 no collective inside the loop, one all_gather of the uint8 images at the end of each step ("scaling": "weak").
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     — dominant kernel (the exact-f32 MFMA implicit-GEMM convolution) measured LIVE with HIP events around
-                 every launch of one extra eager forward on the same stream: algorithmic FLOPs / launch time;
+  roofline     — dominant kernel (the Winograd F(2x2,3x3) fp32-MFMA convolution) measured LIVE with HIP events around
+                 every launch of one extra eager forward on the same stream. `achieved`/`frac` are the EXECUTED matrix-pipe
+                 FLOP/s against the 157.3 TF fp32 MFMA peak (a real roofline fraction, <= 1); the algorithmic
+                 (direct-convolution) rate, which Winograd makes 2.25x larger, is reported beside it;
   cpu_baseline — the CPU oracle (oracle/, a port: the reference cannot be imported without diffusers/librosa) timed on
-                 the host cores on a bounded sample of the same workload.
+                 the host cores on a bounded sample of the same workload;
+  train        — BASELINE.json config 5 beside it: 10 optimizer steps of scripts/train_unet.py's step at 256x256,
+                 batch 16 per GPU, --mixed_precision bf16 (forward + backward + bucketed gradient all-reduce over RCCL +
+                 clip + AdamW/EMA + weight re-pack); samples/s over all ranks;
+  mel          — the audio codec either side of the loop (Mel.audio_slice_to_image / Mel.image_to_audio, batched),
+                 clips/s and algorithmic GB/s on device-resident buffers.
+
+Test hooks (never set by the driver): ADM_BENCH_EMU=1 runs the same code on the CPU-emulation build of the kernels over
+gloo at toy sizes (tests/test_bench_script.py launches this very file with 2 ranks); ADM_BENCH_FORCE_PG=1 builds the
+process group and runs the collectives even at world size 1 (a one-GPU shake-out of the RCCL calls).
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -32,10 +44,16 @@ CFG256 = dict(sample_size=256, in_channels=1, out_channels=1, layers_per_block=2
               block_out_channels=(128, 128, 256, 256, 512, 512),
               down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
               up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4)
+CFG_TOY = dict(sample_size=16, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(32, 64),
+               down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"))
 F1_TFLOP = 0.496          # algorithmic TFLOP per UNet forward per sample @256^2
 A1_GB, W_GB = 1.871, 0.4547  # fused-minimum activation bytes per forward per sample; weight bytes per forward per GPU
 PEAK_F32_TF = 157.3       # MI355X dense fp32 MFMA == vector peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_BF16_TF = 2500.0     # dense bf16 MFMA
 PEAK_HBM_TBS = 8.0
+MEL_CLIP_MB = 0.59        # algorithmic bytes per clip of the Mel codec (4 B/sample + 1 B/pixel)
+EMU = os.environ.get("ADM_BENCH_EMU") == "1"            # test hook: CPU emulation build + gloo, toy sizes
+FORCE_PG = os.environ.get("ADM_BENCH_FORCE_PG") == "1"  # test hook: process group + collectives even at world size 1
 
 
 def parse():
@@ -47,92 +65,195 @@ def parse():
     p.add_argument("--ddim-steps", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-train-leg", action="store_true", help="skip the config-5 training sub-record")
+    p.add_argument("--no-mel-leg", action="store_true", help="skip the Mel codec sub-record")
     p.add_argument("--mode", choices=["sample", "train"], default="sample",
-                   help="sample (default): BASELINE.json's metric. train: config 5 (scripts/train_unet.py step, fp32).")
+                   help="sample (default): BASELINE.json's metric. train: config 5 (scripts/train_unet.py step) as the main line.")
     p.add_argument("--train-batch-per-gpu", type=int, default=16)
-    p.add_argument("--mixed-precision", choices=["no", "bf16"], default="no",
-                   help="train mode only: bf16 = BASELINE.json config 5 as written (bf16 MFMA operands, fp32 accumulate)")
+    p.add_argument("--train-steps", type=int, default=10)
+    p.add_argument("--mixed-precision", choices=["no", "bf16"], default="bf16",
+                   help="training precision: bf16 = BASELINE.json config 5 as written (bf16 MFMA operands, fp32 accumulate)")
     return p.parse_args()
 
 
-def train_main(a, world, rank, dev):
-    """Extra (non-default) leg: one step = fused add_noise + native UNet forward+backward + bucketed gradient all-reduce +
-    clip + fused AdamW/EMA + weight re-pack at 256x256, fp32, batch 16 per GPU, synthetic data (BASELINE.json config 5)."""
+class Job:
+    """Rank / device / process-group plumbing shared by every leg (one process per GPU)."""
+
+    def __init__(self, a):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        assert self.world == a.gpus, (f"--gpus {a.gpus} but WORLD_SIZE={self.world}: launch with "
+                                      f"torch.distributed.run --nproc-per-node {a.gpus}")
+        if EMU:
+            from audiodiffusion import _native
+            _native.load(os.path.join(ROOT, "tests", "emu", "libadm_emu.so"))
+            self.dev = torch.device("cpu")
+        else:
+            assert torch.cuda.is_available(), "bench.py needs a MI355X (the hot path has no CPU fallback)"
+            torch.cuda.set_device(self.local)
+            self.dev = torch.device("cuda", self.local)
+        self.pg = self.world > 1 or FORCE_PG
+        if self.pg:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            if EMU:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)  # RCCL over xGMI
+
+    def sync(self):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        if self.pg:
+            dist.barrier()
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+
+    def timed(self, step, steps, warmup):
+        """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; MAX over ranks."""
+        for _ in range(warmup):
+            step()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.sync()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.dev)
+        if self.pg:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
+
+    def close(self):
+        if self.pg:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def train_leg(job, B, steps, warmup, mixed_precision):
+    """scripts/train_unet.py's step (:226-267) on synthetic data: fused add_noise, native UNet forward + backward with the
+    bucketed gradient all-reduce issued from inside the reverse pass, clip, fused AdamW + EMA, weight re-pack."""
     from audiodiffusion import DDPMScheduler, UNet2DModel
     from audiodiffusion import training as T
-    B = a.train_batch_per_gpu
-    unet = UNet2DModel(**CFG256).init_random(0)
-    flat, grads = unet.enable_training(mixed_precision=a.mixed_precision)
-    opt, ema, red = T.AdamW(flat), T.EMAModel(flat), T.GradAllReducer(grads)
-    if world > 1:
+    cfg = CFG_TOY if EMU else CFG256
+    hw = cfg["sample_size"]
+    mp = "no" if EMU else mixed_precision
+    unet = UNet2DModel(**cfg).init_random(0)
+    flat, grads = unet.enable_training(mixed_precision=mp)
+    opt, ema = T.AdamW(flat), T.EMAModel(flat)
+    red = T.GradAllReducer(grads, force=FORCE_PG)
+    if job.pg:
         red.attach(unet)          # gradient buckets are all-reduced (RCCL) from inside the reverse pass
     sched = DDPMScheduler()
-    g = torch.Generator().manual_seed(7 + rank)
-    clean = (torch.rand(B, 1, 256, 256, generator=g) * 2 - 1).to(dev)
-    noise = torch.randn(B, 1, 256, 256, generator=g).to(dev)
+    g = torch.Generator().manual_seed(7 + job.rank)
+    clean = (torch.rand(B, 1, hw, hw, generator=g) * 2 - 1).to(job.dev)
+    noise = torch.randn(B, 1, hw, hw, generator=g).to(job.dev)
     ts = torch.randint(0, 1000, (B,), generator=g)
+    last = {}
 
     def step():
         noisy = sched.add_noise(clean, noise, ts)
         red.begin_step()
-        loss = unet.train_step(noisy, ts, noise)
+        last["loss"] = unet.train_step(noisy, ts, noise)
+        last["overlapped"] = red.overlapped
         red.start(), red.finish()
         opt.step(grads, clip=T.clip_grad_norm_(grads, 1.0), ema=ema, ema_decay=ema.next_decay())
         unet.refresh_weights()
-        return loss
 
-    def sync():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(a.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    sync()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    if rank == 0:
-        elapsed = float(el.item())
-        value = world * B * a.steps / elapsed
-        print(json.dumps({
-            "metric": "training samples/sec (256x256 UNet2D, fwd+bwd+AdamW+EMA)", "value": round(value, 3),
-            "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if a.mixed_precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"scripts/train_unet.py step, 256x256, batch {B}/GPU, " +
-                                   ("--mixed_precision bf16 (bf16 MFMA operands on the 3x3 convolutions, fp32 accumulate/storage)"
-                                    if a.mixed_precision == "bf16" else "fp32 (reference default mixed_precision=no)"),
-                       "global_batch": world * B, "parallelism": f"data parallel x{world}, bucketed RCCL all-reduce"},
-            "TFLOPs_3x_fwd": round(value * 3 * F1_TFLOP / world, 2), "final_loss": float(loss)}), flush=True)
+    elapsed = job.timed(step, steps, warmup)
+    value = job.world * B * steps / elapsed
+    return {"metric": "training samples/sec (256x256 UNet2D, fwd+bwd+all-reduce+AdamW+EMA)", "value": round(value, 3),
+            "unit": "samples/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 2),
+            "batch_per_gpu": B, "global_batch": job.world * B, "dtype": "bf16" if mp == "bf16" else "f32",
+            "workload": "scripts/train_unet.py step, 256x256, " +
+                        ("--mixed_precision bf16 (bf16 MFMA operands on the 3x3 and 1x1 convolutions of all three passes, fp32 "
+                         "accumulate / storage / optimizer)" if mp == "bf16" else "fp32 (reference default mixed_precision=no)"),
+            "parallelism": f"data parallel x{job.world}, 25 MB gradient buckets all-reduced from inside the reverse pass",
+            "allreduce_buckets": len(red.bounds), "allreduce_buckets_overlapped": last.get("overlapped", 0),
+            "TFLOPs_3x_fwd": round(value * 3 * F1_TFLOP / job.world, 2),
+            ("frac_of_bf16_peak" if mp == "bf16" else "frac_of_fp32_peak"):
+                round(value * 3 * F1_TFLOP / job.world / (PEAK_BF16_TF if mp == "bf16" else PEAK_F32_TF), 4),
+            "final_loss": float(last["loss"])}
 
 
-def cpu_baseline(sd, n_threads):
-    """Oracle (port) on the host cores: 1 warm-up + 3 timed {UNet forward + DDIM step} at B=1, extrapolated x50."""
+def mel_leg(job, n_fwd=256, n_inv=32):
+    """Mel codec on device-resident buffers, batched (the reference converts clip by clip on one host core,
+    pipeline_audio_diffusion.py:135-141,201): forward = audio -> uint8 log-mel image, inverse = image -> audio
+    (NNLS start point + 32 Griffin-Lim iterations)."""
+    from audiodiffusion import Mel
+    from audiodiffusion import _native as N
+    mel = Mel(x_res=16, y_res=16, hop_length=64, n_fft=256, n_iter=2) if EMU else Mel()
+    if EMU:
+        n_fwd, n_inv = 4, 2
+    h = mel._ensure_handle()
+    n = mel.slice_size
+    g = torch.Generator().manual_seed(3)
+    audio = (0.3 * torch.randn(n_fwd, n, generator=g)).to(job.dev)
+    frames = 1 + n // mel.hop_length
+    img = torch.empty((n_fwd, mel.n_mels, frames), dtype=torch.uint8, device=job.dev)
+    st = N.stream_for(audio)
+
+    def fwd():
+        N.check(N.lib().adm_mel_forward(h, N.ptr(audio), 0, n_fwd, n, n, N.ptr(img), st))
+
+    def wall(fn, reps):
+        fn()
+        if job.dev.type == "cuda":
+            torch.cuda.synchronize(job.dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        if job.dev.type == "cuda":
+            torch.cuda.synchronize(job.dev)
+        return (time.perf_counter() - t0) / reps
+
+    t_f = wall(fwd, 1 if EMU else 10)
+    n_bins = 1 + mel.n_fft // 2
+    images = img[:n_inv].contiguous()
+    phase = torch.rand((n_inv, n_bins, frames), dtype=torch.float64, device=job.dev)
+    out = torch.empty((n_inv, mel.hop_length * (frames - 1)), dtype=torch.float32, device=job.dev)
+
+    def inv():
+        N.check(N.lib().adm_mel_inverse(h, N.ptr(images), N.ptr(phase), n_inv, frames, N.ptr(out), None, None, st))
+
+    t_i = wall(inv, 1 if EMU else 3)
+    return {"forward": {"clips_per_s": round(n_fwd / t_f, 1), "batch": n_fwd, "ms": round(t_f * 1e3, 3),
+                        "GB/s_algorithmic": round(n_fwd * MEL_CLIP_MB / 1e3 / t_f, 1),
+                        "frac_of_hbm_peak": round(n_fwd * MEL_CLIP_MB / 1e6 / t_f / PEAK_HBM_TBS, 4)},
+            "inverse": {"clips_per_s": round(n_inv / t_i, 1), "batch": n_inv, "ms": round(t_i * 1e3, 3),
+                        "griffin_lim_iters": mel.n_iter,
+                        "GB/s_algorithmic": round(n_inv * MEL_CLIP_MB / 1e3 / t_i, 2)},
+            "config": "toy" if EMU else "x_res 256, y_res 256, n_fft 2048, hop 512, 22050 Hz (5.9 s clips)"}
+
+
+def cpu_baseline(sd, cores):
+    """Oracle (port) on the host cores: {UNet forward + DDIM step} at B=1, 256x256 fp32, 1 warm-up + 2 timed steps at two
+    thread counts (torch-CPU convolutions stop scaling well before 128 threads); the faster one is reported, x50."""
     from oracle.schedulers import DDIMScheduler
     from oracle.unet import UNet2DModel
-    torch.set_num_threads(n_threads)
     m = UNet2DModel(**CFG256).eval()
     m.load_state_dict(sd)
     s = DDIMScheduler()
     s.set_timesteps(50)
-    x = torch.randn(1, 1, 256, 256, generator=torch.Generator().manual_seed(42))
-    times = []
-    with torch.no_grad():
-        for i, t in enumerate(s.timesteps[:4]):
-            t0 = time.perf_counter()
-            x = s.step(m(x, t)["sample"], t, x, eta=0.0)["prev_sample"]
-            if i > 0:
-                times.append(time.perf_counter() - t0)
-    per_step = sum(times) / len(times)
-    return {"value": 1.0 / (50 * per_step), "unit": "mel-spectrograms/s", "cores": n_threads, "kind": "port",
-            "sample": f"3 timed {{UNet fwd + DDIM step}} of 50 at B=1, 256x256 fp32 (torch-CPU oracle, {per_step:.2f} s/step), "
-                      "linear extrapolation to 50 steps"}
+    tried = {}
+    for nt in sorted({min(32, cores), cores}):
+        torch.set_num_threads(nt)
+        x = torch.randn(1, 1, 256, 256, generator=torch.Generator().manual_seed(42))
+        times = []
+        with torch.no_grad():
+            for i, t in enumerate(s.timesteps[:3]):
+                t0 = time.perf_counter()
+                x = s.step(m(x, t)["sample"], t, x, eta=0.0)["prev_sample"]
+                if i > 0:
+                    times.append(time.perf_counter() - t0)
+        tried[nt] = sum(times) / len(times)
+    nt = min(tried, key=tried.get)
+    per_step = tried[nt]
+    return {"value": 1.0 / (50 * per_step), "unit": "mel-spectrograms/s", "cores": nt, "kind": "port",
+            "sample": f"2 timed {{UNet fwd + DDIM step}} of 50 at B=1, 256x256 fp32 (torch-CPU oracle, {per_step:.2f} s/step on "
+                      f"{nt} threads; tried " + ", ".join(f"{k} threads: {v:.2f} s" for k, v in tried.items()) +
+                      "), linear extrapolation to 50 steps"}
 
 
 def roofline(unet, x, B):
@@ -153,7 +274,7 @@ def roofline(unet, x, B):
     rows = best[1]
     # dominant kernel = the convolution variant with the largest share of the forward
     KERNELS = {
-        4313: "adm::conv_wino3_kernel<false> (Winograd F(2x2,3x3) 3x3 stride-1 conv, v_mfma_f32_16x16x4_f32, persistent "
+        4313: "adm::conv_wino3_kernel (Winograd F(2x2,3x3) 3x3 stride-1 conv, v_mfma_f32_16x16x4_f32, persistent "
               "wave-specialised: 4 producer + 4 consumer waves, 64-cout x 8x16-pixel tile)",
         2314: "adm::conv_mfma_pf_kernel<3,2,2> (v_mfma_f32_32x32x2_f32 implicit GEMM, 3x3 stride 1, 128-cout tile)",
     }
@@ -169,95 +290,82 @@ def roofline(unet, x, B):
         e = by_kind.setdefault(k, [0, 0.0, 0.0, 0.0])
         e[0] += 1; e[1] += t; e[2] += f; e[3] += b
     names = {0: "groupnorm_stats", 1: "conv_mfma", 2: "attention", 3: "conv_small", 4: "temb_proj"}
-    breakdown = {names[k]: {"launches": e[0], "ms": round(e[1], 3), "TFLOP/s": round(e[2] / e[1] / 1e9, 2) if e[1] else None,
-                            "GB/s": round(e[3] / e[1] / 1e6, 1) if e[1] else None} for k, e in by_kind.items()}
+    breakdown = {names.get(k, str(k)): {"launches": e[0], "ms": round(e[1], 3),
+                                        "TFLOP/s": round(e[2] / e[1] / 1e9, 2) if e[1] else None,
+                                        "GB/s": round(e[3] / e[1] / 1e6, 1) if e[1] else None} for k, e in by_kind.items()}
     breakdown["conv_by_variant"] = {str(v): {"launches": e[2], "ms": round(e[0], 3), "TFLOP/s": round(e[1] / e[0] / 1e9, 2)}
                                     for v, e in sorted(per_var.items())}
-    ach = fl / (ms * 1e-3) / 1e12
+    alg = fl / (ms * 1e-3) / 1e12                       # algorithmic (direct-convolution) TFLOP/s of the dominant kernel
+    wino = var // 100 == 43
+    executed = alg / 2.25 if wino else alg              # F(2x2,3x3): 16 MFMA products per 4 outputs instead of 36
+    total_ms = sum(r[2] for r in rows)
     out = {"bound": "mfma", "kernel": KERNELS.get(var, f"conv variant {var}"),
-           "achieved": round(ach, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TF, 4),
+           "achieved": round(executed, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(executed / PEAK_F32_TF, 4),
+           "achieved_definition": "EXECUTED fp32 MFMA FLOPs per launch (algorithmic direct-convolution FLOPs / 2.25 for the "
+                                  "Winograd kernel) / average launch duration, HIP events on the launch stream",
+           "algorithmic_TFLOPs": round(alg, 2), "algorithmic_frac_of_peak": round(alg / PEAK_F32_TF, 4),
            "traffic": None, "launches_per_forward": cnt, "avg_launch_us": round(ms / cnt * 1e3, 2),
-           "avg_flops_per_launch": fl / cnt, "share_of_forward_time": round(ms / sum(r[2] for r in rows), 3),
-           "forward_breakdown": breakdown}
-    # HBM bytes per launch of the dominant kernel: bench.py cannot collect PMC counters itself, so it reports the committed
+           "avg_algorithmic_flops_per_launch": fl / cnt, "share_of_forward_time": round(ms / total_ms, 3),
+           "forward_ms": round(total_ms, 3), "forward_breakdown": breakdown}
+    # HBM bytes per launch of the dominant kernel: bench.py cannot collect PMC counters itself, so it reports the newest committed
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass over one forward of this workload (tools/pmc_forward.py), if present.
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_forward.json")))["by_variant"].get(str(var))
-    except (OSError, ValueError, KeyError):
+    pmc, src = None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_forward.json")), reverse=True):
+        try:
+            pmc, src = json.load(open(f))["by_variant"].get(str(var)), os.path.relpath(f, ROOT)
+        except (OSError, ValueError, KeyError):
+            pmc = None
+        if pmc and pmc.get("launches_per_forward") == cnt:
+            break
         pmc = None
-    if pmc and pmc.get("launches_per_forward") == cnt:
+    if pmc:
         by = sum(r[4] for r in rows if r[0] == 1 and r[1] == var)
         out["traffic"] = round(pmc["hbm_bytes_per_launch"])
         out["traffic_unit"] = "B/launch"
         out["algorithmic_bytes_per_launch"] = round(by / cnt)
-        out["traffic_source"] = ("profiles/r01_pmc_forward.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate "
-                                 "passes over one B=32 forward of this workload; includes Infinity-Cache hits")
-    if var // 100 == 43:
-        # `achieved` is ALGORITHMIC (direct-convolution) FLOPs per second, the contract's definition; the Winograd kernel
-        # executes 16/36 of them on the matrix pipe, so the pipe utilisation is reported separately.
-        out["executed_mfma_TFLOPs"] = round(ach / 2.25, 2)
-        out["mfma_util"] = round(ach / 2.25 / PEAK_F32_TF, 4)
-        out["note"] = ("achieved/frac use algorithmic direct-conv FLOPs (2*Cout*Cin*9*H*W*N per launch); Winograd F(2x2,3x3) "
-                       "executes 1/2.25 of them as MFMA work (mfma_util), so frac may exceed 1")
+        out["traffic_source"] = (f"{src}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes over one B=32 "
+                                 "forward of this workload; includes Infinity-Cache hits")
     return out
 
 
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
-    assert torch.cuda.is_available(), "bench.py needs a MI355X (the hot path has no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+    job = Job(a)
+    world, rank, dev = job.world, job.rank, job.dev
 
     if a.mode == "train":
-        train_main(a, world, rank, dev)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        rec = train_leg(job, a.train_batch_per_gpu, a.steps, a.warmup, a.mixed_precision)
+        if rank == 0:
+            rec.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                        "config": {"workload": rec.pop("workload"), "global_batch": rec["global_batch"],
+                                   "parallelism": rec.pop("parallelism")}})
+            print(json.dumps(rec), flush=True)
+        job.close()
         return
 
     from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, Mel, UNet2DModel
-    unet = UNet2DModel(**CFG256).init_random(0)          # identical seeded weights on every rank
-    pipe = AudioDiffusionPipeline(None, unet, Mel(), DDIMScheduler()).to(dev)
+    cfg = CFG_TOY if EMU else CFG256
+    hw = cfg["sample_size"]
+    unet = UNet2DModel(**cfg).init_random(0)          # identical seeded weights on every rank
+    mel = Mel(x_res=16, y_res=16, hop_length=64, n_fft=256, n_iter=1) if EMU else Mel()
+    pipe = AudioDiffusionPipeline(None, unet, mel, DDIMScheduler()).to(dev)
     pipe.set_progress_bar_config(disable=True)
     B = a.batch_per_gpu
     # global noise from one seed, rank r takes rows [r*B, (r+1)*B): the result does not depend on the GPU count
     g = torch.Generator().manual_seed(42)
-    noise = torch.randn(world * B, 1, 256, 256, generator=g)[rank * B:(rank + 1) * B].contiguous().to(dev)
-    gathered = torch.empty((world * B, 256, 256, 1), dtype=torch.uint8, device=dev) if world > 1 else None
+    noise = torch.randn(world * B, 1, hw, hw, generator=g)[rank * B:(rank + 1) * B].contiguous().to(dev)
+    gathered = torch.empty((world * B, hw, hw, 1), dtype=torch.uint8, device=dev) if job.pg else None
 
     def step():
         _, u8 = pipe._denoise(noise, 0, 0.0, None, None, 0, 0, use_graph=not a.no_graph)
-        if world > 1:
+        if job.pg:
             dist.all_gather_into_tensor(gathered, u8)
         return u8
 
     pipe.scheduler.set_timesteps(a.ddim_steps)
-    for _ in range(a.warmup):
-        step()
+    elapsed = job.timed(step, a.steps, a.warmup)
 
-    def sync():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-
+    res = None
     if rank == 0:
         value = world * B * a.steps / elapsed
         fwd_per_s = value * a.ddim_steps
@@ -269,17 +377,36 @@ def main():
                                    f"DDIM-{a.ddim_steps} eta=0, 256x256, batch {B}/GPU (config 3 per-GPU shard), noise -> uint8 image",
                        "global_batch": world * B, "ddim_steps": a.ddim_steps, "hipgraph": not a.no_graph,
                        "parallelism": f"batch-shard x{world}, no in-loop collective"},
-            "whole_loop": {"fp32_TFLOPs": round(fwd_per_s * F1_TFLOP / world, 2),
-                           "fp32_frac_of_157.3": round(fwd_per_s * F1_TFLOP / world / PEAK_F32_TF, 4),
+            "whole_loop": {"fp32_algorithmic_TFLOPs": round(fwd_per_s * F1_TFLOP / world, 2),
+                           "fp32_algorithmic_frac_of_157.3": round(fwd_per_s * F1_TFLOP / world / PEAK_F32_TF, 4),
                            "hbm_frac_fused_min_bytes": round(fwd_per_s / world * (A1_GB + W_GB / B) / 1e3 / PEAK_HBM_TBS, 4)},
         }
-        res["roofline"] = roofline(unet, noise, B)
-        if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (torchrun pins OMP_NUM_THREADS=1 per rank)
-            res["cpu_baseline"] = cpu_baseline(unet.state_dict(), torch.get_num_threads())
+        if EMU:
+            res["config"]["workload"] = "TEST HOOK ADM_BENCH_EMU=1: toy UNet on the CPU emulation build over gloo (not a measurement)"
+            res["gathered_checksum"] = int(gathered.long().sum()) if gathered is not None else None
+        else:
+            res["roofline"] = roofline(unet, noise, B)
+            if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (torchrun pins OMP_NUM_THREADS=1 per rank)
+                res["cpu_baseline"] = cpu_baseline(unet.state_dict(), os.cpu_count() or torch.get_num_threads())
+        if not a.no_mel_leg:
+            try:
+                res["mel"] = mel_leg(job)
+            except Exception as e:  # noqa: BLE001 - a failing side leg must not cost the headline line
+                res["mel"] = {"error": f"{type(e).__name__}: {e}"}
+    del pipe
+    # config 5 beside the headline: every rank takes part (the gradient all-reduce is a collective)
+    if not a.no_train_leg:
+        job.sync()
+        try:
+            tr = train_leg(job, 2 if EMU else a.train_batch_per_gpu, 2 if EMU else a.train_steps, 1 if EMU else 2,
+                           a.mixed_precision)
+        except Exception as e:  # noqa: BLE001
+            tr = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            res["train"] = tr
+    if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    job.close()
 
 
 if __name__ == "__main__":

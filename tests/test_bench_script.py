@@ -1,0 +1,59 @@
+"""bench.py ITSELF under `--gpus 2` semantics: the driver's launch line (torch.distributed.run, one rank per device), with
+the ADM_BENCH_EMU=1 test hook swapping the MI355X for the CPU-emulation build of the kernels and RCCL for gloo. Everything
+else — rank / world plumbing, row-sharded noise, per-step all_gather, barrier-bracketed timing, MAX over ranks, the
+training leg's bucketed all-reduce issued from inside the reverse pass, the one JSON line on rank 0 — is the code the
+8-GPU scaling run executes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(n, extra=()):
+    from native_backend import ensure_emu_built
+    ensure_emu_built()
+    env = dict(os.environ, ADM_BENCH_EMU="1", ADM_EMU_THREADS="2", OMP_NUM_THREADS="1")
+    port = 29800 + os.getpid() % 1000
+    if n == 1:
+        cmd = [sys.executable, "bench.py"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py"]
+    cmd += ["--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch-per-gpu", "2", "--ddim-steps", "3", *extra]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_py_two_ranks_prints_one_contract_line():
+    d = _run(2)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 4 and d["value"] > 0
+    assert abs(d["value"] - 2 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) <= 0.02 * d["value"]     # whole-job aggregate
+    tr = d["train"]
+    assert "error" not in tr, tr
+    assert tr["global_batch"] == 4 and tr["value"] > 0
+    assert tr["allreduce_buckets_overlapped"] == tr["allreduce_buckets"] >= 1      # every bucket fired inside the reverse pass
+    assert "error" not in d["mel"], d["mel"]
+
+
+def test_bench_py_result_is_independent_of_the_rank_count():
+    """Same global batch on 1 rank and on 2: the gathered uint8 images (checksum) are identical — rows never interact."""
+    one = _run(1, ["--batch-per-gpu", "4", "--no-train-leg", "--no-mel-leg"])
+    os.environ["ADM_BENCH_FORCE_PG"] = "1"      # 1 rank but with the process group, so `gathered` exists
+    try:
+        one_pg = _run(1, ["--batch-per-gpu", "4", "--no-train-leg", "--no-mel-leg"])
+    finally:
+        del os.environ["ADM_BENCH_FORCE_PG"]
+    two = _run(2, ["--no-train-leg", "--no-mel-leg"])
+    assert one["gathered_checksum"] is None
+    assert one_pg["gathered_checksum"] == two["gathered_checksum"] and two["gathered_checksum"] > 0
