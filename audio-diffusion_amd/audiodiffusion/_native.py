@@ -135,6 +135,8 @@ _OPTIONAL_SIGS = {
     "adm_mel_destroy": (None, [C.c_void_p]),
     "adm_mel_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
     "adm_mel_forward_power": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
+    "adm_mel_set_nnls_solver": (C.c_int, [C.c_void_p, C.c_double, C.c_int]),
+    "adm_mel_last_nnls": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "adm_mel_inverse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_float), C.c_void_p]),
 }

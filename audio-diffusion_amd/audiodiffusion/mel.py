@@ -114,7 +114,10 @@ class Mel:
         self.n_iter = n_iter
         self.set_resolution(x_res, y_res)
         self.audio = None
-        self.last_nnls_pg = None  # max |projected gradient| of the last image_to_audio NNLS start point
+        self.last_nnls_pg = None       # max |projected gradient| of the NNLS solution the last image_to_audio returned
+        self.last_nnls_pg_start = None  # ... of its start point clip(pinv(A) S, 0)
+        self.last_nnls_iterations = None  # most solver iterations any column needed (0: start point returned, scipy nit = 0)
+        self.nnls_max_iter = 4000
 
     @property
     def config(self):
@@ -175,6 +178,13 @@ class Mel:
         tw = np.stack([np.cos(2 * np.pi * q / n_fft), -np.sin(2 * np.pi * q / n_fft)], axis=1).astype(np.float64)
         start, count, w32, w64 = slaney_filter_taps(self.sr, n_fft, self.n_mels)
         fb64 = taps_to_dense(start, count, w64, n_bins)
+        # librosa's dense matrix carries a NEGATIVE zero where an FFT bin sits exactly on a filter's lower corner (bin 0 on
+        # filter 0: -(0 - 0) / df = -0.0 survives its np.maximum(0, .)). The value is the same, but LAPACK's SVD inside pinv
+        # propagates the sign into the rounding noise of the rows no filter touches (DC), and 32 Griffin-Lim iterations
+        # amplify that to 1e-3 of the audio: keep the bit pattern librosa has.
+        edge0 = _slaney_hz(np.linspace(_slaney_mel(0.0), _slaney_mel(self.sr / 2.0), self.n_mels + 2))
+        on_corner = np.fft.rfftfreq(n=n_fft, d=1.0 / self.sr)[None, :] == edge0[:self.n_mels, None]
+        fb64[on_corner] = -0.0
         self.filter_taps = (start.copy(), count.copy())
         # CSC (per FFT bin: the mel filters touching it), same tap set
         t_off = np.zeros(n_bins + 1, np.int32)
@@ -197,6 +207,9 @@ class Mel:
         args = [a.ctypes.data_as(C.c_void_p) for a in keep]
         N.check(lib.adm_mel_create(C.byref(cfg), args[0], args[1], args[2], args[3], args[4], args[5], int(len(w64)),
                                    args[6], args[7], args[8], args[9], args[10], nnls_cols, C.byref(h)))
+        # NNLS solver for the blocks L-BFGS-B would iterate on: step 1 / lambda_max(A A^T)
+        lip = float(np.linalg.eigvalsh(fb64 @ fb64.T)[-1])
+        N.check(lib.adm_mel_set_nnls_solver(h, lip, self.nnls_max_iter))
         self._handle = h
         return h
 
@@ -290,9 +303,12 @@ class Mel:
         N.check(N.lib().adm_mel_inverse(h, N.ptr(img), N.ptr(phase.contiguous()), B, frames, N.ptr(out), N.ptr(mag),
                                         C.byref(pg), N.stream_for(img)))
         self.last_nnls_pg = float(pg.value)
+        ps, it = C.c_float(0.0), C.c_int(0)
+        N.check(N.lib().adm_mel_last_nnls(h, C.byref(ps), C.byref(it)))
+        self.last_nnls_pg_start, self.last_nnls_iterations = float(ps.value), int(it.value)
         if self.last_nnls_pg > 1e-5:
-            warnings.warn(f"NNLS start point has projected gradient {self.last_nnls_pg:.3g} > pgtol=1e-5: librosa's "
-                          "L-BFGS-B would iterate here; this path returns the clipped pseudo-inverse solution")
+            warnings.warn(f"NNLS solution has projected gradient {self.last_nnls_pg:.3g} > pgtol=1e-5 after "
+                          f"{self.last_nnls_iterations} iterations (nnls_max_iter={self.nnls_max_iter})")
         audio = out.cpu().numpy()
         if return_magnitude:
             return audio, mag.cpu().numpy().transpose(0, 2, 1)

@@ -772,14 +772,16 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
   p.mPE = magic((long)NI * p.IH * p.IW); p.mIHW = magic((long)p.IH * p.IW); p.mIW = magic(p.IW);
   p.mTX = magic(p.tiles_x); p.mTXY = magic((long)p.tiles_x * p.tiles_y);
   const size_t smem = sizeof(float) * ((size_t)64 * 129 + (size_t)CB * p.PS);
-  ADM_REQUIRE(smem <= 80 * 1024, "conv_wgrad: patch too large for LDS");
+  // 80 KiB covers every layer whose output is at least 4x4; the stride-2 convolutions that end at 2x2 / 1x1 (the deepest
+  // Downsample2D of a 64x64 / 32x32 model) stage 16 / 64 images' 5x5 / 3x3 patches per tile: up to 107 KiB, generic kernel only
+  ADM_REQUIRE(smem <= 128 * 1024, "conv_wgrad: patch too large for LDS");
   const long numel = (long)a.Cout * Ct * a.ks * a.ks;
   dim3 grid(p.n_ct * p.n_chunks * p.split), block(256);
 #if !defined(ADM_EMU)
   static bool once = [] {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_pf_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_pf_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_pf_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);

@@ -553,7 +553,11 @@ struct Wino3Raw {                     // one chunk's raw activations of this thr
   unsigned ok;                        // bit k: item k lies inside the image (zero padding otherwise)
 };
 
-template <bool UP, bool WIDE1, bool PROF>
+// V4 = true: the variant conv_wino4_kernel uses — V images unswizzled (its consumers read whole 128-byte channel rows with
+// ds_read_b64, which is conflict-free as it is) and the raw activations prefetched FOUR chunks ahead instead of two (the
+// registers are free: the kernel's allocation is set by the consumers' accumulators; with two chunks of ~3000 cycles in
+// flight a producer is bound by the loaded HBM latency: measured ~2700 cycles per chunk with the MFMAs removed).
+template <bool UP, bool WIDE1, bool PROF, bool V4 = false>
 __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV, float* ldsP, int tid, int b0, int bs) {
   unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_start = W3_CLK();
@@ -600,7 +604,7 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
   const int pc = tid >> 5, ptile = tid & 31;
   const int tyy = ptile >> 3, txx = ptile & 7;
   const int wbase = UP ? pc * 60 + tyy * 10 + txx : pc * WCS + 2 * tyy * WPW + 2 * txx;
-  const int vofs = pc * 32 + ((ptile + 16 * (pc & 1)) & 31);   // + xi * 256
+  const int vofs = V4 ? pc * 32 + ptile : pc * 32 + ((ptile + 16 * (pc & 1)) & 31);   // + xi * 256
 
   // ---- stage A cursor: (tile, chunk) of the next global load ----------------------------------------------------------------
   int a_v = b0, a_ci = 0, a_left = total;
@@ -701,13 +705,51 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
   // ---- pipeline: interval g stages V(g) [C], the patch of g+1 [B] and the global loads of g+3 [A] ---------------------------
   Wino3Raw r0, r1;
   r0.b = make_float4(0.f, 0.f, 0.f, 0.f); r1.b = r0.b; r0.a = r0.b; r1.a = r0.b; r0.h = 0.f; r1.h = 0.f;
+  unsigned long long tq = 0, tn;
+#define W3_LAP(slot) do { if (PROF) { tn = W3_CLK(); pr[slot] += tn - tq; tq = tn; } } while (0)
+  if constexpr (V4) {          // same schedule with the global loads of g + 5 in flight: four raw-chunk register sets
+    Wino3Raw r2, r3;
+    r2.b = r0.b; r3.b = r0.b; r2.a = r0.b; r3.a = r0.b; r2.h = 0.f; r3.h = 0.f;
+    stage_a(r0); stage_a(r1); stage_a(r2); stage_a(r3);      // chunks 0..3
+    stage_b(r0, 0);
+    stage_a(r0);                                             // chunk 4
+    ADM_BARRIER_KEEP_VMEM(63);
+    if (PROF) tq = W3_CLK();
+    for (int g = 0; g < total; g += 4) {                     // total is a multiple of 4 (nch is)
+      stage_c(g);                W3_LAP(3);
+      stage_b(r1, g + 1);        W3_LAP(4);
+      stage_a(r1);               W3_LAP(5);   // chunk g + 5
+      W3_BARRIER(63, pr, 1, 2);
+      if (PROF) tq = W3_CLK();
+      stage_c(g + 1);            W3_LAP(3);
+      stage_b(r2, g + 2);        W3_LAP(4);
+      stage_a(r2);               W3_LAP(5);   // chunk g + 6
+      W3_BARRIER(63, pr, 1, 2);
+      if (PROF) tq = W3_CLK();
+      stage_c(g + 2);            W3_LAP(3);
+      stage_b(r3, g + 3);        W3_LAP(4);
+      stage_a(r3);               W3_LAP(5);   // chunk g + 7
+      W3_BARRIER(63, pr, 1, 2);
+      if (PROF) tq = W3_CLK();
+      stage_c(g + 3);            W3_LAP(3);
+      stage_b(r0, g + 4);        W3_LAP(4);
+      stage_a(r0);               W3_LAP(5);   // chunk g + 8
+      W3_BARRIER(63, pr, 1, 2);
+      if (PROF) tq = W3_CLK();
+    }
+    ADM_BARRIER_KEEP_VMEM(0);
+    if (PROF && tid == 0) {
+      pr[0] = W3_CLK() - t_start;
+      for (int i = 0; i < 8; ++i) atomicAdd(p.prof + 8 + i, pr[i]);
+    }
+    return;
+  }
   stage_a(r0);                 // chunk 0
   stage_a(r1);                 // chunk 1
   stage_b(r0, 0);
   stage_a(r0);                 // chunk 2
   ADM_BARRIER_KEEP_VMEM(63);   // barrier "-2": patch(0) visible to every producer wave
-  unsigned long long tq = W3_CLK(), tn;
-#define W3_LAP(slot) do { if (PROF) { tn = W3_CLK(); pr[slot] += tn - tq; tq = tn; } } while (0)
+  tq = W3_CLK();
   for (int g = 0; g < total; g += 2) {      // total is even (nch is)
     stage_c(g);                W3_LAP(3);
     stage_b(r1, g + 1);        W3_LAP(4);
@@ -890,6 +932,206 @@ __global__ void __launch_bounds__(512, 2) conv_wino3_kernel(const WinoParams p) 
   else wino3_consumer<PROF>(p, ldsV, ldsU, tid, wave, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// =====================================================================================================================
+// v4 (mode 4) — v3 with the FILTER operand taken out of LDS. What v3's measurements asked for (profiles/r01_pmc_wino.md):
+// its consumer stream alone needs 3200 cycles per chunk against 2048 of MFMA — 550 of them are the eight LDS-DMA pieces
+// per wave that bring the 32 KiB U slab in, and two thirds of its 96 LDS operand reads per chunk are filter words.
+//   * wave w owns 16 couts x ALL 32 Winograd tiles of the workgroup tile (v3: 32 couts x 16 tiles), so no two waves need
+//     the same filter words and every A operand is loaded exactly once per workgroup: straight from L2 into registers,
+//     8 global_load_dwordx4 per wave and chunk from a filter image packed for exactly this access
+//     ([chunk][cout block][point group][k step][lane][4 points]: one contiguous KiB per load), refilled IN PLACE one whole
+//     chunk ahead — the four points of a group are consumed, then the group's registers are reloaded for the next chunk;
+//   * the B operand of both tile blocks comes from one ds_read_b64 (tiles 2 li, 2 li + 1): 32 LDS reads per wave and chunk
+//     over plain, conflict-free 128-byte channel rows; a lane's two tiles are horizontal neighbours, so the lane-local
+//     inverse transform ends in 16-byte stores;
+//   * no LDS-DMA anywhere: the per-chunk barrier only hands V buffers over, and no vmcnt is ever drained at it;
+//   * LDS: V 2 x 16 KiB + patch 2 x 5.6 KiB = 43 KiB.
+constexpr int W4LDS = 2 * W3VSLAB + 2 * W3PSLAB;
+constexpr int W4ABLK = 4 * 2 * 64 * 4;      // floats of one (chunk, 16-cout block) filter image: 8 KiB
+
+template <bool PROF>
+__device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float* ldsV, int tid, int wave, int b0, int bs) {
+  unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_start = W3_CLK();
+  const int lane = tid & 63;
+  const int li = lane & 15, k4 = lane >> 4;
+  const int nch = (p.C1 + p.C2) / WCK;
+  const int n_cblk = p.Cout >> 4;
+  const int ntile = (p.nblk - b0 + bs - 1) / bs;
+  const int total = ntile * nch;
+  const int vlane = k4 * 32 + 2 * li;       // word pair (tile 2 li, 2 li + 1) of channel row k4 (+ 4 ks)
+  // ---- filter stream cursor: (tile, chunk) of the NEXT chunk to load; saturates on the last one ---------------------------
+  int d_v = b0, d_ci = 0, d_left = total;
+  const long chunk_stride = (long)n_cblk * W4ABLK;
+  const float* d_src = p.wu + ((long)(wino3_tile(p, d_v).m0 >> 4) + wave) * W4ABLK + lane * 4;   // chunk 0 of the tile
+  f32x4 a[4][2];                            // [point group][k step]: component e = Winograd point 4 q + e
+#define W4_LOAD_A(q)                                                                   \
+  do {                                                                                 \
+    a[q][0] = *reinterpret_cast<const f32x4*>(d_src + (q) * 512);                      \
+    a[q][1] = *reinterpret_cast<const f32x4*>(d_src + (q) * 512 + 256);                \
+  } while (0)
+  auto advance_a = [&]() {
+    if (d_left > 1) {
+      --d_left;
+      d_src += chunk_stride;
+      if (++d_ci == nch) {
+        ADM_SCHED_FENCE();
+        d_ci = 0; d_v += bs;
+        d_src = p.wu + ((long)(wino3_tile(p, d_v).m0 >> 4) + wave) * W4ABLK + lane * 4;
+      }
+    }
+  };
+  W4_LOAD_A(0); W4_LOAD_A(1); W4_LOAD_A(2); W4_LOAD_A(3);      // chunk 0
+  advance_a();
+  ADM_BARRIER_KEEP_VMEM(63);               // barrier "-2" (producers' patch hand-over)
+  ADM_BARRIER_KEEP_VMEM(63);               // barrier "-1": V(0) complete
+
+  f32x4 acc[16][2];
+  float2 rb[4][2];                         // rolling B window: 4 Winograd points ahead
+  int g = 0;                               // running chunk index
+  for (int v = b0; v < p.nblk; v += bs) {
+    const Wino3Tile t = wino3_tile(p, v);
+    ADM_UNROLL
+    for (int xi = 0; xi < 16; ++xi)
+      ADM_UNROLL
+      for (int c = 0; c < 2; ++c)
+        ADM_UNROLL
+        for (int r = 0; r < 4; ++r) acc[xi][c][r] = 0.f;
+    float cb[4];                            // epilogue constants of this lane's 4 couts
+    ADM_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      const int co = t.m0 + 16 * wave + 4 * k4 + r;
+      cb[r] = p.bias[co] + p.chan_add[(long)t.n * p.chan_add_stride + co];
+    }
+    auto read_group = [&](int slot, int gg, int xi) {
+      const float* V = ldsV + (gg & 1) * W3VSLAB + vlane;
+      rb[slot][0] = *reinterpret_cast<const float2*>(V + (xi * WCK) * 32);
+      rb[slot][1] = *reinterpret_cast<const float2*>(V + (xi * WCK + 4) * 32);
+    };
+    ADM_UNROLL
+    for (int xi = 0; xi < 4; ++xi) read_group(xi, g, xi);
+    for (int ci = 0; ci < nch; ++ci, ++g) {
+      const bool more = ci + 1 < nch;      // the rolling window does not cross into the next tile
+      ADM_UNROLL
+      for (int xi = 0; xi < 16; ++xi) {
+        const int s = xi & 3, q = xi >> 2, e = xi & 3;
+        ADM_UNROLL
+        for (int ks = 0; ks < 2; ++ks) {
+          acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].x, acc[xi][0], 0, 0, 0);
+          acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].y, acc[xi][1], 0, 0, 0);
+        }
+        if (e == 3) {                      // group q consumed: its registers take the NEXT chunk's words
+          if (q == 0) W4_LOAD_A(0);
+          if (q == 1) W4_LOAD_A(1);
+          if (q == 2) W4_LOAD_A(2);
+          if (q == 3) { W4_LOAD_A(3); advance_a(); }
+        }
+        if (xi == 12) W3_BARRIER(63, pr, 1, 2);   // barrier g: every read of V(g) has landed, V(g + 1) is complete
+        if (xi < 12) read_group(s, g, xi + 4);
+        else if (more) read_group(s, g + 1, xi - 12);
+        ADM_SCHED_FENCE();
+      }
+    }
+    // ---- lane-local inverse transform Y = A^T M A: lane holds couts 4 k4 + r and tiles 2 li (c = 0), 2 li + 1 (c = 1) ----------
+    const unsigned long long t_epi = W3_CLK();
+    const int oy = t.ty * 8 + 2 * (li >> 2), ox = t.tx * 16 + 4 * (li & 3);
+    const long planeO = (long)p.Ho * p.Wo;
+    f32x4 res[4][2];
+    if (p.residual != nullptr) {
+      ADM_UNROLL
+      for (int r = 0; r < 4; ++r) {
+        const int co = t.m0 + 16 * wave + 4 * k4 + r;
+        const long o = ((long)t.n * p.Cout + co) * planeO + (long)oy * p.Wo + ox;
+        res[r][0] = *reinterpret_cast<const f32x4*>(p.residual + o);
+        res[r][1] = *reinterpret_cast<const f32x4*>(p.residual + o + p.Wo);
+      }
+    } else {
+      ADM_UNROLL
+      for (int r = 0; r < 4; ++r) { res[r][0] = f32x4{0.f, 0.f, 0.f, 0.f}; res[r][1] = res[r][0]; }
+    }
+    ADM_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      f32x4 y0, y1;
+      ADM_UNROLL
+      for (int c = 0; c < 2; ++c) {
+        float t0[4], t1[4];
+        ADM_UNROLL
+        for (int j = 0; j < 4; ++j) {
+          t0[j] = acc[0 * 4 + j][c][r] + acc[1 * 4 + j][c][r] + acc[2 * 4 + j][c][r];
+          t1[j] = acc[1 * 4 + j][c][r] - acc[2 * 4 + j][c][r] - acc[3 * 4 + j][c][r];
+        }
+        y0[2 * c] = t0[0] + t0[1] + t0[2] + cb[r] + res[r][0][2 * c];
+        y0[2 * c + 1] = t0[1] - t0[2] - t0[3] + cb[r] + res[r][0][2 * c + 1];
+        y1[2 * c] = t1[0] + t1[1] + t1[2] + cb[r] + res[r][1][2 * c];
+        y1[2 * c + 1] = t1[1] - t1[2] - t1[3] + cb[r] + res[r][1][2 * c + 1];
+      }
+      const int co = t.m0 + 16 * wave + 4 * k4 + r;
+      const long o = ((long)t.n * p.Cout + co) * planeO + (long)oy * p.Wo + ox;
+      *reinterpret_cast<f32x4*>(p.out + o) = y0;
+      *reinterpret_cast<f32x4*>(p.out + o + p.Wo) = y1;
+    }
+    if (PROF) pr[3] += W3_CLK() - t_epi;
+  }
+#undef W4_LOAD_A
+  if (PROF && tid == 0) {
+    pr[0] = W3_CLK() - t_start;
+    for (int i = 0; i < 8; ++i) atomicAdd(p.prof + i, pr[i]);
+  }
+}
+
+template <bool UP, bool PROF>
+__global__ void __launch_bounds__(512) conv_wino4_kernel(const WinoParams p) {
+  ADM_DYN_SMEM(float, smem);
+  float* ldsV = smem;
+  float* ldsP = smem + 2 * W3VSLAB;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  if (wave >= 4) {
+#if !defined(ADM_EMU)
+    __builtin_amdgcn_s_setprio(1);         // see conv_wino3_kernel
+#endif
+    if (!UP && wave == 4) wino3_producer<UP, true, PROF, true>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
+    else wino3_producer<UP, false, PROF, true>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
+  }
+  else wino4_consumer<PROF>(p, ldsV, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Filter image of conv_wino4_kernel: U = G g G^T as [Cin/8][Cout/16][point group q][k step ks][lane = 16 k4 + li][e]
+// holding U[xi = 4 q + e][cout = 16 cblk + li][cin = 8 chunk + 4 ks + k4]. transposed: the data-gradient filters (roles of
+// Cout / Cin swapped, taps flipped), as pack_winograd_weight_kernel.
+__global__ void pack_winograd4_weight_kernel(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin,
+                                             int transposed) {
+  const int PCo = transposed ? Cin : Cout, PCi = transposed ? Cout : Cin;      // channel counts of the packed convolution
+  const long total = (long)PCo * PCi;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int li = (int)(i & 15);
+    long r = i >> 4;
+    const int k4 = (int)(r & 3); r >>= 2;
+    const int ks = (int)(r & 1); r >>= 1;
+    const int cblk = (int)(r % (PCo >> 4));
+    const int chunk = (int)(r / (PCo >> 4));
+    const int po = cblk * 16 + li, pi = chunk * 8 + 4 * ks + k4;
+    const int co = transposed ? pi : po, c = transposed ? po : pi;              // indices into w (Cout, Cin, 3, 3)
+    const float* g = w + ((long)co * Cin + c) * 9;
+    float t[4][3];
+    for (int j = 0; j < 3; ++j) {
+      const float g0 = transposed ? g[2 * 3 + (2 - j)] : g[0 * 3 + j];
+      const float g1 = transposed ? g[1 * 3 + (2 - j)] : g[1 * 3 + j];
+      const float g2 = transposed ? g[0 * 3 + (2 - j)] : g[2 * 3 + j];
+      t[0][j] = g0;
+      t[1][j] = 0.5f * (g0 + g1 + g2);
+      t[2][j] = 0.5f * (g0 - g1 + g2);
+      t[3][j] = g2;
+    }
+    float* blk = wu + ((long)chunk * (PCo >> 4) + cblk) * W4ABLK + ((long)ks * 64 + k4 * 16 + li) * 4;
+    for (int a = 0; a < 4; ++a) {          // a = point group q (row of U), e = column
+      f32x4 u;
+      u[0] = t[a][0]; u[1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]); u[2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]); u[3] = t[a][2];
+      *reinterpret_cast<f32x4*>(blk + a * 512) = u;
+    }
+  }
+}
+
 // (Cout,Cin,3,3) -> U = G g G^T laid out [Cin][16][Cout]; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
 // transposed != 0: filters of the DATA-GRADIENT convolution (input channels = Cout, output channels = Cin, taps flipped):
 // U' = G flip(g) G^T laid out [Cout][16][Cin].
@@ -921,10 +1163,20 @@ __global__ void pack_winograd_weight_kernel(const float* __restrict__ w, float* 
   }
 }
 
+static int wino_mode();
+// Which filter image a convolution with these PACKED channel counts uses — decided by the mode and the channel counts
+// alone, so that the packing (done once per layer) and every later launch agree: mode 4 and 64 | couts, 32 | cins -> the
+// conv_wino4_kernel image (such a layer then runs on conv_wino4_kernel or, for arguments that kernel cannot take, on the
+// direct kernel — never on v1-v3, which could not read it). The option must be set before the weights are packed.
+static bool wino4_layout(int couts, int cins) { return wino_mode() == 4 && couts % W3BM == 0 && cins % (4 * WCK) == 0; }
+
 static int pack_winograd(const float* w, float* wu, int Cout, int Cin, int transposed, hipStream_t st) {
   long g = ((long)Cout * Cin + 255) / 256;
   if (g > 4096) g = 4096;
-  ADM_LAUNCH(pack_winograd_weight_kernel, dim3((unsigned)g), dim3(256), 0, st, w, wu, Cout, Cin, transposed);
+  if (wino4_layout(transposed ? Cin : Cout, transposed ? Cout : Cin))
+    ADM_LAUNCH(pack_winograd4_weight_kernel, dim3((unsigned)g), dim3(256), 0, st, w, wu, Cout, Cin, transposed);
+  else
+    ADM_LAUNCH(pack_winograd_weight_kernel, dim3((unsigned)g), dim3(256), 0, st, w, wu, Cout, Cin, transposed);
   return ADM_CHECK_LAUNCH();
 }
 int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st) {
@@ -935,8 +1187,9 @@ int launch_pack_winograd_weight_T(const float* w, float* wu, int Cout, int Cin, 
 }
 
 // 0 direct MFMA kernel only | 1 Winograd v1 | 2 wave-specialised v2 | 3 persistent wave-specialised v3 (default: measured
-// 1.33x on the whole UNet forward); shapes a mode cannot take fall back to the direct kernel.
-static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 3) on first use
+// 1.33x on the whole UNet forward) | 4 v3 with the filters loaded L2 -> registers (conv_wino4_kernel; layers whose channel
+// counts it cannot tile run as in mode 3); shapes a mode cannot take fall back to the direct kernel.
+static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 3) on first use; 4 = conv_wino4_kernel
 void set_winograd_mode(int m) { g_wino_mode = m; }
 static int wino_mode() {
   if (g_wino_mode < 0) { const char* e = getenv("ADM_CONV_WINO"); g_wino_mode = e ? atoi(e) : 3; }
@@ -945,11 +1198,23 @@ static int wino_mode() {
 bool winograd_enabled() { return wino_mode() != 0; }
 
 // Eligibility: 3x3 stride 1 "same", output at least 8x16 with Wo % 16 == 0 and Ho % 8 == 0, Cin % 8, Cout % 32.
+static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+// what the persistent kernels (v3, v4) need beyond the shape: float4 row loads of the activations, identity GroupNorm rows
+// only without SiLU
+static bool wino_persistent_args_ok(const adm_conv_args& a) {
+  const int C2 = a.x2 ? a.C2 : 0;
+  const long x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W, x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
+  return (a.gn_scale != nullptr || !a.act) && aligned16(a.x1) && (a.x2 == nullptr || aligned16(a.x2)) && x1_bs % 4 == 0 &&
+         x2_bs % 4 == 0;
+}
 bool winograd_eligible(const adm_conv_args& a) {
   if (a.ks != 3 || a.stride != 1 || a.pad_lo != 1 || a.w_bstride != 0 || a.wino_packed == nullptr || a.up > 1) return false;
   const int C2 = a.x2 ? a.C2 : 0;
   const int Hi = a.up ? 2 * a.H : a.H, Wi = a.up ? 2 * a.W : a.W;
-  return Wi % 16 == 0 && Hi % 8 == 0 && (a.C1 + C2) % 8 == 0 && a.C1 % 8 == 0 && a.Cout % 32 == 0;
+  if (!(Wi % 16 == 0 && Hi % 8 == 0 && (a.C1 + C2) % 8 == 0 && a.C1 % 8 == 0 && a.Cout % 32 == 0)) return false;
+  if (wino4_layout(a.Cout, a.C1 + C2))     // filters are in the v4 image: conv_wino4_kernel or nothing (-> direct kernel)
+    return wino_persistent_args_ok(a) && aligned16(a.out) && (a.residual == nullptr || aligned16(a.residual));
+  return true;
 }
 
 const float* conv_zero_bias(int n);  // k_conv_mfma.hip
@@ -970,9 +1235,9 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
   p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
-  if (wino_mode() == 3 && a.Cout % W3BM == 0 && (a.C1 + C2) % (2 * WCK) == 0 && (a.gn_scale != nullptr || !a.act) &&
-      (reinterpret_cast<uintptr_t>(a.x1) & 15) == 0 && (a.x2 == nullptr || (reinterpret_cast<uintptr_t>(a.x2) & 15) == 0) &&
-      p.x1_bs % 4 == 0 && p.x2_bs % 4 == 0) {                    // persistent wave-specialised kernel
+  const bool v4 = wino4_layout(a.Cout, a.C1 + C2);             // (winograd_eligible has checked the kernel's other needs)
+  if (v4 || (wino_mode() >= 3 && a.Cout % W3BM == 0 && (a.C1 + C2) % (2 * WCK) == 0 && wino_persistent_args_ok(a))) {
+    // persistent wave-specialised kernels
     p.n_ct = a.Cout / W3BM;
     p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
     p.gn_nstride = a.C1 + C2;
@@ -985,6 +1250,7 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     const size_t need3 = sizeof(float) * W3LDS;
 #if !defined(ADM_EMU)
     static int n_cu = [] {
+      (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS));
       (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
       (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
       (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
@@ -996,7 +1262,7 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     const int n_cu = 3;                                          // exercise persistence (several tiles per block) on the emulator
 #endif
     const int grid = p.nblk < n_cu ? p.nblk : n_cu;
-    set_last_conv_variant(4000 + 313);
+    set_last_conv_variant(4000 + (v4 ? 314 : 313));
     p.prof = nullptr;
 #if !defined(ADM_EMU)
     static const bool want_prof = getenv("ADM_WINO_PROF") != nullptr;
@@ -1004,7 +1270,8 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
       static unsigned long long* dprof = [] { void* q = nullptr; (void)hipMalloc(&q, 16 * sizeof(unsigned long long)); return (unsigned long long*)q; }();
       (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
       p.prof = dprof;
-      ADM_LAUNCH((conv_wino3_kernel<false, true>), dim3(grid), dim3(512), need3, st, p);
+      if (v4) ADM_LAUNCH((conv_wino4_kernel<false, true>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p);
+      else ADM_LAUNCH((conv_wino3_kernel<false, true>), dim3(grid), dim3(512), need3, st, p);
       unsigned long long h[16];
       (void)hipMemcpyAsync(h, dprof, sizeof(h), hipMemcpyDeviceToHost, st);
       (void)hipStreamSynchronize(st);
@@ -1014,6 +1281,11 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
       return ADM_CHECK_LAUNCH();
     }
 #endif
+    if (v4) {
+      if (a.up) ADM_LAUNCH((conv_wino4_kernel<true, false>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p);
+      else ADM_LAUNCH((conv_wino4_kernel<false, false>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p);
+      return ADM_CHECK_LAUNCH();
+    }
     if (a.up) ADM_LAUNCH((conv_wino3_kernel<true, false>), dim3(grid), dim3(512), need3, st, p);
     else ADM_LAUNCH((conv_wino3_kernel<false, false>), dim3(grid), dim3(512), need3, st, p);
     return ADM_CHECK_LAUNCH();

@@ -31,7 +31,15 @@ struct adm_mel {
   void* melspec = nullptr;
   double *angles = nullptr, *mag = nullptr, *ytmp = nullptr, *Smel = nullptr, *Xpow = nullptr, *diff = nullptr;
   float *reb0 = nullptr, *reb1 = nullptr, *y = nullptr;
-  float* pgmax = nullptr;
+  float* pgmax = nullptr;      // [0] max |projected gradient| of the returned point, [1] of the start point
+  float* pgblk = nullptr;      // per (image, NNLS column block): max |projected gradient| of the start point
+  size_t cap_blk = 0;
+  // NNLS solver (adm_mel_set_nnls_solver): step 1 / lipschitz = 1 / lambda_max(A A^T); 0 = start point only
+  double lipschitz = 0.0;
+  int nnls_max_iter = 0;
+  int* iters_dev = nullptr;    // max iterations any column ran in the last inverse
+  int last_iters = 0;
+  float last_pg_start = 0.f;
 };
 
 namespace adm {
@@ -210,9 +218,13 @@ __global__ void __launch_bounds__(256) mel_nnls_pg_kernel(const double* __restri
                                                           const int* __restrict__ fbt_off,
                                                           const int* __restrict__ fbt_idx,
                                                           const double* __restrict__ fbt_w64, int n_bins, int n_mels,
-                                                          int n_frames, int nnls_cols, float* __restrict__ pgmax) {
+                                                          int n_frames, int nnls_cols, float* __restrict__ pgmax,
+                                                          float* __restrict__ pgblk) {
+  // pgblk != nullptr: additionally the maximum per (image, column block) — the unit librosa hands to L-BFGS-B — one
+  // atomic per element there (this pass runs once per inverse; the blocks are few)
   const int b = blockIdx.y;
   const long n = (long)n_bins * n_frames;
+  const int n_blk = (n_frames + nnls_cols - 1) / nnls_cols;
   float local = 0.f;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     const int t = (int)(e / n_bins), f = (int)(e - (long)t * n_bins);
@@ -226,9 +238,118 @@ __global__ void __launch_bounds__(256) mel_nnls_pg_kernel(const double* __restri
     const double x = X[((long)b * n_frames + t) * n_bins + f];
     const double pg = x > 0.0 ? g : (g < 0.0 ? g : 0.0);
     local = fmaxf(local, (float)fabs(pg));
+    if (pgblk != nullptr && pg != 0.0)
+      atomicMax(reinterpret_cast<unsigned*>(pgblk + (long)b * n_blk + t / nnls_cols), __float_as_uint((float)fabs(pg)));
   }
   for (int m = 32; m >= 1; m >>= 1) local = fmaxf(local, __shfl_xor(local, m, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(pgmax), __float_as_uint(local));
+}
+
+// NNLS solver for the column blocks whose start point does NOT satisfy L-BFGS-B's stopping rule (max |projected
+// gradient| > pgtol; librosa.util.nnls -> scipy.optimize.fmin_l_bfgs_b, audiodiffusion/mel.py:165). The problem
+//   min_{X >= 0} 0.5 ||A X - S||^2 / size        (A: n_mels x n_bins sparse triangles)
+// separates over the columns of X, so one workgroup solves one column (frame) entirely in LDS: accelerated projected
+// gradient (FISTA, step 1 / lambda_max(A A^T)) with gradient-based adaptive restart, fp64; it stops when the column's
+// own projected gradient is below tol (a tenth of pgtol: every column, hence every block, then satisfies scipy's rule with
+// margin and the objective is below what L-BFGS-B's early stop reaches) or after max_iter. Blocks that already satisfy
+// the rule are left exactly as they are — that is what scipy returns for them (nit = 0).
+__global__ void __launch_bounds__(256) mel_nnls_solve_kernel(double* __restrict__ X, double* __restrict__ mag,
+                                                             const double* __restrict__ S,
+                                                             const int* __restrict__ fb_start,
+                                                             const int* __restrict__ fb_count,
+                                                             const int* __restrict__ fb_off,
+                                                             const double* __restrict__ fb_w64,
+                                                             const int* __restrict__ fbt_off,
+                                                             const int* __restrict__ fbt_idx,
+                                                             const double* __restrict__ fbt_w64, int n_bins, int n_mels,
+                                                             int n_frames, int nnls_cols, const float* __restrict__ pgblk,
+                                                             float pgtol, double inv_lip, double tol, int max_iter,
+                                                             int* __restrict__ iters_out) {
+  ADM_DYN_SMEM(double, sm);
+  double* x = sm;                    // current iterate
+  double* y = sm + n_bins;           // extrapolated point
+  double* xn = sm + 2 * n_bins;      // candidate
+  double* d = sm + 3 * n_bins;       // residual A y - s (n_mels)
+  double* sv = d + n_mels;           // this column of S
+  __shared__ double red[4];
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int n_blk = (n_frames + nnls_cols - 1) / nnls_cols;
+  if (!(pgblk[(long)b * n_blk + t / nnls_cols] > pgtol)) return;      // block-uniform: scipy returns the start point
+  const int blk0 = (t / nnls_cols) * nnls_cols;
+  const int cols = (blk0 + nnls_cols <= n_frames) ? nnls_cols : n_frames - blk0;
+  const double inv_size = 1.0 / ((double)n_mels * cols);
+  double* xg = X + ((long)b * n_frames + t) * n_bins;
+  for (int k = tid; k < n_bins; k += blockDim.x) { x[k] = xg[k]; y[k] = xg[k]; }
+  for (int m = tid; m < n_mels; m += blockDim.x) sv[m] = S[((long)b * n_mels + m) * n_frames + t];
+  __syncthreads();
+  auto block_sum = [&](double v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  auto block_max = [&](double v) {
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  };
+  auto residual = [&](const double* p) {           // d = A p - s
+    for (int m = tid; m < n_mels; m += blockDim.x) {
+      const int s0 = fb_start[m], c = fb_count[m], o = fb_off[m];
+      double acc = 0.0;
+      for (int i = 0; i < c; ++i) acc += fb_w64[o + i] * p[s0 + i];
+      d[m] = acc - sv[m];
+    }
+    __syncthreads();
+  };
+  auto grad_at = [&](int k) {                       // (A^T d)[k]
+    double g = 0.0;
+    for (int i = fbt_off[k]; i < fbt_off[k + 1]; ++i) g += fbt_w64[i] * d[fbt_idx[i]];
+    return g;
+  };
+  double tk = 1.0;
+  int it = 0;
+  for (; it < max_iter; ++it) {
+    if ((it & 15) == 0) {                           // stopping rule on the iterate itself, every 16 steps
+      residual(x);
+      double pg = 0.0;
+      for (int k = tid; k < n_bins; k += blockDim.x) {
+        const double g = grad_at(k) * inv_size;
+        pg = fmax(pg, fabs(x[k] > 0.0 ? g : (g < 0.0 ? g : 0.0)));
+      }
+      pg = block_max(pg);
+      if (pg <= tol) break;
+    }
+    residual(y);
+    double r = 0.0;
+    for (int k = tid; k < n_bins; k += blockDim.x) {
+      const double v = y[k] - grad_at(k) * inv_lip;
+      const double c = v > 0.0 ? v : 0.0;
+      xn[k] = c;
+      r += (y[k] - c) * (c - x[k]);
+    }
+    r = block_sum(r);
+    if (r > 0.0 && tk > 1.0) {                      // momentum points uphill: restart from the current iterate
+      tk = 1.0;
+      for (int k = tid; k < n_bins; k += blockDim.x) y[k] = x[k];
+    } else {
+      const double tn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * tk * tk));
+      const double beta = (tk - 1.0) / tn;
+      for (int k = tid; k < n_bins; k += blockDim.x) {
+        const double c = xn[k];
+        y[k] = c + beta * (c - x[k]);
+        x[k] = c;
+      }
+      tk = tn;
+    }
+    __syncthreads();
+  }
+  double* mg = mag + ((long)b * n_frames + t) * n_bins;
+  for (int k = tid; k < n_bins; k += blockDim.x) { xg[k] = x[k]; mg[k] = sqrt(x[k]); }
+  if (tid == 0) atomicMax(reinterpret_cast<unsigned*>(iters_out), (unsigned)it);
 }
 
 // Griffin-Lim init: angles = (cos(2*pi*u) + i sin(2*pi*u)) * mag   (librosa.griffinlim init="random")
@@ -382,10 +503,12 @@ int adm_mel_create(const adm_mel_config* cfg, const double* window, const double
   rc |= upload(h, &h->fbt_w64, fbt_w64, nnz);
   rc |= upload(h, &h->pinv, pinv, (size_t)h->n_bins * h->n_mels);
   rc |= upload(h, &h->wss, wss, (size_t)cfg->hop_length * (cfg->x_res - 1));
-  rc |= dmalloc((void**)&h->pgmax, sizeof(float));
+  rc |= dmalloc((void**)&h->pgmax, 2 * sizeof(float));
+  rc |= dmalloc((void**)&h->iters_dev, sizeof(int));
   rc |= stream_sync(nullptr);
   if (rc) { delete h; return -1; }
   h->owned.push_back(h->pgmax);
+  h->owned.push_back(h->iters_dev);
   *out = h;
   return 0;
 }
@@ -394,7 +517,7 @@ void adm_mel_destroy(adm_mel_t* h) {
   if (!h) return;
   for (void* p : h->owned) dfree(p);
   for (void* p : {(void*)h->melspec, (void*)h->angles, (void*)h->mag, (void*)h->ytmp, (void*)h->Smel, (void*)h->Xpow,
-                  (void*)h->diff, (void*)h->reb0, (void*)h->reb1, (void*)h->y})
+                  (void*)h->diff, (void*)h->reb0, (void*)h->reb1, (void*)h->y, (void*)h->pgblk})
     if (p) dfree(p);
   delete h;
 }
@@ -474,11 +597,35 @@ int adm_mel_inverse(adm_mel_t* h, const uint8_t* images, const double* init_phas
              st, images, npix, (double)c.top_db, h->Smel);
   ADM_LAUNCH(mel_pinv_gemm_kernel, dim3(ceil_div(nb, 64), ceil_div(n_frames, 64), B), dim3(256), 0, st, h->pinv, h->Smel,
              nb, nm, n_frames, h->Xpow, h->mag);
-  ADM_TRY(dmemset(h->pgmax, 0, sizeof(float), st));
+  // NNLS (mel.py:165 -> librosa.util.nnls): start point clip(pinv S, 0) above; its projected gradient per column block
+  // decides, as in L-BFGS-B, whether the block is returned as it is (nit = 0: every dB image at the usual configurations)
+  // or solved on the device (mel_nnls_solve_kernel: low sample rates / tiny filterbanks).
+  const int n_blk = ceil_div(n_frames, h->nnls_cols);
+  if (h->cap_blk < (size_t)B * n_blk) {
+    ADM_TRY(stream_sync(st));
+    ADM_TRY(grow(h, (void**)&h->pgblk, sizeof(float) * (size_t)B * n_blk));
+    h->cap_blk = (size_t)B * n_blk;
+  }
+  ADM_TRY(dmemset(h->pgmax, 0, 2 * sizeof(float), st));
+  ADM_TRY(dmemset(h->pgblk, 0, sizeof(float) * (size_t)B * n_blk, st));
+  ADM_TRY(dmemset(h->iters_dev, 0, sizeof(int), st));
   ADM_LAUNCH(mel_nnls_diff_kernel, dim3(256, B), dim3(256), 0, st, h->Xpow, h->Smel, h->fb_start, h->fb_count, h->fb_off,
              h->fb_w64, nb, nm, n_frames, h->diff);
+  const bool solve = h->lipschitz > 0.0 && h->nnls_max_iter > 0;
   ADM_LAUNCH(mel_nnls_pg_kernel, dim3(256, B), dim3(256), 0, st, h->Xpow, h->diff, h->fbt_off, h->fbt_idx, h->fbt_w64, nb,
-             nm, n_frames, h->nnls_cols, h->pgmax);
+             nm, n_frames, h->nnls_cols, h->pgmax + (solve ? 1 : 0), solve ? h->pgblk : (float*)nullptr);
+  if (solve) {
+    const size_t nsm = sizeof(double) * (3 * (size_t)nb + 2 * (size_t)nm);
+    ADM_REQUIRE(nsm <= 64 * 1024, "mel_inverse: filterbank too large for the in-LDS NNLS solver");
+    ADM_LAUNCH(mel_nnls_solve_kernel, dim3(n_frames, B), dim3(256), nsm, st, h->Xpow, h->mag, (const double*)h->Smel,
+               h->fb_start, h->fb_count, h->fb_off, h->fb_w64, h->fbt_off, h->fbt_idx, h->fbt_w64, nb, nm, n_frames,
+               h->nnls_cols, (const float*)h->pgblk, 1e-5f, 1.0 / h->lipschitz, 1e-6, h->nnls_max_iter, h->iters_dev);
+    // projected gradient of the point that is returned
+    ADM_LAUNCH(mel_nnls_diff_kernel, dim3(256, B), dim3(256), 0, st, h->Xpow, h->Smel, h->fb_start, h->fb_count, h->fb_off,
+               h->fb_w64, nb, nm, n_frames, h->diff);
+    ADM_LAUNCH(mel_nnls_pg_kernel, dim3(256, B), dim3(256), 0, st, h->Xpow, h->diff, h->fbt_off, h->fbt_idx, h->fbt_w64, nb,
+               nm, n_frames, h->nnls_cols, h->pgmax, (float*)nullptr);
+  }
   ADM_LAUNCH(gl_init_kernel, dim3(256, B), dim3(256), 0, st, init_phase, h->mag, nb, n_frames, (double2*)h->angles);
   const size_t smem = fft_smem(h);
   const float mom = (float)(0.99 / (1.0 + 0.99));
@@ -503,9 +650,31 @@ int adm_mel_inverse(adm_mel_t* h, const uint8_t* images, const double* init_phas
   ADM_TRY(ADM_CHECK_LAUNCH());
   if (stft_mag_out) ADM_TRY(copy_d2d(stft_mag_out, h->mag, spec * 8, st));  // layout (B, n_frames, n_bins)
   if (pg_max_host) {
-    ADM_TRY(copy_d2h(pg_max_host, h->pgmax, sizeof(float), st));
+    float pg2[2] = {0.f, 0.f};
+    ADM_TRY(copy_d2h(pg2, h->pgmax, 2 * sizeof(float), st));
+    ADM_TRY(copy_d2h(&h->last_iters, h->iters_dev, sizeof(int), st));
     ADM_TRY(stream_sync(st));
+    *pg_max_host = pg2[0];
+    h->last_pg_start = (h->lipschitz > 0.0 && h->nnls_max_iter > 0) ? pg2[1] : pg2[0];
   }
+  return 0;
+}
+
+// Enables the on-device NNLS solver for column blocks whose start point fails L-BFGS-B's projected-gradient rule:
+// lipschitz = lambda_max(A A^T) of the fp64 filterbank (computed by the caller), max_iter = iteration cap per column.
+int adm_mel_set_nnls_solver(adm_mel_t* h, double lipschitz, int max_iter) {
+  ADM_REQUIRE(h && lipschitz >= 0.0 && max_iter >= 0, "mel_set_nnls_solver: bad argument");
+  h->lipschitz = lipschitz;
+  h->nnls_max_iter = max_iter;
+  return 0;
+}
+
+// Diagnostics of the last adm_mel_inverse that was given pg_max_host: max |projected gradient| of the NNLS START point and
+// the largest number of solver iterations any column ran (0: every block was returned as it was, scipy's nit = 0).
+int adm_mel_last_nnls(adm_mel_t* h, float* pg_start, int* iterations) {
+  ADM_REQUIRE(h && pg_start && iterations, "mel_last_nnls: null argument");
+  *pg_start = h->last_pg_start;
+  *iterations = h->last_iters;
   return 0;
 }
 

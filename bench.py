@@ -228,8 +228,8 @@ def mel_leg(job, n_fwd=256, n_inv=32):
 
 
 def cpu_baseline(sd, cores):
-    """Oracle (port) on the host cores: {UNet forward + DDIM step} at B=1, 256x256 fp32, 1 warm-up + 2 timed steps at two
-    thread counts (torch-CPU convolutions stop scaling well before 128 threads); the faster one is reported, x50."""
+    """Oracle (port) on the host cores: {UNet forward + DDIM step} at B=1, 256x256 fp32, 1 warm-up + 2 timed steps at up to
+    three thread counts (torch-CPU convolutions stop scaling well before the box's 256 threads); the fastest is reported, x50."""
     from oracle.schedulers import DDIMScheduler
     from oracle.unet import UNet2DModel
     m = UNet2DModel(**CFG256).eval()
@@ -237,7 +237,7 @@ def cpu_baseline(sd, cores):
     s = DDIMScheduler()
     s.set_timesteps(50)
     tried = {}
-    for nt in sorted({min(32, cores), cores}):
+    for nt in sorted({min(16, cores), min(32, cores), min(64, cores)}):   # all 256 hardware threads of the box: 87 s per step
         torch.set_num_threads(nt)
         x = torch.randn(1, 1, 256, 256, generator=torch.Generator().manual_seed(42))
         times = []

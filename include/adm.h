@@ -353,9 +353,17 @@ int adm_mel_forward_power(adm_mel_t* h, const void* audio, int is_f64, int B, lo
                           void* melspec_out, void* stream);
 /* images: device (B, y_res, n_frames) uint8; init_phase: device (B, n_bins, n_frames) fp64 in [0,1) (Griffin-Lim start
  * phase / 2 pi); audio_out: device (B, hop*(n_frames-1)) fp32; stft_mag_out: NULL or device (B, n_frames, n_bins) fp64;
- * pg_max_host: NULL or receives max |projected gradient| of the NNLS start point (librosa stops there iff <= 1e-5). */
+ * pg_max_host: NULL or receives max |projected gradient| of the NNLS solution returned (librosa's rule: <= 1e-5). */
 int adm_mel_inverse(adm_mel_t* h, const uint8_t* images, const double* init_phase, int B, int n_frames,
                     float* audio_out, double* stft_mag_out, float* pg_max_host, void* stream);
+/* librosa.util.nnls behind mel_to_stft (audiodiffusion/mel.py:165): column blocks whose start point fails L-BFGS-B's rule
+ * (max |projected gradient| > pgtol = 1e-5) are solved on the device (projected accelerated gradient, step 1/lipschitz,
+ * lipschitz = lambda_max(A A^T) of the fp64 filterbank, at most max_iter iterations per column); blocks that satisfy it are
+ * returned as they are, as scipy does (nit = 0). Without this call adm_mel_inverse returns the start point everywhere. */
+int adm_mel_set_nnls_solver(adm_mel_t* h, double lipschitz, int max_iter);
+/* after an adm_mel_inverse with pg_max_host != NULL (which then holds the projected gradient of the RETURNED point):
+ * the start point's max |projected gradient| and the largest iteration count any column needed. */
+int adm_mel_last_nnls(adm_mel_t* h, float* pg_start, int* iterations);
 
 #ifdef __cplusplus
 }

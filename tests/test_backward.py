@@ -52,6 +52,8 @@ WG_CASES = [
     (2, 64, 0, 16, 16, 256, 3, 1, 0, 0, 0),     # ... without GroupNorm, two cout tiles, image borders on every side
     (2, 128, 128, 8, 8, 128, 1, 1, 0, 0, 0),    # ... 1x1 (128-channel chunks) over a concat
     (5, 32, 0, 4, 4, 128, 3, 1, 0, 1, 1),       # ... several images per 64-pixel tile, ragged last image group
+    (2, 32, 0, 4, 4, 32, 3, 2, 0, 0, 0),        # stride 2 down to 2x2 (deepest Downsample2D of a 64x64 model): 16 images x 5x5
+    (3, 32, 0, 2, 2, 32, 3, 2, 0, 0, 0),        # ... down to 1x1 (32x32 model): 64 images x 3x3 patches per tile, 107 KiB of LDS
 ]
 
 

@@ -20,15 +20,17 @@ CASES = [
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("mode", [1, 2, 3], ids=["v1", "v2wavespec", "v3persistent"])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4], ids=["v1", "v2wavespec", "v3persistent", "v4regfilters"])
 @pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
 def test_conv_winograd(backend, case, mode):
     dev = select(backend)
     from audiodiffusion import _native, ops
     if mode >= 2 and case[5] % 64 != 0:
         pytest.skip("v2/v3 tile 64 output channels")
-    if mode == 3 and ((case[8] and not case[7]) or (case[1] + case[2]) % 16 != 0):
-        pytest.skip("v3 needs an even number of 8-channel chunks (and GroupNorm whenever SiLU is requested)")
+    if mode >= 3 and ((case[8] and not case[7]) or (case[1] + case[2]) % 16 != 0):
+        pytest.skip("v3/v4 need an even number of 8-channel chunks (and GroupNorm whenever SiLU is requested)")
+    if mode == 4 and (case[1] + case[2]) % 32 != 0:
+        pytest.skip("v4 tiles 32 input channels (four chunks in flight)")
     _native.check(_native.lib().adm_set_option(b"conv_wino", mode))
     try:
         _run_case(dev, case, 4310 + mode)
@@ -59,15 +61,22 @@ def _run_case(dev, case, want_variant):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_conv_winograd_data_gradient(backend):
-    """3x3 stride-1 backward-data pass as a Winograd convolution with transposed/flipped filters vs torch autograd."""
+@pytest.mark.parametrize("mode,Cin,Cout,variant", [(3, 64, 32, 4313), (4, 64, 32, 4314), (4, 128, 64, 4314)],
+                         ids=["v3", "v4", "v4-two-cout-tiles"])
+def test_conv_winograd_data_gradient(backend, mode, Cin, Cout, variant):
+    """3x3 stride-1 backward-data pass as a Winograd convolution with transposed/flipped filters vs torch autograd
+    (the data-gradient convolution maps Cout -> Cin channels, so ITS output-channel count is the forward's Cin)."""
     dev = select(backend)
     from audiodiffusion import _native, ops
-    Nn, Cin, Cout, H, W = 2, 64, 32, 16, 32
+    Nn, H, W = 2, 16, 32
     w = _rand((Cout, Cin, 3, 3), 11, dev, scale=(Cin * 9) ** -0.5)
     dy = _rand((Nn, Cout, H, W), 12, dev)
     acc = _rand((Nn, Cin, H, W), 13, dev)          # gradient already accumulated in dx (residual fan-in)
-    dx = ops.conv2d(dy, ops.pack_conv_weight_T(w), None, 3, residual=acc, wino=ops.pack_winograd_weight_T(w))
-    assert _native.lib().adm_last_conv_variant() == 4313, "the Winograd kernel was not selected"
+    _native.check(_native.lib().adm_set_option(b"conv_wino", mode))
+    try:
+        dx = ops.conv2d(dy, ops.pack_conv_weight_T(w), None, 3, residual=acc, wino=ops.pack_winograd_weight_T(w))
+        assert _native.lib().adm_last_conv_variant() == variant, "the Winograd kernel was not selected"
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_wino", -1))
     ref = torch.nn.grad.conv2d_input((Nn, Cin, H, W), w.cpu(), dy.cpu(), padding=1) + acc.cpu()
     assert _relerr(dx, ref) < 1e-4, _relerr(dx, ref)

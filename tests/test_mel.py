@@ -92,3 +92,55 @@ def test_batched_forward_matches_single(backend):
     for i, y in enumerate(ys):
         m.load_audio(raw_audio=y)
         assert np.array_equal(batch[i], np.asarray(m.audio_slice_to_image(0)))
+
+
+NNLS_ITERATING = [  # (sample_rate, cfg): low rates make the Slaney triangles tall enough that L-BFGS-B does NOT stop at its start point
+    (1000, dict(x_res=8, y_res=8, n_fft=128, hop_length=32)),
+    (200, dict(x_res=4, y_res=16, n_fft=256, hop_length=64)),
+    (50, dict(x_res=4, y_res=16, n_fft=256, hop_length=64)),
+    (1000, dict(x_res=16, y_res=4, n_fft=64, hop_length=16)),
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", NNLS_ITERATING, ids=[f"sr{c[0]}-{c[1]['y_res']}mels" for c in NNLS_ITERATING])
+def test_nnls_solver_where_lbfgsb_iterates(backend, case):
+    """M7 (`mel.py:165` -> librosa.util.nnls): where scipy's L-BFGS-B really iterates (nit > 0) the device solver must reach
+    an objective at least as low (f_hip <= f_oracle * (1 + 1e-3)) and satisfy the same stopping rule."""
+    select(backend)
+    from audiodiffusion.mel import Mel
+    sr, cfg = case
+    mine, ref = Mel(sample_rate=sr, n_iter=1, **cfg), omel.Mel(sample_rate=sr, n_iter=1, **cfg)
+    rng = np.random.default_rng(sr)
+    img = Image.fromarray(rng.integers(0, 256, (cfg["y_res"], cfg["x_res"]), dtype=np.uint8))
+    info = []
+    ref_mag = ref.image_to_stft_magnitude(img, info)
+    assert all(d["nit"] > 0 for d in info), info                      # the regime this test is about
+    phase = rng.random((1, 1 + cfg["n_fft"] // 2, cfg["x_res"]))
+    _, mag = mine.images_to_audios([img], init_phase=phase, return_magnitude=True)
+    S = omel.db_to_power(np.asarray(img).astype(float) * mine.top_db / 255 - mine.top_db)
+    A = omel.mel_filterbank(sr, cfg["n_fft"], cfg["y_res"], np.float64)
+    f = lambda X: 0.5 * np.sum((A @ X - S) ** 2) / S.size  # noqa: E731  (librosa's objective, _nnls_obj)
+    f_hip, f_ref, f_start = f(mag[0] ** 2), f(ref_mag ** 2), f(np.clip(np.linalg.pinv(A) @ S, 0, None))
+    assert mine.last_nnls_pg_start > 1e-5 and mine.last_nnls_iterations > 0
+    assert mine.last_nnls_pg <= 1e-5                                  # L-BFGS-B's own stopping rule holds at the result
+    assert (mag[0] >= 0).all()
+    assert f_hip <= f_ref * (1 + 1e-3), (f_hip, f_ref)
+    assert f_hip < f_start
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_nnls_solver_leaves_converged_blocks_alone(backend):
+    """The usual regime: the start point already satisfies pgtol, scipy returns it after 0 iterations — so must the device."""
+    select(backend)
+    from audiodiffusion.mel import Mel
+    cfg = dict(x_res=16, y_res=16, n_fft=256, hop_length=64, n_iter=1)
+    mine, ref = Mel(**cfg), omel.Mel(**cfg)
+    rng = np.random.default_rng(5)
+    img = Image.fromarray(rng.integers(0, 256, (16, 16), dtype=np.uint8))
+    info = []
+    ref_mag = ref.image_to_stft_magnitude(img, info)
+    assert all(d["nit"] == 0 for d in info)
+    _, mag = mine.images_to_audios([img], init_phase=rng.random((1, 129, 16)), return_magnitude=True)
+    assert mine.last_nnls_iterations == 0 and mine.last_nnls_pg == mine.last_nnls_pg_start <= 1e-5
+    assert np.abs(mag[0] ** 2 - ref_mag ** 2).max() <= 1e-12 * max(1.0, np.abs(ref_mag ** 2).max())

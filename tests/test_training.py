@@ -122,4 +122,6 @@ def test_flat_ops_match_the_torch_expressions_they_replace(backend):
             y = y0.clone().to(dev)
             T.flat_op(y, None if op == T.FLAT_DIV else x.to(dev), op, a)
             want = ref(y0.clone())
-            assert torch.allclose(y.cpu(), want, rtol=2e-7, atol=1e-9), (n, op, float((y.cpu() - want).abs().max()))
+            # one fp32 ulp of the operands: the device contracts y - a*(y - x) into an fma, torch rounds the product first
+            tol = 2e-7 * float(torch.maximum(y0.abs(), x.abs()).max())
+            assert float((y.cpu() - want).abs().max()) <= tol, (n, op, float((y.cpu() - want).abs().max()))
