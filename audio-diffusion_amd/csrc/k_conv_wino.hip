@@ -557,7 +557,9 @@ struct Wino3Raw {                     // one chunk's raw activations of this thr
 // ds_read_b64, which is conflict-free as it is) and the raw activations prefetched FOUR chunks ahead instead of two (the
 // registers are free: the kernel's allocation is set by the consumers' accumulators; with two chunks of ~3000 cycles in
 // flight a producer is bound by the loaded HBM latency: measured ~2700 cycles per chunk with the MFMAs removed).
-template <bool UP, bool WIDE1, bool PROF, bool V4 = false>
+// ABL (developer aid, timing only — results are wrong): 1 = this role keeps its barriers but stages nothing; 4 = stage C (window
+// gather + transform + V write) skipped; 5 = stage B (activation + patch write) skipped.
+template <bool UP, bool WIDE1, bool PROF, bool V4 = false, int ABL = 0>
 __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV, float* ldsP, int tid, int b0, int bs) {
   unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_start = W3_CLK();
@@ -710,30 +712,30 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
   if constexpr (V4) {          // same schedule with the global loads of g + 5 in flight: four raw-chunk register sets
     Wino3Raw r2, r3;
     r2.b = r0.b; r3.b = r0.b; r2.a = r0.b; r3.a = r0.b; r2.h = 0.f; r3.h = 0.f;
-    stage_a(r0); stage_a(r1); stage_a(r2); stage_a(r3);      // chunks 0..3
-    stage_b(r0, 0);
-    stage_a(r0);                                             // chunk 4
+    if (ABL != 1) stage_a(r0); if (ABL != 1) stage_a(r1); if (ABL != 1) stage_a(r2); if (ABL != 1) stage_a(r3);      // chunks 0..3
+    if (ABL != 1 && ABL != 5) stage_b(r0, 0);
+    if (ABL != 1) stage_a(r0);                                             // chunk 4
     ADM_BARRIER_KEEP_VMEM(63);
     if (PROF) tq = W3_CLK();
     for (int g = 0; g < total; g += 4) {                     // total is a multiple of 4 (nch is)
-      stage_c(g);                W3_LAP(3);
-      stage_b(r1, g + 1);        W3_LAP(4);
-      stage_a(r1);               W3_LAP(5);   // chunk g + 5
+      if (ABL != 1 && ABL != 4) stage_c(g);                W3_LAP(3);
+      if (ABL != 1 && ABL != 5) stage_b(r1, g + 1);        W3_LAP(4);
+      if (ABL != 1) stage_a(r1);               W3_LAP(5);   // chunk g + 5
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
-      stage_c(g + 1);            W3_LAP(3);
-      stage_b(r2, g + 2);        W3_LAP(4);
-      stage_a(r2);               W3_LAP(5);   // chunk g + 6
+      if (ABL != 1 && ABL != 4) stage_c(g + 1);            W3_LAP(3);
+      if (ABL != 1 && ABL != 5) stage_b(r2, g + 2);        W3_LAP(4);
+      if (ABL != 1) stage_a(r2);               W3_LAP(5);   // chunk g + 6
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
-      stage_c(g + 2);            W3_LAP(3);
-      stage_b(r3, g + 3);        W3_LAP(4);
-      stage_a(r3);               W3_LAP(5);   // chunk g + 7
+      if (ABL != 1 && ABL != 4) stage_c(g + 2);            W3_LAP(3);
+      if (ABL != 1 && ABL != 5) stage_b(r3, g + 3);        W3_LAP(4);
+      if (ABL != 1) stage_a(r3);               W3_LAP(5);   // chunk g + 7
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
-      stage_c(g + 3);            W3_LAP(3);
-      stage_b(r0, g + 4);        W3_LAP(4);
-      stage_a(r0);               W3_LAP(5);   // chunk g + 8
+      if (ABL != 1 && ABL != 4) stage_c(g + 3);            W3_LAP(3);
+      if (ABL != 1 && ABL != 5) stage_b(r0, g + 4);        W3_LAP(4);
+      if (ABL != 1) stage_a(r0);               W3_LAP(5);   // chunk g + 8
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
     }
@@ -949,7 +951,8 @@ __global__ void __launch_bounds__(512, 2) conv_wino3_kernel(const WinoParams p) 
 constexpr int W4LDS = 2 * W3VSLAB + 2 * W3PSLAB;
 constexpr int W4ABLK = 4 * 2 * 64 * 4;      // floats of one (chunk, 16-cout block) filter image: 8 KiB
 
-template <bool PROF>
+// ABL (developer aid, timing only): 2 = the MFMAs are replaced by a register dependency (operands still fetched).
+template <bool PROF, int ABL = 0>
 __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float* ldsV, int tid, int wave, int b0, int bs) {
   unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_start = W3_CLK();
@@ -1017,8 +1020,13 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
         const int s = xi & 3, q = xi >> 2, e = xi & 3;
         ADM_UNROLL
         for (int ks = 0; ks < 2; ++ks) {
-          acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].x, acc[xi][0], 0, 0, 0);
-          acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].y, acc[xi][1], 0, 0, 0);
+          if (ABL == 2) {
+            acc[xi][0][0] += a[q][ks][e] * rb[s][ks].x;
+            acc[xi][1][0] += a[q][ks][e] * rb[s][ks].y;
+          } else {
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].x, acc[xi][0], 0, 0, 0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].y, acc[xi][1], 0, 0, 0);
+          }
         }
         if (e == 3) {                      // group q consumed: its registers take the NEXT chunk's words
           if (q == 0) W4_LOAD_A(0);
@@ -1079,7 +1087,7 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   }
 }
 
-template <bool UP, bool PROF>
+template <bool UP, bool PROF, int ABL = 0>
 __global__ void __launch_bounds__(512) conv_wino4_kernel(const WinoParams p) {
   ADM_DYN_SMEM(float, smem);
   float* ldsV = smem;
@@ -1088,12 +1096,12 @@ __global__ void __launch_bounds__(512) conv_wino4_kernel(const WinoParams p) {
   const int wave = tid >> 6;
   if (wave >= 4) {
 #if !defined(ADM_EMU)
-    __builtin_amdgcn_s_setprio(1);         // see conv_wino3_kernel
+    if (ABL != 3) __builtin_amdgcn_s_setprio(1);         // see conv_wino3_kernel (ABL 3: timing without it)
 #endif
-    if (!UP && wave == 4) wino3_producer<UP, true, PROF, true>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
-    else wino3_producer<UP, false, PROF, true>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
+    if (!UP && wave == 4) wino3_producer<UP, true, PROF, true, ABL>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
+    else wino3_producer<UP, false, PROF, true, ABL>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
   }
-  else wino4_consumer<PROF>(p, ldsV, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+  else wino4_consumer<PROF, ABL>(p, ldsV, tid, wave, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Filter image of conv_wino4_kernel: U = G g G^T as [Cin/8][Cout/16][point group q][k step ks][lane = 16 k4 + li][e]
@@ -1186,13 +1194,14 @@ int launch_pack_winograd_weight_T(const float* w, float* wu, int Cout, int Cin, 
   return pack_winograd(w, wu, Cout, Cin, 1, st);
 }
 
-// 0 direct MFMA kernel only | 1 Winograd v1 | 2 wave-specialised v2 | 3 persistent wave-specialised v3 (default: measured
-// 1.33x on the whole UNet forward) | 4 v3 with the filters loaded L2 -> registers (conv_wino4_kernel; layers whose channel
-// counts it cannot tile run as in mode 3); shapes a mode cannot take fall back to the direct kernel.
-static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 3) on first use; 4 = conv_wino4_kernel
+// 0 direct MFMA kernel only | 1 Winograd v1 | 2 wave-specialised v2 | 3 persistent wave-specialised v3 (1.33x the direct
+// kernel on the whole UNet forward) | 4 (default) v3 with the filters loaded L2 -> registers (conv_wino4_kernel: bit-identical
+// to v3, 87.7 vs 100.5 ms per B = 32 forward, profiles/r02_wino_v4.md; layers whose channel counts it cannot tile run as in
+// mode 3); shapes a mode cannot take fall back to the direct kernel.
+static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 4) on first use
 void set_winograd_mode(int m) { g_wino_mode = m; }
 static int wino_mode() {
-  if (g_wino_mode < 0) { const char* e = getenv("ADM_CONV_WINO"); g_wino_mode = e ? atoi(e) : 3; }
+  if (g_wino_mode < 0) { const char* e = getenv("ADM_CONV_WINO"); g_wino_mode = e ? atoi(e) : 4; }
   return g_wino_mode;
 }
 bool winograd_enabled() { return wino_mode() != 0; }
@@ -1278,6 +1287,19 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
       const double nb = grid;
       fprintf(stderr, "[wino3 prof] per-block cycles: consumer total %.0f drain %.0f barrier %.0f epilogue %.0f | producer total %.0f drain %.0f barrier %.0f C %.0f B %.0f A %.0f\n",
               h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[8] / nb, h[9] / nb, h[10] / nb, h[11] / nb, h[12] / nb, h[13] / nb);
+      return ADM_CHECK_LAUNCH();
+    }
+#endif
+#if !defined(ADM_EMU)
+    static const int abl = [] { const char* e = getenv("ADM_WINO_ABL"); return e ? atoi(e) : 0; }();
+    if (v4 && !a.up && abl) {   // developer aid: role ablations of conv_wino4_kernel (TIMING ONLY, wrong results)
+      switch (abl) {
+        case 1: ADM_LAUNCH((conv_wino4_kernel<false, false, 1>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        case 2: ADM_LAUNCH((conv_wino4_kernel<false, false, 2>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        case 3: ADM_LAUNCH((conv_wino4_kernel<false, false, 3>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        case 4: ADM_LAUNCH((conv_wino4_kernel<false, false, 4>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        default: ADM_LAUNCH((conv_wino4_kernel<false, false, 5>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+      }
       return ADM_CHECK_LAUNCH();
     }
 #endif

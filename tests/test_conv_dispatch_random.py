@@ -70,7 +70,9 @@ def test_conv2d_random_dispatch(backend, case):
     # the persistent Winograd kernel must be the one that ran whenever the shape allows it
     eligible = (ks == 3 and stride == 1 and Wi % 16 == 0 and Hi % 8 == 0 and Ct % 16 == 0 and C1 % 8 == 0 and Cout % 64 == 0
                 and (use_gn or not act))
-    assert (variant == 4313) == eligible, (variant, eligible)
+    assert (variant in (4313, 4314)) == eligible, (variant, eligible)
+    if eligible:      # filters L2 -> registers (v4) whenever 32 | input channels, else the LDS-DMA kernel (v3)
+        assert variant == (4314 if Ct % 32 == 0 else 4313), (variant, Ct)
 
 
 def _wg_cases(n, seed):

@@ -1,4 +1,4 @@
-"""Winograd F(2x2,3x3) variants of the fused 3x3 convolution (mode 3 is the default 3x3 stride-1 path) vs torch fp32."""
+"""Winograd F(2x2,3x3) variants of the fused 3x3 convolution (mode 4 is the default 3x3 stride-1 path) vs torch fp32."""
 import pytest  # noqa: E402
 import torch  # noqa: E402
 
