@@ -557,8 +557,8 @@ struct Wino3Raw {                     // one chunk's raw activations of this thr
 // ds_read_b64, which is conflict-free as it is) and the raw activations prefetched FOUR chunks ahead instead of two (the
 // registers are free: the kernel's allocation is set by the consumers' accumulators; with two chunks of ~3000 cycles in
 // flight a producer is bound by the loaded HBM latency: measured ~2700 cycles per chunk with the MFMAs removed).
-// ABL (developer aid, timing only — results are wrong): 1 = this role keeps its barriers but stages nothing; 4 = stage C (window
-// gather + transform + V write) skipped; 5 = stage B (activation + patch write) skipped.
+// ABL (developer aid, timing only — results are wrong): 1 / 7 = this role keeps its barriers but stages nothing; 4 = stage C
+// (window gather + transform + V write) skipped; 5 = stage B (activation + patch write) skipped.
 template <bool UP, bool WIDE1, bool PROF, bool V4 = false, int ABL = 0>
 __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV, float* ldsP, int tid, int b0, int bs) {
   unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -712,30 +712,30 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
   if constexpr (V4) {          // same schedule with the global loads of g + 5 in flight: four raw-chunk register sets
     Wino3Raw r2, r3;
     r2.b = r0.b; r3.b = r0.b; r2.a = r0.b; r3.a = r0.b; r2.h = 0.f; r3.h = 0.f;
-    if (ABL != 1) stage_a(r0); if (ABL != 1) stage_a(r1); if (ABL != 1) stage_a(r2); if (ABL != 1) stage_a(r3);      // chunks 0..3
-    if (ABL != 1 && ABL != 5) stage_b(r0, 0);
-    if (ABL != 1) stage_a(r0);                                             // chunk 4
+    if (ABL != 1 && ABL != 7) stage_a(r0); if (ABL != 1 && ABL != 7) stage_a(r1); if (ABL != 1 && ABL != 7) stage_a(r2); if (ABL != 1 && ABL != 7) stage_a(r3);      // chunks 0..3
+    if (ABL != 1 && ABL != 7 && ABL != 5) stage_b(r0, 0);
+    if (ABL != 1 && ABL != 7) stage_a(r0);                                             // chunk 4
     ADM_BARRIER_KEEP_VMEM(63);
     if (PROF) tq = W3_CLK();
     for (int g = 0; g < total; g += 4) {                     // total is a multiple of 4 (nch is)
-      if (ABL != 1 && ABL != 4) stage_c(g);                W3_LAP(3);
-      if (ABL != 1 && ABL != 5) stage_b(r1, g + 1);        W3_LAP(4);
-      if (ABL != 1) stage_a(r1);               W3_LAP(5);   // chunk g + 5
+      if (ABL != 1 && ABL != 7 && ABL != 4) stage_c(g);                W3_LAP(3);
+      if (ABL != 1 && ABL != 7 && ABL != 5) stage_b(r1, g + 1);        W3_LAP(4);
+      if (ABL != 1 && ABL != 7) stage_a(r1);               W3_LAP(5);   // chunk g + 5
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
-      if (ABL != 1 && ABL != 4) stage_c(g + 1);            W3_LAP(3);
-      if (ABL != 1 && ABL != 5) stage_b(r2, g + 2);        W3_LAP(4);
-      if (ABL != 1) stage_a(r2);               W3_LAP(5);   // chunk g + 6
+      if (ABL != 1 && ABL != 7 && ABL != 4) stage_c(g + 1);            W3_LAP(3);
+      if (ABL != 1 && ABL != 7 && ABL != 5) stage_b(r2, g + 2);        W3_LAP(4);
+      if (ABL != 1 && ABL != 7) stage_a(r2);               W3_LAP(5);   // chunk g + 6
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
-      if (ABL != 1 && ABL != 4) stage_c(g + 2);            W3_LAP(3);
-      if (ABL != 1 && ABL != 5) stage_b(r3, g + 3);        W3_LAP(4);
-      if (ABL != 1) stage_a(r3);               W3_LAP(5);   // chunk g + 7
+      if (ABL != 1 && ABL != 7 && ABL != 4) stage_c(g + 2);            W3_LAP(3);
+      if (ABL != 1 && ABL != 7 && ABL != 5) stage_b(r3, g + 3);        W3_LAP(4);
+      if (ABL != 1 && ABL != 7) stage_a(r3);               W3_LAP(5);   // chunk g + 7
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
-      if (ABL != 1 && ABL != 4) stage_c(g + 3);            W3_LAP(3);
-      if (ABL != 1 && ABL != 5) stage_b(r0, g + 4);        W3_LAP(4);
-      if (ABL != 1) stage_a(r0);               W3_LAP(5);   // chunk g + 8
+      if (ABL != 1 && ABL != 7 && ABL != 4) stage_c(g + 3);            W3_LAP(3);
+      if (ABL != 1 && ABL != 7 && ABL != 5) stage_b(r0, g + 4);        W3_LAP(4);
+      if (ABL != 1 && ABL != 7) stage_a(r0);               W3_LAP(5);   // chunk g + 8
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
     }
@@ -951,7 +951,8 @@ __global__ void __launch_bounds__(512, 2) conv_wino3_kernel(const WinoParams p) 
 constexpr int W4LDS = 2 * W3VSLAB + 2 * W3PSLAB;
 constexpr int W4ABLK = 4 * 2 * 64 * 4;      // floats of one (chunk, 16-cout block) filter image: 8 KiB
 
-// ABL (developer aid, timing only): 2 = the MFMAs are replaced by a register dependency (operands still fetched).
+// ABL (developer aid, timing only): 2 = the MFMAs are replaced by a register dependency (operands still fetched); 6 = barriers
+// only (the producers' own pace); 7 = bare MFMA stream (no operand fetch; with idle producers: the matrix pipe's own pace).
 template <bool PROF, int ABL = 0>
 __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float* ldsV, int tid, int wave, int b0, int bs) {
   unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1015,6 +1016,20 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
     for (int xi = 0; xi < 4; ++xi) read_group(xi, g, xi);
     for (int ci = 0; ci < nch; ++ci, ++g) {
       const bool more = ci + 1 < nch;      // the rolling window does not cross into the next tile
+      if (ABL == 6 || ABL == 7 || ABL == 8) {       // 8 = bare MFMA stream beside WORKING producers
+        ADM_UNROLL
+        for (int xi = 0; xi < 16; ++xi) {
+          if (ABL != 6) {
+            ADM_UNROLL
+            for (int ks = 0; ks < 2; ++ks) {
+              acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[ks], cb[ks + 2], acc[xi][0], 0, 0, 0);
+              acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[ks + 2], cb[ks], acc[xi][1], 0, 0, 0);
+            }
+          }
+          if (xi == 12) W3_BARRIER(63, pr, 1, 2);
+        }
+        continue;
+      }
       ADM_UNROLL
       for (int xi = 0; xi < 16; ++xi) {
         const int s = xi & 3, q = xi >> 2, e = xi & 3;
@@ -1298,7 +1313,10 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
         case 2: ADM_LAUNCH((conv_wino4_kernel<false, false, 2>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         case 3: ADM_LAUNCH((conv_wino4_kernel<false, false, 3>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         case 4: ADM_LAUNCH((conv_wino4_kernel<false, false, 4>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
-        default: ADM_LAUNCH((conv_wino4_kernel<false, false, 5>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        case 5: ADM_LAUNCH((conv_wino4_kernel<false, false, 5>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        case 6: ADM_LAUNCH((conv_wino4_kernel<false, false, 6>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        case 7: ADM_LAUNCH((conv_wino4_kernel<false, false, 7>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        default: ADM_LAUNCH((conv_wino4_kernel<false, false, 8>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
       }
       return ADM_CHECK_LAUNCH();
     }
