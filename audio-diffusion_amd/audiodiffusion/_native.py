@@ -62,6 +62,7 @@ _SIGS = {
     "adm_add_noise": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                 C.c_int, C.c_int, C.c_long, C.c_void_p]),
     "adm_dequant_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+    "adm_slerp_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adm_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adm_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),

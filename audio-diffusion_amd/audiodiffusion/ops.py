@@ -60,6 +60,18 @@ def dequant_u8(x):
     return out
 
 
+def slerp_grid(x0, x1, alphas):
+    """AudioDiffusionPipeline.slerp for every alpha in one launch pair: (len(alphas),) + x0.shape."""
+    _f32(x0), _f32(x1)
+    assert x0.shape == x1.shape
+    al = torch.as_tensor(list(alphas), dtype=torch.float32).to(x0.device)
+    out = torch.empty((al.numel(),) + tuple(x0.shape), dtype=torch.float32, device=x0.device)
+    scratch = torch.zeros(3, dtype=torch.float64, device=x0.device)
+    N.check(N.lib().adm_slerp_grid(N.ptr(x0.contiguous()), N.ptr(x1.contiguous()), x0.numel(), N.ptr(al), al.numel(), N.ptr(out),
+                                   N.ptr(scratch), N.stream_for(x0)))
+    return out
+
+
 def groupnorm_stats(x1, gamma, beta, groups, eps, x2=None):
     """Returns per-(n,c) (scale, shift) of GroupNorm over the virtual concat (x1|x2)."""
     _f32(x1)

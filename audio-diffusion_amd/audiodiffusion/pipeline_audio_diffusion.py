@@ -207,12 +207,14 @@ class AudioDiffusionPipeline(DiffusionPipeline):
         step_noise=None,
         audio=True,
         return_float=False,
+        init_phase=None,
     ) -> Union[PipelineOutput, Tuple[List[Image.Image], Tuple[int, List[np.ndarray]]]]:
         """Generate random mel spectrogram from audio input and convert to audio (reference docstring `:89-112`).
 
         Extra keyword-only knobs (not in the reference; defaults reproduce it): `step_noise` injects the
         per-step scheduler noise (parity tests), `audio=False` skips the image->audio conversion,
-        `return_float=True` additionally returns the final float images."""
+        `return_float=True` additionally returns the final float images, `init_phase` (B, n_bins, frames) replaces the
+        unseeded Griffin-Lim start phase librosa draws (`mel.py:165-167`)."""
         steps = steps or self.get_default_steps()
         self.scheduler.set_timesteps(steps)
         step_generator = step_generator or generator
@@ -274,7 +276,9 @@ class AudioDiffusionPipeline(DiffusionPipeline):
             else map(lambda _: Image.fromarray(_, mode="RGB").convert("L"), arr)
         )
 
-        audios = list(map(lambda _: self.mel.image_to_audio(_), images)) if audio else []
+        # the reference maps image_to_audio over the images one by one on a host core (:201); here the whole batch goes
+        # through the Mel kernels in one launch sequence
+        audios = list(self.mel.images_to_audios(images, init_phase=init_phase)) if audio else []
         if return_float:
             return images, final_float
         if not return_dict:

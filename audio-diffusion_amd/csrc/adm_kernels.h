@@ -18,6 +18,8 @@ int launch_encode_step(float* x, const float* eps, const adm_sched_coef* table, 
                        hipStream_t st);
 int launch_add_noise(const float* x0, long x0_bstride, const float* noise, const float* sa, const float* sb, int cb,
                      int cn, float* out, int B, int N, long P, hipStream_t st);
+int launch_slerp_grid(const float* x0, const float* x1, long n, const float* alphas_dev, int n_alpha, float* out,
+                      double* scratch3, hipStream_t st);
 int launch_dequant(const float* x, uint8_t* out, long n, hipStream_t st);
 
 // k_groupnorm.hip

@@ -49,6 +49,12 @@ int adm_dequant_u8(const float* x, uint8_t* out, long n, void* stream) {
   return launch_dequant(x, out, n, (hipStream_t)stream);
 }
 
+int adm_slerp_grid(const float* x0, const float* x1, long n, const float* alphas_dev, int n_alpha, float* out,
+                   double* scratch3, void* stream) {
+  ADM_REQUIRE(x0 && x1 && alphas_dev && out && scratch3 && n > 0 && n_alpha > 0, "slerp_grid: bad argument");
+  return launch_slerp_grid(x0, x1, n, alphas_dev, n_alpha, out, scratch3, (hipStream_t)stream);
+}
+
 int adm_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int groups, float eps,
                         const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
   ADM_REQUIRE(x1 && gamma && beta && scale && shift, "groupnorm_stats: null argument");

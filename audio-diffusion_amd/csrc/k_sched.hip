@@ -152,6 +152,49 @@ int launch_add_noise(const float* x0, long x0_bstride, const float* noise, const
   return ADM_CHECK_LAUNCH();
 }
 
+// ---- spherical interpolation grid (pipeline_audio_diffusion.py:244-258, batched over alphas) -------------------------------------
+// theta = acos(<x0, x1> / |x0| / |x1|);  out[a] = sin((1 - alpha_a) theta) x0 / sin(theta) + sin(alpha_a theta) x1 / sin(theta)
+// The three reductions accumulate in fp64 (torch: fp32); the blend repeats torch's float32 operation order exactly: python
+// double scalars are cast to float32, then (s0 * x0) / sin(theta) + (s1 * x1) / sin(theta) with IEEE multiplies / divisions.
+__global__ void __launch_bounds__(256) slerp_reduce_kernel(const float* __restrict__ x0, const float* __restrict__ x1, long n,
+                                                           double* __restrict__ acc3) {
+  __shared__ double red[3][4];
+  double d = 0.0, a = 0.0, b = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const double u = x0[i], v = x1[i];
+    d += u * v; a += u * u; b += v * v;
+  }
+  for (int m = 32; m >= 1; m >>= 1) { d += __shfl_xor(d, m, 64); a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = d; red[1][wave] = a; red[2][wave] = b; }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicAdd(acc3 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ void __launch_bounds__(256) slerp_blend_kernel(const float* __restrict__ x0, const float* __restrict__ x1, long n,
+                                                          const double* __restrict__ acc3, const float* __restrict__ alphas,
+                                                          int n_alpha, float* __restrict__ out) {
+  // torch: dot / norm / norm on float32 0-d tensors, then math.acos of the float32 quotient
+  const float dotf = (float)acc3[0], n0 = (float)sqrt(acc3[1]), n1 = (float)sqrt(acc3[2]);
+  const double theta = acos((double)((dotf / n0) / n1));
+  const float st = (float)sin(theta);
+  const int a = blockIdx.y;
+  const double al = (double)alphas[a];
+  const float s0 = (float)sin((1.0 - al) * theta), s1 = (float)sin(al * theta);
+  float* o = out + (long)a * n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    o[i] = __fadd_rn(__fdiv_rn(__fmul_rn(s0, x0[i]), st), __fdiv_rn(__fmul_rn(s1, x1[i]), st));
+}
+
+int launch_slerp_grid(const float* x0, const float* x1, long n, const float* alphas_dev, int n_alpha, float* out,
+                      double* scratch3, hipStream_t st) {
+  ADM_TRY(dmemset(scratch3, 0, 3 * sizeof(double), st));
+  ADM_LAUNCH(slerp_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x0, x1, n, scratch3);
+  ADM_LAUNCH(slerp_blend_kernel, dim3(ew_grid(n), n_alpha), dim3(256), 0, st, x0, x1, n, (const double*)scratch3, alphas_dev,
+             n_alpha, out);
+  return ADM_CHECK_LAUNCH();
+}
+
 int launch_dequant(const float* x, uint8_t* out, long n, hipStream_t st) {
   ADM_REQUIRE(n % 4 == 0, "dequant: size must be a multiple of 4");
   ADM_LAUNCH(dequant_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, st, x, out, n / 4);

@@ -6,7 +6,8 @@ step, image conversion).  Behaviour the parity tests depend on is kept exactly: 
 tensor (:131), only element [0, 0] receives the noised input when `start_step > 0` (:150) and the mask is built from the
 noise AFTER that write (:157), the mask overwrite indexes `mask[:, step]` (:181-185), the uint8 conversion is numpy's
 round-half-to-even (:194).  Extensions for parity tests only: `step_noise` (per-step noise tensors instead of the
-scheduler's own `randn_tensor` draws), `audio=False` (skip the serial image_to_audio map, :201), `return_float`.
+scheduler's own `randn_tensor` draws), `audio=False` (skip the serial image_to_audio map, :201), `return_float`,
+`init_phase` (Griffin-Lim start phases instead of librosa's unseeded draw).
 """
 from math import acos, sin
 
@@ -69,7 +70,7 @@ class AudioDiffusionPipeline:
     @torch.no_grad()
     def __call__(self, batch_size=1, audio_file=None, raw_audio=None, slice=0, start_step=0, steps=None,
                  generator=None, mask_start_secs=0, mask_end_secs=0, step_generator=None, eta=0, noise=None,
-                 encoding=None, return_dict=True, step_noise=None, audio=True, return_float=False):
+                 encoding=None, return_dict=True, step_noise=None, audio=True, return_float=False, init_phase=None):
         sched = self.scheduler
         sched.set_timesteps(steps or self.get_default_steps())
         step_generator = step_generator or generator
@@ -96,7 +97,8 @@ class AudioDiffusionPipeline:
             images = self.vqvae.decode(1 / LATENT_SCALE * images)["sample"]
         final_float = images
         pil = self._to_pil(images)
-        audios = [self.mel.image_to_audio(im) for im in pil] if audio else []
+        audios = [self.mel.image_to_audio(im, init_phase=None if init_phase is None else np.asarray(init_phase)[i])
+                  for i, im in enumerate(pil)] if audio else []
         if return_float:
             return pil, final_float
         if not return_dict:

@@ -317,6 +317,9 @@ static inline float adm_emu_expf(float x) { return expf(x); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline double rsqrt(double x) { return 1.0 / sqrt(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __fdiv_rn(float a, float b) { return a / b; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }   // volatile: no fma contraction
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
 
 template <class T> static inline T atomicAdd(T* p, T v) {

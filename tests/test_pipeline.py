@@ -83,12 +83,19 @@ def test_from_audio_start_step_and_mask(backend):
     kw = dict(raw_audio=raw, slice=0, start_step=1, steps=4, mask_start_secs=0.05, mask_end_secs=0.03, audio=False,
               return_float=True)
     ri, rf = ref(noise=noise.clone(), **kw)
+    # (1) the conditioning image itself: HIP mel vs numpy mel, the codec's own bar (<= 1 LSB)
+    mine.mel.load_audio(raw_audio=raw)
+    ref.mel.load_audio(raw_audio=raw)
+    cond_mine, cond_ref = mine.mel.audio_slice_to_image(0), ref.mel.audio_slice_to_image(0)
+    assert np.abs(np.asarray(cond_mine).astype(int) - np.asarray(cond_ref).astype(int)).max() <= 1
+    # (2) the procedure on the SAME conditioning image (a pixel of it that quantises differently is a difference of the
+    # codec, measured above, not of the start-step / mask logic): full 1e-3 / 1 LSB bars
+    mine.mel.audio_slice_to_image = lambda slice, _img=cond_ref: _img
     mi, mf = mine(noise=noise.clone().to(dev), **kw)
-    # the two pipelines quantise the conditioning image independently (HIP vs numpy mel): allow a few LSB there
-    assert float((mf.cpu() - rf).abs().max()) <= 2e-2
+    assert float((mf.cpu() - rf).abs().max()) <= 1e-3
     a = np.stack([np.asarray(i).astype(int) for i in mi])
     b = np.stack([np.asarray(i).astype(int) for i in ri])
-    assert np.abs(a - b).max() <= 3
+    assert np.abs(a - b).max() <= 1 and (a == b).mean() >= 0.995
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
