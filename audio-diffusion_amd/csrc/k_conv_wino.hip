@@ -557,9 +557,11 @@ struct Wino3Raw {                     // one chunk's raw activations of this thr
 // ds_read_b64, which is conflict-free as it is) and the raw activations prefetched FOUR chunks ahead instead of two (the
 // registers are free: the kernel's allocation is set by the consumers' accumulators; with two chunks of ~3000 cycles in
 // flight a producer is bound by the loaded HBM latency: measured ~2700 cycles per chunk with the MFMAs removed).
-// ABL (developer aid, timing only — results are wrong): 1 / 7 = this role keeps its barriers but stages nothing; 4 = stage C
+constexpr bool wino_abl_idle(int abl) { return abl == 1 || abl == 7 || abl == 9 || abl == 10 || abl == 11; }
+// ABL (developer aid, timing only — results are wrong): 1 / 7 / 9 / 10 / 11 = this role keeps its barriers but stages nothing; 4 = stage C
 // (window gather + transform + V write) skipped; 5 = stage B (activation + patch write) skipped.
-template <bool UP, bool WIDE1, bool PROF, bool V4 = false, int ABL = 0>
+// ACT: -1 = p.act decides at run time (v3); 0 / 1 = compiled without / with SiLU (v4: one select per element less).
+template <bool UP, bool WIDE1, bool PROF, bool V4 = false, int ABL = 0, int ACT = -1>
 __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV, float* ldsP, int tid, int b0, int bs) {
   unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_start = W3_CLK();
@@ -656,14 +658,25 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
       }
     }
   };
-  const bool act_on = p.act != 0;
+  const bool act_on = ACT < 0 ? p.act != 0 : ACT != 0;
   auto act1 = [&](float x, float sc, float sh, unsigned ok) {   // GroupNorm affine (+ SiLU); zero padding applies after it
+    if (V4) {
+      // the caller has zeroed scale AND shift of an out-of-image item: the affine then gives 0, and SiLU(0) = 0 — no per-element
+      // select (the padded positions read clamped, i.e. real and finite, activations)
+      const float v0 = x * sc + sh;
+      return act_on ? silu_w(v0) : v0;
+    }
     const float v = x * sc + sh;
     const float a = act_on ? silu_w(v) : v;
     return ok ? a : 0.f;
   };
-  auto stage_b = [&](const Wino3Raw& r, int g) {        // raw -> activation -> patch buffer g & 1
+  auto stage_b = [&](const Wino3Raw& r0_, int g) {        // raw -> activation -> patch buffer g & 1
     float* P = ldsP + (g & 1) * W3PSLAB;
+    Wino3Raw r = r0_;
+    if (V4) {                                             // zero padding as a zeroed affine: two selects per ITEM
+      r.sc0 = (r.ok & 1u) ? r.sc0 : 0.f; r.sh0 = (r.ok & 1u) ? r.sh0 : 0.f;
+      r.sc1 = (r.ok & 2u) ? r.sc1 : 0.f; r.sh1 = (r.ok & 2u) ? r.sh1 : 0.f;
+    }
     if (UP) {
       P[it_pofs[0]] = act1(r.a.x, r.sc0, r.sh0, r.ok & 1u);
       P[it_pofs[1]] = act1(r.b.x, r.sc1, r.sh1, r.ok & 2u);
@@ -712,30 +725,30 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
   if constexpr (V4) {          // same schedule with the global loads of g + 5 in flight: four raw-chunk register sets
     Wino3Raw r2, r3;
     r2.b = r0.b; r3.b = r0.b; r2.a = r0.b; r3.a = r0.b; r2.h = 0.f; r3.h = 0.f;
-    if (ABL != 1 && ABL != 7) stage_a(r0); if (ABL != 1 && ABL != 7) stage_a(r1); if (ABL != 1 && ABL != 7) stage_a(r2); if (ABL != 1 && ABL != 7) stage_a(r3);      // chunks 0..3
-    if (ABL != 1 && ABL != 7 && ABL != 5) stage_b(r0, 0);
-    if (ABL != 1 && ABL != 7) stage_a(r0);                                             // chunk 4
+    if (!wino_abl_idle(ABL)) stage_a(r0); if (!wino_abl_idle(ABL)) stage_a(r1); if (!wino_abl_idle(ABL)) stage_a(r2); if (!wino_abl_idle(ABL)) stage_a(r3);      // chunks 0..3
+    if (!wino_abl_idle(ABL) && ABL != 5) stage_b(r0, 0);
+    if (!wino_abl_idle(ABL)) stage_a(r0);                                             // chunk 4
     ADM_BARRIER_KEEP_VMEM(63);
     if (PROF) tq = W3_CLK();
     for (int g = 0; g < total; g += 4) {                     // total is a multiple of 4 (nch is)
-      if (ABL != 1 && ABL != 7 && ABL != 4) stage_c(g);                W3_LAP(3);
-      if (ABL != 1 && ABL != 7 && ABL != 5) stage_b(r1, g + 1);        W3_LAP(4);
-      if (ABL != 1 && ABL != 7) stage_a(r1);               W3_LAP(5);   // chunk g + 5
+      if (!wino_abl_idle(ABL) && ABL != 4) stage_c(g);                W3_LAP(3);
+      if (!wino_abl_idle(ABL) && ABL != 5) stage_b(r1, g + 1);        W3_LAP(4);
+      if (!wino_abl_idle(ABL)) stage_a(r1);               W3_LAP(5);   // chunk g + 5
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
-      if (ABL != 1 && ABL != 7 && ABL != 4) stage_c(g + 1);            W3_LAP(3);
-      if (ABL != 1 && ABL != 7 && ABL != 5) stage_b(r2, g + 2);        W3_LAP(4);
-      if (ABL != 1 && ABL != 7) stage_a(r2);               W3_LAP(5);   // chunk g + 6
+      if (!wino_abl_idle(ABL) && ABL != 4) stage_c(g + 1);            W3_LAP(3);
+      if (!wino_abl_idle(ABL) && ABL != 5) stage_b(r2, g + 2);        W3_LAP(4);
+      if (!wino_abl_idle(ABL)) stage_a(r2);               W3_LAP(5);   // chunk g + 6
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
-      if (ABL != 1 && ABL != 7 && ABL != 4) stage_c(g + 2);            W3_LAP(3);
-      if (ABL != 1 && ABL != 7 && ABL != 5) stage_b(r3, g + 3);        W3_LAP(4);
-      if (ABL != 1 && ABL != 7) stage_a(r3);               W3_LAP(5);   // chunk g + 7
+      if (!wino_abl_idle(ABL) && ABL != 4) stage_c(g + 2);            W3_LAP(3);
+      if (!wino_abl_idle(ABL) && ABL != 5) stage_b(r3, g + 3);        W3_LAP(4);
+      if (!wino_abl_idle(ABL)) stage_a(r3);               W3_LAP(5);   // chunk g + 7
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
-      if (ABL != 1 && ABL != 7 && ABL != 4) stage_c(g + 3);            W3_LAP(3);
-      if (ABL != 1 && ABL != 7 && ABL != 5) stage_b(r0, g + 4);        W3_LAP(4);
-      if (ABL != 1 && ABL != 7) stage_a(r0);               W3_LAP(5);   // chunk g + 8
+      if (!wino_abl_idle(ABL) && ABL != 4) stage_c(g + 3);            W3_LAP(3);
+      if (!wino_abl_idle(ABL) && ABL != 5) stage_b(r0, g + 4);        W3_LAP(4);
+      if (!wino_abl_idle(ABL)) stage_a(r0);               W3_LAP(5);   // chunk g + 8
       W3_BARRIER(63, pr, 1, 2);
       if (PROF) tq = W3_CLK();
     }
@@ -951,7 +964,8 @@ __global__ void __launch_bounds__(512, 2) conv_wino3_kernel(const WinoParams p) 
 constexpr int W4LDS = 2 * W3VSLAB + 2 * W3PSLAB;
 constexpr int W4ABLK = 4 * 2 * 64 * 4;      // floats of one (chunk, 16-cout block) filter image: 8 KiB
 
-// ABL (developer aid, timing only): 2 = the MFMAs are replaced by a register dependency (operands still fetched); 6 = barriers
+// ABL (developer aid, timing only): 9 / 10 / 11 = producers idle and no filter loads / no LDS operand reads / no per-chunk barrier;
+// 2 = the MFMAs are replaced by a register dependency (operands still fetched); 6 = barriers
 // only (the producers' own pace); 7 = bare MFMA stream (no operand fetch; with idle producers: the matrix pipe's own pace).
 template <bool PROF, int ABL = 0>
 __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float* ldsV, int tid, int wave, int b0, int bs) {
@@ -1043,15 +1057,17 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
             acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].y, acc[xi][1], 0, 0, 0);
           }
         }
-        if (e == 3) {                      // group q consumed: its registers take the NEXT chunk's words
+        if (e == 3 && ABL != 9) {          // group q consumed: its registers take the NEXT chunk's words
           if (q == 0) W4_LOAD_A(0);
           if (q == 1) W4_LOAD_A(1);
           if (q == 2) W4_LOAD_A(2);
           if (q == 3) { W4_LOAD_A(3); advance_a(); }
         }
-        if (xi == 12) W3_BARRIER(63, pr, 1, 2);   // barrier g: every read of V(g) has landed, V(g + 1) is complete
-        if (xi < 12) read_group(s, g, xi + 4);
-        else if (more) read_group(s, g + 1, xi - 12);
+        if (xi == 12 && ABL != 11) W3_BARRIER(63, pr, 1, 2);   // barrier g: every read of V(g) has landed, V(g + 1) is complete
+        if (ABL != 10) {
+          if (xi < 12) read_group(s, g, xi + 4);
+          else if (more) read_group(s, g + 1, xi - 12);
+        }
         ADM_SCHED_FENCE();
       }
     }
@@ -1102,7 +1118,7 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   }
 }
 
-template <bool UP, bool PROF, int ABL = 0>
+template <bool UP, bool PROF, int ABL = 0, int ACT = -1>
 __global__ void __launch_bounds__(512) conv_wino4_kernel(const WinoParams p) {
   ADM_DYN_SMEM(float, smem);
   float* ldsV = smem;
@@ -1113,8 +1129,8 @@ __global__ void __launch_bounds__(512) conv_wino4_kernel(const WinoParams p) {
 #if !defined(ADM_EMU)
     if (ABL != 3) __builtin_amdgcn_s_setprio(1);         // see conv_wino3_kernel (ABL 3: timing without it)
 #endif
-    if (!UP && wave == 4) wino3_producer<UP, true, PROF, true, ABL>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
-    else wino3_producer<UP, false, PROF, true, ABL>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
+    if (!UP && wave == 4) wino3_producer<UP, true, PROF, true, ABL, ACT>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
+    else wino3_producer<UP, false, PROF, true, ABL, ACT>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
   }
   else wino4_consumer<PROF, ABL>(p, ldsV, tid, wave, (int)blockIdx.x, (int)gridDim.x);
 }
@@ -1316,14 +1332,23 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
         case 5: ADM_LAUNCH((conv_wino4_kernel<false, false, 5>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         case 6: ADM_LAUNCH((conv_wino4_kernel<false, false, 6>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         case 7: ADM_LAUNCH((conv_wino4_kernel<false, false, 7>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
-        default: ADM_LAUNCH((conv_wino4_kernel<false, false, 8>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        case 8: ADM_LAUNCH((conv_wino4_kernel<false, false, 8>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        case 9: ADM_LAUNCH((conv_wino4_kernel<false, false, 9>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        case 10: ADM_LAUNCH((conv_wino4_kernel<false, false, 10>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        default: ADM_LAUNCH((conv_wino4_kernel<false, false, 11>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
       }
       return ADM_CHECK_LAUNCH();
     }
 #endif
     if (v4) {
-      if (a.up) ADM_LAUNCH((conv_wino4_kernel<true, false>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p);
-      else ADM_LAUNCH((conv_wino4_kernel<false, false>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p);
+      const size_t need4 = sizeof(float) * W4LDS;
+      if (a.up) {
+        if (a.act) ADM_LAUNCH((conv_wino4_kernel<true, false, 0, 1>), dim3(grid), dim3(512), need4, st, p);
+        else ADM_LAUNCH((conv_wino4_kernel<true, false, 0, 0>), dim3(grid), dim3(512), need4, st, p);
+      } else {
+        if (a.act) ADM_LAUNCH((conv_wino4_kernel<false, false, 0, 1>), dim3(grid), dim3(512), need4, st, p);
+        else ADM_LAUNCH((conv_wino4_kernel<false, false, 0, 0>), dim3(grid), dim3(512), need4, st, p);
+      }
       return ADM_CHECK_LAUNCH();
     }
     if (a.up) ADM_LAUNCH((conv_wino3_kernel<true, false>), dim3(grid), dim3(512), need3, st, p);

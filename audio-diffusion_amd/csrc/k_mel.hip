@@ -15,6 +15,7 @@
 // FFT: radix-2 in LDS (2048 complex fp64 = 32 KiB), one frame per workgroup, twiddles from an L2-resident table.
 // All spectral arrays are laid out [b][frame][bin] so a workgroup's bins are contiguous (coalesced).
 // Algorithmic bytes: forward 4 B/sample in + 1 B/pixel out; inverse 1 B/pixel in + 4 B/sample out.
+#include <cstdlib>
 #include <vector>
 
 #include "adm_kernels.h"
@@ -114,6 +115,181 @@ __global__ void __launch_bounds__(256) mel_stft_power_kernel(const T* __restrict
     for (int i = 0; i < c; ++i)
       acc += (sizeof(T) == 4 ? (double)fb_w32[o + i] : fb_w64[o + i]) * (double)pw[s + i];
     melspec[((long)b * n_mels + m) * n_frames + frame] = (T)acc;
+  }
+}
+
+// =====================================================================================================================
+// n_fft = 2048 fast path (the configuration of every published audio-diffusion model): one WAVE per frame.
+//   * real-input trick: the 2048 windowed samples are packed as 1024 complex points z[n] = x[2n] + i x[2n+1]; one 1024-point
+//     complex FFT and an untangling pass give bins 0..1024 — half the arithmetic of the complex FFT the generic kernel runs;
+//   * 1024 = 16 x 16 x 4: every lane keeps 16 points in registers and runs two radix-16 passes (each two radix-4 levels,
+//     fully unrolled) and one radix-4 pass, with THREE trips through LDS instead of eleven;
+//   * twiddles are built in registers from one table entry per lane and pass (w, w^2, w^4, w^8 by squaring, the rest by
+//     one product each: <= 4 roundings deep) instead of 15 table gathers per pass;
+//   * a frame belongs to one wave, so nothing in the transform needs a workgroup barrier (LDS executes a wave's operations
+//     in order); LDS rows are pitched 65 complex (1040 B) so that all three exchange patterns are conflict-free;
+//   * a workgroup (4 waves) handles 8 consecutive frames and stores their mel columns as 32-byte row segments.
+// Numerics: fp64 throughout, rounded to float32 exactly where librosa stores into complex64 (as the generic kernel).
+#if defined(ADM_EMU)
+#define ADM_WAVE_SYNC() __syncthreads()      // fibers switch only at collectives: make the cross-lane LDS hand-over visible
+#else
+#define ADM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+constexpr int MF_PITCH = 65;                 // complex elements per LDS row (16 rows)
+constexpr int MF_FRAMES = 8;                 // frames per workgroup (2 per wave)
+
+__device__ __forceinline__ double2 c_mul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 c_add(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 c_sub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 c_mul_mi(double2 a) { return make_double2(a.y, -a.x); }       // a * (-i)
+
+// forward radix-4 butterfly: X[k] = sum_n a[n] (-i)^(n k)
+__device__ __forceinline__ void radix4(double2& a0, double2& a1, double2& a2, double2& a3) {
+  const double2 t0 = c_add(a0, a2), t1 = c_sub(a0, a2), t2 = c_add(a1, a3), t3 = c_mul_mi(c_sub(a1, a3));
+  a0 = c_add(t0, t2); a1 = c_add(t1, t3); a2 = c_sub(t0, t2); a3 = c_sub(t1, t3);
+}
+
+// forward 16-point DFT in registers: v[n] -> v[k] (natural order in and out). n = 4 p + r, k = ka + 4 kb.
+__device__ __forceinline__ void dft16(double2 (&v)[16]) {
+  const double C1 = 0.92387953251128673848, S1 = 0.38268343236508978178, H = 0.70710678118654752440;
+  // W16^m = exp(-2 pi i m / 16)
+  const double2 W1 = make_double2(C1, -S1), W2 = make_double2(H, -H), W3 = make_double2(S1, -C1), W6 = make_double2(-H, -H),
+                W9 = make_double2(-C1, S1);
+  double2 a[4][4];                       // a[ka][r] after the first level
+  ADM_UNROLL
+  for (int r = 0; r < 4; ++r) {
+    double2 x0 = v[r], x1 = v[4 + r], x2 = v[8 + r], x3 = v[12 + r];
+    radix4(x0, x1, x2, x3);
+    a[0][r] = x0; a[1][r] = x1; a[2][r] = x2; a[3][r] = x3;
+  }
+  a[1][1] = c_mul(a[1][1], W1); a[1][2] = c_mul(a[1][2], W2); a[1][3] = c_mul(a[1][3], W3);
+  a[2][1] = c_mul(a[2][1], W2); a[2][2] = c_mul_mi(a[2][2]);   a[2][3] = c_mul(a[2][3], W6);
+  a[3][1] = c_mul(a[3][1], W3); a[3][2] = c_mul(a[3][2], W6); a[3][3] = c_mul(a[3][3], W9);
+  ADM_UNROLL
+  for (int ka = 0; ka < 4; ++ka) {
+    radix4(a[ka][0], a[ka][1], a[ka][2], a[ka][3]);
+    v[ka] = a[ka][0]; v[ka + 4] = a[ka][1]; v[ka + 8] = a[ka][2]; v[ka + 12] = a[ka][3];
+  }
+}
+
+// v[j] *= w^j, j = 1..15, with the powers of w built by squaring (depth <= 4 products)
+__device__ __forceinline__ void twiddle16(double2 (&v)[16], double2 w) {
+  const double2 w2 = c_mul(w, w), w4 = c_mul(w2, w2), w8 = c_mul(w4, w4);
+  const double2 w3 = c_mul(w2, w), w5 = c_mul(w4, w), w6 = c_mul(w4, w2), w7 = c_mul(w4, w3);
+  v[1] = c_mul(v[1], w); v[2] = c_mul(v[2], w2); v[3] = c_mul(v[3], w3); v[4] = c_mul(v[4], w4);
+  v[5] = c_mul(v[5], w5); v[6] = c_mul(v[6], w6); v[7] = c_mul(v[7], w7); v[8] = c_mul(v[8], w8);
+  v[9] = c_mul(v[9], c_mul(w8, w)); v[10] = c_mul(v[10], c_mul(w8, w2)); v[11] = c_mul(v[11], c_mul(w8, w3));
+  v[12] = c_mul(v[12], c_mul(w8, w4)); v[13] = c_mul(v[13], c_mul(w8, w5)); v[14] = c_mul(v[14], c_mul(w8, w6));
+  v[15] = c_mul(v[15], c_mul(w8, w7));
+}
+
+// 1024-point forward complex FFT of one wave's frame. In: lane l holds z[64 n1 + l] in v[n1]. Out: lane t holds
+// Z[t + 64 c] in v[c]. buf: this wave's 16 x MF_PITCH complex LDS rows; tw[q] = exp(-2 pi i q / 2048), q < 1024.
+__device__ __forceinline__ void fft1024_wave(double2 (&v)[16], double2* buf, const double2* __restrict__ tw, int lane) {
+  dft16(v);                                              // over n1 -> A[k1]
+  twiddle16(v, tw[2 * lane]);                            // A[k1] *= W1024^(l k1)
+  ADM_UNROLL
+  for (int k1 = 0; k1 < 16; ++k1) buf[k1 * MF_PITCH + lane] = v[k1];
+  ADM_WAVE_SYNC();
+  const int k1 = lane & 15, m2 = lane >> 4;
+  ADM_UNROLL
+  for (int m1 = 0; m1 < 16; ++m1) v[m1] = buf[k1 * MF_PITCH + 4 * m1 + m2];
+  ADM_WAVE_SYNC();
+  dft16(v);                                              // over m1 -> B[j1]
+  twiddle16(v, tw[32 * m2]);                             // B[j1] *= W64^(m2 j1)
+  ADM_UNROLL
+  for (int j1 = 0; j1 < 16; ++j1) buf[k1 * MF_PITCH + 4 * j1 + m2] = v[j1];
+  ADM_WAVE_SYNC();
+  ADM_UNROLL
+  for (int i = 0; i < 4; ++i) {                          // radix 4 over m2: (k1, j1 = (lane >> 4) + 4 i) -> j2 = 0..3
+    const double2* src = buf + k1 * MF_PITCH + 4 * ((lane >> 4) + 4 * i);
+    double2 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
+    radix4(c0, c1, c2, c3);
+    v[i] = c0; v[i + 4] = c1; v[i + 8] = c2; v[i + 12] = c3;        // Z[lane + 64 (i + 4 j2)]
+  }
+  ADM_WAVE_SYNC();
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) mel_stft2048_kernel(const T* __restrict__ audio, long slice_stride, int n_samples,
+                                                          int hop, const double* __restrict__ window,
+                                                          const double2* __restrict__ tw,
+                                                          const int* __restrict__ fb_start, const int* __restrict__ fb_count,
+                                                          const int* __restrict__ fb_off, const float* __restrict__ fb_w32,
+                                                          const double* __restrict__ fb_w64, int n_mels, int n_frames,
+                                                          T* __restrict__ melspec) {
+  ADM_DYN_SMEM(double2, sm);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double2* buf = sm + wave * 16 * MF_PITCH;
+  T* stage = reinterpret_cast<T*>(sm + 4 * 16 * MF_PITCH);         // [n_mels][MF_FRAMES]
+  const int b = blockIdx.y, f0 = blockIdx.x * MF_FRAMES;
+  const T* y = audio + (long)b * slice_stride;
+#pragma unroll 1
+  for (int fi = 0; fi < MF_FRAMES / 4; ++fi) {
+    const int slot = wave + 4 * fi, frame = f0 + slot;            // beyond n_frames: computed on zeros, never stored
+    double2 v[16];
+    ADM_UNROLL
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int n = 64 * n1 + lane;
+      const long src = (long)frame * hop + 2 * n - 1024;            // center=True, pad_mode="constant"
+      const bool live = frame < n_frames;
+      const double a0 = (live && src >= 0 && src < n_samples) ? (double)y[src] : 0.0;
+      const double a1 = (live && src + 1 >= 0 && src + 1 < n_samples) ? (double)y[src + 1] : 0.0;
+      const double2 w = *reinterpret_cast<const double2*>(window + 2 * n);
+      v[n1] = make_double2(w.x * a0, w.y * a1);
+    }
+    fft1024_wave(v, buf, tw, lane);
+    // untangle: X[k] = E + (-i) W2048^k O, E = (Z[k] + conj Z[1024-k]) / 2, O = (Z[k] - conj Z[1024-k]) / 2
+    ADM_UNROLL
+    for (int c = 0; c < 16; ++c) buf[lane + 64 * c] = v[c];
+    ADM_WAVE_SYNC();
+    // every partner Z[1024 - k] is read and consumed on the spot; only the 16 power values stay in registers until all
+    // lanes have finished reading, then they overwrite the (dead) exchange rows as bins 0..1024
+    T pv[16];
+    double2 wk = tw[lane];                                          // W2048^(lane + 64 c), advanced by W32 per c
+    const double2 w32 = tw[64];
+    ADM_UNROLL
+    for (int c = 0; c < 16; ++c) {
+      const double2 zq = buf[(1024 - (lane + 64 * c)) & 1023];
+      const double2 zk = v[c], zc = make_double2(zq.x, -zq.y);
+      const double2 e = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+      const double2 o = make_double2(0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y));
+      const double2 x = c_add(e, c_mul_mi(c_mul(wk, o)));
+      if (sizeof(T) == 4) {
+        const float a = hypotf((float)x.x, (float)x.y);              // complex64 store, np.abs -> float32
+        pv[c] = (T)(a * a);
+      } else {
+        const double a = hypot(x.x, x.y);
+        pv[c] = (T)(a * a);
+      }
+      wk = c_mul(wk, w32);
+    }
+    const double xn = v[0].x - v[0].y;                               // lane 0: X[1024] = Re Z[0] - Im Z[0] (real)
+    ADM_WAVE_SYNC();
+    T* pw = reinterpret_cast<T*>(buf);
+    ADM_UNROLL
+    for (int c = 0; c < 16; ++c) pw[lane + 64 * c] = pv[c];
+    if (lane == 0) {
+      if (sizeof(T) == 4) { const float a = fabsf((float)xn); pw[1024] = (T)(a * a); }
+      else { const double a = fabs(xn); pw[1024] = (T)(a * a); }
+    }
+    ADM_WAVE_SYNC();
+    for (int m = lane; m < n_mels; m += 64) {
+      const int s = fb_start[m], cnt = fb_count[m], o = fb_off[m];
+      double acc = 0.0;
+      for (int i = 0; i < cnt; ++i)
+        acc += (sizeof(T) == 4 ? (double)fb_w32[o + i] : fb_w64[o + i]) * (double)pw[s + i];
+      stage[m * MF_FRAMES + slot] = (T)acc;
+    }
+    ADM_WAVE_SYNC();
+  }
+  __syncthreads();
+  // [n_mels][MF_FRAMES] -> melspec[b][m][f0 .. f0 + 8): one row segment per thread pass
+  for (int e = tid; e < n_mels * MF_FRAMES; e += blockDim.x) {
+    const int m = e / MF_FRAMES, s = e % MF_FRAMES;
+    if (f0 + s < n_frames) melspec[((long)b * n_mels + m) * n_frames + f0 + s] = stage[e];
   }
 }
 
@@ -533,6 +709,29 @@ int adm_mel_forward_power(adm_mel_t* h, const void* audio, int is_f64, int B, lo
   const int n_frames = 1 + n_samples / c.hop_length;
   dim3 grid(n_frames, B);
   const size_t smem = fft_smem(h);
+  static const int fast = [] { const char* e = getenv("ADM_MEL_FAST"); return e ? atoi(e) : 1; }();
+  if (c.n_fft == 2048 && fast) {             // one wave per frame, real-input radix-16 FFT (mel_stft2048_kernel)
+    dim3 g2(ceil_div(n_frames, MF_FRAMES), B);
+    const size_t sm2 = sizeof(double2) * 4 * 16 * MF_PITCH + (is_f64 ? 8 : 4) * (size_t)h->n_mels * MF_FRAMES;
+    ADM_REQUIRE(sm2 <= 96 * 1024, "mel_forward: too many mel bands for the fast path staging buffer");
+#if !defined(ADM_EMU)
+    static bool once = [] {
+      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      return true;
+    }();
+    (void)once;
+#endif
+    if (is_f64)
+      ADM_LAUNCH((mel_stft2048_kernel<double>), g2, dim3(256), sm2, st, (const double*)audio, slice_stride, n_samples,
+                 c.hop_length, h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count, h->fb_off, h->fb_w32,
+                 h->fb_w64, h->n_mels, n_frames, (double*)melspec_out);
+    else
+      ADM_LAUNCH((mel_stft2048_kernel<float>), g2, dim3(256), sm2, st, (const float*)audio, slice_stride, n_samples,
+                 c.hop_length, h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count, h->fb_off, h->fb_w32,
+                 h->fb_w64, h->n_mels, n_frames, (float*)melspec_out);
+    return ADM_CHECK_LAUNCH();
+  }
   if (is_f64) {
     ADM_LAUNCH((mel_stft_power_kernel<double>), grid, dim3(256), smem, st, (const double*)audio, slice_stride, n_samples,
                c.n_fft, h->log2n, c.hop_length, h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count,
