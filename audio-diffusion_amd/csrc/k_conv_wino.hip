@@ -1005,8 +1005,16 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   ADM_BARRIER_KEEP_VMEM(63);               // barrier "-1": V(0) complete
 
   f32x4 acc[16][2];
-  float2 rb[4][2];                         // rolling B window: 4 Winograd points ahead
+  float2 rb[4][2];                         // rolling B window: 4 Winograd points ahead, running across tile boundaries
+  auto read_group = [&](int slot, int gg, int xi) {
+    const float* V = ldsV + (gg & 1) * W3VSLAB + vlane;
+    rb[slot][0] = *reinterpret_cast<const float2*>(V + (xi * WCK) * 32);
+    rb[slot][1] = *reinterpret_cast<const float2*>(V + (xi * WCK + 4) * 32);
+  };
+  ADM_UNROLL
+  for (int xi = 0; xi < 4; ++xi) read_group(xi, 0, xi);
   int g = 0;                               // running chunk index
+  const long planeO = (long)p.Ho * p.Wo;
   for (int v = b0; v < p.nblk; v += bs) {
     const Wino3Tile t = wino3_tile(p, v);
     ADM_UNROLL
@@ -1015,34 +1023,37 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
       for (int c = 0; c < 2; ++c)
         ADM_UNROLL
         for (int r = 0; r < 4; ++r) acc[xi][c][r] = 0.f;
-    float cb[4];                            // epilogue constants of this lane's 4 couts
-    ADM_UNROLL
-    for (int r = 0; r < 4; ++r) {
-      const int co = t.m0 + 16 * wave + 4 * k4 + r;
-      cb[r] = p.bias[co] + p.chan_add[(long)t.n * p.chan_add_stride + co];
-    }
-    auto read_group = [&](int slot, int gg, int xi) {
-      const float* V = ldsV + (gg & 1) * W3VSLAB + vlane;
-      rb[slot][0] = *reinterpret_cast<const float2*>(V + (xi * WCK) * 32);
-      rb[slot][1] = *reinterpret_cast<const float2*>(V + (xi * WCK + 4) * 32);
-    };
-    ADM_UNROLL
-    for (int xi = 0; xi < 4; ++xi) read_group(xi, g, xi);
+    const int oy = t.ty * 8 + 2 * (li >> 2), ox = t.tx * 16 + 4 * (li & 3);
+    const long obase = ((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4) * planeO + (long)oy * p.Wo + ox;   // cout row r: + r * planeO
+    // Bias, per-sample term and residual enter in the WINOGRAD domain: Y = A^T M A has Y00 / Y01 / Y10 / Y11 depend on the corner
+    // entries M00 / M03 / M30 / M33 alone with weights +1 / -1 / -1 / +1, so adding (b + res) there is adding it to the output.
+    // One cout row per chunk over the first four chunks: the loads are issued when the chunk starts and consumed when it ends
+    // — a whole chunk of latency cover for 10 registers — and the epilogue is left with arithmetic and stores only.
+    f32x4 fr0 = {0.f, 0.f, 0.f, 0.f}, fr1 = fr0;
+    float fb0 = 0.f, fb1 = 0.f;
     for (int ci = 0; ci < nch; ++ci, ++g) {
-      const bool more = ci + 1 < nch;      // the rolling window does not cross into the next tile
       if (ABL == 6 || ABL == 7 || ABL == 8) {       // 8 = bare MFMA stream beside WORKING producers
         ADM_UNROLL
         for (int xi = 0; xi < 16; ++xi) {
           if (ABL != 6) {
             ADM_UNROLL
             for (int ks = 0; ks < 2; ++ks) {
-              acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[ks], cb[ks + 2], acc[xi][0], 0, 0, 0);
-              acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[ks + 2], cb[ks], acc[xi][1], 0, 0, 0);
+              acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb0, fb1, acc[xi][0], 0, 0, 0);
+              acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb1, fb0, acc[xi][1], 0, 0, 0);
             }
           }
           if (xi == 12) W3_BARRIER(63, pr, 1, 2);
         }
         continue;
+      }
+      if (ci < 4) {                        // wave-uniform: this chunk carries cout row r = ci of the fold
+        const int co = t.m0 + 16 * wave + 4 * k4 + ci;
+        fb0 = p.bias[co];
+        fb1 = p.chan_add[(long)t.n * p.chan_add_stride + co];
+        if (p.residual != nullptr) {
+          fr0 = *reinterpret_cast<const f32x4*>(p.residual + obase + ci * planeO);
+          fr1 = *reinterpret_cast<const f32x4*>(p.residual + obase + ci * planeO + p.Wo);
+        }
       }
       ADM_UNROLL
       for (int xi = 0; xi < 16; ++xi) {
@@ -1066,28 +1077,28 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
         if (xi == 12 && ABL != 11) W3_BARRIER(63, pr, 1, 2);   // barrier g: every read of V(g) has landed, V(g + 1) is complete
         if (ABL != 10) {
           if (xi < 12) read_group(s, g, xi + 4);
-          else if (more) read_group(s, g + 1, xi - 12);
+          else read_group(s, g + 1, xi - 12);   // next chunk — of this tile or the next one (past the end: stale words, unused)
         }
         ADM_SCHED_FENCE();
+      }
+      if (ci < 4) {
+        const float bsum = fb0 + fb1;
+#define W4_FOLD(R)                                                                                         \
+  do {                                                                                                     \
+    acc[0][0][R] += bsum + fr0[0];  acc[0][1][R] += bsum + fr0[2];                                          \
+    acc[3][0][R] -= bsum + fr0[1];  acc[3][1][R] -= bsum + fr0[3];                                          \
+    acc[12][0][R] -= bsum + fr1[0]; acc[12][1][R] -= bsum + fr1[2];                                         \
+    acc[15][0][R] += bsum + fr1[1]; acc[15][1][R] += bsum + fr1[3];                                         \
+  } while (0)
+        if (ci == 0) W4_FOLD(0);
+        else if (ci == 1) W4_FOLD(1);
+        else if (ci == 2) W4_FOLD(2);
+        else W4_FOLD(3);
+#undef W4_FOLD
       }
     }
     // ---- lane-local inverse transform Y = A^T M A: lane holds couts 4 k4 + r and tiles 2 li (c = 0), 2 li + 1 (c = 1) ----------
     const unsigned long long t_epi = W3_CLK();
-    const int oy = t.ty * 8 + 2 * (li >> 2), ox = t.tx * 16 + 4 * (li & 3);
-    const long planeO = (long)p.Ho * p.Wo;
-    f32x4 res[4][2];
-    if (p.residual != nullptr) {
-      ADM_UNROLL
-      for (int r = 0; r < 4; ++r) {
-        const int co = t.m0 + 16 * wave + 4 * k4 + r;
-        const long o = ((long)t.n * p.Cout + co) * planeO + (long)oy * p.Wo + ox;
-        res[r][0] = *reinterpret_cast<const f32x4*>(p.residual + o);
-        res[r][1] = *reinterpret_cast<const f32x4*>(p.residual + o + p.Wo);
-      }
-    } else {
-      ADM_UNROLL
-      for (int r = 0; r < 4; ++r) { res[r][0] = f32x4{0.f, 0.f, 0.f, 0.f}; res[r][1] = res[r][0]; }
-    }
     ADM_UNROLL
     for (int r = 0; r < 4; ++r) {
       f32x4 y0, y1;
@@ -1099,15 +1110,13 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
           t0[j] = acc[0 * 4 + j][c][r] + acc[1 * 4 + j][c][r] + acc[2 * 4 + j][c][r];
           t1[j] = acc[1 * 4 + j][c][r] - acc[2 * 4 + j][c][r] - acc[3 * 4 + j][c][r];
         }
-        y0[2 * c] = t0[0] + t0[1] + t0[2] + cb[r] + res[r][0][2 * c];
-        y0[2 * c + 1] = t0[1] - t0[2] - t0[3] + cb[r] + res[r][0][2 * c + 1];
-        y1[2 * c] = t1[0] + t1[1] + t1[2] + cb[r] + res[r][1][2 * c];
-        y1[2 * c + 1] = t1[1] - t1[2] - t1[3] + cb[r] + res[r][1][2 * c + 1];
+        y0[2 * c] = t0[0] + t0[1] + t0[2];
+        y0[2 * c + 1] = t0[1] - t0[2] - t0[3];
+        y1[2 * c] = t1[0] + t1[1] + t1[2];
+        y1[2 * c + 1] = t1[1] - t1[2] - t1[3];
       }
-      const int co = t.m0 + 16 * wave + 4 * k4 + r;
-      const long o = ((long)t.n * p.Cout + co) * planeO + (long)oy * p.Wo + ox;
-      *reinterpret_cast<f32x4*>(p.out + o) = y0;
-      *reinterpret_cast<f32x4*>(p.out + o + p.Wo) = y1;
+      *reinterpret_cast<f32x4*>(p.out + obase + r * planeO) = y0;
+      *reinterpret_cast<f32x4*>(p.out + obase + r * planeO + p.Wo) = y1;
     }
     if (PROF) pr[3] += W3_CLK() - t_epi;
   }

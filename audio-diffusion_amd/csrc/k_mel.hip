@@ -28,8 +28,9 @@ struct adm_mel {
   int *fb_start = nullptr, *fb_count = nullptr, *fb_off = nullptr, *fbt_off = nullptr, *fbt_idx = nullptr;
   std::vector<void*> owned;
   // scratch (grown on demand)
-  size_t cap_fwd = 0, cap_inv = 0;
+  size_t cap_fwd = 0, cap_inv = 0, cap_max = 0;
   void* melspec = nullptr;
+  unsigned long long* spec_max = nullptr;   // per-spectrogram maximum (fast forward path)
   double *angles = nullptr, *mag = nullptr, *ytmp = nullptr, *Smel = nullptr, *Xpow = nullptr, *diff = nullptr;
   float *reb0 = nullptr, *reb1 = nullptr, *y = nullptr;
   float* pgmax = nullptr;      // [0] max |projected gradient| of the returned point, [1] of the start point
@@ -212,18 +213,31 @@ __device__ __forceinline__ void fft1024_wave(double2 (&v)[16], double2* buf, con
   ADM_WAVE_SYNC();
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256, 2) mel_stft2048_kernel(const T* __restrict__ audio, long slice_stride, int n_samples,
+// MINW = waves per SIMD the register allocation is held to: 1 = ~390 registers, no spills, one workgroup per CU;
+// 2 = 256 registers (some spills to scratch), two workgroups per CU. ADM_MEL_OCC selects (measured on the MI355X).
+template <typename T, int MINW>
+__global__ void __launch_bounds__(256, MINW) mel_stft2048_kernel(const T* __restrict__ audio, long slice_stride, int n_samples,
                                                           int hop, const double* __restrict__ window,
                                                           const double2* __restrict__ tw,
                                                           const int* __restrict__ fb_start, const int* __restrict__ fb_count,
                                                           const int* __restrict__ fb_off, const float* __restrict__ fb_w32,
                                                           const double* __restrict__ fb_w64, int n_mels, int n_frames,
-                                                          T* __restrict__ melspec) {
+                                                          T* __restrict__ melspec, unsigned long long* __restrict__ spec_max) {
+  // spec_max (nullptr ok): per-spectrogram maximum for power_to_db(ref=np.max), as the bit pattern of the non-negative
+  // double (order-preserving), so that the dB pass needs no reduction of its own
   ADM_DYN_SMEM(double2, sm);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double2* buf = sm + wave * 16 * MF_PITCH;
   T* stage = reinterpret_cast<T*>(sm + 4 * 16 * MF_PITCH);         // [n_mels][MF_FRAMES]
+  // the filterbank, staged once per workgroup: taps as (first bin, count, offset) per filter + the weights in T
+  int* f_start = reinterpret_cast<int*>(stage + n_mels * MF_FRAMES);
+  int* f_count = f_start + n_mels;
+  int* f_off = f_count + n_mels;
+  T* f_w = reinterpret_cast<T*>(f_off + n_mels + (n_mels & 1));     // keeps 8-byte alignment for T = double
+  const int nnz = fb_off[n_mels];
+  for (int m = tid; m < n_mels; m += blockDim.x) { f_start[m] = fb_start[m]; f_count[m] = fb_count[m]; f_off[m] = fb_off[m]; }
+  for (int i = tid; i < nnz; i += blockDim.x) f_w[i] = sizeof(T) == 4 ? (T)fb_w32[i] : (T)fb_w64[i];
+  __syncthreads();
   const int b = blockIdx.y, f0 = blockIdx.x * MF_FRAMES;
   const T* y = audio + (long)b * slice_stride;
 #pragma unroll 1
@@ -258,7 +272,10 @@ __global__ void __launch_bounds__(256, 2) mel_stft2048_kernel(const T* __restric
       const double2 o = make_double2(0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y));
       const double2 x = c_add(e, c_mul_mi(c_mul(wk, o)));
       if (sizeof(T) == 4) {
-        const float a = hypotf((float)x.x, (float)x.y);              // complex64 store, np.abs -> float32
+        // complex64 store, then np.abs -> float32 hypot. glibc's hypotf IS sqrt in double of the exactly representable
+        // re^2 + im^2 rounded once to float: the same three operations here, without ocml's range-scaling hypotf
+        const double re = (double)(float)x.x, im = (double)(float)x.y;
+        const float a = (float)sqrt(re * re + im * im);
         pv[c] = (T)(a * a);
       } else {
         const double a = hypot(x.x, x.y);
@@ -277,19 +294,56 @@ __global__ void __launch_bounds__(256, 2) mel_stft2048_kernel(const T* __restric
     }
     ADM_WAVE_SYNC();
     for (int m = lane; m < n_mels; m += 64) {
-      const int s = fb_start[m], cnt = fb_count[m], o = fb_off[m];
-      double acc = 0.0;
-      for (int i = 0; i < cnt; ++i)
-        acc += (sizeof(T) == 4 ? (double)fb_w32[o + i] : fb_w64[o + i]) * (double)pw[s + i];
+      const int s = f_start[m], cnt = f_count[m], o = f_off[m];
+      double acc = 0.0;                                             // taps in order, as the generic kernel sums them
+      int i = 0;
+      for (; i + 4 <= cnt; i += 4) {                                // four taps' operands in flight
+        const double w0 = (double)f_w[o + i], w1 = (double)f_w[o + i + 1], w2 = (double)f_w[o + i + 2], w3 = (double)f_w[o + i + 3];
+        const double p0 = (double)pw[s + i], p1 = (double)pw[s + i + 1], p2 = (double)pw[s + i + 2], p3 = (double)pw[s + i + 3];
+        acc += w0 * p0; acc += w1 * p1; acc += w2 * p2; acc += w3 * p3;
+      }
+      for (; i < cnt; ++i) acc += (double)f_w[o + i] * (double)pw[s + i];
       stage[m * MF_FRAMES + slot] = (T)acc;
     }
     ADM_WAVE_SYNC();
   }
   __syncthreads();
   // [n_mels][MF_FRAMES] -> melspec[b][m][f0 .. f0 + 8): one row segment per thread pass
+  double mx = 0.0;
   for (int e = tid; e < n_mels * MF_FRAMES; e += blockDim.x) {
     const int m = e / MF_FRAMES, s = e % MF_FRAMES;
-    if (f0 + s < n_frames) melspec[((long)b * n_mels + m) * n_frames + f0 + s] = stage[e];
+    if (f0 + s < n_frames) {
+      melspec[((long)b * n_mels + m) * n_frames + f0 + s] = stage[e];
+      mx = fmax(mx, (double)stage[e]);
+    }
+  }
+  if (spec_max != nullptr) {
+    for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+    if (lane == 0) atomicMax(spec_max + b, (unsigned long long)__double_as_longlong(mx));
+  }
+}
+
+// power_to_db + u8 quantise with the per-spectrogram maximum already known (mel_stft2048_kernel's spec_max): plain
+// elementwise grid, same arithmetic as mel_db_u8_kernel.
+template <typename T>
+__global__ void __launch_bounds__(256) mel_db_u8_grid_kernel(const T* __restrict__ melspec, int n, float top_db,
+                                                              const unsigned long long* __restrict__ spec_max,
+                                                              unsigned char* __restrict__ img) {
+  const int b = blockIdx.y;
+  const double mx = __longlong_as_double((long long)spec_max[b]);
+  const T* s = melspec + (long)b * n;
+  const T amin = (T)1e-10;
+  const T ref_db = (T)10.0 * (T)log10((double)(((T)mx > amin) ? (T)mx : amin));
+  const T peak = (T)10.0 * (T)log10((double)(((T)mx > amin) ? (T)mx : amin)) - ref_db;  // log_spec.max()
+  const T floor_db = peak - (T)top_db;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const T v = s[i] > amin ? s[i] : amin;
+    T db = (T)10.0 * (T)log10((double)v);
+    db = db - ref_db;
+    db = db > floor_db ? db : floor_db;
+    T q = (db + (T)top_db) * (T)255 / (T)top_db;
+    q = q < (T)0 ? (T)0 : (q > (T)255 ? (T)255 : q);
+    img[(long)b * n + i] = (unsigned char)(q + (T)0.5);  // astype(uint8) truncation
   }
 }
 
@@ -389,24 +443,24 @@ __global__ void __launch_bounds__(256) mel_nnls_diff_kernel(const double* __rest
     diff[(long)b * n + e] = acc - S[(long)b * n + e];
   }
 }
-// NNLS check b: projected gradient of 0.5*||AX-S||^2/size at X (bounds [0,inf)), max-abs over everything.
+// NNLS check b: projected gradient of 0.5*||AX-S||^2/size at X (bounds [0,inf)): max-abs over everything into pgmax and,
+// when pgblk != nullptr, per (image, column block) — the unit librosa hands to L-BFGS-B. blockIdx.x = block * parts + part:
+// a workgroup stays inside ONE column block, so both maxima cost one atomic per wave.
 __global__ void __launch_bounds__(256) mel_nnls_pg_kernel(const double* __restrict__ X, const double* __restrict__ diff,
                                                           const int* __restrict__ fbt_off,
                                                           const int* __restrict__ fbt_idx,
                                                           const double* __restrict__ fbt_w64, int n_bins, int n_mels,
-                                                          int n_frames, int nnls_cols, float* __restrict__ pgmax,
+                                                          int n_frames, int nnls_cols, int parts, float* __restrict__ pgmax,
                                                           float* __restrict__ pgblk) {
-  // pgblk != nullptr: additionally the maximum per (image, column block) — the unit librosa hands to L-BFGS-B — one
-  // atomic per element there (this pass runs once per inverse; the blocks are few)
-  const int b = blockIdx.y;
-  const long n = (long)n_bins * n_frames;
+  const int b = blockIdx.y, blk = blockIdx.x / parts, part = blockIdx.x % parts;
   const int n_blk = (n_frames + nnls_cols - 1) / nnls_cols;
+  const int blk0 = blk * nnls_cols;
+  const int cols = (blk0 + nnls_cols <= n_frames) ? nnls_cols : n_frames - blk0;
+  const double inv_size = 1.0 / ((double)n_mels * cols);
+  const long n = (long)n_bins * cols;
   float local = 0.f;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    const int t = (int)(e / n_bins), f = (int)(e - (long)t * n_bins);
-    const int blk0 = (t / nnls_cols) * nnls_cols;
-    const int cols = (blk0 + nnls_cols <= n_frames) ? nnls_cols : n_frames - blk0;
-    const double inv_size = 1.0 / ((double)n_mels * cols);
+  for (long e = (long)part * blockDim.x + threadIdx.x; e < n; e += (long)parts * blockDim.x) {
+    const int t = blk0 + (int)(e / n_bins), f = (int)(e % n_bins);
     double g = 0.0;
     for (int i = fbt_off[f]; i < fbt_off[f + 1]; ++i)
       g += fbt_w64[i] * diff[((long)b * n_mels + fbt_idx[i]) * n_frames + t];
@@ -414,11 +468,12 @@ __global__ void __launch_bounds__(256) mel_nnls_pg_kernel(const double* __restri
     const double x = X[((long)b * n_frames + t) * n_bins + f];
     const double pg = x > 0.0 ? g : (g < 0.0 ? g : 0.0);
     local = fmaxf(local, (float)fabs(pg));
-    if (pgblk != nullptr && pg != 0.0)
-      atomicMax(reinterpret_cast<unsigned*>(pgblk + (long)b * n_blk + t / nnls_cols), __float_as_uint((float)fabs(pg)));
   }
   for (int m = 32; m >= 1; m >>= 1) local = fmaxf(local, __shfl_xor(local, m, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(pgmax), __float_as_uint(local));
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(reinterpret_cast<unsigned*>(pgmax), __float_as_uint(local));
+    if (pgblk != nullptr) atomicMax(reinterpret_cast<unsigned*>(pgblk + (long)b * n_blk + blk), __float_as_uint(local));
+  }
 }
 
 // NNLS solver for the column blocks whose start point does NOT satisfy L-BFGS-B's stopping rule (max |projected
@@ -693,7 +748,7 @@ void adm_mel_destroy(adm_mel_t* h) {
   if (!h) return;
   for (void* p : h->owned) dfree(p);
   for (void* p : {(void*)h->melspec, (void*)h->angles, (void*)h->mag, (void*)h->ytmp, (void*)h->Smel, (void*)h->Xpow,
-                  (void*)h->diff, (void*)h->reb0, (void*)h->reb1, (void*)h->y, (void*)h->pgblk})
+                  (void*)h->diff, (void*)h->reb0, (void*)h->reb1, (void*)h->y, (void*)h->pgblk, (void*)h->spec_max})
     if (p) dfree(p);
   delete h;
 }
@@ -701,35 +756,43 @@ void adm_mel_destroy(adm_mel_t* h) {
 // audio: device, B slices of n_samples (fp32 or fp64), consecutive slices `slice_stride` elements apart.
 // melspec_out: device (B, n_mels, n_frames) in the audio's precision, n_frames = 1 + n_samples / hop:
 // librosa.feature.melspectrogram (mel.py:140-147) before the dB conversion.
-int adm_mel_forward_power(adm_mel_t* h, const void* audio, int is_f64, int B, long slice_stride, int n_samples,
-                          void* melspec_out, void* stream) {
+static bool mel_fast_path(const adm_mel* h) {
+  static const int fast = [] { const char* e = getenv("ADM_MEL_FAST"); return e ? atoi(e) : 1; }();
+  return h->cfg.n_fft == 2048 && fast;
+}
+
+static int mel_forward_power_impl(adm_mel_t* h, const void* audio, int is_f64, int B, long slice_stride, int n_samples,
+                                  void* melspec_out, unsigned long long* spec_max, void* stream) {
   ADM_REQUIRE(h && audio && melspec_out && B > 0 && n_samples > 0, "mel_forward_power: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const adm_mel_config& c = h->cfg;
   const int n_frames = 1 + n_samples / c.hop_length;
   dim3 grid(n_frames, B);
   const size_t smem = fft_smem(h);
-  static const int fast = [] { const char* e = getenv("ADM_MEL_FAST"); return e ? atoi(e) : 1; }();
-  if (c.n_fft == 2048 && fast) {             // one wave per frame, real-input radix-16 FFT (mel_stft2048_kernel)
+  if (mel_fast_path(h)) {                    // one wave per frame, real-input radix-16 FFT (mel_stft2048_kernel)
     dim3 g2(ceil_div(n_frames, MF_FRAMES), B);
-    const size_t sm2 = sizeof(double2) * 4 * 16 * MF_PITCH + (is_f64 ? 8 : 4) * (size_t)h->n_mels * MF_FRAMES;
-    ADM_REQUIRE(sm2 <= 96 * 1024, "mel_forward: too many mel bands for the fast path staging buffer");
+    const size_t tsz = is_f64 ? 8 : 4;
+    const size_t sm2 = sizeof(double2) * 4 * 16 * MF_PITCH + tsz * (size_t)h->n_mels * MF_FRAMES +
+                       sizeof(int) * (3 * (size_t)h->n_mels + 2) + tsz * (size_t)h->nnz;
+    ADM_REQUIRE(sm2 <= 128 * 1024, "mel_forward: too many mel bands for the fast path staging buffer");
 #if !defined(ADM_EMU)
     static bool once = [] {
-      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<double, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       return true;
     }();
     (void)once;
 #endif
-    if (is_f64)
-      ADM_LAUNCH((mel_stft2048_kernel<double>), g2, dim3(256), sm2, st, (const double*)audio, slice_stride, n_samples,
-                 c.hop_length, h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count, h->fb_off, h->fb_w32,
-                 h->fb_w64, h->n_mels, n_frames, (double*)melspec_out);
-    else
-      ADM_LAUNCH((mel_stft2048_kernel<float>), g2, dim3(256), sm2, st, (const float*)audio, slice_stride, n_samples,
-                 c.hop_length, h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count, h->fb_off, h->fb_w32,
-                 h->fb_w64, h->n_mels, n_frames, (float*)melspec_out);
+    static const int occ = [] { const char* e = getenv("ADM_MEL_OCC"); return e ? atoi(e) : 1; }();
+#define ADM_MEL_FAST_LAUNCH(T_, W_)                                                                                          \
+  ADM_LAUNCH((mel_stft2048_kernel<T_, W_>), g2, dim3(256), sm2, st, (const T_*)audio, slice_stride, n_samples, c.hop_length,   \
+             h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count, h->fb_off, h->fb_w32, h->fb_w64, h->n_mels,     \
+             n_frames, (T_*)melspec_out, spec_max)
+    if (is_f64) { if (occ == 2) ADM_MEL_FAST_LAUNCH(double, 2); else ADM_MEL_FAST_LAUNCH(double, 1); }
+    else { if (occ == 2) ADM_MEL_FAST_LAUNCH(float, 2); else ADM_MEL_FAST_LAUNCH(float, 1); }
+#undef ADM_MEL_FAST_LAUNCH
     return ADM_CHECK_LAUNCH();
   }
   if (is_f64) {
@@ -744,6 +807,11 @@ int adm_mel_forward_power(adm_mel_t* h, const void* audio, int is_f64, int B, lo
   return ADM_CHECK_LAUNCH();
 }
 
+int adm_mel_forward_power(adm_mel_t* h, const void* audio, int is_f64, int B, long slice_stride, int n_samples,
+                          void* melspec_out, void* stream) {
+  return mel_forward_power_impl(h, audio, is_f64, B, slice_stride, n_samples, melspec_out, nullptr, stream);
+}
+
 // image_out: device (B, n_mels, n_frames) uint8 = the dB conversion + quantisation (mel.py:148-150) of the above.
 int adm_mel_forward(adm_mel_t* h, const void* audio, int is_f64, int B, long slice_stride, int n_samples,
                     uint8_t* image_out, void* stream) {
@@ -753,6 +821,18 @@ int adm_mel_forward(adm_mel_t* h, const void* audio, int is_f64, int B, long sli
   const int n_frames = 1 + n_samples / c.hop_length;
   const size_t need = (size_t)B * h->n_mels * n_frames * 8;
   if (h->cap_fwd < need) { ADM_TRY(stream_sync(st)); ADM_TRY(grow(h, &h->melspec, need)); h->cap_fwd = need; }
+  if (mel_fast_path(h)) {                    // the STFT kernel also delivers each spectrogram's maximum
+    if (h->cap_max < (size_t)B) { ADM_TRY(stream_sync(st)); ADM_TRY(grow(h, (void**)&h->spec_max, sizeof(unsigned long long) * B)); h->cap_max = B; }
+    ADM_TRY(dmemset(h->spec_max, 0, sizeof(unsigned long long) * B, st));
+    ADM_TRY(mel_forward_power_impl(h, audio, is_f64, B, slice_stride, n_samples, h->melspec, h->spec_max, stream));
+    const int n = h->n_mels * n_frames;
+    dim3 g(ceil_div(n, 256 * 4), B);
+    if (is_f64) ADM_LAUNCH((mel_db_u8_grid_kernel<double>), g, dim3(256), 0, st, (const double*)h->melspec, n, (float)c.top_db,
+                           (const unsigned long long*)h->spec_max, image_out);
+    else ADM_LAUNCH((mel_db_u8_grid_kernel<float>), g, dim3(256), 0, st, (const float*)h->melspec, n, (float)c.top_db,
+                    (const unsigned long long*)h->spec_max, image_out);
+    return ADM_CHECK_LAUNCH();
+  }
   ADM_TRY(adm_mel_forward_power(h, audio, is_f64, B, slice_stride, n_samples, h->melspec, stream));
   if (is_f64) {
     ADM_LAUNCH((mel_db_u8_kernel<double>), dim3(B), dim3(256), 0, st, (const double*)h->melspec, h->n_mels * n_frames,
@@ -811,8 +891,9 @@ int adm_mel_inverse(adm_mel_t* h, const uint8_t* images, const double* init_phas
   ADM_LAUNCH(mel_nnls_diff_kernel, dim3(256, B), dim3(256), 0, st, h->Xpow, h->Smel, h->fb_start, h->fb_count, h->fb_off,
              h->fb_w64, nb, nm, n_frames, h->diff);
   const bool solve = h->lipschitz > 0.0 && h->nnls_max_iter > 0;
-  ADM_LAUNCH(mel_nnls_pg_kernel, dim3(256, B), dim3(256), 0, st, h->Xpow, h->diff, h->fbt_off, h->fbt_idx, h->fbt_w64, nb,
-             nm, n_frames, h->nnls_cols, h->pgmax + (solve ? 1 : 0), solve ? h->pgblk : (float*)nullptr);
+  const int pg_parts = ceil_div(256, n_blk) > 0 ? ceil_div(256, n_blk) : 1;     // ~256 workgroups per image, whole blocks each
+  ADM_LAUNCH(mel_nnls_pg_kernel, dim3(n_blk * pg_parts, B), dim3(256), 0, st, h->Xpow, h->diff, h->fbt_off, h->fbt_idx, h->fbt_w64,
+             nb, nm, n_frames, h->nnls_cols, pg_parts, h->pgmax + (solve ? 1 : 0), solve ? h->pgblk : (float*)nullptr);
   if (solve) {
     const size_t nsm = sizeof(double) * (3 * (size_t)nb + 2 * (size_t)nm);
     ADM_REQUIRE(nsm <= 64 * 1024, "mel_inverse: filterbank too large for the in-LDS NNLS solver");
@@ -822,8 +903,8 @@ int adm_mel_inverse(adm_mel_t* h, const uint8_t* images, const double* init_phas
     // projected gradient of the point that is returned
     ADM_LAUNCH(mel_nnls_diff_kernel, dim3(256, B), dim3(256), 0, st, h->Xpow, h->Smel, h->fb_start, h->fb_count, h->fb_off,
                h->fb_w64, nb, nm, n_frames, h->diff);
-    ADM_LAUNCH(mel_nnls_pg_kernel, dim3(256, B), dim3(256), 0, st, h->Xpow, h->diff, h->fbt_off, h->fbt_idx, h->fbt_w64, nb,
-               nm, n_frames, h->nnls_cols, h->pgmax, (float*)nullptr);
+    ADM_LAUNCH(mel_nnls_pg_kernel, dim3(n_blk * pg_parts, B), dim3(256), 0, st, h->Xpow, h->diff, h->fbt_off, h->fbt_idx,
+               h->fbt_w64, nb, nm, n_frames, h->nnls_cols, pg_parts, h->pgmax, (float*)nullptr);
   }
   ADM_LAUNCH(gl_init_kernel, dim3(256, B), dim3(256), 0, st, init_phase, h->mag, nb, n_frames, (double2*)h->angles);
   const size_t smem = fft_smem(h);

@@ -144,3 +144,22 @@ def test_nnls_solver_leaves_converged_blocks_alone(backend):
     _, mag = mine.images_to_audios([img], init_phase=rng.random((1, 129, 16)), return_magnitude=True)
     assert mine.last_nnls_iterations == 0 and mine.last_nnls_pg == mine.last_nnls_pg_start <= 1e-5
     assert np.abs(mag[0] ** 2 - ref_mag ** 2).max() <= 1e-12 * max(1.0, np.abs(ref_mag ** 2).max())
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fast_path_n_fft_2048_image_matches_the_oracle(backend, dtype):
+    """n_fft = 2048 takes the wave-per-frame radix-16 real-FFT kernel and the grid dB kernel (per-spectrogram maximum from the
+    STFT kernel's atomics): same bars as the generic path, on a frame count that leaves the last workgroup ragged."""
+    select(backend)
+    from audiodiffusion.mel import Mel
+    cfg = dict(x_res=11, y_res=256, n_fft=2048, hop_length=512)      # 11 frames: workgroups of 8 frames, the second one ragged
+    mine, ref = Mel(**cfg), omel.Mel(**cfg)
+    y = _audio(mine.slice_size * 2 + 7, seed=4, dtype=dtype)
+    for m in (mine, ref):
+        m.load_audio(raw_audio=y)
+    got = mine.audio_slices_to_images([mine.get_audio_slice(0), mine.get_audio_slice(1)])
+    for s in (0, 1):
+        a, b = got[s].astype(int), np.asarray(ref.audio_slice_to_image(s)).astype(int)
+        assert a.shape == b.shape == (256, 11)
+        assert np.abs(a - b).max() <= 1 and (a == b).mean() >= 0.999, (np.abs(a - b).max(), (a == b).mean())
