@@ -681,6 +681,103 @@ __global__ void __launch_bounds__(256) gl_stft_update_kernel(const float* __rest
   }
 }
 
+// ---- n_fft = 2048 fast paths of the two Griffin-Lim FFT kernels (one wave per frame, fft1024_wave) --------------------------------
+// irfft: X[0..1024] -> E[k] = (X[k] + conj X[1024-k]) / 2, Od[k] = conj(W2048^k) (X[k] - conj X[1024-k]) / 2, Z = E + i Od is the
+// spectrum of z[n] = y[2n] + i y[2n+1]; z = conj(FFT(conj Z)) / 1024.
+__global__ void __launch_bounds__(256) gl_istft_frames2048_kernel(const double2* __restrict__ angles,
+                                                                  const double* __restrict__ window,
+                                                                  const double2* __restrict__ tw, int n_frames,
+                                                                  double* __restrict__ ytmp) {
+  ADM_DYN_SMEM(double2, sm);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double2* buf = sm + wave * 16 * MF_PITCH;
+  const int b = blockIdx.y, frame = blockIdx.x * 4 + wave;
+  const bool live = frame < n_frames;
+  const double2* X = angles + ((long)b * n_frames + (live ? frame : 0)) * 1025;
+  double2 v[16];
+  double2 wk = tw[lane];                                          // W2048^(lane + 64 n1)
+  const double2 w32 = tw[64];
+  ADM_UNROLL
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const int k = 64 * n1 + lane;
+    double2 xk = X[k], xp = X[1024 - k];
+    if (k == 0) { xk.y = 0.0; xp.y = 0.0; }                       // numpy's irfft ignores the imaginary parts of DC and Nyquist
+    const double2 e = make_double2(0.5 * (xk.x + xp.x), 0.5 * (xk.y - xp.y));
+    const double2 d = make_double2(0.5 * (xk.x - xp.x), 0.5 * (xk.y + xp.y));
+    const double2 od = c_mul(make_double2(wk.x, -wk.y), d);       // conj(W^k) * d
+    const double2 z = make_double2(e.x - od.y, e.y + od.x);       // E + i Od
+    v[n1] = make_double2(z.x, -z.y);                              // conj(Z): the forward engine then yields conj(z) * 1024
+    wk = c_mul(wk, w32);
+  }
+  fft1024_wave(v, buf, tw, lane);
+  const double fct = 1.0 / 1024.0;
+  double* dst = ytmp + ((long)b * n_frames + (live ? frame : 0)) * 2048;
+  ADM_UNROLL
+  for (int c = 0; c < 16; ++c) {
+    const int j = lane + 64 * c;
+    const double2 w = *reinterpret_cast<const double2*>(window + 2 * j);
+    if (live) *reinterpret_cast<double2*>(dst + 2 * j) = make_double2(w.x * (v[c].x * fct), w.y * (-v[c].y * fct));
+  }
+}
+
+// STFT of y (float32) -> rebuilt (complex64) + the momentum / projection update of `angles` (see gl_stft_update_kernel).
+__global__ void __launch_bounds__(256) gl_stft_update2048_kernel(const float* __restrict__ y, int out_len, int hop,
+                                                                 const double* __restrict__ window,
+                                                                 const double2* __restrict__ tw, int n_frames,
+                                                                 float2* __restrict__ rebuilt, const float2* __restrict__ tprev,
+                                                                 float mom, const double* __restrict__ mag,
+                                                                 double2* __restrict__ angles) {
+  ADM_DYN_SMEM(double2, sm);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double2* buf = sm + wave * 16 * MF_PITCH;
+  const int b = blockIdx.y, frame = blockIdx.x * 4 + wave;
+  const bool live = frame < n_frames;
+  const float* yb = y + (long)b * out_len;
+  double2 v[16];
+  ADM_UNROLL
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const int n = 64 * n1 + lane;
+    const long src = (long)frame * hop + 2 * n - 1024;
+    const double a0 = (live && src >= 0 && src < out_len) ? (double)yb[src] : 0.0;
+    const double a1 = (live && src + 1 >= 0 && src + 1 < out_len) ? (double)yb[src + 1] : 0.0;
+    const double2 w = *reinterpret_cast<const double2*>(window + 2 * n);
+    v[n1] = make_double2(w.x * a0, w.y * a1);
+  }
+  fft1024_wave(v, buf, tw, lane);
+  ADM_UNROLL
+  for (int c = 0; c < 16; ++c) buf[lane + 64 * c] = v[c];
+  ADM_WAVE_SYNC();
+  const long base = ((long)b * n_frames + (live ? frame : 0)) * 1025;
+  auto emit = [&](int k, double xr, double xi) {
+    const float2 r = make_float2((float)xr, (float)xi);
+    rebuilt[base + k] = r;
+    double ar = (double)r.x, ai = (double)r.y;
+    if (tprev != nullptr) {
+      const float2 tp = tprev[base + k];
+      ar -= (double)(mom * tp.x);
+      ai -= (double)(mom * tp.y);
+    }
+    const double den = hypot(ar, ai) + 2.2250738585072014e-308;
+    const double scl = 1.0 / den;
+    const double m = mag[base + k];
+    angles[base + k] = make_double2(ar * scl * m, ai * scl * m);
+  };
+  double2 wk = tw[lane];
+  const double2 w32 = tw[64];
+  ADM_UNROLL
+  for (int c = 0; c < 16; ++c) {
+    const double2 zq = buf[(1024 - (lane + 64 * c)) & 1023];
+    const double2 zk = v[c], zc = make_double2(zq.x, -zq.y);
+    const double2 e = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+    const double2 o = make_double2(0.5 * (zk.x - zc.x), 0.5 * (zk.y - zc.y));
+    const double2 x = c_add(e, c_mul_mi(c_mul(wk, o)));
+    if (live) emit(lane + 64 * c, x.x, x.y);
+    wk = c_mul(wk, w32);
+  }
+  if (live && lane == 0) emit(1024, v[0].x - v[0].y, 0.0);
+  ADM_WAVE_SYNC();
+}
+
 static int grow(adm_mel* h, void** p, size_t bytes) {
   if (*p) dfree(*p);
   *p = nullptr;
@@ -913,19 +1010,36 @@ int adm_mel_inverse(adm_mel_t* h, const uint8_t* images, const double* init_phas
   float2* tprev = nullptr;
   float2* spare = (float2*)h->reb1;
   dim3 fgrid(n_frames, B), ogrid(ceil_div(out_len, 256) > 1024 ? 1024 : ceil_div(out_len, 256), B);
+  const bool fast = mel_fast_path(h);
+  const dim3 fgrid4(ceil_div(n_frames, 4), B);
+  const size_t smem4 = sizeof(double2) * 4 * 16 * MF_PITCH;
+#if !defined(ADM_EMU)
+  static bool once_gl = [] {
+    (void)hipFuncSetAttribute((const void*)gl_istft_frames2048_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)gl_stft_update2048_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    return true;
+  }();
+  (void)once_gl;
+#endif
+  auto istft_frames = [&]() {
+    if (fast) ADM_LAUNCH(gl_istft_frames2048_kernel, fgrid4, dim3(256), smem4, st, (const double2*)h->angles, h->window,
+                         (const double2*)h->twiddle, n_frames, h->ytmp);
+    else ADM_LAUNCH(gl_istft_frames_kernel, fgrid, dim3(256), smem, st, (const double2*)h->angles, nfft, h->log2n, h->window,
+                    (const double2*)h->twiddle, n_frames, h->ytmp);
+  };
   for (int it = 0; it < c.n_iter; ++it) {
-    ADM_LAUNCH(gl_istft_frames_kernel, fgrid, dim3(256), smem, st, (const double2*)h->angles, nfft, h->log2n, h->window,
-               (const double2*)h->twiddle, n_frames, h->ytmp);
+    istft_frames();
     ADM_LAUNCH(gl_overlap_add_kernel, ogrid, dim3(256), 0, st, h->ytmp, nfft, hop, n_frames, h->wss, out_len, h->y);
-    ADM_LAUNCH(gl_stft_update_kernel, fgrid, dim3(256), smem, st, h->y, out_len, nfft, h->log2n, hop, h->window,
-               (const double2*)h->twiddle, n_frames, reb, (const float2*)tprev, mom, h->mag, (double2*)h->angles);
+    if (fast) ADM_LAUNCH(gl_stft_update2048_kernel, fgrid4, dim3(256), smem4, st, h->y, out_len, hop, h->window,
+                         (const double2*)h->twiddle, n_frames, reb, (const float2*)tprev, mom, h->mag, (double2*)h->angles);
+    else ADM_LAUNCH(gl_stft_update_kernel, fgrid, dim3(256), smem, st, h->y, out_len, nfft, h->log2n, hop, h->window,
+                    (const double2*)h->twiddle, n_frames, reb, (const float2*)tprev, mom, h->mag, (double2*)h->angles);
     // rebuilt, tprev = tprev, rebuilt
     float2* old = tprev;
     tprev = reb;
     reb = old ? old : spare;
   }
-  ADM_LAUNCH(gl_istft_frames_kernel, fgrid, dim3(256), smem, st, (const double2*)h->angles, nfft, h->log2n, h->window,
-             (const double2*)h->twiddle, n_frames, h->ytmp);
+  istft_frames();
   ADM_LAUNCH(gl_overlap_add_kernel, ogrid, dim3(256), 0, st, h->ytmp, nfft, hop, n_frames, h->wss, out_len, audio_out);
   ADM_TRY(ADM_CHECK_LAUNCH());
   if (stft_mag_out) ADM_TRY(copy_d2d(stft_mag_out, h->mag, spec * 8, st));  // layout (B, n_frames, n_bins)
