@@ -35,6 +35,7 @@ class ConvArgs(C.Structure):
         ("x1_bstride", C.c_long), ("x2_bstride", C.c_long), ("w_bstride", C.c_long),
         ("wino_packed", C.c_void_p),
         ("bf16_packed", C.c_void_p),
+        ("stats_out", C.c_void_p), ("stats_tiles", C.c_int),
     ]
 
 
@@ -66,6 +67,9 @@ _SIGS = {
     "adm_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adm_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "adm_conv_stats_tiles": (C.c_int, [C.POINTER(ConvArgs)]),
+    "adm_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adm_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "adm_pack_conv_weight_T": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "adm_pack_winograd_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

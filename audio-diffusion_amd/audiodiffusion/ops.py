@@ -133,8 +133,9 @@ def pack_bf16_weight(w, transposed=False):
 
 
 def conv2d(x1, wpacked, bias, ks, x2=None, up=False, stride=1, pad_lo=1, gn=None, act=False, chan_add=None,
-           residual=None, wino=None, bf16=None):
-    """Fused convolution (see include/adm.h adm_conv_args)."""
+           residual=None, wino=None, bf16=None, stats=False):
+    """Fused convolution (see include/adm.h adm_conv_args). stats=True: also returns the GroupNorm partial sums of the output
+    the kernel's epilogue wrote, (N, Cout, tiles, 2) fp64 — None when the dispatched kernel has no such epilogue."""
     _f32(x1)
     Nn, C1, H, W = x1.shape
     Cout = wpacked.shape[2]
@@ -157,8 +158,26 @@ def conv2d(x1, wpacked, bias, ks, x2=None, up=False, stride=1, pad_lo=1, gn=None
     a.wino_packed = N.ptr(wino)
     a.bf16_packed = C.c_void_p(bf16.data_ptr()) if bf16 is not None else None
     a.out = N.ptr(out)
+    st = None
+    if stats:
+        tiles = N.lib().adm_conv_stats_tiles(C.byref(a))
+        if tiles > 0:
+            st = torch.full((Nn, Cout, tiles, 2), float("nan"), dtype=torch.float64, device=x1.device)
+            a.stats_out, a.stats_tiles = N.ptr(st), tiles
     N.check(N.lib().adm_conv2d(C.byref(a), N.stream_for(x1)))
-    return out
+    return (out, st) if stats else out
+
+
+def groupnorm_finalize(st1, gamma, beta, groups, eps, hw, st2=None):
+    """GroupNorm (scale, shift) from the per-tile partial sums convolutions wrote (conv2d(..., stats=True)); st2: the second
+    part of a virtual channel concat."""
+    Nn, C1, t1 = st1.shape[:3]
+    C2, t2 = (st2.shape[1], st2.shape[2]) if st2 is not None else (0, 0)
+    scale = torch.empty((Nn, C1 + C2), dtype=torch.float32, device=st1.device)
+    shift = torch.empty_like(scale)
+    N.check(N.lib().adm_groupnorm_finalize(N.ptr(st1), C1, t1, N.ptr(st2), C2, t2, Nn, hw, groups, float(eps), N.ptr(gamma),
+                                           N.ptr(beta), N.ptr(scale), N.ptr(shift), N.stream_for(st1)))
+    return scale, shift
 
 
 def attention(qkv, head_dim):

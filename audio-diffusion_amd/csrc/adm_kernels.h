@@ -23,6 +23,11 @@ int launch_slerp_grid(const float* x0, const float* x1, long n, const float* alp
 int launch_dequant(const float* x, uint8_t* out, long n, hipStream_t st);
 
 // k_groupnorm.hip
+int launch_groupnorm_finalize(const double* st1, int C1, int tiles1, const double* st2, int C2, int tiles2, int N, int HW,
+                              int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,
+                              hipStream_t st);
+int conv_stats_tiles(const adm_conv_args& a);        // k_conv_mfma.hip: statistic tiles the dispatched kernel would emit (0: none)
+int winograd_stats_tiles(const adm_conv_args& a);    // k_conv_wino.hip
 int launch_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int groups, float eps,
                            const float* gamma, const float* beta, float* scale, float* shift, hipStream_t st,
                            float* mean_rstd = nullptr);

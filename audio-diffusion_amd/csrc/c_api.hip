@@ -61,6 +61,16 @@ int adm_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N,
   return launch_groupnorm_stats(x1, C1, x2, C2, N, HW, groups, eps, gamma, beta, scale, shift, (hipStream_t)stream);
 }
 
+int adm_conv_stats_tiles(const adm_conv_args* a) { return a ? conv_stats_tiles(*a) : 0; }
+
+int adm_groupnorm_finalize(const double* stats1, int C1, int tiles1, const double* stats2, int C2, int tiles2, int N, int HW,
+                           int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,
+                           void* stream) {
+  ADM_REQUIRE(stats1 && gamma && beta && scale && shift, "groupnorm_finalize: null argument");
+  return launch_groupnorm_finalize(stats1, C1, tiles1, stats2, C2, tiles2, N, HW, groups, eps, gamma, beta, scale, shift,
+                                   (hipStream_t)stream);
+}
+
 int adm_conv2d(const adm_conv_args* a, void* stream) {
   ADM_REQUIRE(a && a->x1 && a->wpacked && a->out, "conv2d: null argument");
   return launch_conv2d(*a, (hipStream_t)stream);

@@ -500,11 +500,24 @@ static int dispatch_bm(const ConvParams& p, int bm, size_t smem, hipStream_t st)
   return ADM_CHECK_LAUNCH();
 }
 
+// Mirrors launch_conv2d's dispatch: the number of GroupNorm statistic tiles per (sample, output channel) the kernel that would
+// run for `a` emits into a.stats_out, or 0 when that kernel has no statistics epilogue (the consumer then runs gn_stats_kernel).
+int conv_stats_tiles(const adm_conv_args& a) {
+  const int C2 = a.x2 ? a.C2 : 0, Ct = a.C1 + C2;
+  if (Ct % CK != 0 || a.C1 % CK != 0 || a.Cout % 4 != 0 || a.Cout < 32) return 0;
+  if (conv_bf16_enabled() && conv_bf16_eligible(a)) return 0;
+  if (conv_bf16_mode() >= 2 && conv1x1_bf16_eligible(a)) return 0;
+  if (winograd_enabled() && winograd_eligible(a)) return winograd_stats_tiles(a);
+  return 0;
+}
+
 int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   const int C2 = a.x2 ? a.C2 : 0;
   const int Ct = a.C1 + C2;
   ADM_REQUIRE(a.ks == 3 || a.ks == 1, "conv2d: ks must be 1 or 3");
   ADM_REQUIRE(a.stride == 1 || a.stride == 2, "conv2d: stride must be 1 or 2");
+  ADM_REQUIRE(a.stats_out == nullptr || a.stats_tiles == conv_stats_tiles(a),
+              "conv2d: stats_tiles does not match adm_conv_stats_tiles for these arguments");
   if (Ct % CK != 0 || a.C1 % CK != 0 || a.Cout % 4 != 0 || a.Cout < 32)
     return launch_conv_small(a, st);  // conv_in / conv_out class (tiny Cin or Cout): direct kernel
   ADM_REQUIRE(!(a.ks == 1 && (a.stride != 1 || a.up)), "conv2d: 1x1 supports stride 1, no upsample");

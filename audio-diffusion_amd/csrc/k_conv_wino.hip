@@ -33,6 +33,7 @@ struct WinoParams {
   long x1_bs, x2_bs;
   int gn_nstride;             // per-sample stride of gn_scale / gn_shift (0: shared identity rows, conv without GroupNorm)
   unsigned long long* prof;   // optional cycle counters of the wave-specialised kernel (ADM_WINO_PROF=1), else NULL
+  double* stats;              // optional (v4): GroupNorm partial sums of the output, [n][cout][tile][2] (adm_conv_args.stats_out)
 };
 
 __device__ __forceinline__ float silu_w(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
@@ -1117,6 +1118,21 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
       }
       *reinterpret_cast<f32x4*>(p.out + obase + r * planeO) = y0;
       *reinterpret_cast<f32x4*>(p.out + obase + r * planeO + p.Wo) = y1;
+      if (p.stats != nullptr) {            // wave-uniform: (sum, sum of squares) of this cout row over the 8 x 16 tile, fp64
+        double s1 = 0.0, s2 = 0.0;
+        ADM_UNROLL
+        for (int j = 0; j < 4; ++j) {
+          s1 += (double)y0[j] + (double)y1[j];
+          s2 += (double)y0[j] * (double)y0[j] + (double)y1[j] * (double)y1[j];
+        }
+        ADM_UNROLL
+        for (int m = 8; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }   // the 16 lanes of this k4
+        if (li == 0) {
+          const int tiles = p.tiles_x * p.tiles_y;
+          double* dst = p.stats + (((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4 + r) * tiles + t.ty * p.tiles_x + t.tx) * 2;
+          dst[0] = s1; dst[1] = s2;
+        }
+      }
     }
     if (PROF) pr[3] += W3_CLK() - t_epi;
   }
@@ -1268,8 +1284,17 @@ bool winograd_eligible(const adm_conv_args& a) {
 
 const float* conv_zero_bias(int n);  // k_conv_mfma.hip
 
+// GroupNorm statistic tiles of the output (one per 8 x 16-pixel tile) — only conv_wino4_kernel has the epilogue
+int winograd_stats_tiles(const adm_conv_args& a) {
+  const int C2 = a.x2 ? a.C2 : 0;
+  if (!wino4_layout(a.Cout, a.C1 + C2)) return 0;
+  const int Ho = a.up ? 2 * a.H : a.H, Wo = a.up ? 2 * a.W : a.W;
+  return (Wo / 16) * (Ho / 8);
+}
+
 int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
   WinoParams p;
+  p.stats = nullptr;
   const int C2 = a.x2 ? a.C2 : 0;
   p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2;
   p.N = a.N; p.Hs = a.H; p.Ws = a.W;
@@ -1313,6 +1338,7 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     const int grid = p.nblk < n_cu ? p.nblk : n_cu;
     set_last_conv_variant(4000 + (v4 ? 314 : 313));
     p.prof = nullptr;
+    p.stats = v4 ? a.stats_out : nullptr;
 #if !defined(ADM_EMU)
     static const bool want_prof = getenv("ADM_WINO_PROF") != nullptr;
     if (want_prof && !a.up) {   // developer aid: per-role cycle accounting, printed after every launch (synchronous)

@@ -102,6 +102,65 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
   }
 }
 
+// GroupNorm statistics from per-tile partial sums that the PRODUCING convolutions wrote in their epilogues
+// (adm_conv_args.stats_out: fp64 (sum, sum of squares) per (sample, channel, pixel tile)) — the read-only pass over the
+// activation disappears: 16 bytes per 128-pixel tile instead of 512. One workgroup per (sample, group); the partials of
+// the group's channels are summed in a fixed order (thread-strided, then the same shuffle / LDS tree as gn_stats_kernel), so
+// the result is deterministic. Virtual concat: channels >= C1 come from the second producer's buffer.
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const double* __restrict__ st1, int C1, int tiles1,
+                                                          const double* __restrict__ st2, int C2, int tiles2, int HW,
+                                                          int groups, float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int C = C1 + C2, cg = C / groups;
+  double s = 0.0, ss = 0.0;
+  for (int cl = 0; cl < cg; ++cl) {
+    const int c = g * cg + cl;
+    const double2* src;
+    int tiles;
+    if (c < C1) { src = reinterpret_cast<const double2*>(st1) + ((long)n * C1 + c) * tiles1; tiles = tiles1; }
+    else { src = reinterpret_cast<const double2*>(st2) + ((long)n * C2 + (c - C1)) * tiles2; tiles = tiles2; }
+    for (int t = tid; t < tiles; t += 256) { const double2 v = src[t]; s += v.x; ss += v.y; }
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  __shared__ double red[2][4];
+  __shared__ float stat[2];
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+  __syncthreads();
+  if (tid == 0) {
+    const double total = (double)cg * HW;
+    const double S = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double SS = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double mean = S / total;
+    double var = SS / total - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[0] = (float)mean;
+    stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+  for (int cl = tid; cl < cg; cl += 256) {
+    const int c = g * cg + cl;
+    const float sc = rstd * gamma[c];
+    scale[(long)n * C + c] = sc;
+    shift[(long)n * C + c] = -sc * mean + beta[c];
+  }
+}
+
+int launch_groupnorm_finalize(const double* st1, int C1, int tiles1, const double* st2, int C2, int tiles2, int N, int HW,
+                              int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,
+                              hipStream_t st) {
+  if (st2 == nullptr) { C2 = 0; tiles2 = 0; }
+  ADM_REQUIRE(st1 && tiles1 > 0 && (C2 == 0 || tiles2 > 0), "groupnorm_finalize: missing partial sums");
+  ADM_REQUIRE((C1 + C2) % groups == 0, "groupnorm: channels not divisible by groups");
+  ADM_LAUNCH(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, st, st1, C1, tiles1, st2, C2, tiles2, HW, groups, eps, gamma,
+             beta, scale, shift);
+  return ADM_CHECK_LAUNCH();
+}
+
 int launch_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int groups, float eps,
                            const float* gamma, const float* beta, float* scale, float* shift, hipStream_t st,
                            float* mean_rstd) {

@@ -62,6 +62,11 @@ struct Tensor {
   bool external = false;
   float* grad = nullptr;  // training: gradient buffer (same shape), ginit = already holds a contribution
   bool ginit = false;
+  // inference: GroupNorm partial sums written by the producing convolution's epilogue ([n][c][tile][2] fp64), when some
+  // GroupNorm reads this tensor and the producing kernel can emit them (stat_tiles > 0)
+  bool want_stats = false;
+  double* stats = nullptr;
+  int stat_tiles = 0;
 };
 struct GnBuf {
   int C = 0;
@@ -130,6 +135,7 @@ struct Net {
   int transformer(const std::string& p, int x, int C, int heads, int cross_dim, int* rc);
   int stacked_qkv(const std::string& prefix, int C, bool bias, const ConvW** out);
   void finish_liveness();
+  void fill_conv_args(const Op& o, int B, const float* temb_all, int temb_stride, adm_conv_args* a) const;
 
   // ---- execution ----------------------------------------------------------------------------------------
   int arena_alloc(void** p, size_t bytes);

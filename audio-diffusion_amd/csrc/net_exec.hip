@@ -1,4 +1,6 @@
 // net_exec.hip — implementation of the generic flat-op-list executor (see net_exec.h).
+#include <cstdlib>
+
 #include "net_exec.h"
 
 #include <cmath>
@@ -402,6 +404,29 @@ int Net::plan(int B) {
     ADM_TRY(arena_alloc((void**)&g.shift, sizeof(float) * (size_t)B * g.C));
     if (training) ADM_TRY(arena_alloc((void**)&g.mean_rstd, sizeof(float) * (size_t)B * groups * 2));
   }
+  // GroupNorm statistics folded into the producing convolution (inference; after the scale / shift buffers exist, which the
+  // kernels' eligibility rules look at): every tensor some GroupNorm reads gets a
+  // partial-sum buffer when the kernel that will produce it has the epilogue (adm_conv_stats_tiles > 0 for its arguments).
+  static const int fold = [] { const char* e = getenv("ADM_GN_FOLD"); return e ? atoi(e) : 1; }();
+  for (Tensor& t : tensors) { t.stats = nullptr; t.stat_tiles = 0; t.want_stats = false; }
+  if (!training && fold) {
+    for (const Op& o : ops)
+      if (o.kind == Op::GN) {
+        tensors[o.in1].want_stats = true;
+        if (o.in2 >= 0) tensors[o.in2].want_stats = true;
+      }
+    for (const Op& o : ops) {
+      if (o.kind != Op::CONV || o.wt >= 0 || !tensors[o.out].want_stats || tensors[o.out].external) continue;
+      if (tensors[o.in1].external || (o.in2 >= 0 && tensors[o.in2].external)) continue;   // pointer (alignment) unknown until run
+      adm_conv_args a;
+      fill_conv_args(o, B, nullptr, 0, &a);
+      const int tiles = conv_stats_tiles(a);
+      if (tiles <= 0) continue;
+      Tensor& t = tensors[o.out];
+      ADM_TRY(arena_alloc((void**)&t.stats, sizeof(double) * 2 * (size_t)B * t.C * tiles));
+      t.stat_tiles = tiles;
+    }
+  }
   if (training) {
     // gradient buffer for every tensor except the network input; scratch sized for the largest layer
     size_t max_da = 0, max_ws = 0, max_w = 0;
@@ -436,6 +461,35 @@ int Net::plan(int B) {
   return 0;
 }
 
+void Net::fill_conv_args(const Op& o, int B, const float* temb_all, int temb_stride, adm_conv_args* ap) const {
+  adm_conv_args& a = *ap;
+  memset(&a, 0, sizeof(a));
+  const Tensor& t1 = tensors[o.in1];
+  const long plane = (long)t1.H * t1.W;
+  a.x1 = t1.ptr + (long)o.in1_coff * plane;
+  a.C1 = o.in1_C ? o.in1_C : t1.C;
+  a.x1_bstride = (long)t1.C * plane;
+  if (o.in2 >= 0) { a.x2 = tensors[o.in2].ptr; a.C2 = tensors[o.in2].C; }
+  a.N = B; a.H = t1.H; a.W = t1.W;
+  a.up = o.up; a.stride = o.stride; a.ks = o.ks; a.pad_lo = o.pad_lo;
+  if (o.gn >= 0) { a.gn_scale = gnbufs[o.gn].scale; a.gn_shift = gnbufs[o.gn].shift; }
+  a.act = o.act;
+  if (o.wt >= 0) {  // per-sample weights living in an activation tensor
+    const Tensor& tw = tensors[o.wt];
+    const long wplane = (long)tw.H * tw.W;
+    a.wpacked = tw.ptr + (long)o.wt_coff * wplane;
+    a.w_bstride = (long)tw.C * wplane;
+    a.bias = nullptr;
+    a.Cout = o.dyn_cout;
+  } else {
+    a.wpacked = o.w->wp; a.bias = o.w->bias; a.Cout = o.w->Cout;
+    if (o.stride == 1) { a.wino_packed = o.w->wu; a.bf16_packed = o.w->wb; }   // eligibility (shape, mode): the launcher
+  }
+  if (o.temb_off >= 0 && temb_all) { a.chan_add = temb_all + o.temb_off; a.chan_add_stride = temb_stride; }
+  if (o.res >= 0) a.residual = tensors[o.res].ptr;
+  a.out = tensors[o.out].ptr;
+}
+
 int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_stride, hipStream_t st, OpTimer* tm) {
   OpTimer none;
   if (!tm) tm = &none;
@@ -449,35 +503,23 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
       const GnBuf& g = gnbufs[o.gn];
       const float* x2 = o.in2 >= 0 ? tensors[o.in2].ptr : nullptr;
       const int C2 = o.in2 >= 0 ? tensors[o.in2].C : 0;
-      ADM_TRY(launch_groupnorm_stats(t1.ptr, t1.C, x2, C2, B, t1.H * t1.W, groups, o.eps > 0.f ? o.eps : eps, o.g->gamma,
-                                     o.g->beta, g.scale, g.shift, st, g.mean_rstd));
-      tm->end(0, 0, 3.0 * B * (t1.C + C2) * t1.H * t1.W, 4.0 * B * (t1.C + C2) * t1.H * t1.W);
+      const bool folded = t1.stats != nullptr && (o.in2 < 0 || tensors[o.in2].stats != nullptr);
+      if (folded) {    // the producing convolutions left per-tile partial sums: no pass over the activation
+        const Tensor* t2 = o.in2 >= 0 ? &tensors[o.in2] : nullptr;
+        ADM_TRY(launch_groupnorm_finalize(t1.stats, t1.C, t1.stat_tiles, t2 ? t2->stats : nullptr, C2, t2 ? t2->stat_tiles : 0, B,
+                                          t1.H * t1.W, groups, o.eps > 0.f ? o.eps : eps, o.g->gamma, o.g->beta, g.scale, g.shift,
+                                          st));
+        tm->end(0, 1, 3.0 * B * (t1.C + C2) * t1.H * t1.W,
+                16.0 * B * ((double)t1.C * t1.stat_tiles + (t2 ? (double)C2 * t2->stat_tiles : 0.0)));
+      } else {
+        ADM_TRY(launch_groupnorm_stats(t1.ptr, t1.C, x2, C2, B, t1.H * t1.W, groups, o.eps > 0.f ? o.eps : eps, o.g->gamma,
+                                       o.g->beta, g.scale, g.shift, st, g.mean_rstd));
+        tm->end(0, 0, 3.0 * B * (t1.C + C2) * t1.H * t1.W, 4.0 * B * (t1.C + C2) * t1.H * t1.W);
+      }
     } else if (o.kind == Op::CONV) {
       adm_conv_args a;
-      memset(&a, 0, sizeof(a));
-      const long plane = (long)t1.H * t1.W;
-      a.x1 = t1.ptr + (long)o.in1_coff * plane;
-      a.C1 = o.in1_C ? o.in1_C : t1.C;
-      a.x1_bstride = (long)t1.C * plane;
-      if (o.in2 >= 0) { a.x2 = tensors[o.in2].ptr; a.C2 = tensors[o.in2].C; }
-      a.N = B; a.H = t1.H; a.W = t1.W;
-      a.up = o.up; a.stride = o.stride; a.ks = o.ks; a.pad_lo = o.pad_lo;
-      if (o.gn >= 0) { a.gn_scale = gnbufs[o.gn].scale; a.gn_shift = gnbufs[o.gn].shift; }
-      a.act = o.act;
-      if (o.wt >= 0) {  // per-sample weights living in an activation tensor
-        const Tensor& tw = tensors[o.wt];
-        const long wplane = (long)tw.H * tw.W;
-        a.wpacked = tw.ptr + (long)o.wt_coff * wplane;
-        a.w_bstride = (long)tw.C * wplane;
-        a.bias = nullptr;
-        a.Cout = o.dyn_cout;
-      } else {
-        a.wpacked = o.w->wp; a.bias = o.w->bias; a.Cout = o.w->Cout;
-        if (o.stride == 1) { a.wino_packed = o.w->wu; a.bf16_packed = o.w->wb; }   // eligibility (shape, mode): the launcher
-      }
-      if (o.temb_off >= 0 && temb_all) { a.chan_add = temb_all + o.temb_off; a.chan_add_stride = temb_stride; }
-      if (o.res >= 0) a.residual = tensors[o.res].ptr;
-      a.out = tensors[o.out].ptr;
+      fill_conv_args(o, B, temb_all, temb_stride, &a);
+      if (tensors[o.out].stats != nullptr) { a.stats_out = tensors[o.out].stats; a.stats_tiles = tensors[o.out].stat_tiles; }
       ADM_TRY(launch_conv2d(a, st));
       const Tensor& to = tensors[o.out];
       const double Cin = a.C1 + a.C2, outel = (double)B * to.C * to.H * to.W;

@@ -105,7 +105,20 @@ typedef struct adm_conv_args {
   /* optional: the same 3x3 weights as bf16 MFMA operands (adm_pack_bf16_weight: [tap][Cin/8][Cout][8] bf16); used when
    * option "conv_bf16" is on and the shape is eligible (stride 1, output a multiple of 16x16, Cout % 128 == 0). */
   const void* bf16_packed;
+  /* optional: GroupNorm statistics of the OUTPUT, produced by the convolution's own epilogue instead of a separate read
+   * pass: per (sample, output channel, pixel tile) the fp64 pair (sum, sum of squares) of the final output values,
+   * stats_out[((n * Cout + c) * stats_tiles + tile) * 2 + {0, 1}]. stats_tiles must equal adm_conv_stats_tiles(args) (> 0
+   * only for the kernels that can do it: today the Winograd v4 kernel); adm_groupnorm_finalize turns them into
+   * scale / shift. */
+  double* stats_out; int stats_tiles;
 } adm_conv_args;
+/* number of statistic tiles per (sample, channel) the kernel chosen for these arguments would emit, 0 = it cannot. */
+int adm_conv_stats_tiles(const adm_conv_args* a);
+/* GroupNorm scale / shift (as adm_groupnorm_stats) from the per-tile partial sums of one tensor or of a virtual concat
+ * (x1 | x2) whose parts were produced by different convolutions (stats2 NULL / C2 0: one part); HW = pixels per channel. */
+int adm_groupnorm_finalize(const double* stats1, int C1, int tiles1, const double* stats2, int C2, int tiles2, int N, int HW,
+                           int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,
+                           void* stream);
 int adm_conv2d(const adm_conv_args* a, void* stream);
 /* (Cout,Cin,ks,ks) -> [Cin][ks*ks][Cout]; both device pointers. */
 int adm_pack_conv_weight(const float* w, float* wpacked, int Cout, int Cin, int ks, void* stream);

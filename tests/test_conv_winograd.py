@@ -80,3 +80,41 @@ def test_conv_winograd_data_gradient(backend, mode, Cin, Cout, variant):
         _native.check(_native.lib().adm_set_option(b"conv_wino", -1))
     ref = torch.nn.grad.conv2d_input((Nn, Cin, H, W), w.cpu(), dy.cpu(), padding=1) + acc.cpu()
     assert _relerr(dx, ref) < 1e-4, _relerr(dx, ref)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_groupnorm_statistics_from_the_conv_epilogue(backend):
+    """The v4 kernel's epilogue writes (sum, sum of squares) per (sample, cout, 8x16 tile) of its FINAL output (bias, per-sample
+    term and residual included); adm_groupnorm_finalize on them must give what the read pass (adm_groupnorm_stats) gives on the
+    stored output — one producer, and a virtual concat of two producers with different tile counts."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn = 2
+    x = _rand((Nn, 64, 16, 32), 1, dev)
+    w1 = _rand((64, 64, 3, 3), 2, dev, scale=(64 * 9) ** -0.5)
+    w2 = _rand((128, 64, 3, 3), 3, dev, scale=(64 * 9) ** -0.5)
+    b1, b2 = _rand((64,), 4, dev), _rand((128,), 5, dev)
+    temb, res = _rand((Nn, 64), 6, dev), _rand((Nn, 64, 16, 32), 7, dev)
+    gin = ops.groupnorm_stats(x, _rand((64,), 8, dev), _rand((64,), 9, dev), 32, 1e-5)
+    y1, s1 = ops.conv2d(x, ops.pack_conv_weight(w1), b1, 3, gn=gin, act=True, chan_add=temb, residual=res,
+                        wino=ops.pack_winograd_weight(w1), stats=True)
+    assert _native.lib().adm_last_conv_variant() == 4314 and s1 is not None and tuple(s1.shape) == (Nn, 64, 4, 2)
+    assert not torch.isnan(s1).any()                                         # every (sample, cout, tile) slot was written
+    want = torch.stack([y1.double().reshape(Nn, 64, 2, 8, 2, 16).sum((3, 5)).reshape(Nn, 64, 4),
+                        (y1.double() ** 2).reshape(Nn, 64, 2, 8, 2, 16).sum((3, 5)).reshape(Nn, 64, 4)], -1)
+    assert torch.allclose(s1.cpu(), want.cpu(), rtol=1e-12, atol=1e-12)
+    gamma, beta = _rand((64,), 10, dev), _rand((64,), 11, dev)
+    sc, sh = ops.groupnorm_finalize(s1, gamma, beta, 32, 1e-5, 16 * 32)
+    rsc, rsh = ops.groupnorm_stats(y1, gamma, beta, 32, 1e-5)
+    assert torch.allclose(sc.cpu(), rsc.cpu(), rtol=2e-6, atol=1e-7) and torch.allclose(sh.cpu(), rsh.cpu(), rtol=2e-6, atol=2e-7)
+    # second producer: nearest-x2 upsample folded (8x16 -> 16x32 output), 128 couts; concat (y2 | y1) = 192 channels, 32 groups of 6
+    xs = _rand((Nn, 64, 8, 16), 12, dev)
+    y2, s2 = ops.conv2d(xs, ops.pack_conv_weight(w2), b2, 3, up=True, wino=ops.pack_winograd_weight(w2), stats=True)
+    assert s2 is not None and tuple(s2.shape) == (Nn, 128, 4, 2)
+    g2, be2 = _rand((192,), 13, dev), _rand((192,), 14, dev)
+    sc, sh = ops.groupnorm_finalize(s2, g2, be2, 32, 1e-5, 16 * 32, st2=s1)
+    rsc, rsh = ops.groupnorm_stats(y2, g2, be2, 32, 1e-5, x2=y1)
+    assert torch.allclose(sc.cpu(), rsc.cpu(), rtol=2e-6, atol=1e-7) and torch.allclose(sh.cpu(), rsh.cpu(), rtol=2e-6, atol=2e-7)
+    # a kernel without the epilogue reports 0 tiles
+    _, none = ops.conv2d(x, ops.pack_conv_weight(w1[:, :, :1, :1].contiguous()), b1, 1, pad_lo=0, stats=True)
+    assert none is None
