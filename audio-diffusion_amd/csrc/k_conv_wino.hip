@@ -1118,13 +1118,13 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
       }
       *reinterpret_cast<f32x4*>(p.out + obase + r * planeO) = y0;
       *reinterpret_cast<f32x4*>(p.out + obase + r * planeO + p.Wo) = y1;
-      if (p.stats != nullptr) {            // wave-uniform: (sum, sum of squares) of this cout row over the 8 x 16 tile, fp64
-        double s1 = 0.0, s2 = 0.0;
-        ADM_UNROLL
-        for (int j = 0; j < 4; ++j) {
-          s1 += (double)y0[j] + (double)y1[j];
-          s2 += (double)y0[j] * (double)y0[j] + (double)y1[j] * (double)y1[j];
-        }
+      if (p.stats != nullptr) {            // wave-uniform: (sum, sum of squares) of this cout row over the 8 x 16 tile
+        // the lane's 8 values in fp32 (8 + 8 operations), everything across lanes and tiles in fp64: the fp32 part adds a
+        // relative error of ~1e-7 to a 8-term sum, far below what the consumer (an fp32 scale / shift) resolves
+        float f1 = (y0[0] + y0[1]) + (y0[2] + y0[3]) + ((y1[0] + y1[1]) + (y1[2] + y1[3]));
+        float f2 = (y0[0] * y0[0] + y0[1] * y0[1]) + (y0[2] * y0[2] + y0[3] * y0[3]) +
+                   ((y1[0] * y1[0] + y1[1] * y1[1]) + (y1[2] * y1[2] + y1[3] * y1[3]));
+        double s1 = (double)f1, s2 = (double)f2;
         ADM_UNROLL
         for (int m = 8; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }   // the 16 lanes of this k4
         if (li == 0) {

@@ -102,7 +102,7 @@ def test_groupnorm_statistics_from_the_conv_epilogue(backend):
     assert not torch.isnan(s1).any()                                         # every (sample, cout, tile) slot was written
     want = torch.stack([y1.double().reshape(Nn, 64, 2, 8, 2, 16).sum((3, 5)).reshape(Nn, 64, 4),
                         (y1.double() ** 2).reshape(Nn, 64, 2, 8, 2, 16).sum((3, 5)).reshape(Nn, 64, 4)], -1)
-    assert torch.allclose(s1.cpu(), want.cpu(), rtol=1e-12, atol=1e-12)
+    assert torch.allclose(s1.cpu(), want.cpu(), rtol=2e-6, atol=2e-5)       # 8 values per lane are summed in fp32, the rest in fp64
     gamma, beta = _rand((64,), 10, dev), _rand((64,), 11, dev)
     sc, sh = ops.groupnorm_finalize(s1, gamma, beta, 32, 1e-5, 16 * 32)
     rsc, rsh = ops.groupnorm_stats(y1, gamma, beta, 32, 1e-5)
