@@ -49,7 +49,11 @@ struct ConvW {
   std::string qkv_prefix; // non-empty: q|k|v stacked from <prefix>.to_q/.to_k/.to_v
   bool has_bias = true;   // false: Linear(bias=False) (Transformer2DModel's to_q/to_k/to_v); qkv: the stacked bias stays zero
   float* stacked = nullptr;  // (3C, C) stacked master copy of q|k|v
+  // training: which derived packings the convolution dispatch has actually read since the last plan (bit 0 wp, 1 wpT,
+  // 2 wu, 3 wuT, 4 wb, 5 wbT). Once a whole step has run (Net::use_known), refresh_weights re-packs only those.
+  mutable unsigned used = 0;
 };
+enum { PK_WP = 1, PK_WPT = 2, PK_WU = 4, PK_WUT = 8, PK_WB = 16, PK_WBT = 32 };
 struct GNW {
   float* gamma = nullptr;
   float* beta = nullptr;
@@ -115,6 +119,10 @@ struct Net {
   size_t arena_bytes = 0;
   // training
   bool training = false;             // keep every activation, allocate gradient buffers, maintain wpT
+  bool use_known = false;            // a forward + backward pass has run on the current plan: ConvW::used is complete
+  bool stale_packings = false;       // a refresh has skipped packings (see begin_inference)
+  int begin_inference(hipStream_t st, std::vector<unsigned>* saved);
+  void end_inference(const std::vector<unsigned>& saved);
   const float* params_base = nullptr;  // flat master parameter buffer and the matching flat gradient buffer
   float* grads_base = nullptr;
   float *tmp_da = nullptr, *wgrad_ws = nullptr, *s12 = nullptr, *tmp_w = nullptr;

@@ -146,17 +146,21 @@ static int pack_one(Net* net, ConvW& w, hipStream_t st) {
     src = net->ps->P(w.key + ".weight");
     w.bias = w.has_bias ? net->ps->P(w.key + ".bias") : nullptr;
   }
-  ADM_TRY(launch_pack_conv_weight(src, w.wp, w.Cout, w.Cin, w.ks, st));
+  // every packing is produced when the layer is first built (allocation + contents); a REFRESH after an optimizer step skips
+  // the packings the dispatch has not read during the last complete step (e.g. the fp32 and Winograd images of a layer whose
+  // three passes all run on bf16 operands): `need` is the mask of what to write now
+  const unsigned need = (net->training && net->use_known) ? w.used : ~0u;
+  if (need & PK_WP) ADM_TRY(launch_pack_conv_weight(src, w.wp, w.Cout, w.Cin, w.ks, st));
   if (w.ks == 3 && w.qkv_prefix.empty() && winograd_enabled() && w.Cout % 32 == 0 && w.Cin % 8 == 0) {
     if (!w.wu) ADM_TRY(net->dalloc((void**)&w.wu, sizeof(float) * (size_t)w.Cout * w.Cin * 16));
-    ADM_TRY(launch_pack_winograd_weight(src, w.wu, w.Cout, w.Cin, st));
+    if (need & PK_WU) ADM_TRY(launch_pack_winograd_weight(src, w.wu, w.Cout, w.Cin, st));
   }
   if (net->training) {
     if (!w.wpT) ADM_TRY(net->dalloc((void**)&w.wpT, sizeof(float) * (size_t)w.Cout * w.Cin * w.ks * w.ks));
-    ADM_TRY(launch_pack_conv_weight_T(src, w.wpT, w.Cout, w.Cin, w.ks, st));
+    if (need & PK_WPT) ADM_TRY(launch_pack_conv_weight_T(src, w.wpT, w.Cout, w.Cin, w.ks, st));
     if (w.ks == 3 && w.qkv_prefix.empty() && winograd_enabled() && w.Cin % 32 == 0 && w.Cout % 8 == 0) {
       if (!w.wuT) ADM_TRY(net->dalloc((void**)&w.wuT, sizeof(float) * (size_t)w.Cout * w.Cin * 16));
-      ADM_TRY(launch_pack_winograd_weight_T(src, w.wuT, w.Cout, w.Cin, st));
+      if (need & PK_WUT) ADM_TRY(launch_pack_winograd_weight_T(src, w.wuT, w.Cout, w.Cin, st));
     }
     // mixed precision (`--mixed_precision bf16`): the filters as bf16 MFMA operands, re-rounded from the fp32 masters after
     // every optimizer step; only training nets carry them, so sampling stays fp32 whatever the option says
@@ -166,8 +170,8 @@ static int pack_one(Net* net, ConvW& w, hipStream_t st) {
       const size_t bytes = 2 * (size_t)w.Cout * w.Cin * w.ks * w.ks;
       if (!w.wb) ADM_TRY(net->dalloc(&w.wb, bytes));
       if (!w.wbT) ADM_TRY(net->dalloc(&w.wbT, bytes));
-      ADM_TRY(launch_pack_bf16_weight(src, w.wb, w.Cout, w.Cin, 0, st, w.ks));
-      ADM_TRY(launch_pack_bf16_weight(src, w.wbT, w.Cout, w.Cin, 1, st, w.ks));
+      if (need & PK_WB) ADM_TRY(launch_pack_bf16_weight(src, w.wb, w.Cout, w.Cin, 0, st, w.ks));
+      if (need & PK_WBT) ADM_TRY(launch_pack_bf16_weight(src, w.wbT, w.Cout, w.Cin, 1, st, w.ks));
     }
   }
   return 0;
@@ -209,7 +213,28 @@ void Net::mark_ready(const float* master_param, size_t numel) {
 
 int Net::refresh_weights(hipStream_t st) {
   for (ConvW& w : convs) ADM_TRY(pack_one(this, w, st));
+  if (training && use_known) stale_packings = true;     // the packings no training pass reads were left as they were
   return 0;
+}
+// An inference entry point on a TRAINING net (evaluation samples through the live model): bring every packing up to date first,
+// and keep what the inference dispatch reads out of the training masks.
+int Net::begin_inference(hipStream_t st, std::vector<unsigned>* saved) {
+  saved->clear();
+  if (!training) return 0;
+  if (stale_packings) {
+    const bool known = use_known;
+    use_known = false;
+    for (ConvW& w : convs) ADM_TRY(pack_one(this, w, st));
+    use_known = known;
+    stale_packings = false;
+  }
+  for (const ConvW& w : convs) saved->push_back(w.used);
+  return 0;
+}
+void Net::end_inference(const std::vector<unsigned>& saved) {
+  if (!training) return;
+  size_t i = 0;
+  for (ConvW& w : convs) w.used = saved[i++];
 }
 const GNW* Net::make_gn(const std::string& p, int c) {
   GNW g;
@@ -377,6 +402,8 @@ void Net::destroy() {
 // Assign activation buffers for batch B: exact-size free lists driven by liveness.
 int Net::plan(int B) {
   if (planned_B == B) return 0;
+  use_known = false;                       // another batch size may dispatch other kernels: re-learn which packings are read
+  for (ConvW& w : convs) w.used = 0;
   // the shared all-zero bias buffer is created lazily with a device allocation: do it here, outside any stream capture
   ADM_REQUIRE(conv_zero_bias(8192) != nullptr && conv_const_ones(8192) != nullptr, "plan: constant buffers");
   free_plan();
@@ -461,6 +488,13 @@ int Net::plan(int B) {
   return 0;
 }
 
+// which weight packing the convolution that just ran read: `fwd` = forward pass (wp / wu / wb) or data gradient (wpT / wuT / wbT)
+static unsigned packing_of_variant(int var, bool fwd) {
+  if (var / 1000 == 5) return fwd ? PK_WB : PK_WBT;         // bf16-operand kernels (3x3: 5316, 1x1: 5116)
+  if (var / 1000 == 4) return fwd ? PK_WU : PK_WUT;         // Winograd kernels
+  return fwd ? PK_WP : PK_WPT;                              // direct MFMA / small-channel kernels
+}
+
 void Net::fill_conv_args(const Op& o, int B, const float* temb_all, int temb_stride, adm_conv_args* ap) const {
   adm_conv_args& a = *ap;
   memset(&a, 0, sizeof(a));
@@ -521,6 +555,7 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
       fill_conv_args(o, B, temb_all, temb_stride, &a);
       if (tensors[o.out].stats != nullptr) { a.stats_out = tensors[o.out].stats; a.stats_tiles = tensors[o.out].stat_tiles; }
       ADM_TRY(launch_conv2d(a, st));
+      if (o.w) o.w->used |= packing_of_variant(last_conv_variant(), true);
       const Tensor& to = tensors[o.out];
       const double Cin = a.C1 + a.C2, outel = (double)B * to.C * to.H * to.W;
       const int var = last_conv_variant();
@@ -697,6 +732,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
         a.out = tmp_da;
       }
       ADM_TRY(launch_conv2d(a, st));
+      o.w->used |= packing_of_variant(last_conv_variant(), false);
       if (direct) { t1.ginit = true; continue; }
     }
     const long plane_i = (long)t1.H * t1.W;
@@ -721,6 +757,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       if (o.in2 >= 0) ADM_TRY(contribute(o.in2, tmp_da + (long)C1 * plane_i, (long)Ct * plane_i, C2));
     }
   }
+  use_known = true;      // a complete forward + backward has run on this plan: ConvW::used now lists every packing that is read
   return 0;
 }
 

@@ -129,6 +129,13 @@ struct Bf16Scope {
   ~Bf16Scope() { set_conv_bf16(prev); }
 };
 
+// Inference through a training handle: packings refreshed in full first (begin_inference), training's usage masks restored after.
+struct InferenceScope {
+  Net* n; std::vector<unsigned> saved; int rc;
+  InferenceScope(Net* net, hipStream_t st) : n(net) { rc = n->begin_inference(st, &saved); }
+  ~InferenceScope() { if (rc == 0) n->end_inference(saved); }
+};
+
 static int finalize(adm_unet* h) {
   Bf16Scope pack_scope(h->training ? h->bf16_level : 0);
   if (h->finalized) return 0;
@@ -431,6 +438,8 @@ int adm_unet_forward(adm_unet_t* h, const float* x, const float* timesteps_host,
   ADM_TRY(copy_h2d(h->t_dev, t.data(), sizeof(float) * B, st));
   ADM_TRY(stream_sync(st));  // t is a stack/vector buffer: make the copy complete before returning
   Bf16Scope fp32(0);
+  InferenceScope inf(&h->net, st);
+  ADM_TRY(inf.rc);
   return run_forward(h, x, out, B, nullptr, st);
 }
 
@@ -541,6 +550,8 @@ int adm_unet_profile(adm_unet_t* h, const float* x, float timestep, float* out, 
   OpTimer tm;
   tm.recs = &v;
   Bf16Scope fp32(0);
+  InferenceScope inf(&h->net, st);
+  ADM_TRY(inf.rc);
   ADM_TRY(run_forward(h, x, out, B, nullptr, st, &tm));
   *n_out = (int)v.size();
   for (int i = 0; i < (int)v.size() && i < cap; ++i) recs[i] = v[i];
@@ -553,6 +564,9 @@ int adm_sample_loop(adm_unet_t* h, float* x, int B, const adm_sched_coef* coef_h
   ADM_REQUIRE(h && x && coef_host && n_steps > 0, "sample_loop: bad argument");
   LoopArgs a{x, B, n_steps, step_noise, mask, mask_start, mask_end, u8_out, 0};
   Bf16Scope fp32(0);
+  ADM_TRY(finalize(h));
+  InferenceScope inf(&h->net, (hipStream_t)stream);
+  ADM_TRY(inf.rc);
   return run_loop(h, a, coef_host, use_graph, (hipStream_t)stream);
 }
 
@@ -561,6 +575,9 @@ int adm_encode_loop(adm_unet_t* h, float* x, int B, const adm_sched_coef* coef_h
   ADM_REQUIRE(h && x && coef_host && n_steps > 0, "encode_loop: bad argument");
   LoopArgs a{x, B, n_steps, nullptr, nullptr, 0, 0, nullptr, 1};
   Bf16Scope fp32(0);
+  ADM_TRY(finalize(h));
+  InferenceScope inf(&h->net, (hipStream_t)stream);
+  ADM_TRY(inf.rc);
   return run_loop(h, a, coef_host, use_graph, (hipStream_t)stream);
 }
 

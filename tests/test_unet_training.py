@@ -246,6 +246,22 @@ def test_mixed_precision_bf16_training_step(backend):
         m.refresh_weights()
         loss2 = float(m.train_step(x.to(dev), ts, tgt.to(dev)))
         assert loss2 < loss                                                                # (4)
+        # (5) refresh_weights re-packs only the weight images the training passes read (here: the bf16 ones); an inference call
+        # through the SAME handle (evaluation samples, `--save_images_epochs`) runs fp32 and must first bring the fp32 /
+        # Winograd images up to date: equal to a fresh inference model built from the current master weights
+        opt.step(grads, clip=T.clip_grad_norm_(grads, 1.0))
+        m.refresh_weights()                  # second refresh: the usage masks are known now, fp32 / Winograd images are skipped
+        through_training_handle = m(x.to(dev), ts)["sample"].cpu()
+        m.sync_state_dict_from_flat()
+        fresh = UNet2DModel(**BF16CFG).load_state_dict(m.state_dict())
+        want = fresh(x.to(dev), ts)["sample"].cpu()
+        # (not bit-equal: the inference model takes its GroupNorm statistics from the convolutions' epilogues, the training
+        # model from the read pass) — two optimizer steps moved the output by far more than the bar
+        assert float((through_training_handle - want).abs().max()) <= 2e-5 * float(want.abs().max())
+        before = UNet2DModel(**BF16CFG).load_state_dict(ref.state_dict())(x.to(dev), ts)["sample"].cpu()
+        assert float((before - want).abs().max()) >= 2e-3 * float(want.abs().max())
+        loss3 = float(m.train_step(x.to(dev), ts, tgt.to(dev)))                            # and training goes on unharmed
+        assert loss3 < loss2
     finally:
         _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
     # the option is per training setup: a model enabled with "no" afterwards is fp32 again
