@@ -86,10 +86,6 @@ _SIGS = {
     "adm_geglu_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_long, C.c_void_p]),
     "adm_cross_attention_backward": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.c_void_p]),
     "adm_attention_backward_blocked": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
-    "adm_gn_apply_bf16_blocked": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "adm_conv2d_bf16_blocked": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                          C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adm_sepconv_block": (C.c_int, [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "adm_dense_act": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "adm_unet_create": (C.c_int, [C.POINTER(UNetConfig), C.POINTER(C.c_void_p)]),

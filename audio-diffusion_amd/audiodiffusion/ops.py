@@ -189,30 +189,6 @@ def attention(qkv, head_dim):
     return out
 
 
-# ---------------------------------------------------------------------------------------------- blocked bf16 prototype
-def gn_apply_bf16_blocked(x1, x2=None, gn=None, act=False):
-    """-> xb (N, C/8, H, W, 8) bf16 = round(act(x * scale + shift)) in the channel-group-blocked layout."""
-    _f32(x1)
-    Nn, C1, H, W = x1.shape
-    C2 = x2.shape[1] if x2 is not None else 0
-    xb = torch.empty((Nn, (C1 + C2) // 8, H, W, 8), dtype=torch.bfloat16, device=x1.device)
-    N.check(N.lib().adm_gn_apply_bf16_blocked(N.ptr(x1), C1, N.ptr(x2), C2, Nn, H, W, N.ptr(gn[0]) if gn else None,
-                                              N.ptr(gn[1]) if gn else None, int(act), C.c_void_p(xb.data_ptr()),
-                                              N.stream_for(x1)))
-    return xb
-
-
-def conv2d_bf16_blocked(xb, wb, bias, Cout, up=0, chan_add=None, residual=None):
-    """3x3 stride-1 convolution of a blocked bf16 input with bf16-packed filters (pack_bf16_weight) -> fp32 (N,Cout,Ho,Wo)."""
-    Nn, KG, H, W, _ = xb.shape
-    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
-    out = torch.empty((Nn, Cout, Ho, Wo), dtype=torch.float32, device=xb.device)
-    ca, cas = (C.c_void_p(chan_add.data_ptr()), chan_add.stride(0)) if chan_add is not None else (None, 0)
-    N.check(N.lib().adm_conv2d_bf16_blocked(C.c_void_p(xb.data_ptr()), KG * 8, Nn, H, W, int(up), C.c_void_p(wb.data_ptr()),
-                                            N.ptr(bias), Cout, ca, cas, N.ptr(residual), N.ptr(out), N.stream_for(out)))
-    return out
-
-
 # ---------------------------------------------------------------------------------------------- Transformer2DModel pieces
 def layernorm_nct(x, gamma, beta, eps=1e-5):
     """LayerNorm over the channel axis of (N,C,H,W) for every token (BasicTransformerBlock.norm1/2/3)."""

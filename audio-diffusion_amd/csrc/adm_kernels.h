@@ -58,11 +58,6 @@ int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int tra
 void set_conv_bf16(int m);   // 0 off (default), 1 = 3x3 convs, 2 = 3x3, 1x1 and stride-2 data-gradient convs, -1 = ADM_CONV_BF16
 bool conv_bf16_enabled();
 int conv_bf16_mode();
-// k_conv_bf16_blocked.hip (prototype: blocked bf16 activations, op level only)
-int launch_gn_apply_bf16_blocked(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, const float* gn_scale,
-                                 const float* gn_shift, int act, void* xb, hipStream_t st);
-int launch_conv2d_bf16_blocked(const void* xb, int Ct, int N, int H, int W, int up, const void* wb, const float* bias, int Cout,
-                               const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st);
 // k_conv1x1_bf16.hip (mode 2)
 bool conv1x1_bf16_eligible(const adm_conv_args& a);
 int launch_conv1x1_bf16(const adm_conv_args& a, hipStream_t st);

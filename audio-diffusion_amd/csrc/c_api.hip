@@ -154,17 +154,6 @@ int adm_attention_backward_blocked(const float* qkv, const float* dout, float* d
   ADM_REQUIRE(qkv && dout && dqkv && stats, "attention_backward_blocked: null argument");
   return launch_attention_bwd_blocked(qkv, dout, dqkv, stats, N, C, T, head_dim, block, (hipStream_t)stream);
 }
-int adm_gn_apply_bf16_blocked(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, const float* gn_scale,
-                              const float* gn_shift, int act, void* xb, void* stream) {
-  ADM_REQUIRE(x1 && xb && ((gn_scale == nullptr) == (gn_shift == nullptr)), "gn_apply_bf16_blocked: bad argument");
-  return launch_gn_apply_bf16_blocked(x1, C1, x2, C2, N, H, W, gn_scale, gn_shift, act, xb, (hipStream_t)stream);
-}
-int adm_conv2d_bf16_blocked(const void* xb, int Ct, int N, int H, int W, int up, const void* wb, const float* bias, int Cout,
-                            const float* chan_add, int chan_add_stride, const float* residual, float* out, void* stream) {
-  ADM_REQUIRE(xb && wb && out, "conv2d_bf16_blocked: null argument");
-  return launch_conv2d_bf16_blocked(xb, Ct, N, H, W, up, wb, bias, Cout, chan_add, chan_add_stride, residual, out,
-                                    (hipStream_t)stream);
-}
 int adm_sepconv_block(const float* x, const float* dw, const float* pw, const float* pb, const float* bn_scale,
                       const float* bn_shift, float slope, float* tmp, float* y, int N, int Ci, int Co, int H, int W,
                       void* stream) {

@@ -184,16 +184,6 @@ int adm_sepconv_block(const float* x, const float* dw, const float* pw, const fl
 int adm_dense_act(const float* x, const float* W, const float* b, const float* post_scale, const float* post_shift,
                   float slope, int leaky, float* y, int N, int K, int J, int hwc_C, void* stream);
 
-/* PROTOTYPE (op level only, DESIGN.md "structural direction for the bf16 path"): the activated conv input as bf16 in the
- * channel-group-blocked layout xb[n][C/8][H][W][8] (2 bytes per element), written once by adm_gn_apply_bf16_blocked
- * (x * scale + shift, optional SiLU, round-to-nearest-even; gn_scale NULL = identity) and consumed by
- * adm_conv2d_bf16_blocked (3x3, stride 1, "same"; up = 0 | 1 nearest x2 | 2 zero insertion; wb from adm_pack_bf16_weight)
- * with no conversion work in the convolution. Emulator parity only so far. */
-int adm_gn_apply_bf16_blocked(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, const float* gn_scale,
-                              const float* gn_shift, int act, void* xb, void* stream);
-int adm_conv2d_bf16_blocked(const void* xb, int Ct, int N, int H, int W, int up, const void* wb, const float* bias, int Cout,
-                            const float* chan_add, int chan_add_stride, const float* residual, float* out, void* stream);
-
 /* ---------------------------------------------------------------- UNet2DModel executor (rows U1-U8)
  * Replaces `self.unet(images, t)["sample"]` (pipeline_audio_diffusion.py:163,237; train_unet.py:257). */
 typedef struct adm_unet adm_unet_t;

@@ -297,44 +297,3 @@ def test_conv_bf16_stride2_data_gradient_by_zero_insertion(backend):
         _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
     exact = torch.nn.grad.conv2d_input((Nn, Cin, H, W), _bf(w.cpu()), _bf(dy.cpu()), stride=2, padding=1)
     assert _relerr(dx.double(), exact) < 2e-6, _relerr(dx.double(), exact)
-
-
-# ---------------------------------------------------------------- prototype: blocked bf16 activations (op level)
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("case", CASES + PERSIST_CASES, ids=[str(i) for i in range(len(CASES) + len(PERSIST_CASES))])
-def test_blocked_bf16_activation_prototype_matches_fused_load_kernel(backend, case):
-    """GroupNorm-apply pass -> xb[n][C/8][H][W][8] bf16 -> convolution with no conversion work: the same rounded operands
-    and the same per-tile accumulation order as the fused-load kernel, hence bit-identical results."""
-    dev = select(backend)
-    from audiodiffusion import _native, ops
-    Nn, C1, C2, H, W, Cout, up, use_gn, act, use_temb, use_res = case
-    x1 = _rand((Nn, C1, H, W), 1, dev)
-    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
-    Ct = C1 + C2
-    w = _rand((Cout, Ct, 3, 3), 3, dev, scale=(Ct * 9) ** -0.5)
-    b = _rand((Cout,), 4, dev)
-    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
-    gn = ops.groupnorm_stats(x1, gamma, beta, 32 if Ct % 32 == 0 else 16, 1e-5, x2=x2) if use_gn else None
-    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
-    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
-    res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
-    wb = ops.pack_bf16_weight(w)
-    _native.check(_native.lib().adm_set_option(b"conv_bf16", 1))
-    try:
-        fused = ops.conv2d(x1, ops.pack_conv_weight(w), b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb,
-                           residual=res, bf16=wb)
-    finally:
-        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
-    xb = ops.gn_apply_bf16_blocked(x1, x2=x2, gn=gn, act=bool(act))
-    assert xb.shape == (Nn, Ct // 8, H, W, 8)
-    # the blocked tensor is exactly the rounded activation, channel group by channel group
-    a = torch.cat([x1, x2], 1).cpu() if C2 else x1.cpu()
-    if use_gn:
-        a = a * gn[0].cpu()[:, :, None, None] + gn[1].cpu()[:, :, None, None]
-    want = a.view(Nn, Ct // 8, 8, H, W).permute(0, 1, 3, 4, 2)
-    if not act:       # exact up to one bf16 step where the device contracts x * scale + shift into an fma
-        got, ref = xb.cpu().float(), want.to(torch.bfloat16).float()
-        assert float((got != ref).float().mean()) < 2e-3
-        assert float(((got - ref).abs() / (ref.abs() + 1e-6)).max()) <= 2 ** -7
-    out = ops.conv2d_bf16_blocked(xb, wb, b, Cout, up=int(up), chan_add=temb, residual=res)
-    assert torch.equal(out.cpu(), fused.cpu())

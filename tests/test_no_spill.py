@@ -36,7 +36,6 @@ def _usage(src):
                                          # generic 1x1 fallback `pf_kernel<1, false>` is known to spill; it serves odd chunkings only)
     ("k_conv_bf16.hip", 0),              # measured defaults: forward / data gradient, weight gradient, packing
     ("k_conv1x1_bf16.hip", 0),
-    ("k_conv_bf16_blocked.hip", 0),
 ])
 def test_conv_kernels_compile_without_spills(src, max_scratch):
     src, _, only = src.partition(":")
