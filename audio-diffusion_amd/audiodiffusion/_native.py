@@ -123,6 +123,8 @@ _OPTIONAL_SIGS = {
     "adm_conv_small_cout_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "adm_mse_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adm_grad_norm_clip": (C.c_int, [C.c_void_p, C.c_long, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "adm_grad_norm_clip_scaled": (C.c_int, [C.c_void_p, C.c_long, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "adm_unet_set_loss_scale": (C.c_int, [C.c_void_p, C.c_float]),
     "adm_adamw_ema_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long] + [C.c_float] * 5 +
                            [C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
     "adm_flat_op": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_void_p]),

@@ -74,6 +74,42 @@ def clip_grad_norm_(flat_grads, max_norm):
     return out
 
 
+class GradScaler:
+    """torch.cuda.amp.GradScaler as accelerate drives it for `--mixed_precision fp16` (train_unet.py:391-395): dynamic loss
+    scale (init 65536, x2 after `growth_interval` = 2000 finite steps, x0.5 on an overflow); un-scaling and clipping are ONE
+    pass over the flat gradient buffer (`adm_grad_norm_clip_scaled`); an overflow (non-finite gradient norm) skips the
+    optimizer step. Reading the norm back is the one host sync of an fp16 step (GradScaler's `found_inf.item()` likewise)."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.scale, self.growth_factor, self.backoff_factor = float(init_scale), growth_factor, backoff_factor
+        self.growth_interval, self._good = growth_interval, 0
+        self.step_was_skipped = False
+
+    def get_scale(self):
+        return self.scale
+
+    def unscale_and_clip_(self, flat_grads, max_norm):
+        """-> (norm_clip device tensor [true norm, coefficient incl. 1/scale] for AdamW.step(clip=...), found_inf: bool)."""
+        out = torch.empty(2, dtype=torch.float32, device=flat_grads.device)
+        scratch = torch.zeros(1, dtype=torch.float64, device=flat_grads.device)
+        N.check(N.lib().adm_grad_norm_clip_scaled(N.ptr(flat_grads), flat_grads.numel(), float(max_norm), 1.0 / self.scale,
+                                                  N.ptr(out), N.ptr(scratch), N.stream_for(flat_grads)))
+        found_inf = not math.isfinite(float(out[0]))
+        return out, found_inf
+
+    def update(self, found_inf):
+        """scaler.update(): back off on an overflow, grow after `growth_interval` consecutive finite steps."""
+        self.step_was_skipped = bool(found_inf)
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self._good = 0
+        else:
+            self._good += 1
+            if self._good >= self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good = 0
+
+
 class EMAModel:
     """diffusers==0.24.0 training_utils.EMAModel as the reference constructs it (train_unet.py:185-190): passing a
     module enables the warm-up schedule decay = min(1 - (1 + step/inv_gamma)^-power, max_value)."""

@@ -288,14 +288,18 @@ class UNet2DModel:
         optimizer step) with fp32 accumulation; everything stored — weights, activations, gradients, optimizer state —
         stays fp32, so checkpoints and the fp32 sampling path are unaffected."""
         from .training import FlatBuffer
-        if mixed_precision not in ("no", "bf16"):
-            raise ValueError(f"mixed_precision must be 'no' or 'bf16', got {mixed_precision!r}")
+        if mixed_precision not in ("no", "bf16", "fp16"):
+            raise ValueError(f"mixed_precision must be 'no', 'bf16' or 'fp16', got {mixed_precision!r}")
         # level 2 (default; measured 98.6 vs 113.5 ms per step at level 1, profiles/r02_first_contact.md): the 1x1
         # convolutions and the stride-2 data gradients take bf16 operands too; ADM_BF16_LEVEL=1 keeps them fp32.
         # The level is read by adm_unet_enable_training and belongs to THIS model from then on: the process-wide option is
         # put back to 0 below, and the native sampling entry points always run fp32.
-        level = int(os.environ.get("ADM_BF16_LEVEL", "2")) if mixed_precision == "bf16" else 0
+        # "fp16" (`train_unet.py:391-395`): the same kernels on IEEE binary16 operands (v_mfma_f32_32x32x16_f16); binary16's
+        # narrow exponent needs the gradient side scaled: training.GradScaler + train_step(loss_scale=), as accelerate's
+        # torch.cuda.amp.GradScaler does for the reference.
+        level = int(os.environ.get("ADM_BF16_LEVEL", "2")) if mixed_precision in ("bf16", "fp16") else 0
         N.check(N.lib().adm_set_option(b"conv_bf16", level))
+        N.check(N.lib().adm_set_option(b"conv_op16_f16", int(mixed_precision == "fp16")))
         self.mixed_precision = mixed_precision
         if sample_hw is not None:
             self.sample_size = tuple(sample_hw)
@@ -312,12 +316,17 @@ class UNet2DModel:
             N.check(lib.adm_unet_enable_training(h, N.ptr(self.flat.data), self.flat.numel))
         finally:
             N.check(lib.adm_set_option(b"conv_bf16", 0))
+            N.check(lib.adm_set_option(b"conv_op16_f16", 0))
         self._training = True
         return self.flat.data, self.flat_grads
 
-    def train_step(self, noisy, timesteps, target):
-        """loss = mse(unet(noisy, t), target) and its gradient w.r.t. every parameter (into `flat_grads`)."""
+    def train_step(self, noisy, timesteps, target, loss_scale=1.0):
+        """loss = mse(unet(noisy, t), target) and its gradient w.r.t. every parameter (into `flat_grads`). loss_scale (fp16):
+        the gradients carry that factor (the returned loss does not); `training.GradScaler` un-scales them."""
         assert getattr(self, "_training", False), "call enable_training() first"
+        if loss_scale != getattr(self, "_loss_scale", 1.0):
+            N.check(N.lib().adm_unet_set_loss_scale(self._handle, float(loss_scale)))
+            self._loss_scale = float(loss_scale)
         x, tgt = noisy.contiguous(), target.contiguous()
         B = x.shape[0]
         t = self._timesteps(timesteps, B)
@@ -431,8 +440,8 @@ class UNet2DConditionModel(UNet2DModel):
 
     __call__ = forward
 
-    def train_step(self, noisy, timesteps, target, encoder_hidden_states):
+    def train_step(self, noisy, timesteps, target, encoder_hidden_states, loss_scale=1.0):
         """`model(noisy_images, timesteps, batch["encoding"])` + mse + backward (scripts/train_unet.py:254-259)."""
         assert getattr(self, "_training", False), "call enable_training() first"
         self._set_encoding(self._handle, encoder_hidden_states, noisy.shape[0], noisy.device)
-        return UNet2DModel.train_step(self, noisy, timesteps, target)
+        return UNet2DModel.train_step(self, noisy, timesteps, target, loss_scale=loss_scale)

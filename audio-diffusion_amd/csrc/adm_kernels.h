@@ -58,6 +58,8 @@ int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int tra
 void set_conv_bf16(int m);   // 0 off (default), 1 = 3x3 convs, 2 = 3x3, 1x1 and stride-2 data-gradient convs, -1 = ADM_CONV_BF16
 bool conv_bf16_enabled();
 int conv_bf16_mode();
+void set_conv_op16_f16(int v);   // operand format of the 16-bit-operand kernels: 0 = bf16 (default), 1 = IEEE binary16
+bool conv_op16_f16();
 // k_conv1x1_bf16.hip (mode 2)
 bool conv1x1_bf16_eligible(const adm_conv_args& a);
 int launch_conv1x1_bf16(const adm_conv_args& a, hipStream_t st);

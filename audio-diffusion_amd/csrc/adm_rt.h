@@ -26,7 +26,9 @@
 // bf16 operand plumbing (k_conv_bf16.hip): two floats -> one dword of 2 x bf16 (round-to-nearest-even, low half = a),
 // v_mfma_f32_32x32x16_bf16 on 4-dword operands, v_alignbit_b32
 #define ADM_PK_BF16(a, b) adm_emu::pk_bf16((a), (b))
-#define ADM_MFMA_BF16(a, b, c) adm_emu::mfma_f32_32x32x16_bf16((a), (b), (c))
+#define ADM_MFMA_BF16(a, b, c) adm_emu::mfma_f32_32x32x16_op16<false>((a), (b), (c))
+#define ADM_PK_F16(a, b) adm_emu::pk_f16((a), (b))
+#define ADM_MFMA_F16(a, b, c) adm_emu::mfma_f32_32x32x16_op16<true>((a), (b), (c))
 #define ADM_ALIGNBIT(hi, lo, sh) ((unsigned)((((uint64_t)(hi) << 32) | (uint64_t)(lo)) >> (sh)))
 #define ADM_OPAQUE_V(x) ((void)0)
 #else
@@ -42,6 +44,12 @@ typedef __bf16 adm_bf16x2 __attribute__((ext_vector_type(2)));
 // any k assignment is valid as long as A and B use the same one. C/D: col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).
 #define ADM_MFMA_BF16(a, b, c) \
   __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(adm_bf16x8, (a)), __builtin_bit_cast(adm_bf16x8, (b)), (c), 0, 0, 0)
+// the same two operations on IEEE binary16 operands (`--mixed_precision fp16`): v_cvt_f16_f32 (RNE) x2 + pack, v_mfma_f32_32x32x16_f16
+typedef _Float16 adm_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 adm_f16x2 __attribute__((ext_vector_type(2)));
+#define ADM_PK_F16(a, b) __builtin_bit_cast(unsigned, adm_f16x2{(_Float16)(a), (_Float16)(b)})
+#define ADM_MFMA_F16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(adm_f16x8, (a)), __builtin_bit_cast(adm_f16x8, (b)), (c), 0, 0, 0)
 #define ADM_ALIGNBIT(hi, lo, sh) __builtin_amdgcn_alignbit((hi), (lo), (sh))
 // makes a per-lane value opaque to the optimiser (no instruction): stops it from folding a loop-invariant lane offset into
 // dozens of pre-computed 64-bit addresses that then live in registers across the whole loop
@@ -87,6 +95,10 @@ typedef __bf16 adm_bf16x2 __attribute__((ext_vector_type(2)));
     __builtin_amdgcn_sched_barrier(0);                                      \
   } while (0)
 #endif
+
+// 16-bit MFMA operand format as a compile-time flag of the kernels (F16_ false: bf16, true: IEEE binary16)
+#define ADM_PK16(F16_, a, b) ((F16_) ? ADM_PK_F16((a), (b)) : ADM_PK_BF16((a), (b)))
+#define ADM_MFMA16(F16_, a, b, c) ((F16_) ? ADM_MFMA_F16((a), (b), (c)) : ADM_MFMA_BF16((a), (b), (c)))
 
 namespace adm {
 

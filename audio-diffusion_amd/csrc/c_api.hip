@@ -19,6 +19,7 @@ int adm_set_option(const char* name, int value) {
   if (std::string(name) == "conv_wino") { adm::set_winograd_mode(value); return 0; }
   if (std::string(name) == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
   if (std::string(name) == "conv_bf16") { adm::set_conv_bf16(value); return 0; }
+  if (std::string(name) == "conv_op16_f16") { adm::set_conv_op16_f16(value); return 0; }
   ADM_FAIL(std::string("set_option: unknown option ") + name);
 }
 int adm_last_conv_variant(void) { return adm::last_conv_variant(); }

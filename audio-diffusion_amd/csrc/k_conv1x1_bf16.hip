@@ -31,7 +31,7 @@ __device__ __forceinline__ float silu_p(float v) { return v * ADM_RCP(1.0f + __e
 
 struct PwStage { float v[2][8]; };
 
-template <bool ACT>
+template <bool ACT, bool F16 = false>
 __global__ void __launch_bounds__(256, 1) conv1x1_bf16_kernel(const Bf16PwParams p) {
   ADM_DYN_SMEM(u32x4, lds);                 // [2 buffers][2 channel groups][256 pixels] + GroupNorm rows [2][Ct] floats
   const int tid = threadIdx.x, lane = tid & 63, wave = ADM_UNIFORM(tid >> 6);
@@ -79,8 +79,8 @@ __global__ void __launch_bounds__(256, 1) conv1x1_bf16_kernel(const Bf16PwParams
         v[e] = t;
       }
       u32x4 w;
-      w[0] = ADM_PK_BF16(v[0], v[1]); w[1] = ADM_PK_BF16(v[2], v[3]);
-      w[2] = ADM_PK_BF16(v[4], v[5]); w[3] = ADM_PK_BF16(v[6], v[7]);
+      w[0] = ADM_PK16(F16, v[0], v[1]); w[1] = ADM_PK16(F16, v[2], v[3]);
+      w[2] = ADM_PK16(F16, v[4], v[5]); w[3] = ADM_PK16(F16, v[6], v[7]);
       buf[g * 256 + tid] = w;
     }
   };
@@ -102,8 +102,8 @@ __global__ void __launch_bounds__(256, 1) conv1x1_bf16_kernel(const Bf16PwParams
     ADM_UNROLL
     for (int pt = 0; pt < 4; ++pt) {
       const u32x4 B = cur[bbase + 32 * pt];
-      acc[0][pt] = ADM_MFMA_BF16(f[0], B, acc[0][pt]);
-      acc[1][pt] = ADM_MFMA_BF16(f[1], B, acc[1][pt]);
+      acc[0][pt] = ADM_MFMA16(F16, f[0], B, acc[0][pt]);
+      acc[1][pt] = ADM_MFMA16(F16, f[1], B, acc[1][pt]);
     }
   };
   // same pipeline as conv_bf16_kernel: LDS double buffer, two patch register sets (two chunks ahead), filters one chunk ahead
@@ -180,8 +180,13 @@ int launch_conv1x1_bf16(const adm_conv_args& a, hipStream_t st) {
   const size_t smem = sizeof(u32x4) * 4 * 256 + sizeof(float) * 2 * Ct;
   ADM_REQUIRE(smem <= 64 * 1024, "conv1x1_bf16: too many input channels for the LDS GroupNorm rows");
   set_last_conv_variant(5000 + 116);
-  if (a.act) ADM_LAUNCH((conv1x1_bf16_kernel<true>), dim3(p.nblk), dim3(256), smem, st, p);
-  else ADM_LAUNCH((conv1x1_bf16_kernel<false>), dim3(p.nblk), dim3(256), smem, st, p);
+  if (conv_op16_f16()) {
+    if (a.act) ADM_LAUNCH((conv1x1_bf16_kernel<true, true>), dim3(p.nblk), dim3(256), smem, st, p);
+    else ADM_LAUNCH((conv1x1_bf16_kernel<false, true>), dim3(p.nblk), dim3(256), smem, st, p);
+  } else {
+    if (a.act) ADM_LAUNCH((conv1x1_bf16_kernel<true, false>), dim3(p.nblk), dim3(256), smem, st, p);
+    else ADM_LAUNCH((conv1x1_bf16_kernel<false, false>), dim3(p.nblk), dim3(256), smem, st, p);
+  }
   return ADM_CHECK_LAUNCH();
 }
 
@@ -200,7 +205,7 @@ struct Bf16PwWgradParams {
 // raw fp32 prefetch of one 64-pixel stage: 4 dy items + 4 input items per thread, 8 pixels (two float4) each
 struct PwWgStage { float4 d[4][2]; float4 x[4][2]; int n; };
 
-template <bool ACT>
+template <bool ACT, bool F16 = false>
 __global__ void __launch_bounds__(256, 1) conv1x1_wgrad_bf16_kernel(const Bf16PwWgradParams p) {
   constexpr int LD = 130;                   // fragments per pixel-group row of 128 channels (padded: see k_conv_bf16.hip)
   constexpr int BUF4 = 2 * 8 * LD;          // dy rows then input rows: [8 pixel groups][130]
@@ -256,8 +261,8 @@ __global__ void __launch_bounds__(256, 1) conv1x1_wgrad_bf16_kernel(const Bf16Pw
   };
   auto pack8 = [&](const float4& a, const float4& b) __attribute__((always_inline)) {
     u32x4 w;
-    w[0] = ADM_PK_BF16(a.x, a.y); w[1] = ADM_PK_BF16(a.z, a.w);
-    w[2] = ADM_PK_BF16(b.x, b.y); w[3] = ADM_PK_BF16(b.z, b.w);
+    w[0] = ADM_PK16(F16, a.x, a.y); w[1] = ADM_PK16(F16, a.z, a.w);
+    w[2] = ADM_PK16(F16, b.x, b.y); w[3] = ADM_PK16(F16, b.z, b.w);
     return w;
   };
   auto stash_stage = [&](const PwWgStage& s, u32x4* buf) __attribute__((always_inline)) {
@@ -289,7 +294,7 @@ __global__ void __launch_bounds__(256, 1) conv1x1_wgrad_bf16_kernel(const Bf16Pw
       ADM_UNROLL
       for (int a = 0; a < 2; ++a)
         ADM_UNROLL
-        for (int b = 0; b < 2; ++b) acc[a][b] = ADM_MFMA_BF16(A[a], B[b], acc[a][b]);
+        for (int b = 0; b < 2; ++b) acc[a][b] = ADM_MFMA16(F16, A[a], B[b], acc[a][b]);
     }
   };
   PwWgStage P, Q;
@@ -357,14 +362,21 @@ int launch_conv1x1_wgrad_bf16(const adm_conv_args& a, const float* dy, float* wo
   ADM_REQUIRE(smem <= 160 * 1024, "conv1x1_wgrad_bf16: batch too large for the LDS GroupNorm rows");
 #if !defined(ADM_EMU)
   static bool once = [] {
-    (void)hipFuncSetAttribute((const void*)conv1x1_wgrad_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv1x1_wgrad_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv1x1_wgrad_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv1x1_wgrad_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv1x1_wgrad_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv1x1_wgrad_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)once;
 #endif
-  if (a.act) ADM_LAUNCH((conv1x1_wgrad_bf16_kernel<true>), dim3(p.nblk), dim3(256), smem, st, p);
-  else ADM_LAUNCH((conv1x1_wgrad_bf16_kernel<false>), dim3(p.nblk), dim3(256), smem, st, p);
+  if (conv_op16_f16()) {
+    if (a.act) ADM_LAUNCH((conv1x1_wgrad_bf16_kernel<true, true>), dim3(p.nblk), dim3(256), smem, st, p);
+    else ADM_LAUNCH((conv1x1_wgrad_bf16_kernel<false, true>), dim3(p.nblk), dim3(256), smem, st, p);
+  } else {
+    if (a.act) ADM_LAUNCH((conv1x1_wgrad_bf16_kernel<true, false>), dim3(p.nblk), dim3(256), smem, st, p);
+    else ADM_LAUNCH((conv1x1_wgrad_bf16_kernel<false, false>), dim3(p.nblk), dim3(256), smem, st, p);
+  }
   return p.split;      // > 0: number of partial slabs written (the reduction must sum exactly these)
 }
 

@@ -43,7 +43,7 @@ template <int NA> struct Bf16Filt { u32x4 a[9][NA]; };  // the wave's A fragment
 // WIDE = false: waves as 2 (64 couts) x 2 (8 pixel rows), 2 x 4 accumulator tiles, the two waves of a cout half fetch the
 // same filter fragments.  WIDE = true: waves as 4 (32 couts) x 1, 1 x 8 accumulator tiles: every filter fragment is
 // fetched once per workgroup (half the L2 requests, 36 registers less) at one LDS read per MFMA instead of one per two.
-template <bool UP, bool ACT, bool WIDE>
+template <bool UP, bool ACT, bool WIDE, bool F16 = false>
 __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams p) {
   constexpr int NA = WIDE ? 1 : 2, NP = WIDE ? 8 : 4;
   // One workgroup per CU (up to 512 registers per lane) so that everything that comes from memory is requested a full
@@ -130,8 +130,8 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams 
         v[e] = so < 0 ? 0.f : t;                                   // zero padding applies to the activated tensor
       }
       u32x4 w;
-      w[0] = ADM_PK_BF16(v[0], v[1]); w[1] = ADM_PK_BF16(v[2], v[3]);
-      w[2] = ADM_PK_BF16(v[4], v[5]); w[3] = ADM_PK_BF16(v[6], v[7]);
+      w[0] = ADM_PK16(F16, v[0], v[1]); w[1] = ADM_PK16(F16, v[2], v[3]);
+      w[2] = ADM_PK16(F16, v[4], v[5]); w[3] = ADM_PK16(F16, v[6], v[7]);
       if (r < 2) buf[kg * BPP + 64 * wave + lane] = w;
       else if (has2) buf[kg * BPP + q2] = w;
       ADM_SCHED_FENCE();      // one round at a time: 24 interleaved SiLU chains cost ~70 temporaries
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams 
       ADM_UNROLL
       for (int pt = 0; pt < NP; ++pt) {
         ADM_UNROLL
-        for (int a = 0; a < NA; ++a) acc[a][pt] = ADM_MFMA_BF16(F.a[t][a], Bc[pt], acc[a][pt]);
+        for (int a = 0; a < NA; ++a) acc[a][pt] = ADM_MFMA16(F16, F.a[t][a], Bc[pt], acc[a][pt]);
       }
       ADM_SCHED_FENCE();
       fetch_tap(F, chn, t);
@@ -274,7 +274,7 @@ __device__ __forceinline__ int bdiv(int n, int d, unsigned magic) {   // n / d; 
 // raw fp32 prefetch of one 16x4-pixel tile: 4 dy items (8 pixels each), 7 patch pixel pairs, their in-bounds bits, image
 struct Bf16WgStage { float4 d[4][2]; float xa[7], xb[7]; unsigned ok; int n; };
 
-template <bool UP, bool ACT>
+template <bool UP, bool ACT, bool F16 = false>
 __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16WgradParams p) {
   // One workgroup per CU, everything from memory requested two tiles ahead (two register sets P/Q), converted into the
   // LDS buffer the MFMAs are not reading, one barrier per tile.  The first version loaded, converted and multiplied tile
@@ -373,8 +373,8 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
     for (int j = 0; j < 4; ++j) {
       const float4 v0 = s.d[j][0], v1 = s.d[j][1];
       u32x4 w;
-      w[0] = ADM_PK_BF16(v0.x, v0.y); w[1] = ADM_PK_BF16(v0.z, v0.w);
-      w[2] = ADM_PK_BF16(v1.x, v1.y); w[3] = ADM_PK_BF16(v1.z, v1.w);
+      w[0] = ADM_PK16(F16, v0.x, v0.y); w[1] = ADM_PK16(F16, v0.z, v0.w);
+      w[2] = ADM_PK16(F16, v1.x, v1.y); w[3] = ADM_PK16(F16, v1.z, v1.w);
       buf[ldsd[j]] = w;
     }
     ADM_UNROLL
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
       a = (s.ok >> (2 * j)) & 1u ? a : 0.f;          // zero padding applies to the activated tensor
       b = (s.ok >> (2 * j)) & 2u ? b : 0.f;
       unsigned* dst = ldsx[j] >= 0 ? bufX + ldsx[j] : dummy + tid;
-      *dst = ADM_PK_BF16(a, b);
+      *dst = ADM_PK16(F16, a, b);
     }
   };
   auto mfma_tile = [&](const u32x4* buf, bool valid) __attribute__((always_inline)) {
@@ -403,9 +403,9 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
         s1[0] = ADM_ALIGNBIT(d[1], d[0], 16); s1[1] = ADM_ALIGNBIT(d[2], d[1], 16);
         s1[2] = ADM_ALIGNBIT(d[3], d[2], 16); s1[3] = ADM_ALIGNBIT(d4, d[3], 16);
         s2[0] = d[1]; s2[1] = d[2]; s2[2] = d[3]; s2[3] = d4;
-        acc[dy3 * 3 + 0] = ADM_MFMA_BF16(A, d, acc[dy3 * 3 + 0]);
-        acc[dy3 * 3 + 1] = ADM_MFMA_BF16(A, s1, acc[dy3 * 3 + 1]);
-        acc[dy3 * 3 + 2] = ADM_MFMA_BF16(A, s2, acc[dy3 * 3 + 2]);
+        acc[dy3 * 3 + 0] = ADM_MFMA16(F16, A, d, acc[dy3 * 3 + 0]);
+        acc[dy3 * 3 + 1] = ADM_MFMA16(F16, A, s1, acc[dy3 * 3 + 1]);
+        acc[dy3 * 3 + 2] = ADM_MFMA16(F16, A, s2, acc[dy3 * 3 + 2]);
       }
     }
   };
@@ -441,10 +441,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
   }
 }
 
+bool conv_op16_f16();
 static int g_bf16_mode = -1;   // -1: ADM_CONV_BF16 from the environment (default 0 = fp32 everywhere; 2 = 1x1 convs too)
 bool conv_bf16_enabled();
 
 // ---------------------------------------------------------------- filters: fp32 (Cout,Cin,3,3) -> bf16 [tap][Cin/8][Cout][8]
+template <bool F16>
 __global__ void pack_bf16_weight_kernel(const float* __restrict__ w, unsigned* __restrict__ wb, int Cout, int Cin,
                                         int transposed, int taps) {
   // one thread per bf16 PAIR of the packed tensor. transposed: the data-gradient filters (roles of Cout/Cin swapped, taps
@@ -467,7 +469,7 @@ __global__ void pack_bf16_weight_kernel(const float* __restrict__ w, unsigned* _
     a = w[((long)ci * Cin + co) * taps + (taps - 1 - t)];
     b = w[((long)(ci + 1) * Cin + co) * taps + (taps - 1 - t)];
   }
-  wb[i] = ADM_PK_BF16(a, b);
+  wb[i] = ADM_PK16(F16, a, b);
 }
 
 int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transposed, hipStream_t st, int ks) {
@@ -475,8 +477,12 @@ int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int tra
   ADM_REQUIRE(ks == 3 || ks == 1, "pack_bf16_weight: ks must be 1 or 3");
   const int taps = ks * ks;
   const long total = (long)taps * Cin * Cout / 2;
-  ADM_LAUNCH(pack_bf16_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (unsigned*)wb, Cout, Cin,
-             transposed, taps);
+  if (conv_op16_f16())
+    ADM_LAUNCH(pack_bf16_weight_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (unsigned*)wb, Cout, Cin,
+               transposed, taps);
+  else
+    ADM_LAUNCH(pack_bf16_weight_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (unsigned*)wb, Cout, Cin,
+               transposed, taps);
   return ADM_CHECK_LAUNCH();
 }
 int conv_bf16_mode() {
@@ -485,6 +491,9 @@ int conv_bf16_mode() {
 }
 
 // ---------------------------------------------------------------- dispatch
+static int g_op16_f16 = 0;     // operand format of the 16-bit kernels: 0 = bf16, 1 = IEEE binary16 (`--mixed_precision fp16`)
+void set_conv_op16_f16(int v) { g_op16_f16 = v != 0; }
+bool conv_op16_f16() { return g_op16_f16 != 0; }
 void set_conv_bf16(int m) { g_bf16_mode = m; }
 bool conv_bf16_enabled() {
   if (g_bf16_mode < 0) { const char* e = getenv("ADM_CONV_BF16"); g_bf16_mode = e ? atoi(e) : 0; }
@@ -527,7 +536,11 @@ int launch_conv_bf16(const adm_conv_args& a, hipStream_t st) {
   ADM_REQUIRE(smem <= 64 * 1024, "conv_bf16: too many input channels for the LDS GroupNorm rows");
   set_last_conv_variant(5000 + 316);
   // WIDE = true (waves 4 x 1) measured 640 vs 634 us on 128->128 @256^2: not instantiated
-#define ADM_BF16_LAUNCH(UP_, ACT_) ADM_LAUNCH((conv_bf16_kernel<UP_, ACT_, false>), dim3(p.nblk), dim3(256), smem, st, p)
+#define ADM_BF16_LAUNCH(UP_, ACT_)                                                                          \
+  do {                                                                                                      \
+    if (conv_op16_f16()) ADM_LAUNCH((conv_bf16_kernel<UP_, ACT_, false, true>), dim3(p.nblk), dim3(256), smem, st, p);   \
+    else ADM_LAUNCH((conv_bf16_kernel<UP_, ACT_, false, false>), dim3(p.nblk), dim3(256), smem, st, p);                  \
+  } while (0)
   if (a.up) {
     if (a.act) ADM_BF16_LAUNCH(true, true);
     else ADM_BF16_LAUNCH(true, false);
@@ -577,12 +590,17 @@ int launch_conv_wgrad_bf16(const adm_conv_args& a, const float* dy, float* dW, i
   const size_t smem = 2 * (sizeof(u32x4) * 8 * 130 + sizeof(unsigned) * 6 * 32 * 12) + sizeof(unsigned) * 256 +
                       sizeof(float) * 64 * (size_t)a.N;
   ADM_REQUIRE(smem <= 64 * 1024, "conv_wgrad_bf16: batch too large for the LDS GroupNorm rows");
+#define ADM_WG16_LAUNCH(UP_, ACT_)                                                                             \
+  do {                                                                                                         \
+    if (conv_op16_f16()) ADM_LAUNCH((conv_wgrad_bf16_kernel<UP_, ACT_, true>), dim3(p.nblk), dim3(256), smem, st, p);  \
+    else ADM_LAUNCH((conv_wgrad_bf16_kernel<UP_, ACT_, false>), dim3(p.nblk), dim3(256), smem, st, p);                 \
+  } while (0)
   if (a.up) {
-    if (a.act) ADM_LAUNCH((conv_wgrad_bf16_kernel<true, true>), dim3(p.nblk), dim3(256), smem, st, p);
-    else ADM_LAUNCH((conv_wgrad_bf16_kernel<true, false>), dim3(p.nblk), dim3(256), smem, st, p);
+    if (a.act) ADM_WG16_LAUNCH(true, true);
+    else ADM_WG16_LAUNCH(true, false);
   } else {
-    if (a.act) ADM_LAUNCH((conv_wgrad_bf16_kernel<false, true>), dim3(p.nblk), dim3(256), smem, st, p);
-    else ADM_LAUNCH((conv_wgrad_bf16_kernel<false, false>), dim3(p.nblk), dim3(256), smem, st, p);
+    if (a.act) ADM_WG16_LAUNCH(false, true);
+    else ADM_WG16_LAUNCH(false, false);
   }
   return ADM_CHECK_LAUNCH();
 }

@@ -49,10 +49,17 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
 
 // out[0] = loss or norm helper: finalises scalars on the device so no host sync is needed inside the step.
 __global__ void finalize_scalars_kernel(const double* __restrict__ acc, double inv_n, float max_norm,
-                                        float* __restrict__ out) {
-  // mode by inv_n: >0 -> out[0] = acc*inv_n (mean); ==0 -> out[0] = total_norm, out[1] = clip coefficient
+                                        float* __restrict__ out, float inv_scale = 1.0f) {
+  // mode by inv_n: >0 -> out[0] = acc*inv_n (mean); ==0 -> out[0] = total_norm, out[1] = clip coefficient.
+  // inv_scale (fp16 loss scaling): the gradients carry the factor 1/inv_scale; the norm is reported unscaled and the
+  // coefficient un-scales and clips in one multiply. A non-finite norm stays non-finite (the caller skips the step).
   if (inv_n > 0.0) {
     out[0] = (float)(acc[0] * inv_n);
+  } else if (inv_scale != 1.0f) {
+    const float total = (float)sqrt(acc[0]) * inv_scale;
+    out[0] = total;
+    const float coef = max_norm / (total + 1e-6f);
+    out[1] = (coef < 1.0f ? coef : 1.0f) * inv_scale;
   } else {
     const float total = (float)sqrt(acc[0]);
     out[0] = total;
@@ -142,6 +149,18 @@ int adm_grad_norm_clip(const float* grads, long n, float max_norm, float* norm_c
   ADM_TRY(dmemset(scratch, 0, sizeof(double), st));
   ADM_LAUNCH(sqnorm_kernel, dim3(tgrid(n / 4 + 1)), dim3(256), 0, st, grads, n, scratch);
   ADM_LAUNCH(finalize_scalars_kernel, dim3(1), dim3(1), 0, st, (const double*)scratch, 0.0, max_norm, norm_clip_out);
+  return ADM_CHECK_LAUNCH();
+}
+
+// clip_grad_norm_ on loss-SCALED gradients (GradScaler.unscale_ + clip in one): norm_clip_out = {||g||_2 * inv_scale,
+// min(1, max_norm/(that + 1e-6)) * inv_scale}; non-finite gradients give a non-finite norm.
+int adm_grad_norm_clip_scaled(const float* grads, long n, float max_norm, float inv_scale, float* norm_clip_out, double* scratch,
+                              void* stream) {
+  ADM_REQUIRE(grads && norm_clip_out && scratch && n > 0 && inv_scale > 0.f, "grad_norm_clip_scaled: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  ADM_TRY(dmemset(scratch, 0, sizeof(double), st));
+  ADM_LAUNCH(sqnorm_kernel, dim3(tgrid(n / 4 + 1)), dim3(256), 0, st, grads, n, scratch);
+  ADM_LAUNCH(finalize_scalars_kernel, dim3(1), dim3(1), 0, st, (const double*)scratch, 0.0, max_norm, norm_clip_out, inv_scale);
   return ADM_CHECK_LAUNCH();
 }
 

@@ -42,6 +42,8 @@ struct adm_unet {
   bool training = false;
   int warm_B = 0;         // batch size at which an uncaptured forward has already run (see run_loop)
   int bf16_level = 0;     // mixed-precision level of THIS model (option conv_bf16 as it stood at adm_unet_enable_training)
+  int op16_f16 = 0;       // ... and the operand format of its 16-bit kernels (option conv_op16_f16: fp16 instead of bf16)
+  float loss_scale = 1.f; // fp16 loss scaling (adm_unet_set_loss_scale)
   long params_numel = 0;
   float *dtemb_all = nullptr, *demb = nullptr, *dz = nullptr, *save_sinus = nullptr, *save_z = nullptr;
   double* scratch_d = nullptr;
@@ -124,9 +126,12 @@ static int restack_temb(adm_unet* h, hipStream_t st) {
 // training entry points runs (and while its weights are packed), and every inference entry point runs at level 0 — so the
 // sampling path stays fp32 even through a training handle, and one model's setting never leaks into another's.
 struct Bf16Scope {
-  int prev;
-  explicit Bf16Scope(int level) : prev(conv_bf16_mode()) { set_conv_bf16(level); }
-  ~Bf16Scope() { set_conv_bf16(prev); }
+  int prev, prev_fmt;
+  explicit Bf16Scope(int level, int f16 = 0) : prev(conv_bf16_mode()), prev_fmt(conv_op16_f16() ? 1 : 0) {
+    set_conv_bf16(level);
+    set_conv_op16_f16(f16);
+  }
+  ~Bf16Scope() { set_conv_bf16(prev); set_conv_op16_f16(prev_fmt); }
 };
 
 // Inference through a training handle: packings refreshed in full first (begin_inference), training's usage masks restored after.
@@ -137,7 +142,7 @@ struct InferenceScope {
 };
 
 static int finalize(adm_unet* h) {
-  Bf16Scope pack_scope(h->training ? h->bf16_level : 0);
+  Bf16Scope pack_scope(h->training ? h->bf16_level : 0, h->training ? h->op16_f16 : 0);
   if (h->finalized) return 0;
   std::string missing;
   const int nmiss = h->ps.missing(&missing);
@@ -465,14 +470,21 @@ int adm_unet_enable_training(adm_unet_t* h, const float* params_base, long numel
                 "unet_enable_training: parameter " + kv.first + " is not bound inside the flat buffer");
   h->training = true;
   h->bf16_level = conv_bf16_mode();
+  h->op16_f16 = conv_op16_f16() ? 1 : 0;
   h->params_numel = numel;
   h->net.params_base = params_base;
   return 0;
 }
 
+int adm_unet_set_loss_scale(adm_unet_t* h, float scale) {
+  ADM_REQUIRE(h && scale > 0.f, "unet_set_loss_scale: bad argument");
+  h->loss_scale = scale;
+  return 0;
+}
+
 int adm_unet_refresh_weights(adm_unet_t* h, void* stream) {
   ADM_REQUIRE(h && h->finalized, "unet_refresh_weights: model not finalized");
-  Bf16Scope own(h->bf16_level);
+  Bf16Scope own(h->bf16_level, h->op16_f16);
   ADM_TRY(h->net.refresh_weights((hipStream_t)stream));
   return restack_temb(h, (hipStream_t)stream);
 }
@@ -485,7 +497,7 @@ int adm_unet_forward_backward(adm_unet_t* h, const float* x, const float* timest
   ADM_REQUIRE(h->training, "unet_forward_backward: call adm_unet_enable_training first");
   ADM_REQUIRE(n_timesteps == 1 || n_timesteps == B, "unet_forward_backward: need 1 or B timesteps");
   hipStream_t st = (hipStream_t)stream;
-  Bf16Scope own(h->bf16_level);
+  Bf16Scope own(h->bf16_level, h->op16_f16);
   ADM_TRY(finalize(h));
   ADM_TRY(plan(h, B));
   std::vector<float> t(B);
@@ -497,6 +509,8 @@ int adm_unet_forward_backward(adm_unet_t* h, const float* x, const float* timest
   const adm_unet_config& c = h->cfg;
   const long n_out = (long)B * c.out_channels * c.sample_h * c.sample_w;
   ADM_TRY(adm_mse_loss(h->eps_buf, target, n_out, loss_dev, net.tensors[net.t_out].grad, h->scratch_d, st));
+  if (h->loss_scale != 1.f)   // fp16 loss scaling: every gradient of the reverse pass carries the factor
+    ADM_TRY(adm_flat_op(net.tensors[net.t_out].grad, net.tensors[net.t_out].grad, n_out, 1, h->loss_scale, st));
   net.grads_base = grads_base;
   net.bucket_reset();
   ADM_TRY(dmemset(grads_base, 0, sizeof(float) * (size_t)h->params_numel, st));

@@ -54,9 +54,6 @@ def load_images(args, resolution):
 
 
 def main(args):
-    if args.mixed_precision == "fp16":
-        raise NotImplementedError("mixed_precision: 'no' (fp32, the reference default) and 'bf16' are implemented; fp16 "
-                                  "would need loss scaling, which gfx950's bf16 MFMA path makes pointless")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,6 +132,7 @@ def main(args):
     if world > 1 and args.gradient_accumulation_steps == 1:
         reducer.attach(model)        # DDP overlap: buckets are all-reduced while the reverse pass is still running
     accum = T.GradAccumulator(grads, args.gradient_accumulation_steps)     # accelerator.accumulate(model), :252
+    scaler = T.GradScaler() if args.mixed_precision == "fp16" else None     # accelerate's GradScaler under fp16 (:391-395)
 
     global_step = 0
     for epoch in range(args.num_epochs):
@@ -157,17 +155,31 @@ def main(args):
             timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (clean.shape[0],)).long()
             noisy = noise_scheduler.add_noise(clean.contiguous(), noise, timesteps)
             reducer.begin_step()
+            ls = scaler.get_scale() if scaler is not None else 1.0
             if enc_table is not None:                                      # :254-255
-                loss = model.train_step(noisy, timesteps, noise, enc_table[idx].to(dev))
+                loss = model.train_step(noisy, timesteps, noise, enc_table[idx].to(dev), loss_scale=ls)
             else:
-                loss = model.train_step(noisy, timesteps, noise)
+                loss = model.train_step(noisy, timesteps, noise, loss_scale=ls)
             if accum.add(last_batch=(it == steps_per_epoch - 1)):          # accelerator.sync_gradients
                 reducer.start()
                 reducer.finish()
-                clip = T.clip_grad_norm_(grads, 1.0)
-                optimizer.step(grads, clip=clip, ema=ema, ema_decay=ema.next_decay() if ema is not None else 0.0)
-                lr_scheduler.step()
-                model.refresh_weights()
+                found_inf = False
+                if scaler is not None:                                     # unscale_ + clip_grad_norm_ in one pass; overflow check
+                    clip, found_inf = scaler.unscale_and_clip_(grads, 1.0)
+                    if world > 1:                                          # every rank takes the same decision
+                        flag = torch.tensor([float(found_inf)], device=dev)
+                        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                        found_inf = bool(flag.item())
+                    scaler.update(found_inf)
+                else:
+                    clip = T.clip_grad_norm_(grads, 1.0)
+                if found_inf:                                              # GradScaler.step skips the optimizer; accelerate then
+                    if ema is not None:                                    # skips the LR scheduler too; the EMA still steps
+                        ema.step(flat)
+                else:
+                    optimizer.step(grads, clip=clip, ema=ema, ema_decay=ema.next_decay() if ema is not None else 0.0)
+                    lr_scheduler.step()
+                    model.refresh_weights()
             elif ema is not None:                                           # micro-step: no collective (no_sync), optimizer and
                 ema.step(flat)                                              # scheduler skipped, EMA still stepped (:265-266)
             global_step += 1

@@ -71,7 +71,7 @@ def parse():
                    help="sample (default): BASELINE.json's metric. train: config 5 (scripts/train_unet.py step) as the main line.")
     p.add_argument("--train-batch-per-gpu", type=int, default=16)
     p.add_argument("--train-steps", type=int, default=10)
-    p.add_argument("--mixed-precision", choices=["no", "bf16"], default="bf16",
+    p.add_argument("--mixed-precision", choices=["no", "bf16", "fp16"], default="bf16",
                    help="training precision: bf16 = BASELINE.json config 5 as written (bf16 MFMA operands, fp32 accumulate)")
     return p.parse_args()
 
@@ -152,28 +152,37 @@ def train_leg(job, B, steps, warmup, mixed_precision):
     ts = torch.randint(0, 1000, (B,), generator=g)
     last = {}
 
+    scaler = T.GradScaler() if mp == "fp16" else None
+
     def step():
         noisy = sched.add_noise(clean, noise, ts)
         red.begin_step()
-        last["loss"] = unet.train_step(noisy, ts, noise)
+        last["loss"] = unet.train_step(noisy, ts, noise, loss_scale=scaler.get_scale() if scaler else 1.0)
         last["overlapped"] = red.overlapped
         red.start(), red.finish()
-        opt.step(grads, clip=T.clip_grad_norm_(grads, 1.0), ema=ema, ema_decay=ema.next_decay())
+        if scaler:                      # GradScaler: un-scale + clip in one pass, skip the step on an overflow
+            clip, found_inf = scaler.unscale_and_clip_(grads, 1.0)
+            scaler.update(found_inf)
+            if found_inf:
+                return
+        else:
+            clip = T.clip_grad_norm_(grads, 1.0)
+        opt.step(grads, clip=clip, ema=ema, ema_decay=ema.next_decay())
         unet.refresh_weights()
 
     elapsed = job.timed(step, steps, warmup)
     value = job.world * B * steps / elapsed
     return {"metric": "training samples/sec (256x256 UNet2D, fwd+bwd+all-reduce+AdamW+EMA)", "value": round(value, 3),
             "unit": "samples/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 2),
-            "batch_per_gpu": B, "global_batch": job.world * B, "dtype": "bf16" if mp == "bf16" else "f32",
+            "batch_per_gpu": B, "global_batch": job.world * B, "dtype": mp if mp in ("bf16", "fp16") else "f32",
             "workload": "scripts/train_unet.py step, 256x256, " +
-                        ("--mixed_precision bf16 (bf16 MFMA operands on the 3x3 and 1x1 convolutions of all three passes, fp32 "
-                         "accumulate / storage / optimizer)" if mp == "bf16" else "fp32 (reference default mixed_precision=no)"),
+                        (f"--mixed_precision {mp} ({mp} MFMA operands on the 3x3 and 1x1 convolutions of all three passes, fp32 "
+                         "accumulate / storage / optimizer)" if mp != "no" else "fp32 (reference default mixed_precision=no)"),
             "parallelism": f"data parallel x{job.world}, 25 MB gradient buckets all-reduced from inside the reverse pass",
             "allreduce_buckets": len(red.bounds), "allreduce_buckets_overlapped": last.get("overlapped", 0),
             "TFLOPs_3x_fwd": round(value * 3 * F1_TFLOP / job.world, 2),
-            ("frac_of_bf16_peak" if mp == "bf16" else "frac_of_fp32_peak"):
-                round(value * 3 * F1_TFLOP / job.world / (PEAK_BF16_TF if mp == "bf16" else PEAK_F32_TF), 4),
+            ("frac_of_16bit_mfma_peak" if mp != "no" else "frac_of_fp32_peak"):
+                round(value * 3 * F1_TFLOP / job.world / (PEAK_BF16_TF if mp != "no" else PEAK_F32_TF), 4),
             "final_loss": float(last["loss"])}
 
 

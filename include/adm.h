@@ -236,6 +236,9 @@ int adm_unet_refresh_weights(adm_unet_t* h, void* stream);
  * Every activation is kept for the reverse pass; GroupNorm/SiLU are recomputed in the weight-gradient load path. */
 int adm_unet_forward_backward(adm_unet_t* h, const float* x, const float* timesteps_host, int n_timesteps,
                               const float* target, float* loss_dev, float* grads_base, int B, void* stream);
+/* `--mixed_precision fp16`: the factor the loss gradient is multiplied with before the reverse pass (GradScaler's scale;
+ * 1 = off). The gradients adm_unet_forward_backward writes then carry it: un-scale with adm_grad_norm_clip_scaled. */
+int adm_unet_set_loss_scale(adm_unet_t* h, float scale);
 /* Data-parallel overlap (DistributedDataParallel's bucketed all-reduce running under autograd, train_unet.py:259): cut the
  * flat gradient buffer into n_buckets ranges [bounds[b], bounds[b+1]) (elements, ascending, n_buckets + 1 values);
  * fn(user, b) is called on the calling thread during adm_unet_forward_backward as soon as the last kernel writing into
@@ -288,6 +291,11 @@ int adm_mse_loss(const float* pred, const float* target, long n, float* loss_out
                  void* stream);
 /* clip_grad_norm_ (:261-262): norm_clip_out = {||g||_2, min(1, max_norm/(||g||_2+1e-6))}; scratch: double[1]. */
 int adm_grad_norm_clip(const float* grads, long n, float max_norm, float* norm_clip_out, double* scratch, void* stream);
+/* the same on loss-scaled gradients (`--mixed_precision fp16`: GradScaler.unscale_ + clip_grad_norm_ in one pass):
+ * norm_clip_out = {||g||_2 * inv_scale, min(1, max_norm/(norm + 1e-6)) * inv_scale}; inf / nan gradients give a non-finite
+ * norm, on which the caller skips the optimizer step and backs the scale off. */
+int adm_grad_norm_clip_scaled(const float* grads, long n, float max_norm, float inv_scale, float* norm_clip_out, double* scratch,
+                              void* stream);
 /* torch.optim.AdamW step (:263; lr/betas/wd/eps :166-172) fused with the clip factor (device scalar, NULL = 1) and
  * diffusers EMAModel.step (:265-266; ema == NULL skips): shadow -= (1-ema_decay)*(shadow-param). step is 1-based. */
 int adm_adamw_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, long n, float lr,

@@ -291,8 +291,36 @@ static inline uint32_t bf16_bits(float f) {        // round-to-nearest-even, NaN
 }
 static inline unsigned pk_bf16(float a, float b) { return bf16_bits(a) | (bf16_bits(b) << 16); }
 static inline float bf16_val(uint32_t dword, int hi) { uint32_t u = hi ? (dword & 0xffff0000u) : (dword << 16); float f; memcpy(&f, &u, 4); return f; }
-// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8(l>>5)+e], B[k][j=l&31]; exact products, fp32 accumulation in k order
-static inline f32x16 mfma_f32_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
+// IEEE binary16 <-> binary32 (round-to-nearest-even on the way down, as v_cvt_f16_f32; subnormals kept)
+static inline uint32_t f16_bits(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u, ax = u & 0x7fffffffu;
+  if (ax > 0x7f800000u) return sign | 0x7e00u;                       // NaN
+  if (ax >= 0x477ff000u) return sign | 0x7c00u;                      // >= 65520 rounds to inf (also inf)
+  if (ax < 0x33000001u) return sign;                                 // < 2^-25 (or exactly 2^-25: ties to even = 0)
+  int e = (int)(ax >> 23) - 127;
+  uint32_t m = (ax & 0x7fffffu) | 0x800000u;                         // 24-bit significand
+  int shift = e < -14 ? 13 + (-14 - e) : 13;                         // bits dropped (subnormal: more)
+  uint32_t half = m >> shift, rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+  if (rem > mid || (rem == mid && (half & 1u))) ++half;
+  if (e < -14) return sign | half;                                   // subnormal (a carry into 0x400 is the smallest normal)
+  return sign | (uint32_t)(((e + 15) << 10) + (half - 0x400u));      // a carry out of the significand bumps the exponent
+}
+static inline float f16_val(uint32_t dword, int hi) {
+  const uint32_t h = hi ? (dword >> 16) : (dword & 0xffffu);
+  const uint32_t sign = (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+  uint32_t u;
+  if (e == 0) {
+    if (m == 0) u = sign;
+    else { int k = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; ++k; } u = sign | (uint32_t)((113 - k) << 23) | ((mm & 0x3ffu) << 13); }
+  } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+  else u = sign | ((e + 112u) << 23) | (m << 13);
+  float f; memcpy(&f, &u, 4); return f;
+}
+static inline unsigned pk_f16(float a, float b) { return f16_bits(a) | (f16_bits(b) << 16); }
+// v_mfma_f32_32x32x16_bf16 / _f16: A[i=l&31][k=8(l>>5)+e], B[k][j=l&31]; exact products, fp32 accumulation in k order
+template <bool F16>
+static inline f32x16 mfma_f32_32x32x16_op16(u32x4 a, u32x4 b, f32x16 c) {
   int lane = flat_tid() & 63;
   Wave& w = S().waves[flat_tid() >> 6];
   for (int q = 0; q < 4; ++q) { w.a8[lane][q] = a[q]; w.b8[lane][q] = b[q]; }
@@ -303,8 +331,11 @@ static inline f32x16 mfma_f32_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
     int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     float acc = c[r];
     for (int h = 0; h < 2; ++h)
-      for (int e = 0; e < 8; ++e)
-        acc = fmaf(bf16_val(w.a8[i + 32 * h][e >> 1], e & 1), bf16_val(w.b8[j + 32 * h][e >> 1], e & 1), acc);
+      for (int e = 0; e < 8; ++e) {
+        const float x = F16 ? f16_val(w.a8[i + 32 * h][e >> 1], e & 1) : bf16_val(w.a8[i + 32 * h][e >> 1], e & 1);
+        const float y = F16 ? f16_val(w.b8[j + 32 * h][e >> 1], e & 1) : bf16_val(w.b8[j + 32 * h][e >> 1], e & 1);
+        acc = fmaf(x, y, acc);
+      }
     d[r] = acc;
   }
   wave_sync();

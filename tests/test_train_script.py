@@ -73,7 +73,8 @@ def _rank_main(rank, world, port, start_dir, out_dir, res_dir):
                                    "--synthetic_size", "8", "--output_dir", out_dir, "--train_batch_size", "2",
                                    "--num_epochs", "1", "--save_model_epochs", "1", "--lr_warmup_steps", "1",
                                    "--learning_rate", "1e-3", "--hop_length", "64", "--sample_rate", "4000", "--n_fft", "256",
-                                   "--mixed_precision", "bf16"]))     # accepted; this width has no bf16-eligible conv
+                                   "--mixed_precision", "fp16"]))     # GradScaler path: loss scale 65536, un-scale + clip in one
+                                                                      # pass, overflow flag all-reduced (this width has few 16-bit-eligible convs)
     np.save(os.path.join(res_dir, f"flat{rank}.npy"), model.flat.data.cpu().numpy())
 
 

@@ -269,3 +269,77 @@ def test_mixed_precision_bf16_training_step(backend):
     e32 = max(float((grads32[m32.flat.offsets[n][0]:m32.flat.offsets[n][0] + g32[n].numel()].view(g32[n].shape).cpu()
                      - g32[n]).abs().max()) / max(float(g32[n].abs().max()), 1e-2 * gmax) for n in g32)
     assert e32 < 2e-4 and abs(loss32 - float(loss_ref.detach())) <= 1e-5 * float(loss_ref.detach())
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_mixed_precision_fp16_training_step_and_grad_scaler(backend):
+    """`--mixed_precision fp16` (train_unet.py:391-395): the 16-bit-operand kernels on IEEE binary16 + GradScaler semantics.
+    (1) with the loss scaled by 65536 the UN-scaled gradient is within fp16 tolerance of the fp32 autograd oracle (and closer
+    than bf16's bar: 11 significand bits instead of 8); (2) the scale does not change the un-scaled result beyond rounding;
+    (3) gradients too small for binary16 are flushed without the scale and survive with it; (4) an overflow is detected, the step skipped and the
+    scale halved; (5) the scale doubles after `growth_interval` finite steps."""
+    dev = select(backend)
+    from audiodiffusion import training as T
+    from audiodiffusion.unet import UNet2DModel
+    torch.manual_seed(0)
+    ref = OracleUNet(**BF16CFG)
+    g = torch.Generator().manual_seed(1)
+    x, tgt = torch.randn((2, 1, 16, 16), generator=g), torch.randn((2, 1, 16, 16), generator=g)
+    ts = torch.tensor([5, 700])
+    loss_ref = F.mse_loss(ref(x, ts)["sample"], tgt)
+    loss_ref.backward()
+    g32 = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    gnorm = float(torch.sqrt(sum(v.double().pow(2).sum() for v in g32.values())))
+
+    m = UNet2DModel(**BF16CFG).load_state_dict(ref.state_dict())
+    flat, grads = m.enable_training(mixed_precision="fp16")
+    scaler = T.GradScaler(growth_interval=2)
+
+    def rel_err(scale):
+        loss = float(m.train_step(x.to(dev), ts, tgt.to(dev), loss_scale=scale))
+        num = den = 0.0
+        for n, p in ref.named_parameters():
+            off = m.flat.offsets[n][0]
+            d = grads[off:off + p.numel()].view(p.shape).cpu() / scale - g32[n]
+            num += float(d.double().pow(2).sum()); den += float(g32[n].double().pow(2).sum())
+        return loss, (num / den) ** 0.5
+
+    loss, e_scaled = rel_err(scaler.get_scale())
+    assert abs(loss - float(loss_ref.detach())) <= 2e-3 * float(loss_ref.detach())
+    assert 1e-6 < e_scaled < 3e-3, e_scaled                                                  # (1) fp16 rounding visible, far inside bf16's 1.5e-2
+    clip, found_inf = scaler.unscale_and_clip_(grads, 1.0)
+    assert not found_inf and abs(float(clip[0]) - gnorm) <= 5e-3 * gnorm                      # the TRUE norm is reported
+    assert abs(float(clip[1]) * scaler.get_scale() - min(1.0, 1.0 / (gnorm + 1e-6))) <= 5e-3   # coefficient = clip / scale
+    _, e_one = rel_err(1.0)
+    assert abs(e_one - e_scaled) < 3e-3                                                       # (2)
+    # (3) binary16's range is why the scale exists: with the loss gradient scaled DOWN by 1e-7 (what small late-training
+    # gradients look like) the first layer's gradient — which has come through every binary16 data-gradient convolution — is
+    # flushed away, while at 65536 it is within a percent of fp32 autograd
+    off, n_in = m.flat.offsets["conv_in.weight"][0], g32["conv_in.weight"].numel()
+    want = g32["conv_in.weight"].flatten()
+
+    def first_layer_err(scale):
+        m.train_step(x.to(dev), ts, tgt.to(dev), loss_scale=scale)
+        return float(((grads[off:off + n_in].cpu() / scale - want).norm() / want.norm()))
+
+    assert first_layer_err(65536.0) < 1e-2
+    assert first_layer_err(1e-7) > 0.5
+    # (4) overflow: a huge scale makes the operands infinite -> non-finite norm -> skipped step, scale halves
+    m.train_step(x.to(dev), ts, tgt.to(dev), loss_scale=1e38)
+    big = T.GradScaler(init_scale=1e38)
+    _, inf = big.unscale_and_clip_(grads, 1.0)
+    assert inf
+    big.update(inf)
+    assert big.step_was_skipped and big.get_scale() == 0.5e38
+    # (5) growth
+    s0 = scaler.get_scale()
+    scaler.update(False); assert scaler.get_scale() == s0
+    scaler.update(False); assert scaler.get_scale() == 2 * s0 and not scaler.step_was_skipped
+    # an optimizer step with the scaled-gradient coefficient lowers the loss
+    loss_a, _ = rel_err(s0)
+    clip, _ = T.GradScaler(init_scale=s0).unscale_and_clip_(grads, 1.0)
+    opt = T.AdamW(flat, lr=1e-4)
+    opt.step(grads, clip=clip)
+    m.refresh_weights()
+    loss_b, _ = rel_err(s0)
+    assert loss_b < loss_a
