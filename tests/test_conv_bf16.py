@@ -297,3 +297,47 @@ def test_conv_bf16_stride2_data_gradient_by_zero_insertion(backend):
         _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
     exact = torch.nn.grad.conv2d_input((Nn, Cin, H, W), _bf(w.cpu()), _bf(dy.cpu()), stride=2, padding=1)
     assert _relerr(dx.double(), exact) < 2e-6, _relerr(dx.double(), exact)
+
+
+# ---------------------------------------------------------------- the same kernels on IEEE binary16 operands (`--mixed_precision fp16`)
+def _h(t):
+    return t.to(torch.float16).to(torch.float64)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_fp16_operand_format_forward_wgrad_and_1x1(backend):
+    """Option conv_op16_f16 = 1 switches the 16-bit-operand kernels from bf16 to binary16 (template flag: same staging, same
+    MFMA shape, `v_cvt_f16_f32` + `v_mfma_f32_32x32x16_f16`). Bare convolutions (no GroupNorm / SiLU): the result must equal the
+    float64 convolution of the fp16-rounded operands to accumulation-order precision, and differ from the bf16 result."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    lib = _native.lib()
+    Nn, Ci, Co, H, W = 2, 32, 128, 16, 16
+    x = _rand((Nn, Ci, H, W), 1, dev)
+    w = _rand((Co, Ci, 3, 3), 3, dev, scale=(Ci * 9) ** -0.5)
+    b = _rand((Co,), 4, dev)
+    dy = _rand((Nn, Co, H, W), 7, dev)
+    w1 = _rand((128, 128, 1, 1), 8, dev, scale=128 ** -0.5)
+    x1 = _rand((Nn, 128, 16, 16), 9, dev)
+    out = {}
+    for f16 in (0, 1):
+        _native.check(lib.adm_set_option(b"conv_op16_f16", f16))
+        _native.check(lib.adm_set_option(b"conv_bf16", 2))
+        try:
+            y = ops.conv2d(x, ops.pack_conv_weight(w), b, 3, bf16=ops.pack_bf16_weight(w))
+            assert lib.adm_last_conv_variant() == 5316
+            dW = ops.conv2d_wgrad(x, dy, Co, 3)
+            y1 = ops.conv2d(x1, ops.pack_conv_weight(w1), None, 1, pad_lo=0, bf16=ops.pack_bf16_weight(w1))
+            assert lib.adm_last_conv_variant() == 5116
+            out[f16] = (y.cpu().double(), dW.cpu().double(), y1.cpu().double())
+        finally:
+            _native.check(lib.adm_set_option(b"conv_bf16", 0))
+            _native.check(lib.adm_set_option(b"conv_op16_f16", 0))
+    c = lambda t: t.cpu()  # noqa: E731
+    ref_y = F.conv2d(_h(c(x)), _h(c(w)), None, padding=1) + c(b).double()[None, :, None, None]
+    ref_dW = torch.nn.grad.conv2d_weight(_h(c(x)), (Co, Ci, 3, 3), _h(c(dy)), padding=1)
+    ref_y1 = F.conv2d(_h(c(x1)), _h(c(w1)), None)
+    for got, ref in zip(out[1], (ref_y, ref_dW, ref_y1)):
+        assert _relerr(got, ref) < 2e-6, _relerr(got, ref)
+    for k in range(3):
+        assert 1e-5 < _relerr(out[1][k], out[0][k]) < 8e-3        # bf16 and binary16 round differently, both close to fp32
