@@ -397,9 +397,16 @@ def main():
             res["config"]["workload"] = "TEST HOOK ADM_BENCH_EMU=1: toy UNet on the CPU emulation build over gloo (not a measurement)"
             res["gathered_checksum"] = int(gathered.long().sum()) if gathered is not None else None
         else:
-            res["roofline"] = roofline(unet, noise, B)
+            # side legs never cost the headline line: a failure is reported in place
+            try:
+                res["roofline"] = roofline(unet, noise, B)
+            except Exception as e:  # noqa: BLE001
+                res["roofline"] = {"error": f"{type(e).__name__}: {e}"}
             if not a.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (torchrun pins OMP_NUM_THREADS=1 per rank)
-                res["cpu_baseline"] = cpu_baseline(unet.state_dict(), os.cpu_count() or torch.get_num_threads())
+                try:
+                    res["cpu_baseline"] = cpu_baseline(unet.state_dict(), os.cpu_count() or torch.get_num_threads())
+                except Exception as e:  # noqa: BLE001
+                    res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         if not a.no_mel_leg:
             try:
                 res["mel"] = mel_leg(job)
