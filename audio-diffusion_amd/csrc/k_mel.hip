@@ -137,7 +137,6 @@ __global__ void __launch_bounds__(256) mel_stft_power_kernel(const T* __restrict
 #define ADM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 constexpr int MF_PITCH = 65;                 // complex elements per LDS row (16 rows)
-constexpr int MF_FRAMES = 8;                 // frames per workgroup (2 per wave)
 
 __device__ __forceinline__ double2 c_mul(double2 a, double2 b) {
   return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -213,10 +212,11 @@ __device__ __forceinline__ void fft1024_wave(double2 (&v)[16], double2* buf, con
   ADM_WAVE_SYNC();
 }
 
-// MINW = waves per SIMD the register allocation is held to: 1 = ~390 registers, no spills, one workgroup per CU;
-// 2 = 256 registers (some spills to scratch), two workgroups per CU. ADM_MEL_OCC selects (measured on the MI355X).
+// MINW = waves per SIMD: 1 = 4 waves per workgroup (8 frames), ~390 registers; 2 = 8 waves per workgroup (16 frames, one shared
+// filterbank copy: 157 KiB of LDS), 212 registers — the loads of a frame are then issued in four batches instead of sixteen
+// at once, which is what keeps the allocation under 256 without spills. ADM_MEL_OCC selects (measured on the MI355X).
 template <typename T, int MINW>
-__global__ void __launch_bounds__(256, MINW) mel_stft2048_kernel(const T* __restrict__ audio, long slice_stride, int n_samples,
+__global__ void __launch_bounds__(256 * MINW, 1) mel_stft2048_kernel(const T* __restrict__ audio, long slice_stride, int n_samples,
                                                           int hop, const double* __restrict__ window,
                                                           const double2* __restrict__ tw,
                                                           const int* __restrict__ fb_start, const int* __restrict__ fb_count,
@@ -227,10 +227,11 @@ __global__ void __launch_bounds__(256, MINW) mel_stft2048_kernel(const T* __rest
   // double (order-preserving), so that the dB pass needs no reduction of its own
   ADM_DYN_SMEM(double2, sm);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr int NW = 4 * MINW, FR = 2 * NW;                        // waves and frames per workgroup
   double2* buf = sm + wave * 16 * MF_PITCH;
-  T* stage = reinterpret_cast<T*>(sm + 4 * 16 * MF_PITCH);         // [n_mels][MF_FRAMES]
+  T* stage = reinterpret_cast<T*>(sm + NW * 16 * MF_PITCH);        // [n_mels][FR]
   // the filterbank, staged once per workgroup: taps as (first bin, count, offset) per filter + the weights in T
-  int* f_start = reinterpret_cast<int*>(stage + n_mels * MF_FRAMES);
+  int* f_start = reinterpret_cast<int*>(stage + n_mels * FR);
   int* f_count = f_start + n_mels;
   int* f_off = f_count + n_mels;
   T* f_w = reinterpret_cast<T*>(f_off + n_mels + (n_mels & 1));     // keeps 8-byte alignment for T = double
@@ -238,11 +239,11 @@ __global__ void __launch_bounds__(256, MINW) mel_stft2048_kernel(const T* __rest
   for (int m = tid; m < n_mels; m += blockDim.x) { f_start[m] = fb_start[m]; f_count[m] = fb_count[m]; f_off[m] = fb_off[m]; }
   for (int i = tid; i < nnz; i += blockDim.x) f_w[i] = sizeof(T) == 4 ? (T)fb_w32[i] : (T)fb_w64[i];
   __syncthreads();
-  const int b = blockIdx.y, f0 = blockIdx.x * MF_FRAMES;
+  const int b = blockIdx.y, f0 = blockIdx.x * FR;
   const T* y = audio + (long)b * slice_stride;
 #pragma unroll 1
-  for (int fi = 0; fi < MF_FRAMES / 4; ++fi) {
-    const int slot = wave + 4 * fi, frame = f0 + slot;            // beyond n_frames: computed on zeros, never stored
+  for (int fi = 0; fi < 2; ++fi) {
+    const int slot = wave + NW * fi, frame = f0 + slot;            // beyond n_frames: computed on zeros, never stored
     double2 v[16];
     ADM_UNROLL
     for (int n1 = 0; n1 < 16; ++n1) {
@@ -253,6 +254,7 @@ __global__ void __launch_bounds__(256, MINW) mel_stft2048_kernel(const T* __rest
       const double a1 = (live && src + 1 >= 0 && src + 1 < n_samples) ? (double)y[src + 1] : 0.0;
       const double2 w = *reinterpret_cast<const double2*>(window + 2 * n);
       v[n1] = make_double2(w.x * a0, w.y * a1);
+      if (MINW == 2 && (n1 & 3) == 3) ADM_SCHED_FENCE();            // 256-register build: four batches of loads, not sixteen
     }
     fft1024_wave(v, buf, tw, lane);
     // untangle: X[k] = E + (-i) W2048^k O, E = (Z[k] + conj Z[1024-k]) / 2, O = (Z[k] - conj Z[1024-k]) / 2
@@ -303,15 +305,15 @@ __global__ void __launch_bounds__(256, MINW) mel_stft2048_kernel(const T* __rest
         acc += w0 * p0; acc += w1 * p1; acc += w2 * p2; acc += w3 * p3;
       }
       for (; i < cnt; ++i) acc += (double)f_w[o + i] * (double)pw[s + i];
-      stage[m * MF_FRAMES + slot] = (T)acc;
+      stage[m * FR + slot] = (T)acc;
     }
     ADM_WAVE_SYNC();
   }
   __syncthreads();
-  // [n_mels][MF_FRAMES] -> melspec[b][m][f0 .. f0 + 8): one row segment per thread pass
+  // [n_mels][FR] -> melspec[b][m][f0 .. f0 + FR): one row segment per thread pass
   double mx = 0.0;
-  for (int e = tid; e < n_mels * MF_FRAMES; e += blockDim.x) {
-    const int m = e / MF_FRAMES, s = e % MF_FRAMES;
+  for (int e = tid; e < n_mels * FR; e += blockDim.x) {
+    const int m = e / FR, s = e % FR;
     if (f0 + s < n_frames) {
       melspec[((long)b * n_mels + m) * n_frames + f0 + s] = stage[e];
       mx = fmax(mx, (double)stage[e]);
@@ -867,24 +869,29 @@ static int mel_forward_power_impl(adm_mel_t* h, const void* audio, int is_f64, i
   dim3 grid(n_frames, B);
   const size_t smem = fft_smem(h);
   if (mel_fast_path(h)) {                    // one wave per frame, real-input radix-16 FFT (mel_stft2048_kernel)
-    dim3 g2(ceil_div(n_frames, MF_FRAMES), B);
+    static const int occ_env = [] { const char* e = getenv("ADM_MEL_OCC"); return e ? atoi(e) : 2; }();
     const size_t tsz = is_f64 ? 8 : 4;
-    const size_t sm2 = sizeof(double2) * 4 * 16 * MF_PITCH + tsz * (size_t)h->n_mels * MF_FRAMES +
-                       sizeof(int) * (3 * (size_t)h->n_mels + 2) + tsz * (size_t)h->nnz;
-    ADM_REQUIRE(sm2 <= 128 * 1024, "mel_forward: too many mel bands for the fast path staging buffer");
+    auto lds_bytes = [&](int nw_) {
+      return sizeof(double2) * nw_ * 16 * MF_PITCH + tsz * (size_t)h->n_mels * 2 * nw_ + sizeof(int) * (3 * (size_t)h->n_mels + 2) +
+             tsz * (size_t)h->nnz;
+    };
+    const int occ = (occ_env == 2 && lds_bytes(8) <= 160 * 1024) ? 2 : 1;     // fp64 audio at 256 mels: the 8-wave image exceeds the LDS
+    const int nw = occ == 2 ? 8 : 4, fr = 2 * nw;
+    dim3 g2(ceil_div(n_frames, fr), B);
+    const size_t sm2 = lds_bytes(nw);
+    ADM_REQUIRE(sm2 <= 160 * 1024, "mel_forward: too many mel bands for the fast path staging buffer");
 #if !defined(ADM_EMU)
     static bool once = [] {
-      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<double, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mel_stft2048_kernel<double, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       return true;
     }();
     (void)once;
 #endif
-    static const int occ = [] { const char* e = getenv("ADM_MEL_OCC"); return e ? atoi(e) : 1; }();
 #define ADM_MEL_FAST_LAUNCH(T_, W_)                                                                                          \
-  ADM_LAUNCH((mel_stft2048_kernel<T_, W_>), g2, dim3(256), sm2, st, (const T_*)audio, slice_stride, n_samples, c.hop_length,   \
+  ADM_LAUNCH((mel_stft2048_kernel<T_, W_>), g2, dim3(256 * W_), sm2, st, (const T_*)audio, slice_stride, n_samples, c.hop_length,   \
              h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count, h->fb_off, h->fb_w32, h->fb_w64, h->n_mels,     \
              n_frames, (T_*)melspec_out, spec_max)
     if (is_f64) { if (occ == 2) ADM_MEL_FAST_LAUNCH(double, 2); else ADM_MEL_FAST_LAUNCH(double, 1); }
