@@ -433,11 +433,16 @@ __global__ void __launch_bounds__(256) mel_nnls_diff_kernel(const double* __rest
                                                             const int* __restrict__ fb_count,
                                                             const int* __restrict__ fb_off,
                                                             const double* __restrict__ fb_w64, int n_bins, int n_mels,
-                                                            int n_frames, double* __restrict__ diff) {
+                                                            int n_frames, double* __restrict__ diff,
+                                                            const float* __restrict__ known_blk = nullptr, int nnls_cols = 1,
+                                                            float pgtol = 0.f) {
+  // known_blk != nullptr (after the solver): columns of blocks the solver left alone keep the residual they have
   const int b = blockIdx.y;
   const long n = (long)n_mels * n_frames;
+  const int n_blk = (n_frames + nnls_cols - 1) / nnls_cols;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     const int m = (int)(e / n_frames), t = (int)(e - (long)m * n_frames);
+    if (known_blk != nullptr && !(known_blk[(long)b * n_blk + t / nnls_cols] > pgtol)) continue;
     const int s = fb_start[m], c = fb_count[m], o = fb_off[m];
     const double* xr = X + ((long)b * n_frames + t) * n_bins;
     double acc = 0.0;
@@ -453,9 +458,19 @@ __global__ void __launch_bounds__(256) mel_nnls_pg_kernel(const double* __restri
                                                           const int* __restrict__ fbt_idx,
                                                           const double* __restrict__ fbt_w64, int n_bins, int n_mels,
                                                           int n_frames, int nnls_cols, int parts, float* __restrict__ pgmax,
-                                                          float* __restrict__ pgblk) {
+                                                          float* __restrict__ pgblk, const float* __restrict__ known_blk,
+                                                          float pgtol) {
+  // known_blk != nullptr (the pass AFTER the solver): a block whose start point already satisfied the rule was not touched,
+  // its maximum is the one recorded before — no second walk over it
   const int b = blockIdx.y, blk = blockIdx.x / parts, part = blockIdx.x % parts;
   const int n_blk = (n_frames + nnls_cols - 1) / nnls_cols;
+  if (known_blk != nullptr) {
+    const float k = known_blk[(long)b * n_blk + blk];
+    if (!(k > pgtol)) {
+      if (threadIdx.x == 0 && part == 0) atomicMax(reinterpret_cast<unsigned*>(pgmax), __float_as_uint(k));
+      return;
+    }
+  }
   const int blk0 = blk * nnls_cols;
   const int cols = (blk0 + nnls_cols <= n_frames) ? nnls_cols : n_frames - blk0;
   const double inv_size = 1.0 / ((double)n_mels * cols);
@@ -759,8 +774,10 @@ __global__ void __launch_bounds__(256) gl_stft_update2048_kernel(const float* __
       ar -= (double)(mom * tp.x);
       ai -= (double)(mom * tp.y);
     }
-    const double den = hypot(ar, ai) + 2.2250738585072014e-308;
-    const double scl = 1.0 / den;
+    // angles /= |angles| + tiny: 1 / (hypot + tiny) as one reciprocal square root (|a| is far from the overflow range here;
+    // a = 0 keeps angles = 0, as 0 / tiny does)
+    const double s2 = ar * ar + ai * ai;
+    const double scl = s2 > 0.0 ? rsqrt(s2) : 0.0;
     const double m = mag[base + k];
     angles[base + k] = make_double2(ar * scl * m, ai * scl * m);
   };
@@ -997,7 +1014,8 @@ int adm_mel_inverse(adm_mel_t* h, const uint8_t* images, const double* init_phas
   const bool solve = h->lipschitz > 0.0 && h->nnls_max_iter > 0;
   const int pg_parts = ceil_div(256, n_blk) > 0 ? ceil_div(256, n_blk) : 1;     // ~256 workgroups per image, whole blocks each
   ADM_LAUNCH(mel_nnls_pg_kernel, dim3(n_blk * pg_parts, B), dim3(256), 0, st, h->Xpow, h->diff, h->fbt_off, h->fbt_idx, h->fbt_w64,
-             nb, nm, n_frames, h->nnls_cols, pg_parts, h->pgmax + (solve ? 1 : 0), solve ? h->pgblk : (float*)nullptr);
+             nb, nm, n_frames, h->nnls_cols, pg_parts, h->pgmax + (solve ? 1 : 0), solve ? h->pgblk : (float*)nullptr,
+             (const float*)nullptr, 0.f);
   if (solve) {
     const size_t nsm = sizeof(double) * (3 * (size_t)nb + 2 * (size_t)nm);
     ADM_REQUIRE(nsm <= 64 * 1024, "mel_inverse: filterbank too large for the in-LDS NNLS solver");
@@ -1006,9 +1024,9 @@ int adm_mel_inverse(adm_mel_t* h, const uint8_t* images, const double* init_phas
                h->nnls_cols, (const float*)h->pgblk, 1e-5f, 1.0 / h->lipschitz, 1e-6, h->nnls_max_iter, h->iters_dev);
     // projected gradient of the point that is returned
     ADM_LAUNCH(mel_nnls_diff_kernel, dim3(256, B), dim3(256), 0, st, h->Xpow, h->Smel, h->fb_start, h->fb_count, h->fb_off,
-               h->fb_w64, nb, nm, n_frames, h->diff);
+               h->fb_w64, nb, nm, n_frames, h->diff, (const float*)h->pgblk, h->nnls_cols, 1e-5f);
     ADM_LAUNCH(mel_nnls_pg_kernel, dim3(n_blk * pg_parts, B), dim3(256), 0, st, h->Xpow, h->diff, h->fbt_off, h->fbt_idx,
-               h->fbt_w64, nb, nm, n_frames, h->nnls_cols, pg_parts, h->pgmax, (float*)nullptr);
+               h->fbt_w64, nb, nm, n_frames, h->nnls_cols, pg_parts, h->pgmax, (float*)nullptr, (const float*)h->pgblk, 1e-5f);
   }
   ADM_LAUNCH(gl_init_kernel, dim3(256, B), dim3(256), 0, st, init_phase, h->mag, nb, n_frames, (double2*)h->angles);
   const size_t smem = fft_smem(h);
