@@ -55,7 +55,14 @@ __global__ void __launch_bounds__(256) conv_small_cout_kernel(const float* __res
                                                               float* __restrict__ out, int tiles_x) {
   __shared__ float tile[SC][18][18 + 1];
   const int tid = threadIdx.x;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, n = blockIdx.y;
+  // Workgroups are dealt to the 8 XCDs round-robin and each XCD has its own L2: give every XCD a contiguous
+  // run of (image, tile) pairs so the halo rows and the half-used 128-byte lines that neighbouring tiles share
+  // are fetched from HBM once per XCD run instead of once per tile.
+  int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  const int total = gridDim.x * gridDim.y;
+  if ((total & 7) == 0) wg = (wg & 7) * (total >> 3) + (wg >> 3);
+  const int n = wg / (int)gridDim.x, tl = wg - n * (int)gridDim.x;
+  const int tx = tl % tiles_x, ty = tl / tiles_x;
   const int lx = tid & 15, ly = tid >> 4;
   const int ox = tx * 16 + lx, oy = ty * 16 + ly;
   const long HW = (long)H * W;

@@ -9,7 +9,10 @@ the reference tree and NOT installed here; see `requirements-lock.txt:25,57`).
 PARITY UNPINNED: the reference ships no tests, fixtures or stored notebook
 outputs for this path and neither third-party package can be imported in this
 container, so the oracle is pinned only by the analytic anchors of SURVEY.md
-§8(c) (see tests/test_oracle_anchors.py).
+§8(c) (see tests/test_oracle_anchors.py).  One exception: the Mel forward rows
+(M3-M5: Slaney filterbank, centred STFT, power_to_db, u8 image) are checked against
+vectors produced by a third-party implementation, transformers.audio_utils
+(tests/golden/make_thirdparty_mel.py, tests/test_thirdparty_pin.py).
 
 Modules: `unet` (UNet2DModel), `unet_condition` (UNet2DConditionModel: Transformer2DModel blocks, cross-attention on the
 encoding), `schedulers` (DDPM / DDIM), `pipeline` (the sampling procedure, `encode`, `slerp`), `mel` (librosa's
