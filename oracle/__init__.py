@@ -12,7 +12,13 @@ container, so the oracle is pinned only by the analytic anchors of SURVEY.md
 §8(c) (see tests/test_oracle_anchors.py).  One exception: the Mel forward rows
 (M3-M5: Slaney filterbank, centred STFT, power_to_db, u8 image) are checked against
 vectors produced by a third-party implementation, transformers.audio_utils
-(tests/golden/make_thirdparty_mel.py, tests/test_thirdparty_pin.py).
+(tests/golden/make_thirdparty_mel.py, tests/test_thirdparty_pin.py).  And the
+restatement of the reference's OWN files on the path (`pipeline.py`, `mel.Mel`,
+`audio_encoder.py`) is checked bit for bit against the reference's code executed
+in the build container over stand-ins for its two missing imports
+(tests/golden/make_reference_golden.py, tests/refshim/, tests/test_reference_pin.py);
+what remains unpinned is the third-party arithmetic: UNet / VAE wiring, scheduler
+formulas, NNLS, Griffin-Lim.
 
 Modules: `unet` (UNet2DModel), `unet_condition` (UNet2DConditionModel: Transformer2DModel blocks, cross-attention on the
 encoding), `schedulers` (DDPM / DDIM), `pipeline` (the sampling procedure, `encode`, `slerp`), `mel` (librosa's

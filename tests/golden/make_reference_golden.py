@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Golden vectors produced by EXECUTING THE REFERENCE'S OWN CODE (tests/golden/reference_pipeline.npz).
+
+`/root/reference/audiodiffusion/pipeline_audio_diffusion.py` (AudioDiffusionPipeline.__call__ / encode / slerp) and
+`/root/reference/audiodiffusion/mel.py` (Mel) are imported from where they lie and run as written.  Their two third-party
+imports, diffusers 0.24 and librosa 0.10.2, are not in this image; `tests/refshim/` supplies stand-ins whose classes and
+functions forward to the CPU oracle.  So what this fixture pins is the reference's own program text on the path — argument
+handling, noise aliasing (`images = noise`, the in-place `images[0, 0] = ...`), the audio-conditioned start, the mask
+tensor and the order it is applied in, latent scaling by 0.18215, `(x*255).round()` to uint8, the DDIM inversion loop,
+slerp, and the Mel class's slicing / zero padding / byte <-> dB conversions — while the UNet, scheduler, VAE, STFT/NNLS/
+Griffin-Lim arithmetic underneath is the oracle's (unpinned, except the Mel forward rows: make_thirdparty_mel.py).
+
+tests/test_reference_pin.py then requires (a) the oracle's restatement of the pipeline to reproduce these numbers exactly,
+(b) the product path (HIP kernels through the C-ABI) to reproduce them within the path's tolerances, and (c) — wherever
+/root/reference is present — this script to regenerate the committed file bit for bit.
+Run:  python tests/golden/make_reference_golden.py [output.npz]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+
+UNET_CFG = dict(sample_size=16, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(32, 32),
+                down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"))
+MEL16 = dict(x_res=16, y_res=16, hop_length=128, n_fft=512, n_iter=4, sample_rate=22050)
+VAE_CFG = dict(sample_size=(32, 32), in_channels=1, out_channels=1, latent_channels=1, layers_per_block=1,
+               block_out_channels=(32, 32), down_block_types=("DownEncoderBlock2D",) * 2,
+               up_block_types=("UpDecoderBlock2D",) * 2)
+MEL32 = dict(x_res=32, y_res=32, hop_length=128, n_fft=512, n_iter=4, sample_rate=22050)
+
+
+def pcm(v):
+    return (np.round(v * 32767.0).clip(-32768, 32767) / 32768.0).astype(np.float32)
+
+
+def phases(rng, mel_cfg, n):
+    return rng.random_sample((n, mel_cfg["n_fft"] // 2 + 1, mel_cfg["x_res"])).astype(np.float32).astype(np.float64)
+
+
+def u8(images):
+    return np.stack([np.asarray(i) for i in images])
+
+
+def main(out_path):
+    sys.path[:0] = [os.path.join(ROOT, "tests", "refshim"), REFERENCE, ROOT]
+    import audiodiffusion as ref                       # the reference package itself
+    assert os.path.realpath(ref.__file__).startswith(REFERENCE + "/"), ref.__file__
+    from librosa.feature import inverse as gl          # the stand-in: queue of Griffin-Lim start phases
+    from oracle.schedulers import DDIMScheduler, DDPMScheduler
+    from oracle.unet import UNet2DModel
+    from oracle.vae import AutoencoderKL
+    RefPipeline, RefMel = ref.AudioDiffusionPipeline, ref.mel.Mel
+
+    z = np.load(os.path.join(HERE, "unet_tiny.npz"))
+    unet = UNet2DModel(**UNET_CFG).eval()
+    unet.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")})
+    rs = np.random.RandomState(77)
+    out = {}
+
+    def fresh_unet():
+        unet.sample_size = UNET_CFG["sample_size"]     # __call__ rewrites it to a tuple (:118-119)
+        return unet
+
+    # ---- A: DDIM, given noise, eta = 0; images + audio (return_dict=False) and the dict form
+    g = torch.Generator().manual_seed(42)
+    noise = torch.randn(2, 1, 16, 16, generator=g)
+    ph = phases(rs, MEL16, 2)
+    pipe = RefPipeline(None, fresh_unet(), RefMel(**MEL16), DDIMScheduler())
+    gl.INIT_PHASES[:] = list(ph)
+    images, (sr, audios) = pipe(batch_size=2, steps=4, noise=noise.clone(), return_dict=False)
+    out.update({"A:noise": noise.numpy(), "A:phase": ph.astype(np.float32), "A:images": u8(images), "A:audios": np.stack(audios), "A:sr": np.array(sr)})
+    gl.INIT_PHASES[:] = list(ph)
+    d = pipe(batch_size=2, steps=4, noise=noise.clone())
+    assert np.array_equal(u8(d.images), out["A:images"]) and d.audios.shape == (2, 1, out["A:audios"].shape[1])
+    out["A:default_steps"] = np.array(pipe.get_default_steps())
+
+    # ---- B: DDIM eta = 0.7, initial noise and per-step noise drawn from one generator
+    pipe = RefPipeline(None, fresh_unet(), RefMel(**MEL16), DDIMScheduler())
+    gl.INIT_PHASES[:] = list(ph)
+    images, _ = pipe(batch_size=2, steps=4, eta=0.7, generator=torch.Generator().manual_seed(7), return_dict=False)
+    out["B:images"] = u8(images)
+
+    # ---- C: DDPM, 3 steps, separate generators for the start and for the steps
+    pipe = RefPipeline(None, fresh_unet(), RefMel(**MEL16), DDPMScheduler())
+    gl.INIT_PHASES[:] = list(ph)
+    images, _ = pipe(batch_size=2, steps=3, generator=torch.Generator().manual_seed(11),
+                     step_generator=torch.Generator().manual_seed(12), return_dict=False)
+    out["C:images"] = u8(images)
+    out["C:default_steps"] = np.array(pipe.get_default_steps())
+
+    # ---- D: audio-conditioned start (slice 1 of a 2.3-slice clip), start_step 2 of 6, both masks.  Batch 1: the
+    # reference's in-place `images[0, 0] = add_noise(...)` (:150) and its mask writes (:182-185) only broadcast for one row
+    # (D3 / D4 record that both raise for two); D2 is the form without a start step (masks only)
+    n_s = MEL16["x_res"] * MEL16["hop_length"]
+    t = np.arange(int(2.3 * n_s)) / MEL16["sample_rate"]
+    raw = pcm(0.3 * np.sin(2 * np.pi * 1200 * t * (1 + 3 * t)) + 0.05 * rs.standard_normal(len(t)))
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(2, 1, 16, 16, generator=g)
+    pipe = RefPipeline(None, fresh_unet(), RefMel(**MEL16), DDIMScheduler())
+    gl.INIT_PHASES[:] = list(ph)
+    kw = dict(raw_audio=raw, slice=1, steps=6, mask_start_secs=0.02, mask_end_secs=0.03)
+    noise_io = noise[:1].clone()
+    images, _ = pipe(batch_size=1, noise=noise_io, start_step=2, return_dict=False, **kw)
+    out.update({"D:raw": raw, "D:noise": noise.numpy(), "D:images": u8(images), "D:noise_after": noise_io.numpy(),
+                "D:cond_image": np.asarray(pipe.mel.audio_slice_to_image(1)), "D:slices": np.array(pipe.mel.get_number_of_slices())})
+    gl.INIT_PHASES[:] = list(ph)
+    images, _ = pipe(batch_size=1, noise=noise[1:].clone(), start_step=0, return_dict=False, **kw)
+    out["D2:images"] = u8(images)
+    for key, ss in (("D3:raises", 2), ("D4:raises", 0)):    # two rows: neither the start-step write nor the mask write broadcasts
+        try:
+            pipe(batch_size=2, noise=noise.clone(), start_step=ss, return_dict=False, **kw)
+            out[key] = np.array("")
+        except RuntimeError as e:
+            out[key] = np.array(type(e).__name__)
+
+    # ---- E: latent diffusion: AutoencoderKL encode(...).latent_dist.sample(generator) -> loop -> decode
+    torch.manual_seed(5)
+    vae = AutoencoderKL(**VAE_CFG).eval()
+    for k, v in vae.state_dict().items():
+        out["vae:" + k] = v.numpy()
+    raw32 = pcm(0.2 * rs.standard_normal(MEL32["x_res"] * MEL32["hop_length"] + 17))
+    noise = torch.randn(2, 1, 16, 16, generator=g)
+    ph32 = phases(rs, MEL32, 2)
+    pipe = RefPipeline(vae, fresh_unet(), RefMel(**MEL32), DDIMScheduler())
+    gl.INIT_PHASES[:] = list(ph32)
+    images, (_, audios) = pipe(batch_size=2, steps=3, noise=noise.clone(), return_dict=False)
+    out.update({"E:noise": noise.numpy(), "E:phase": ph32.astype(np.float32), "E:images": u8(images), "E:audios": np.stack(audios)})
+    gl.INIT_PHASES[:] = list(ph32)
+    images, _ = pipe(batch_size=1, steps=3, noise=noise[:1].clone(), raw_audio=raw32, start_step=1, mask_end_secs=0.01,
+                     generator=torch.Generator().manual_seed(9), return_dict=False)
+    out.update({"E:raw": raw32, "E:images_from_audio": u8(images)})
+
+    # ---- F: DDIM inversion of A's images, and slerp
+    pipe = RefPipeline(None, fresh_unet(), RefMel(**MEL16), DDIMScheduler())
+    enc = pipe.encode([__import__("PIL.Image").Image.fromarray(a) for a in out["A:images"]], steps=5)
+    out["F:encoded"] = enc.numpy()
+    x0, x1 = torch.randn(1, 16, 16, generator=g), torch.randn(1, 16, 16, generator=g)
+    out.update({"F:x0": x0.numpy(), "F:x1": x1.numpy(), "F:slerp": RefPipeline.slerp(x0, x1, 0.3).numpy()})
+
+    # ---- G: the Mel class on its own: padding of a short clip, slice count, both conversions
+    mel = RefMel(**MEL32)
+    short = pcm(0.25 * rs.standard_normal(1000))
+    mel.load_audio(raw_audio=short)
+    out.update({"G:short": short, "G:padded_len": np.array(len(mel.audio)), "G:padded_dtype": np.array(str(mel.audio.dtype)),
+                "G:slices_short": np.array(mel.get_number_of_slices()), "G:image_short": np.asarray(mel.audio_slice_to_image(0))})
+    mel.load_audio(raw_audio=raw32)
+    img = mel.audio_slice_to_image(0)
+    gl.INIT_PHASES[:] = [ph32[0]]
+    out.update({"G:image": np.asarray(img), "G:audio": mel.image_to_audio(img), "G:slice_size": np.array(mel.slice_size),
+                "G:sample_rate": np.array(mel.get_sample_rate())})
+
+    # ---- H: the AudioEncoder module (audio_encoder.py:62-84), eval mode as `encode` runs it (:87-88); 42 M weights, so the
+    # fixture holds the seeds (oracle.audio_encoder.random_state_dict) and a digest instead of the state dict
+    import hashlib
+    from audiodiffusion.audio_encoder import AudioEncoder as RefEncoder
+    from oracle import audio_encoder as oenc
+    sd = oenc.random_state_dict(3)
+    enc = RefEncoder()
+    enc.load_state_dict(sd, strict=True)               # every key name and shape of the reference module
+    enc.eval()
+    x = torch.rand((2, 1, 96, 216), generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        y = enc(x)
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(sd[k].numpy().tobytes())
+    out.update({"H:embedding": y.numpy(), "H:sd_seed": np.array(3), "H:x_seed": np.array(4), "H:sd_sha256": np.array(h.hexdigest()),
+                "H:mel_res": np.array([enc.mel.x_res, enc.mel.y_res])})
+
+    np.savez_compressed(out_path, **out)
+    print({k: (v.shape, str(v.dtype)) for k, v in out.items() if not k.startswith("vae:")})
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "reference_pipeline.npz"))
