@@ -220,8 +220,10 @@ class Mel:
         if audio_file is not None:
             import scipy.io.wavfile
             sr, data = scipy.io.wavfile.read(audio_file)
-            if data.dtype.kind in "iu":
-                data = data.astype(np.float32) / np.iinfo(data.dtype).max
+            if data.dtype.kind == "u":                    # 8-bit WAV is offset binary
+                data = (data.astype(np.float32) - 128.0) / 128.0
+            elif data.dtype.kind == "i":                  # libsndfile's (= librosa.load's) normalisation: / 2^(bits-1)
+                data = data.astype(np.float32) / float(-int(np.iinfo(data.dtype).min))
             if data.ndim > 1:
                 data = data.mean(axis=1)
             if sr != self.sr:

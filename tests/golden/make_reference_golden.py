@@ -46,6 +46,33 @@ def u8(images):
     return np.stack([np.asarray(i) for i in images])
 
 
+DATASET_RES = (32, 16)
+
+
+def dataset_wavs(root):
+    """The input directory of case I (also rebuilt by the tests): {relative path: sha256 of the file}."""
+    import hashlib
+    import wave
+    rs = np.random.RandomState(99)
+    n = DATASET_RES[0] * 128 - 1                                  # slice_size at hop 128
+    t = np.arange(int(2.6 * n)) / 22050
+    a = 0.4 * np.sin(2 * np.pi * 800 * t * (1 + 2 * t)) + 0.02 * rs.standard_normal(len(t))
+    b = np.concatenate([np.zeros(n), 0.1 * rs.standard_normal(n + 40)])
+    files = {"a.wav": a, os.path.join("sub", "b.WAV"): b}
+    digests = {}
+    os.makedirs(os.path.join(root, "sub"), exist_ok=True)
+    for rel, x in files.items():
+        with wave.open(os.path.join(root, rel), "wb") as w:
+            w.setnchannels(1), w.setsampwidth(2), w.setframerate(22050)
+            w.writeframes(np.round(np.clip(x, -1, 1) * 32767).astype("<i2").tobytes())
+    with open(os.path.join(root, "c.mp3"), "wb") as f:
+        f.write(b"not an audio file")
+    for rel in list(files) + ["c.mp3"]:
+        with open(os.path.join(root, rel), "rb") as f:
+            digests[rel] = hashlib.sha256(f.read()).hexdigest()
+    return digests
+
+
 def main(out_path):
     sys.path[:0] = [os.path.join(ROOT, "tests", "refshim"), REFERENCE, ROOT]
     import audiodiffusion as ref                       # the reference package itself
@@ -171,6 +198,28 @@ def main(out_path):
         h.update(sd[k].numpy().tobytes())
     out.update({"H:embedding": y.numpy(), "H:sd_seed": np.array(3), "H:x_seed": np.array(4), "H:sd_sha256": np.array(h.hexdigest()),
                 "H:mel_res": np.array([enc.mel.x_res, enc.mel.y_res])})
+
+    # ---- I: the dataset builder script (scripts/audio_to_images.py main(), run as written) on three files: a chirp of 2.6
+    # slices, a file whose first slice is digital silence (skipped, :48-51), and one the decoder rejects (reported and
+    # skipped, :36-42).  Non-square resolution: width 32 = x_res frames, height 16 = mel bins.
+    import argparse
+    import importlib.util
+    import tempfile
+    from datasets import load_from_disk
+    spec = importlib.util.spec_from_file_location("reference_audio_to_images", os.path.join(REFERENCE, "scripts", "audio_to_images.py"))
+    script = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(script)
+    with tempfile.TemporaryDirectory() as tmp:
+        wavs = dataset_wavs(os.path.join(tmp, "in"))
+        args = argparse.Namespace(input_dir=os.path.join(tmp, "in"), output_dir=os.path.join(tmp, "out"), resolution=DATASET_RES,
+                                  hop_length=128, push_to_hub=None, sample_rate=22050, n_fft=512)
+        script.main(args)
+        ds = load_from_disk(args.output_dir)["train"]
+        rows = sorted(((os.path.relpath(r["audio_file"], args.input_dir), int(r["slice"]), np.asarray(r["image"])) for r in ds),
+                      key=lambda r: r[:2])
+        out.update({"I:files": np.array([r[0] for r in rows]), "I:slices": np.array([r[1] for r in rows], dtype=np.int16),
+                    "I:images": np.stack([r[2] for r in rows]), "I:features": np.array(str(ds.features)),
+                    "I:wav_sha256": np.array([wavs[k] for k in sorted(wavs)])})
 
     np.savez_compressed(out_path, **out)
     print({k: (v.shape, str(v.dtype)) for k, v in out.items() if not k.startswith("vae:")})
