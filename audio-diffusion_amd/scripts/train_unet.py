@@ -53,6 +53,72 @@ def load_images(args, resolution):
     return torch.from_numpy(np.stack(imgs))[:, None], files
 
 
+class Trainer:
+    """One rank's training state and the step of the reference's loop body (train_unet.py:226-267) on given tensors:
+    add_noise -> native forward + backward -> (accumulate) -> bucketed all-reduce -> clip_grad_norm_(1.0) -> AdamW -> LR
+    schedule -> EMA -> weight re-pack.  `main` feeds it batches; tests/test_reference_train_pin.py feeds it the batches, noise
+    and timesteps recorded from a run of the reference's own script."""
+
+    def __init__(self, args, model, resolution, steps_per_epoch, world=1, dev=None):
+        self.args, self.model, self.world, self.dev = args, model, world, dev
+        # identical init on every rank (same seed / checkpoint). bf16: eligible 3x3 convolutions (forward, data and weight
+        # gradient) run on bf16 MFMA operands with fp32 accumulation; master weights, optimizer state and gradients stay fp32
+        self.flat, self.grads = model.enable_training(resolution, mixed_precision=args.mixed_precision)
+        self.optimizer = T.AdamW(self.flat, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
+                                 weight_decay=args.adam_weight_decay, eps=args.adam_epsilon)
+        # the LR scheduler steps on synchronising steps only (:178): its length is divided by the accumulation factor
+        num_training_steps = (steps_per_epoch * args.num_epochs) // args.gradient_accumulation_steps
+        self.lr_scheduler = T.LambdaLR(self.optimizer, T.get_cosine_schedule_with_warmup(args.lr_warmup_steps, num_training_steps)
+                                       if args.lr_scheduler == "cosine" else (lambda s: 1.0))
+        self.ema = T.EMAModel(self.flat, inv_gamma=args.ema_inv_gamma, power=args.ema_power,
+                              max_value=args.ema_max_decay) if args.use_ema else None
+        self.reducer = T.GradAllReducer(self.grads)
+        if world > 1 and args.gradient_accumulation_steps == 1:
+            self.reducer.attach(model)   # DDP overlap: buckets are all-reduced while the reverse pass is still running
+        self.accum = T.GradAccumulator(self.grads, args.gradient_accumulation_steps)   # accelerator.accumulate(model), :252
+        self.scaler = T.GradScaler() if args.mixed_precision == "fp16" else None       # accelerate's GradScaler under fp16 (:391-395)
+
+    def step(self, noise_scheduler, clean, noise, timesteps, encoding=None, last_batch=False):
+        model, ema, grads, flat, scaler = self.model, self.ema, self.grads, self.flat, self.scaler
+        noisy = noise_scheduler.add_noise(clean.contiguous(), noise, timesteps)
+        self.reducer.begin_step()
+        ls = scaler.get_scale() if scaler is not None else 1.0
+        if encoding is not None:                                       # :254-255
+            loss = model.train_step(noisy, timesteps, noise, encoding, loss_scale=ls)
+        else:
+            loss = model.train_step(noisy, timesteps, noise, loss_scale=ls)
+        if self.accum.add(last_batch=last_batch):                      # accelerator.sync_gradients
+            self.reducer.start()
+            self.reducer.finish()
+            found_inf = False
+            if scaler is not None:                                     # unscale_ + clip_grad_norm_ in one pass; overflow check
+                clip, found_inf = scaler.unscale_and_clip_(grads, 1.0)
+                if self.world > 1:                                     # every rank takes the same decision
+                    flag = torch.tensor([float(found_inf)], device=self.dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                    found_inf = bool(flag.item())
+                scaler.update(found_inf)
+            else:
+                clip = T.clip_grad_norm_(grads, 1.0)
+            if found_inf:                                              # GradScaler.step skips the optimizer; accelerate then
+                if ema is not None:                                    # skips the LR scheduler too; the EMA still steps
+                    ema.step(flat)
+            else:
+                self.optimizer.step(grads, clip=clip, ema=ema, ema_decay=ema.next_decay() if ema is not None else 0.0)
+                self.lr_scheduler.step()
+                model.refresh_weights()
+        elif ema is not None:                                          # micro-step: no collective (no_sync), optimizer and
+            ema.step(flat)                                             # scheduler skipped, EMA still stepped (:265-266)
+        return loss
+
+    def copy_ema_into_model(self):
+        """:292-294: at every save epoch the EMA weights go INTO the live model, and training continues from them."""
+        if self.ema is not None:
+            self.ema.copy_to(self.flat)
+            self.model.refresh_weights()
+        self.model.sync_state_dict_from_flat()
+
+
 def main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -112,27 +178,13 @@ def main(args):
                   n_fft=args.n_fft)
     noise_scheduler = (DDPMScheduler if args.scheduler == "ddpm" else DDIMScheduler)(num_train_timesteps=args.num_train_steps)
 
-    # identical init on every rank (same seed / checkpoint). bf16: eligible 3x3 convolutions (forward, data and weight
-    # gradient) run on bf16 MFMA operands with fp32 accumulation; master weights, optimizer state and gradients stay fp32
-    flat, grads = model.enable_training(resolution if vqvae is None else latent_resolution,
-                                        mixed_precision=args.mixed_precision)
-    optimizer = T.AdamW(flat, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
-                        weight_decay=args.adam_weight_decay, eps=args.adam_epsilon)
     n_local = len(images) // world
     # len(train_dataloader) of the reference (:91, DataLoader default drop_last=False): the last batch may be partial
     steps_per_epoch = -(-n_local // args.train_batch_size)
     if steps_per_epoch == 0:
         raise ValueError(f"dataset of {len(images)} images leaves rank {rank} of {world} without a single sample")
-    # the LR scheduler steps on synchronising steps only (:178): its length is divided by the accumulation factor
-    num_training_steps = (steps_per_epoch * args.num_epochs) // args.gradient_accumulation_steps
-    lr_scheduler = T.LambdaLR(optimizer, T.get_cosine_schedule_with_warmup(args.lr_warmup_steps, num_training_steps)
-                              if args.lr_scheduler == "cosine" else (lambda s: 1.0))
-    ema = T.EMAModel(flat, inv_gamma=args.ema_inv_gamma, power=args.ema_power, max_value=args.ema_max_decay) if args.use_ema else None
-    reducer = T.GradAllReducer(grads)
-    if world > 1 and args.gradient_accumulation_steps == 1:
-        reducer.attach(model)        # DDP overlap: buckets are all-reduced while the reverse pass is still running
-    accum = T.GradAccumulator(grads, args.gradient_accumulation_steps)     # accelerator.accumulate(model), :252
-    scaler = T.GradScaler() if args.mixed_precision == "fp16" else None     # accelerate's GradScaler under fp16 (:391-395)
+    tr = Trainer(args, model, resolution if vqvae is None else latent_resolution, steps_per_epoch, world, dev)
+    flat, ema, lr_scheduler = tr.flat, tr.ema, tr.lr_scheduler
 
     global_step = 0
     for epoch in range(args.num_epochs):
@@ -153,35 +205,8 @@ def main(args):
                 clean = vqvae.encode(clean.contiguous()).latent_dist.sample() * 0.18215
             noise = torch.randn(clean.shape).to(dev)                          # CPU RNG then H2D, as :238
             timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (clean.shape[0],)).long()
-            noisy = noise_scheduler.add_noise(clean.contiguous(), noise, timesteps)
-            reducer.begin_step()
-            ls = scaler.get_scale() if scaler is not None else 1.0
-            if enc_table is not None:                                      # :254-255
-                loss = model.train_step(noisy, timesteps, noise, enc_table[idx].to(dev), loss_scale=ls)
-            else:
-                loss = model.train_step(noisy, timesteps, noise, loss_scale=ls)
-            if accum.add(last_batch=(it == steps_per_epoch - 1)):          # accelerator.sync_gradients
-                reducer.start()
-                reducer.finish()
-                found_inf = False
-                if scaler is not None:                                     # unscale_ + clip_grad_norm_ in one pass; overflow check
-                    clip, found_inf = scaler.unscale_and_clip_(grads, 1.0)
-                    if world > 1:                                          # every rank takes the same decision
-                        flag = torch.tensor([float(found_inf)], device=dev)
-                        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                        found_inf = bool(flag.item())
-                    scaler.update(found_inf)
-                else:
-                    clip = T.clip_grad_norm_(grads, 1.0)
-                if found_inf:                                              # GradScaler.step skips the optimizer; accelerate then
-                    if ema is not None:                                    # skips the LR scheduler too; the EMA still steps
-                        ema.step(flat)
-                else:
-                    optimizer.step(grads, clip=clip, ema=ema, ema_decay=ema.next_decay() if ema is not None else 0.0)
-                    lr_scheduler.step()
-                    model.refresh_weights()
-            elif ema is not None:                                           # micro-step: no collective (no_sync), optimizer and
-                ema.step(flat)                                              # scheduler skipped, EMA still stepped (:265-266)
+            loss = tr.step(noise_scheduler, clean, noise, timesteps, None if enc_table is None else enc_table[idx].to(dev),
+                           last_batch=(it == steps_per_epoch - 1))
             global_step += 1
             seen += clean.shape[0] * world
             if rank == 0 and (it % args.log_every == 0 or it == steps_per_epoch - 1):
@@ -193,10 +218,7 @@ def main(args):
         save_model = (epoch + 1) % args.save_model_epochs == 0 or epoch == args.num_epochs - 1
         save_images = (epoch + 1) % args.save_images_epochs == 0
         if rank == 0 and (save_model or save_images):               # :286-298
-            if ema is not None:
-                ema.copy_to(flat)                                   # :292-294: EMA weights go INTO the live model
-                model.refresh_weights()
-            model.sync_state_dict_from_flat()
+            tr.copy_ema_into_model()                                # :292-294
             pipeline = AudioDiffusionPipeline(vqvae=vqvae, unet=model, mel=mel, scheduler=noise_scheduler)
             if save_model:
                 pipeline.save_pretrained(output_dir)
