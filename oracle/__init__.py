@@ -16,7 +16,9 @@ vectors produced by a third-party implementation, transformers.audio_utils
 restatement of the reference's OWN files on the path (`pipeline.py`, `mel.Mel`,
 `audio_encoder.py`) is checked bit for bit against the reference's code executed
 in the build container over stand-ins for its two missing imports
-(tests/golden/make_reference_golden.py, tests/refshim/, tests/test_reference_pin.py);
+(tests/golden/make_reference_golden.py, tests/refshim/, tests/test_reference_pin.py;
+the training rows likewise against a run of the reference's scripts/train_unet.py:
+tests/golden/make_reference_train_golden.py, tests/test_reference_train_pin.py);
 what remains unpinned is the third-party arithmetic: UNet / VAE wiring, scheduler
 formulas, NNLS, Griffin-Lim.
 

@@ -26,6 +26,8 @@ import tempfile
 import numpy as np
 import torch
 
+sys.dont_write_bytecode = True      # the reference tree is read-only input: no __pycache__ next to its sources
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REFERENCE = "/root/reference"
