@@ -277,9 +277,11 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
   const int planeS = p.Hs * p.Ws;
   const int IHW = p.IH * p.IW;
 
-  // gather plan: one patch element per thread (per SPL threads for 1x1); CS <= 256 / SPL
-  const int q = SPL == 1 ? tid : (tid & 127);
-  const int csub = SPL == 1 ? 0 : (tid >> 7) * NCH;   // first channel (inside the chunk) this thread stages
+  // gather plan: one patch element per thread; CS <= 256.  1x1 (the patch IS the 128-pixel tile, rows of TW >= 4 pixels):
+  // four consecutive pixels x four channels per thread, so that every global load is a dwordx4 of a contiguous row and
+  // every LDS store a float4 (lanes 0..31 cover one channel's 512 bytes, lanes 32..63 the next channel's)
+  const int q = KS == 1 ? 4 * (tid & 31) : tid;
+  const int csub = KS == 1 ? (tid >> 5) : 0;          // 1x1: channels csub + 8 k of the chunk, k = 0..3
   const bool qv = q < NI * IHW;
   int soff = -1, qn = n0;
   if (qv) {
@@ -309,9 +311,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
   const int a_lane = wm * TM * 32 + l31;
   const bool has_gn = p.gn_scale != nullptr;
 
-  float xr[NCH], gs[NCH], gh[NCH];
+  constexpr int NG = KS == 1 ? 4 : NCH;     // channels per thread (1x1: four, each with four pixels in xr)
+  float xr[NCH], gs[NG], gh[NG];
   ADM_UNROLL
-  for (int c = 0; c < NCH; ++c) { xr[c] = 0.f; gs[c] = 1.f; gh[c] = 0.f; }
+  for (int c = 0; c < NCH; ++c) xr[c] = 0.f;
+  ADM_UNROLL
+  for (int c = 0; c < NG; ++c) { gs[c] = 1.f; gh[c] = 0.f; }
 
   auto issue = [&](int c0, int buf) {
     const bool from1 = c0 < p.C1;
@@ -320,13 +325,21 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
     const int cb0 = (from1 ? c0 : c0 - p.C1) + csub;
     if (soff >= 0) {
       const float* src = xb + (long)qn * xbs + (long)cb0 * planeS + soff;
-      ADM_UNROLL
-      for (int c = 0; c < NCH; ++c) xr[c] = src[(long)c * planeS];
+      if constexpr (KS == 1) {
+        ADM_UNROLL
+        for (int k = 0; k < 4; ++k) {
+          const float4 v = *reinterpret_cast<const float4*>(src + (long)(8 * k) * planeS);
+          xr[4 * k + 0] = v.x; xr[4 * k + 1] = v.y; xr[4 * k + 2] = v.z; xr[4 * k + 3] = v.w;
+        }
+      } else {
+        ADM_UNROLL
+        for (int c = 0; c < NCH; ++c) xr[c] = src[(long)c * planeS];
+      }
       if (has_gn) {
         const float* sp = p.gn_scale + (long)qn * Ct + c0 + csub;
         const float* hp = p.gn_shift + (long)qn * Ct + c0 + csub;
         ADM_UNROLL
-        for (int c = 0; c < NCH; ++c) { gs[c] = sp[c]; gh[c] = hp[c]; }
+        for (int c = 0; c < NG; ++c) { gs[c] = sp[KS == 1 ? 8 * c : c]; gh[c] = hp[KS == 1 ? 8 * c : c]; }
       }
     }
     constexpr int ROW4 = BM / 4;
@@ -350,7 +363,23 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
 #if !defined(ADM_EMU)
     __builtin_amdgcn_s_setprio(3);   // the short stash/issue phase should not queue behind the other workgroup's MFMAs
 #endif
-    if (qv) {
+    if constexpr (KS == 1) {
+      if (qv) {
+        const bool live = soff >= 0;
+        ADM_UNROLL
+        for (int k = 0; k < 4; ++k) {
+          float v[4];
+          ADM_UNROLL
+          for (int e = 0; e < 4; ++e) v[e] = xr[4 * k + e] * gs[k] + gh[k];      // gs = 1, gh = 0 without GroupNorm
+          if (p.act) {                      // wave-uniform: shortcut convolutions and attention projections skip it
+            ADM_UNROLL
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+          }
+          *reinterpret_cast<float4*>(ldsX + (csub + 8 * k) * p.CS + q) =
+              live ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    } else if (qv) {
       const bool live = soff >= 0;
       ADM_UNROLL
       for (int c = 0; c < NCH; ++c) {
@@ -540,7 +569,12 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
   p.wp_bs = a.w_bstride;
-  const int TW = p.Wo >= 16 ? 16 : p.Wo, TH = p.Ho >= 8 ? 8 : p.Ho;
+  // 3x3: 16 x 8 pixel tiles (small halo); 1x1 has no halo: rows as long as the image allows (<= 128 pixels), so that the
+  // pipelined kernel loads and stores whole contiguous row segments
+  int TW = p.Wo >= 16 ? 16 : p.Wo, TH = p.Ho >= 8 ? 8 : p.Ho;
+  const bool wide1x1 = a.ks == 1 && use_pf() && (p.Wo & (p.Wo - 1)) == 0 && (p.Ho & (p.Ho - 1)) == 0 && p.Wo >= 4 &&
+                       (long)p.Wo * p.Ho >= 128;
+  if (wide1x1) { TW = p.Wo >= 128 ? 128 : p.Wo; TH = 128 / TW; }
   ADM_REQUIRE((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "conv2d: output dims below 16x8 must be powers of two");
   p.lTW = ilog2(TW); p.lTH = ilog2(TH);
   const int NI = 128 / (TW * TH);
@@ -564,7 +598,7 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
     g_last_variant += 2000;
     return dispatch_pf<3>(p, bm, st);
   }
-  if (use_pf() && a.ks == 1 && p.CS == 128 && Ct % 32 == 0 && a.C1 % 32 == 0) {
+  if (use_pf() && a.ks == 1 && p.CS == 128 && Ct % 32 == 0 && a.C1 % 32 == 0 && TW % 4 == 0 && p.Wo % 4 == 0 && a.W % 4 == 0) {
     g_last_variant += 2000;
     return dispatch_pf<1>(p, bm, st);
   }

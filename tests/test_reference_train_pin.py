@@ -135,8 +135,8 @@ def test_product_trainer_reproduces_the_reference_run():
         if (i + 1) % PER_EPOCH == 0:
             tr.copy_ema_into_model()
             sd = model.state_dict()
-            # AdamW's first updates are +-lr whatever the gradient's size: an entry whose gradient is rounding noise may move
-            # the other way, by at most the learning rates summed so far
-            got = _check_summary([(n, sd[n].cpu()) for n in names], (i + 1) // PER_EPOCH - 1, rel_l2=2e-4, abs_head=4e-4)
+            # measured on MI355X: per-tensor L2 within 2.9e-6, entries within 1.2e-8 (AdamW's first updates are +-lr whatever
+            # the gradient's size, so an entry whose gradient is rounding noise could in principle move the other way)
+            got = _check_summary([(n, sd[n].cpu()) for n in names], (i + 1) // PER_EPOCH - 1, rel_l2=5e-5, abs_head=5e-6)
             print(f"epoch {(i + 1) // PER_EPOCH - 1}: worst per-tensor L2 difference {got[0]:.2e} (relative), worst entry difference {got[1]:.2e}")
     print(f"worst relative loss difference vs the reference run: {worst:.2e}")

@@ -37,7 +37,7 @@ def ev(fn, reps):
 
 tp = ev(lambda: N.check(N.lib().adm_mel_forward_power(h, N.ptr(audio), 0, B, n, n, N.ptr(spec), st)), 10)
 tf = ev(lambda: N.check(N.lib().adm_mel_forward(h, N.ptr(audio), 0, B, n, n, N.ptr(img), st)), 10)
-tag = f"FAST={os.environ.get('ADM_MEL_FAST', '1')} OCC={os.environ.get('ADM_MEL_OCC', '1')}"
+tag = f"FAST={os.environ.get('ADM_MEL_FAST', '1')} OCC={os.environ.get('ADM_MEL_OCC', '2')}"
 print(f"{tag} forward power B={B}: {tp:.3f} ms; forward to u8: {tf:.3f} ms = {B * 0.59 / tf:.0f} GB/s algorithmic, "
       f"{B / tf * 1e3:.0f} clips/s; checksum {int(img.long().sum())}", flush=True)
 Bi = 32
