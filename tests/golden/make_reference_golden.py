@@ -49,6 +49,29 @@ def u8(images):
 
 
 DATASET_RES = (32, 16)
+COND_SEED = 21
+COND_CFG = dict(sample_size=16, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(32, 64),
+                down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
+                cross_attention_dim=12, attention_head_dim=4)
+
+
+def state_sha256(sd):
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(sd[k].detach().numpy().tobytes())
+    return h.hexdigest()
+
+
+def cond_unet():
+    from oracle.unet_condition import UNet2DConditionModel
+    torch.manual_seed(COND_SEED)
+    m = UNet2DConditionModel(**COND_CFG).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "norm" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    return m
 
 
 def dataset_wavs(root):
@@ -182,6 +205,18 @@ def main(out_path):
     gl.INIT_PHASES[:] = [ph32[0]]
     out.update({"G:image": np.asarray(img), "G:audio": mel.image_to_audio(img), "G:slice_size": np.array(mel.slice_size),
                 "G:sample_rate": np.array(mel.get_sample_rate())})
+
+    # ---- J: conditional generation (:160-161: `self.unet(images, t, encoding)` when the model is a UNet2DConditionModel);
+    # weights = torch.manual_seed(COND_SEED) + the oracle's constructor (digest in the fixture, not the tensors)
+    cond = cond_unet()
+    g = torch.Generator().manual_seed(8)
+    noise = torch.randn(2, 1, 16, 16, generator=g)
+    enc = torch.randn(2, 3, COND_CFG["cross_attention_dim"], generator=g)
+    pipe = RefPipeline(None, cond, RefMel(**MEL16), DDIMScheduler())
+    gl.INIT_PHASES[:] = list(ph)
+    images, _ = pipe(batch_size=2, steps=4, noise=noise.clone(), encoding=enc, return_dict=False)
+    out.update({"J:noise": noise.numpy(), "J:encoding": enc.numpy(), "J:images": u8(images),
+                "J:sd_sha256": np.array(state_sha256(cond.state_dict()))})
 
     # ---- H: the AudioEncoder module (audio_encoder.py:62-84), eval mode as `encode` runs it (:87-88); 42 M weights, so the
     # fixture holds the seeds (oracle.audio_encoder.random_state_dict) and a digest instead of the state dict
