@@ -138,9 +138,11 @@ class AudioDiffusionPipeline(DiffusionPipeline):
 
     # ---- the native denoising loop (pipeline_audio_diffusion.py:159-185 + :192-194) ----------------------
     def _denoise(self, images, start_step, eta, step_generator, mask, mask_start, mask_end, step_noise=None,
-                 use_graph=True, want_u8=True, encoding=None):
+                 use_graph=True, want_u8=True, encoding=None, stop_step=None):
+        """The denoising loop (`:159-185`) as ONE native call per chunk of steps. `stop_step` (tests only) ends the loop
+        before that step index, so that a single step of a long schedule can be compared in isolation."""
         sched, unet = self.scheduler, self.unet
-        rows = sched.coef_rows(eta)[start_step:]
+        rows = sched.coef_rows(eta)[start_step:stop_step]
         n = len(rows)
         x = images.contiguous().clone()  # the reference never writes the loop state back into `noise`
         B, Cc, H, W = x.shape

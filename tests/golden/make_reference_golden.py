@@ -17,9 +17,11 @@ Run:  python tests/golden/make_reference_golden.py [output.npz]
 """
 import os
 import sys
+import tempfile
 
 import numpy as np
 import torch
+from PIL import Image
 
 sys.dont_write_bytecode = True      # the reference tree is read-only input: no __pycache__ next to its sources
 
@@ -53,6 +55,58 @@ COND_SEED = 21
 COND_CFG = dict(sample_size=16, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(32, 64),
                 down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
                 cross_attention_dim=12, attention_head_dim=4)
+
+
+# ---- the notebook cells (case N)
+MEL_NB = dict(x_res=32, y_res=16, hop_length=1024, n_fft=2048, n_iter=4, sample_rate=8000)   # 4.1 s slices: the cells' 2 s overlap fits
+NB_SEED, NB_START_STEP, NB_REMIX_SLICES, NB_CALLS, NB_REMIX_SEED = 31, 3, 4, 18, 20260924
+
+
+def notebook_phases():
+    """Griffin-Lim start phases of the NB_CALLS pipeline calls of case N (frozen RandomState stream; float32-exact values)."""
+    return np.random.RandomState(41).random_sample((NB_CALLS, MEL_NB["n_fft"] // 2 + 1, MEL_NB["x_res"])).astype(np.float32)
+
+
+def notebook_cells():
+    import json
+    with open(os.path.join(REFERENCE, "notebooks", "audio_diffusion_pipeline.ipynb")) as f:
+        return ["".join(c["source"]) for c in json.load(f)["cells"] if c["cell_type"] == "code"]
+
+
+def cell_source(cells, marker, params):
+    """The one code cell containing `marker`, as written; a `name = value  #@param ...` form line takes params[name] if given."""
+    hits = [c for c in cells if marker in c]
+    assert len(hits) == 1, (marker, len(hits))
+    lines = []
+    for line in hits[0].split("\n"):
+        name = line.split("=")[0].strip()
+        if "#@param" in line and name in params:
+            line = f"{name} = {params[name]!r}"
+        lines.append(line)
+    return "\n".join(lines)
+
+
+def notebook_clip(n_slices, seed):
+    rs = np.random.RandomState(seed)
+    n = int(n_slices * MEL_NB["x_res"] * MEL_NB["hop_length"])
+    t = np.arange(n) / MEL_NB["sample_rate"]
+    return pcm(0.3 * np.sin(2 * np.pi * 300 * t * (1 + 0.3 * t)) + 0.1 * np.sin(2 * np.pi * 1234 * t) + 0.03 * rs.standard_normal(n))
+
+
+def notebook_wav(path):
+    import wave
+    x = notebook_clip(2.3, 4)
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1), w.setsampwidth(2), w.setframerate(MEL_NB["sample_rate"])
+        w.writeframes(np.round(x * 32768.0).astype("<i2").tobytes())
+    return x
+
+
+def notebook_images():
+    rs = np.random.RandomState(6)
+    base = rs.randint(0, 256, (2, MEL_NB["y_res"], MEL_NB["x_res"])).astype(np.float64)
+    ramp = np.linspace(0, 120, MEL_NB["x_res"])[None, None, :]
+    return np.clip(0.5 * base + ramp, 0, 255).astype(np.uint8)
 
 
 def state_sha256(sd):
@@ -218,6 +272,56 @@ def main(out_path):
     out.update({"J:noise": noise.numpy(), "J:encoding": enc.numpy(), "J:images": u8(images),
                 "J:sd_sha256": np.array(state_sha256(cond.state_dict()))})
 
+    # ---- N: the long-form procedures = code cells of notebooks/audio_diffusion_pipeline.ipynb, exec'd as written (form fields
+    # marked `#@param` may be overridden, as the notebook intends; `display` / `Audio` are no-ops)
+    import librosa
+    cells = notebook_cells()
+    mel_n = RefMel(**MEL_NB)
+    unet.sample_size = (MEL_NB["y_res"], MEL_NB["x_res"])
+    pipe = RefPipeline(None, unet, mel_n, DDIMScheduler())
+    ns = dict(audio_diffusion=pipe, mel=mel_n, sample_rate=mel_n.get_sample_rate(), display=lambda *a, **k: None,
+              Audio=lambda *a, **k: None, np=np, torch=torch, librosa=librosa, device="cpu", generator=torch.Generator())
+    phn = notebook_phases()
+
+    class FixedSeedGenerator(torch.Generator):        # the remix cell draws its seed from the OS (`generator.seed()`)
+        def seed(self):
+            self.manual_seed(NB_REMIX_SEED)
+            return NB_REMIX_SEED
+    # cell "Generate continuations ('out-painting')": 12 segments, each pinned to the previous tail by mask_start_secs
+    ns["audio"] = notebook_clip(1.0, 3)
+    gl.INIT_PHASES[:] = [p.astype(np.float64) for p in phn[:12]]
+    torch.manual_seed(NB_SEED)
+    exec(cell_source(cells, "mask_start_secs=overlap_secs)", {}), ns)
+    track = np.asarray(ns["track"], dtype=np.float32)
+    out.update({"N:outpaint_len": np.array(len(track)), "N:outpaint_track_every4": track[::4].copy(),
+                "N:outpaint_segment_l2": np.array([np.linalg.norm(seg.astype(np.float64)) for seg in np.array_split(track, 13)]),
+                "N:outpaint_last_image": np.asarray(ns["image2"])})
+    # cell "Remix (style transfer)": a file, overlapping slices from start_step, generated tail re-inserted into the next slice
+    with tempfile.TemporaryDirectory() as tmp:
+        ns["audio_file"] = os.path.join(tmp, "track.wav")
+        notebook_wav(ns["audio_file"])
+        gl.INIT_PHASES[:] = [p.astype(np.float64) for p in phn[12:12 + NB_REMIX_SLICES]]
+        import types
+        ns_remix = dict(ns, torch=types.SimpleNamespace(Generator=FixedSeedGenerator))
+        exec(cell_source(cells, "not_first = 0", {"start_step": NB_START_STEP}), ns_remix)
+        ns.update({k: ns_remix[k] for k in ("track", "track_audio", "stride", "seed", "audio2")})
+    assert len(ns["track_audio"]) // ns["stride"] == NB_REMIX_SLICES and not gl.INIT_PHASES
+    assert ns["seed"] == NB_REMIX_SEED
+    out.update({"N:remix_track": np.asarray(ns["track"], dtype=np.float32)})
+    # cells "Encode / reconstruct / interpolate": two images, DDIM inversion, reconstruction, slerp at alpha, sampling
+    ima, imb = [Image.fromarray(a) for a in notebook_images()]
+    ns["ds"] = {"train": {264: {"image": ima}, 15978: {"image": imb}}}
+    for marker, ph_i in (("image = ds['train'][264]['image']", None), ("noise = audio_diffusion.encode([image])", None),
+                         ("# Reconstruct original audio from noise", 16), ("image2 = ds['train'][15978]['image']", None),
+                         ("noise2 = audio_diffusion.encode([image2])", None), ("audio_diffusion.slerp(noise, noise2, alpha)", 17)):
+        gl.INIT_PHASES[:] = [] if ph_i is None else [phn[ph_i].astype(np.float64)]
+        exec(cell_source(cells, marker, {}), ns)
+        if marker.startswith("# Reconstruct"):
+            out.update({"N:reconstructed_image": np.asarray(ns["image"]), "N:reconstructed_audio": np.asarray(ns["audio"], dtype=np.float32)})
+    out.update({"N:noise": ns["noise"].numpy(), "N:noise2": ns["noise2"].numpy(), "N:alpha": np.array(ns["alpha"]),
+                "N:slerp_audio": np.asarray(ns["audio"], dtype=np.float32), "N:slerp_image": np.asarray(ns["output"].images[0])})
+    unet.sample_size = UNET_CFG["sample_size"]
+
     # ---- H: the AudioEncoder module (audio_encoder.py:62-84), eval mode as `encode` runs it (:87-88); 42 M weights, so the
     # fixture holds the seeds (oracle.audio_encoder.random_state_dict) and a digest instead of the state dict
     import hashlib
@@ -241,7 +345,6 @@ def main(out_path):
     # skipped, :36-42).  Non-square resolution: width 32 = x_res frames, height 16 = mel bins.
     import argparse
     import importlib.util
-    import tempfile
     from datasets import load_from_disk
     spec = importlib.util.spec_from_file_location("reference_audio_to_images", os.path.join(REFERENCE, "scripts", "audio_to_images.py"))
     script = importlib.util.module_from_spec(spec)
