@@ -109,6 +109,18 @@ def notebook_images():
     return np.clip(0.5 * base + ramp, 0, 255).astype(np.uint8)
 
 
+def encoder_wav(path):
+    """2.4 slices of the encoder's Mel (216 frames x hop 512 at 22050 Hz), 16-bit PCM."""
+    import wave
+    rs = np.random.RandomState(12)
+    n = int(2.4 * 216 * 512)
+    t = np.arange(n) / 22050
+    x = 0.3 * np.sin(2 * np.pi * 220 * t * (1 + 0.2 * t)) + 0.2 * np.sin(2 * np.pi * 2500 * t) * (t % 0.5 < 0.1) + 0.02 * rs.standard_normal(n)
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1), w.setsampwidth(2), w.setframerate(22050)
+        w.writeframes(np.round(np.clip(x, -1, 1) * 32767).astype("<i2").tobytes())
+
+
 def state_sha256(sd):
     import hashlib
     h = hashlib.sha256()
@@ -339,6 +351,16 @@ def main(out_path):
         h.update(sd[k].numpy().tobytes())
     out.update({"H:embedding": y.numpy(), "H:sd_seed": np.array(3), "H:x_seed": np.array(4), "H:sd_sha256": np.array(h.hexdigest()),
                 "H:mel_res": np.array([enc.mel.x_res, enc.mel.y_res])})
+    # AudioEncoder.encode (:86-107) as written: file -> every 216-frame slice -> image / 255 -> forward -> mean over the slices
+    with tempfile.TemporaryDirectory() as tmp:
+        wav = os.path.join(tmp, "clip.wav")
+        encoder_wav(wav)
+        out["H:encode_average"] = enc.encode([wav, wav]).numpy()
+        try:                                            # pool="max" assigns the (values, indices) pair of torch.max and fails
+            enc.encode([wav], pool="max")
+            out["H:encode_max_raises"] = np.array("")
+        except Exception as e:                          # noqa: BLE001
+            out["H:encode_max_raises"] = np.array(type(e).__name__)
 
     # ---- I: the dataset builder script (scripts/audio_to_images.py main(), run as written) on three files: a chirp of 2.6
     # slices, a file whose first slice is digital silence (skipped, :48-51), and one the decoder rejects (reported and
