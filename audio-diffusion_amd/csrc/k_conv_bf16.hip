@@ -31,9 +31,18 @@ struct Bf16ConvParams {
   int tiles_x, tiles_y, n_ct, nblk;
   long x1_bs, x2_bs;
   int zins;   // UP kernels: 1 = zero-insertion x2 (data gradient of a stride-2 convolution) instead of nearest x2
+  unsigned long long* prof;   // developer aid (ADM_BF16_PROF=1): per-phase cycle counters, else NULL
 };
 
 constexpr int BPW = 18, BPP = BPW * BPW;   // input patch of a 16x16 output tile
+
+#if defined(ADM_EMU)
+#define B16_CLK() 0ull
+#else
+#define B16_CLK() ((unsigned long long)__builtin_readcyclecounter())
+#endif
+// per-phase cycle accounting of one wave (PROF kernels only): slot += time since the previous lap
+#define B16_LAP(slot) do { if (PROF) { const unsigned long long tn_ = B16_CLK(); pr[slot] += tn_ - tq; tq = tn_; } } while (0)
 
 __device__ __forceinline__ float silu_b(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
 
@@ -43,9 +52,12 @@ template <int NA> struct Bf16Filt { u32x4 a[9][NA]; };  // the wave's A fragment
 // WIDE = false: waves as 2 (64 couts) x 2 (8 pixel rows), 2 x 4 accumulator tiles, the two waves of a cout half fetch the
 // same filter fragments.  WIDE = true: waves as 4 (32 couts) x 1, 1 x 8 accumulator tiles: every filter fragment is
 // fetched once per workgroup (half the L2 requests, 36 registers less) at one LDS read per MFMA instead of one per two.
-template <bool UP, bool ACT, bool WIDE, bool F16 = false>
+template <bool UP, bool ACT, bool WIDE, bool F16 = false, bool PROF = false>
 __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams p) {
   constexpr int NA = WIDE ? 1 : 2, NP = WIDE ? 8 : 4;
+  unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
+  const unsigned long long t_start = B16_CLK();
+  if (PROF) tq = t_start;
   // One workgroup per CU (up to 512 registers per lane) so that everything that comes from memory is requested a full
   // chunk (filters, L2) or two chunks (input patch, HBM) before it is used: the first version requested the next tap's
   // filters 8 MFMAs ahead and queued them behind the patch loads of the in-order vector-memory counter — 17k cycles per
@@ -203,15 +215,24 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams 
   stash(X, buf0, 0);
   issue(X, 2);
   __syncthreads();
+  B16_LAP(1);                             // prologue
   for (int ch = 0; ch < n_chunks; ch += 2) {
     mfma_chunk(buf0, ch);                 // even chunk: LDS buffer 0; Y holds chunk ch + 1, X (in flight) ch + 2
+    B16_LAP(2);
     stash(Y, buf1, ch + 1);
+    B16_LAP(3);
     issue(Y, ch + 3);
+    B16_LAP(4);
     __syncthreads();
+    B16_LAP(5);
     mfma_chunk(buf1, ch + 1);             // odd chunk: LDS buffer 1; X holds chunk ch + 2, Y (in flight) ch + 3
+    B16_LAP(2);
     stash(X, buf0, ch + 2);
+    B16_LAP(3);
     issue(X, ch + 4);
+    B16_LAP(4);
     __syncthreads();
+    B16_LAP(5);
   }
 
   // epilogue: D row = output channel, column = pixel; fp32 bias + per-(n, channel) term + residual
@@ -245,6 +266,12 @@ __global__ void __launch_bounds__(256, 1) conv_bf16_kernel(const Bf16ConvParams 
       }
     }
   }
+  if (PROF) {
+    B16_LAP(6);                           // epilogue (issue only: the stores drain after the wave has left)
+    pr[0] = B16_CLK() - t_start;
+    if (lane == 0)
+      for (int i = 0; i < 8; ++i) atomicAdd(p.prof + i, pr[i]);
+  }
 }
 
 // ---------------------------------------------------------------- weight gradient
@@ -265,6 +292,7 @@ struct Bf16WgradParams {
   int tiles_x, tiles_y, n_ptiles, n_ct, n_chunks, split, tiles_per_block, nblk;
   long x1_bs, x2_bs;
   unsigned mTX, mTXY;       // floor(2^32 / d) + 1 for d = tiles_x, tiles_x * tiles_y (0: d == 1 or tile count >= 2^16)
+  unsigned long long* prof; // developer aid (ADM_BF16_PROF=1): per-phase cycle counters, else NULL
 };
 
 __device__ __forceinline__ int bdiv(int n, int d, unsigned magic) {   // n / d; exact via umulhi for n, d < 2^16
@@ -274,8 +302,11 @@ __device__ __forceinline__ int bdiv(int n, int d, unsigned magic) {   // n / d; 
 // raw fp32 prefetch of one 16x4-pixel tile: 4 dy items (8 pixels each), 7 patch pixel pairs, their in-bounds bits, image
 struct Bf16WgStage { float4 d[4][2]; float xa[7], xb[7]; unsigned ok; int n; };
 
-template <bool UP, bool ACT, bool F16 = false>
+template <bool UP, bool ACT, bool F16 = false, bool PROF = false>
 __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16WgradParams p) {
+  unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
+  const unsigned long long t_start = B16_CLK();
+  if (PROF) tq = t_start;
   // One workgroup per CU, everything from memory requested two tiles ahead (two register sets P/Q), converted into the
   // LDS buffer the MFMAs are not reading, one barrier per tile.  The first version loaded, converted and multiplied tile
   // by tile: 13k cycles per tile against 1.2k of MFMA work (profiles/r01_train_bf16_v1_kernel_stats.md).
@@ -419,15 +450,24 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
   stash_tile(P, buf0);
   load_tile(P, t_begin + 2);
   __syncthreads();
+  B16_LAP(1);                              // prologue
   for (int pt = t_begin; pt < t_end; pt += 2) {
     mfma_tile(buf0, true);                 // tile pt; Q holds pt + 1, P (in flight) pt + 2
+    B16_LAP(2);
     stash_tile(Q, buf1);
+    B16_LAP(3);
     load_tile(Q, pt + 3);
+    B16_LAP(4);
     __syncthreads();
+    B16_LAP(5);
     mfma_tile(buf1, pt + 1 < t_end);       // tile pt + 1; P holds pt + 2, Q (in flight) pt + 3
+    B16_LAP(2);
     stash_tile(P, buf0);
+    B16_LAP(3);
     load_tile(P, pt + 4);
+    B16_LAP(4);
     __syncthreads();
+    B16_LAP(5);
   }
   float* out = p.part + (long)sp * p.Cout * Ct * 9;
   ADM_UNROLL
@@ -438,6 +478,13 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
       const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       out[((long)co * Ct + cc) * 9 + t] = acc[t][r];
     }
+  }
+  if (PROF) {
+    B16_LAP(6);
+    pr[0] = B16_CLK() - t_start;
+    pr[7] = (unsigned long long)(((t_end - t_begin) + 1) & ~1);      // tile slots this workgroup ran
+    if (lane == 0)
+      for (int i = 0; i < 8; ++i) atomicAdd(p.prof + i, pr[i]);
   }
 }
 
@@ -535,6 +582,24 @@ int launch_conv_bf16(const adm_conv_args& a, hipStream_t st) {
   const size_t smem = sizeof(u32x4) * 2 * 2 * BPP + sizeof(float) * 2 * Ct;
   ADM_REQUIRE(smem <= 64 * 1024, "conv_bf16: too many input channels for the LDS GroupNorm rows");
   set_last_conv_variant(5000 + 316);
+  p.prof = nullptr;
+#if !defined(ADM_EMU)
+  static const bool want_prof = getenv("ADM_BF16_PROF") != nullptr;
+  if (want_prof && !a.up && a.act && !conv_op16_f16()) {   // developer aid: per-phase cycle accounting, printed after the launch (synchronous)
+    static unsigned long long* dprof = [] { void* q = nullptr; (void)hipMalloc(&q, 8 * sizeof(unsigned long long)); return (unsigned long long*)q; }();
+    (void)hipMemsetAsync(dprof, 0, 8 * sizeof(unsigned long long), st);
+    p.prof = dprof;
+    ADM_LAUNCH((conv_bf16_kernel<false, true, false, false, true>), dim3(p.nblk), dim3(256), smem, st, p);
+    unsigned long long h[8];
+    (void)hipMemcpyAsync(h, dprof, sizeof(h), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    const double w = 4.0 * p.nblk, nch = (double)(a.C1 + C2) / 16;
+    fprintf(stderr, "[bf16 prof] %d->%d @%dx%d N=%d: per wave and workgroup: total %.0f | prologue %.0f | per chunk: mfma %.0f stash %.0f "
+            "issue %.0f barrier %.0f | epilogue %.0f cycles (%d chunks; 72 MFMAs = 2304)\n", a.C1 + C2, a.Cout, p.Hi, p.Wi, a.N,
+            h[0] / w, h[1] / w, h[2] / w / nch, h[3] / w / nch, h[4] / w / nch, h[5] / w / nch, h[6] / w, (int)nch);
+    return ADM_CHECK_LAUNCH();
+  }
+#endif
   // WIDE = true (waves 4 x 1) measured 640 vs 634 us on 128->128 @256^2: not instantiated
 #define ADM_BF16_LAUNCH(UP_, ACT_)                                                                          \
   do {                                                                                                      \
@@ -590,6 +655,24 @@ int launch_conv_wgrad_bf16(const adm_conv_args& a, const float* dy, float* dW, i
   const size_t smem = 2 * (sizeof(u32x4) * 8 * 130 + sizeof(unsigned) * 6 * 32 * 12) + sizeof(unsigned) * 256 +
                       sizeof(float) * 64 * (size_t)a.N;
   ADM_REQUIRE(smem <= 64 * 1024, "conv_wgrad_bf16: batch too large for the LDS GroupNorm rows");
+  p.prof = nullptr;
+#if !defined(ADM_EMU)
+  static const bool want_prof = getenv("ADM_BF16_PROF") != nullptr;
+  if (want_prof && !a.up && a.act && !conv_op16_f16()) {   // developer aid: per-phase cycle accounting, printed after the launch (synchronous)
+    static unsigned long long* dprof = [] { void* q = nullptr; (void)hipMalloc(&q, 8 * sizeof(unsigned long long)); return (unsigned long long*)q; }();
+    (void)hipMemsetAsync(dprof, 0, 8 * sizeof(unsigned long long), st);
+    p.prof = dprof;
+    ADM_LAUNCH((conv_wgrad_bf16_kernel<false, true, false, true>), dim3(p.nblk), dim3(256), smem, st, p);
+    unsigned long long h[8];
+    (void)hipMemcpyAsync(h, dprof, sizeof(h), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    const double w = 4.0 * p.nblk, nt = (double)h[7] / w;
+    fprintf(stderr, "[bf16 wgrad prof] %d->%d @%dx%d N=%d split=%d: per wave and workgroup: total %.0f | prologue %.0f | per tile: mfma %.0f "
+            "stash %.0f load %.0f barrier %.0f | epilogue %.0f cycles (%.1f tiles; 36 MFMAs = 1152)\n", Ct, a.Cout, p.Hi, p.Wi, a.N, split,
+            h[0] / w, h[1] / w, h[2] / w / nt, h[3] / w / nt, h[4] / w / nt, h[5] / w / nt, h[6] / w, nt);
+    return ADM_CHECK_LAUNCH();
+  }
+#endif
 #define ADM_WG16_LAUNCH(UP_, ACT_)                                                                             \
   do {                                                                                                         \
     if (conv_op16_f16()) ADM_LAUNCH((conv_wgrad_bf16_kernel<UP_, ACT_, true>), dim3(p.nblk), dim3(256), smem, st, p);  \

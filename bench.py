@@ -31,6 +31,7 @@ import glob
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -71,6 +72,8 @@ def parse():
                    help="sample (default): BASELINE.json's metric. train: config 5 (scripts/train_unet.py step) as the main line.")
     p.add_argument("--train-batch-per-gpu", type=int, default=16)
     p.add_argument("--train-steps", type=int, default=10)
+    p.add_argument("--train-leg-timeout", type=float, default=300.0,
+                   help="seconds after which a hung training leg is reported as a failure beside the measured headline")
     p.add_argument("--mixed-precision", choices=["no", "bf16", "fp16"], default="bf16",
                    help="training precision: bf16 = BASELINE.json config 5 as written (bf16 MFMA operands, fp32 accumulate)")
     return p.parse_args()
@@ -415,12 +418,23 @@ def main():
     del pipe
     # config 5 beside the headline: every rank takes part (the gradient all-reduce is a collective)
     if not a.no_train_leg:
+        # The headline is measured; a side leg that HANGS (a collective that never completes on some rank) must not cost it:
+        # every rank arms the same watchdog, rank 0 prints the line with the failure in place, all ranks leave.
+        def give_up():
+            if rank == 0:
+                res["train"] = {"error": f"timeout: the training leg did not finish within {a.train_leg_timeout:.0f} s"}
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+        dog = threading.Timer(a.train_leg_timeout, give_up)
+        dog.daemon = True
+        dog.start()
         job.sync()
         try:
             tr = train_leg(job, 2 if EMU else a.train_batch_per_gpu, 2 if EMU else a.train_steps, 1 if EMU else 2,
                            a.mixed_precision)
         except Exception as e:  # noqa: BLE001
             tr = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
         if rank == 0:
             res["train"] = tr
     if rank == 0:
