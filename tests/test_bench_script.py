@@ -57,3 +57,11 @@ def test_bench_py_result_is_independent_of_the_rank_count():
     two = _run(2, ["--no-train-leg", "--no-mel-leg"])
     assert one["gathered_checksum"] is None
     assert one_pg["gathered_checksum"] == two["gathered_checksum"] and two["gathered_checksum"] > 0
+
+
+def test_bench_py_reports_a_hung_training_leg_beside_the_measured_headline():
+    """The side legs run after the headline is measured; a training leg that does not come back (a collective some rank never
+    reaches) must cost its own record only: every rank's watchdog fires, rank 0 prints the line with the failure in place."""
+    d = _run(2, ["--no-mel-leg", "--train-leg-timeout", "0.05"])
+    assert d["value"] > 0 and d["n_gpus"] == 2
+    assert "timeout" in d["train"]["error"]
