@@ -125,6 +125,152 @@ __global__ void __launch_bounds__(256) conv_small_cout_kernel(const float* __res
   }
 }
 
+// ---- Cout <= 4, wide tiles (round 2): 64 x 16 output pixels per workgroup ----------------------------------------------
+// The 16x16 kernel above fetches 4.27 GB for a 1.07 GB input at B = 32 (profiles/r01_pmc_forward.json): its 18-pixel patch rows
+// are 72-byte pieces of 128-byte lines, gathered one dword per lane (one cache line per ~40 useful bytes; the vector L1 charges
+// ~4 cycles per line an instruction touches, profiles/r02_bf16_training.md). Here a patch row is the tile's 64 aligned pixels
+// = two whole lines, loaded as float4 by 16 consecutive lanes (4 rows = 8 lines per instruction), plus one dword each side;
+// the halo is 66 x 18 / (64 x 16) = 1.16x. A thread computes four horizontally adjacent outputs: 18 staged values per channel
+// (one ds_read_b128 + two ds_read_b32 per row) instead of 36. Same arithmetic and summation order per output as above.
+constexpr int SWP = 72;                          // LDS row pitch: [3] = left halo, [4..67] = the 64 pixels (16-byte aligned), [68] = right halo
+template <int COUT>
+__global__ void __launch_bounds__(256) conv_small_cout_wide_kernel(const float* __restrict__ x, int Cin, int N, int H,
+                                                                   int W, const float* __restrict__ gn_scale,
+                                                                   const float* __restrict__ gn_shift, int act,
+                                                                   const float* __restrict__ wp,  // [Cin][tap][Cout]
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ residual,
+                                                                   float* __restrict__ out, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) float tile[SC][18][SWP];
+  const int tid = threadIdx.x;
+  int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  const int total = gridDim.x * gridDim.y;
+  if ((total & 7) == 0) wg = (wg & 7) * (total >> 3) + (wg >> 3);      // an XCD walks neighbouring tiles (shared halo rows)
+  const int n = wg / (int)gridDim.x, tl = wg - n * (int)gridDim.x;
+  const int tx = tl % tiles_x, ty = tl / tiles_x;
+  const int lx4 = tid & 15, ly = tid >> 4;
+  const long HW = (long)H * W;
+  const int gx0 = tx * 64, gy0 = ty * 16 - 1;
+  // staging plan: 9 float4 items (channel, patch row, 4-pixel group) per thread and chunk + the halo columns (288 items)
+  int m_off[9], m_c[9], m_lds[9];
+  ADM_UNROLL
+  for (int k = 0; k < 9; ++k) {
+    const int id = tid + 256 * k, x4 = id & 15, r = id >> 4, yy = r % 18, c = r / 18;
+    const int gy = gy0 + yy;
+    m_c[k] = c;
+    m_lds[k] = (c * 18 + yy) * SWP + 4 + 4 * x4;
+    m_off[k] = (gy >= 0 && gy < H) ? gy * W + gx0 + 4 * x4 : -1;
+  }
+  int e_off[2], e_c[2], e_lds[2];
+  ADM_UNROLL
+  for (int k = 0; k < 2; ++k) {
+    const int id = tid + 256 * k;
+    e_off[k] = -2;                                   // -2: not mine, -1: zero padding
+    e_c[k] = 0; e_lds[k] = 0;
+    if (id < SC * 18 * 2) {
+      const int side = id & 1, r = id >> 1, yy = r % 18, c = r / 18;
+      const int gy = gy0 + yy, gx = side ? gx0 + 64 : gx0 - 1;
+      e_c[k] = c;
+      e_lds[k] = (c * 18 + yy) * SWP + (side ? 68 : 3);
+      e_off[k] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+    }
+  }
+  float acc[4][COUT];
+  ADM_UNROLL
+  for (int px = 0; px < 4; ++px)
+    ADM_UNROLL
+    for (int co = 0; co < COUT; ++co) acc[px][co] = 0.f;
+  float* tl0 = &tile[0][0][0];
+  // software pipeline: the raw values of chunk c0 + SC are requested before the FMAs of chunk c0 run (36 + 2 registers); the
+  // first version loaded, activated, stored and computed chunk by chunk and sat at 2.0 TB/s with the load latency exposed
+  float4 mr[9];
+  float er[2];
+  auto fetch = [&](int c0) __attribute__((always_inline)) {
+    ADM_UNROLL
+    for (int k = 0; k < 9; ++k) {
+      const int c = c0 + m_c[k];
+      mr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m_off[k] >= 0 && c < Cin) mr[k] = *reinterpret_cast<const float4*>(x + ((long)n * Cin + c) * HW + m_off[k]);
+    }
+    ADM_UNROLL
+    for (int k = 0; k < 2; ++k) {
+      const int c = c0 + e_c[k];
+      er[k] = 0.f;
+      if (e_off[k] >= 0 && c < Cin) er[k] = x[((long)n * Cin + c) * HW + e_off[k]];
+    }
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < Cin; c0 += SC) {
+    ADM_UNROLL
+    for (int k = 0; k < 9; ++k) {
+      const int c = c0 + m_c[k];
+      float4 v = mr[k];
+      if (m_off[k] >= 0 && c < Cin) {
+        if (gn_scale) {
+          const float sc = gn_scale[(long)n * Cin + c], sh = gn_shift[(long)n * Cin + c];
+          v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+        }
+        if (act) {
+          v.x = __fdividef(v.x, 1.0f + __expf(-v.x)); v.y = __fdividef(v.y, 1.0f + __expf(-v.y));
+          v.z = __fdividef(v.z, 1.0f + __expf(-v.z)); v.w = __fdividef(v.w, 1.0f + __expf(-v.w));
+        }
+      }
+      *reinterpret_cast<float4*>(tl0 + m_lds[k]) = v;
+    }
+    ADM_UNROLL
+    for (int k = 0; k < 2; ++k) {
+      if (e_off[k] != -2) {
+        const int c = c0 + e_c[k];
+        float v = er[k];
+        if (e_off[k] >= 0 && c < Cin) {
+          if (gn_scale) v = v * gn_scale[(long)n * Cin + c] + gn_shift[(long)n * Cin + c];
+          if (act) v = __fdividef(v, 1.0f + __expf(-v));
+        }
+        tl0[e_lds[k]] = v;
+      }
+    }
+    __syncthreads();
+    if (c0 + SC < Cin) fetch(c0 + SC);
+    ADM_UNROLL
+    for (int c = 0; c < SC; ++c) {
+      if (c0 + c < Cin) {
+        const float* wr = wp + (long)(c0 + c) * 9 * COUT;  // uniform address -> scalar loads
+        float v[3][6];
+        ADM_UNROLL
+        for (int dy = 0; dy < 3; ++dy) {
+          const float* row = &tile[c][ly + dy][4 * lx4 + 3];
+          const float4 m = *reinterpret_cast<const float4*>(row + 1);
+          v[dy][0] = row[0]; v[dy][1] = m.x; v[dy][2] = m.y; v[dy][3] = m.z; v[dy][4] = m.w; v[dy][5] = row[5];
+        }
+        ADM_UNROLL
+        for (int t = 0; t < 9; ++t)
+          ADM_UNROLL
+          for (int px = 0; px < 4; ++px)
+            ADM_UNROLL
+            for (int co = 0; co < COUT; ++co) acc[px][co] = fmaf(wr[t * COUT + co], v[t / 3][px + t % 3], acc[px][co]);
+      }
+    }
+    __syncthreads();
+  }
+  const int oy = ty * 16 + ly, ox = gx0 + 4 * lx4;
+  ADM_UNROLL
+  for (int co = 0; co < COUT; ++co) {
+    const long o = ((long)n * COUT + co) * HW + (long)oy * W + ox;
+    const float b = bias ? bias[co] : 0.f;
+    float4 r = make_float4(acc[0][co] + b, acc[1][co] + b, acc[2][co] + b, acc[3][co] + b);
+    if (residual) {
+      const float4 q = *reinterpret_cast<const float4*>(residual + o);
+      r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+    }
+    *reinterpret_cast<float4*>(out + o) = r;
+  }
+}
+
+static bool use_wide_cout() {   // ADM_CONV_OUT_WIDE=0 keeps the 16x16 kernel (A/B timing)
+  static const int v = [] { const char* e = getenv("ADM_CONV_OUT_WIDE"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+
 int launch_conv_small(const adm_conv_args& a, hipStream_t st) {
   ADM_REQUIRE(a.x2 == nullptr || a.C2 == 0, "conv_small: virtual concat not supported");
   ADM_REQUIRE(a.stride == 1 && !a.up, "conv_small: stride 1, no upsample only");
@@ -147,6 +293,17 @@ int launch_conv_small(const adm_conv_args& a, hipStream_t st) {
     ADM_FAIL("conv_small(cin): unsupported (Cin, ks)");
   }
   ADM_REQUIRE(a.Cout <= 4 && a.ks == 3 && a.pad_lo == 1, "conv_small: unsupported shape (need Cin<=4 or Cout<=4, 3x3)");
+  if (a.W % 64 == 0 && a.H % 16 == 0 && use_wide_cout()) {   // whole 64 x 16 tiles: the wide kernel (16-byte aligned rows)
+    const int wx = a.W / 64, wy = a.H / 16;
+#define ADM_COUTW_CASE(CO)                                                                                              \
+  if (a.Cout == CO) {                                                                                                   \
+    ADM_LAUNCH((conv_small_cout_wide_kernel<CO>), dim3(wx * wy, a.N), dim3(256), 0, st, a.x1, a.C1, a.N, a.H, a.W,      \
+               a.gn_scale, a.gn_shift, a.act, a.wpacked, a.bias, a.residual, a.out, wx);                                \
+    return ADM_CHECK_LAUNCH();                                                                                          \
+  }
+    ADM_COUTW_CASE(1) ADM_COUTW_CASE(2) ADM_COUTW_CASE(3) ADM_COUTW_CASE(4)
+#undef ADM_COUTW_CASE
+  }
   const int tiles_x = ceil_div(a.W, 16), tiles_y = ceil_div(a.H, 16);
 #define ADM_COUT_CASE(CO)                                                                                          \
   if (a.Cout == CO) {                                                                                              \

@@ -185,6 +185,37 @@ def test_conv_in_out_small(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("Cin,Cout,H,W,use_gn,use_res", [(32, 1, 32, 128, 1, 0), (12, 3, 16, 64, 0, 1), (64, 1, 48, 192, 1, 1)])
+def test_conv_out_wide_tiles(backend, Cin, Cout, H, W, use_gn, use_res):
+    """conv_out class on rows of whole 64-pixel tiles (conv_small_cout_wide_kernel): several tiles in both directions (left /
+    inner / right halo columns, top / bottom padding rows), a channel count that is not a multiple of the 8-channel chunk,
+    residual, up to 3 output channels; and a crop to a width of 48 pixels through the 16x16-tile kernel."""
+    dev = select(backend)
+    from audiodiffusion import ops
+    h = _rand((2, Cin, H, W), 4, dev)
+    w2, b2 = _rand((Cout, Cin, 3, 3), 7, dev, 0.1), _rand((Cout,), 8, dev)
+    res = _rand((2, Cout, H, W), 9, dev) if use_res else None
+    gn, a = None, h.cpu()
+    if use_gn:
+        gamma, beta = _rand((Cin,), 5, dev), _rand((Cin,), 6, dev)
+        gn = ops.groupnorm_stats(h, gamma, beta, 32 if Cin % 32 == 0 else 4, 1e-5)
+        a = F.silu(F.group_norm(a, 32 if Cin % 32 == 0 else 4, gamma.cpu(), beta.cpu(), 1e-5))
+    out = ops.conv2d(h, ops.pack_conv_weight(w2), b2, 3, gn=gn, act=bool(use_gn), residual=res)
+    ref = F.conv2d(a, w2.cpu(), b2.cpu(), padding=1) + (res.cpu() if use_res else 0)
+    assert _relerr(out, ref) < 1e-4
+    # same inputs through the narrow kernel: a width that is not a multiple of 64 selects it (crop of the same problem)
+    hc = h[..., :48].contiguous()
+    gnc = None
+    if use_gn:
+        gnc = ops.groupnorm_stats(hc, gamma, beta, 32 if Cin % 32 == 0 else 4, 1e-5)
+        ac = F.silu(F.group_norm(hc.cpu(), 32 if Cin % 32 == 0 else 4, gamma.cpu(), beta.cpu(), 1e-5))
+    else:
+        ac = hc.cpu()
+    outc = ops.conv2d(hc, ops.pack_conv_weight(w2), b2, 3, gn=gnc, act=bool(use_gn))
+    assert _relerr(outc, F.conv2d(ac, w2.cpu(), b2.cpu(), padding=1)) < 1e-4
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("C,T,d", [(32, 64, 8), (64, 256, 8), (32, 16, 8), (32, 4, 8)])
 def test_attention_core(backend, C, T, d):
     dev = select(backend)
