@@ -436,6 +436,7 @@ void set_last_conv_variant(int v) { g_last_variant = v; }
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 int launch_conv_small(const adm_conv_args& a, hipStream_t st);  // k_conv_small.hip
+int conv_small_stats_tiles(const adm_conv_args& a);
 
 #if !defined(ADM_EMU)
 template <class K>
@@ -533,7 +534,7 @@ static int dispatch_bm(const ConvParams& p, int bm, size_t smem, hipStream_t st)
 // run for `a` emits into a.stats_out, or 0 when that kernel has no statistics epilogue (the consumer then runs gn_stats_kernel).
 int conv_stats_tiles(const adm_conv_args& a) {
   const int C2 = a.x2 ? a.C2 : 0, Ct = a.C1 + C2;
-  if (Ct % CK != 0 || a.C1 % CK != 0 || a.Cout % 4 != 0 || a.Cout < 32) return 0;
+  if (Ct % CK != 0 || a.C1 % CK != 0 || a.Cout % 4 != 0 || a.Cout < 32) return conv_small_stats_tiles(a);
   if (conv_bf16_enabled() && conv_bf16_eligible(a)) return 0;
   if (conv_bf16_mode() >= 2 && conv1x1_bf16_eligible(a)) return 0;
   if (winograd_enabled() && winograd_eligible(a)) return winograd_stats_tiles(a);

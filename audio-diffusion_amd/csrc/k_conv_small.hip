@@ -41,6 +41,73 @@ __global__ void __launch_bounds__(256) conv_small_cin_kernel(const float* __rest
   }
 }
 
+// ---- Cin <= 4, four pixels per thread (round 2; W % 4 == 0): float4 stores, and optionally the GroupNorm partial sums of
+// the output (adm_conv_args.stats_out): per (sample, cout, wave of 256 pixels) the pair (sum, sum of squares) — the lane's four
+// values and the 64 lanes of the wave in fp32 (relative error ~1e-7 on a 256-term sum, below what the fp32 scale / shift of the
+// consumer resolves), across tiles in fp64 by gn_finalize_kernel. conv_in's output is read by two GroupNorms (the first resnet
+// and, through the skip connection, the last one): 0.6 ms of read-only statistics passes per forward at B = 32.
+template <int CIN>
+__global__ void __launch_bounds__(256) conv_small_cin_wide_kernel(const float* __restrict__ x, int N, int H, int W,
+                                                                  const float* __restrict__ wp,  // [Cin][tap][Cout]
+                                                                  const float* __restrict__ bias, int Cout,
+                                                                  const float* __restrict__ residual,
+                                                                  float* __restrict__ out, double* __restrict__ stats,
+                                                                  int stats_tiles) {
+  const long HW = (long)H * W;
+  const long pix = 4 * ((long)blockIdx.x * blockDim.x + threadIdx.x);     // first of the thread's four pixels (same row)
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = pix < HW;
+  const int y = live ? (int)(pix / W) : 0, xx = live ? (int)(pix % W) : 0;
+  const bool x_al = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  float v[CIN][3][6];                                                      // rows y - 1 .. y + 1, columns xx - 1 .. xx + 4
+  ADM_UNROLL
+  for (int c = 0; c < CIN; ++c)
+    ADM_UNROLL
+    for (int dy = 0; dy < 3; ++dy) {
+      const int gy = y + dy - 1;
+      const bool rok = live && gy >= 0 && gy < H;
+      const float* row = x + ((long)n * CIN + c) * HW + (long)(rok ? gy : 0) * W + xx;
+      float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rok) {                       // the network input is the caller's pointer: 16-byte loads only when it allows them (uniform)
+        if (x_al) m = *reinterpret_cast<const float4*>(row);
+        else m = make_float4(row[0], row[1], row[2], row[3]);
+      }
+      v[c][dy][0] = (rok && xx > 0) ? row[-1] : 0.f;
+      v[c][dy][1] = m.x; v[c][dy][2] = m.y; v[c][dy][3] = m.z; v[c][dy][4] = m.w;
+      v[c][dy][5] = (rok && xx + 4 < W) ? row[4] : 0.f;
+    }
+  for (int co = 0; co < Cout; ++co) {
+    const float b = bias ? bias[co] : 0.f;
+    float acc[4] = {b, b, b, b};
+    ADM_UNROLL
+    for (int c = 0; c < CIN; ++c)
+      ADM_UNROLL
+      for (int t = 0; t < 9; ++t) {
+        const float w = wp[(long)(c * 9 + t) * Cout + co];               // uniform -> scalar load
+        ADM_UNROLL
+        for (int px = 0; px < 4; ++px) acc[px] = fmaf(w, v[c][t / 3][px + t % 3], acc[px]);
+      }
+    const long o = ((long)n * Cout + co) * HW + pix;
+    if (live) {
+      if (residual) {
+        const float4 q = *reinterpret_cast<const float4*>(residual + o);
+        acc[0] += q.x; acc[1] += q.y; acc[2] += q.z; acc[3] += q.w;
+      }
+      *reinterpret_cast<float4*>(out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    if (stats != nullptr) {                                               // uniform
+      float s1 = live ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : 0.f;
+      float s2 = live ? (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]) : 0.f;
+      ADM_UNROLL
+      for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+      if (lane == 0) {
+        double* dst = stats + (((long)n * Cout + co) * stats_tiles + blockIdx.x * 4 + wave) * 2;
+        dst[0] = (double)s1; dst[1] = (double)s2;
+      }
+    }
+  }
+}
+
 // ---- Cout <= 4: 16x16 output tile per workgroup, channels staged 8 at a time through LDS ----------------
 // Weights are wave-uniform: they are read straight from global memory (scalar loads into SGPRs), not from LDS,
 // so the only LDS traffic in the inner loop is the 9 activated taps per channel.
@@ -266,6 +333,16 @@ __global__ void __launch_bounds__(256) conv_small_cout_wide_kernel(const float* 
   }
 }
 
+static bool use_wide_cin() {    // ADM_CONV_IN_WIDE=0 keeps the one-pixel-per-thread kernel (A/B timing)
+  static const int v = [] { const char* e = getenv("ADM_CONV_IN_WIDE"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+// statistic tiles per (sample, cout) of the conv_in class kernel launch_conv_small would run for `a` (0: no epilogue)
+int conv_small_stats_tiles(const adm_conv_args& a) {
+  if (a.C1 > 4 || (a.x2 && a.C2) || a.ks != 3 || a.stride != 1 || a.up || a.W % 4 != 0 || !use_wide_cin()) return 0;
+  if (a.gn_scale || a.act || a.chan_add) return 0;
+  return (int)(((long)a.H * a.W / 4 + 255) / 256) * 4;
+}
 static bool use_wide_cout() {   // ADM_CONV_OUT_WIDE=0 keeps the 16x16 kernel (A/B timing)
   static const int v = [] { const char* e = getenv("ADM_CONV_OUT_WIDE"); return e ? atoi(e) : 1; }();
   return v != 0;
@@ -280,6 +357,19 @@ int launch_conv_small(const adm_conv_args& a, hipStream_t st) {
     ADM_REQUIRE(a.gn_scale == nullptr && !a.act, "conv_small(cin): no fused norm/activation");
     ADM_REQUIRE(a.ks == 3 || a.ks == 1, "conv_small: ks");
     const long HW = (long)a.H * a.W;
+    if (a.ks == 3 && a.W % 4 == 0 && use_wide_cin()) {     // four pixels per thread; the only variant with the statistics epilogue
+      const dim3 gw((unsigned)((HW / 4 + 255) / 256), a.N);
+      ADM_REQUIRE(a.stats_out == nullptr || a.stats_tiles == (int)gw.x * 4, "conv_small(cin): stats_tiles mismatch");
+#define ADM_CINW_CASE(CI)                                                                                          \
+  if (a.C1 == CI) {                                                                                                \
+    ADM_LAUNCH((conv_small_cin_wide_kernel<CI>), gw, dim3(256), 0, st, a.x1, a.N, a.H, a.W, a.wpacked, a.bias,      \
+               a.Cout, a.residual, a.out, a.stats_out, a.stats_tiles);                                             \
+    return ADM_CHECK_LAUNCH();                                                                                     \
+  }
+      ADM_CINW_CASE(1) ADM_CINW_CASE(2) ADM_CINW_CASE(3) ADM_CINW_CASE(4)
+#undef ADM_CINW_CASE
+    }
+    ADM_REQUIRE(a.stats_out == nullptr, "conv_small(cin): this variant has no statistics epilogue");
     dim3 grid((unsigned)((HW + 255) / 256), a.N), block(256);
 #define ADM_CIN_CASE(CI, KK)                                                                                       \
   if (a.C1 == CI && a.ks == KK) {                                                                                  \

@@ -444,9 +444,10 @@ int Net::plan(int B) {
       }
     for (const Op& o : ops) {
       if (o.kind != Op::CONV || o.wt >= 0 || !tensors[o.out].want_stats || tensors[o.out].external) continue;
-      if (tensors[o.in1].external || (o.in2 >= 0 && tensors[o.in2].external)) continue;   // pointer (alignment) unknown until run
       adm_conv_args a;
       fill_conv_args(o, B, nullptr, 0, &a);
+      // an external input's pointer (alignment) is unknown until run: only the conv_in class kernel does not depend on it
+      if ((tensors[o.in1].external || (o.in2 >= 0 && tensors[o.in2].external)) && a.C1 > 4) continue;
       const int tiles = conv_stats_tiles(a);
       if (tiles <= 0) continue;
       Tensor& t = tensors[o.out];

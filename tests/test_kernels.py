@@ -185,6 +185,26 @@ def test_conv_in_out_small(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("Cin,H,W", [(1, 16, 32), (1, 40, 52), (3, 8, 12)])
+def test_conv_in_statistics_epilogue(backend, Cin, H, W):
+    """conv_in class, four pixels per thread: the output, and the GroupNorm partial sums its epilogue writes per (sample, cout,
+    wave of 256 pixels) — adm_groupnorm_finalize on them must give what the read pass (adm_groupnorm_stats) gives on the output
+    (ragged last wave: 40 x 52 = 2080 pixels = 8 full waves + 32 pixels; 8 x 12: a single partial wave)."""
+    dev = select(backend)
+    from audiodiffusion import ops
+    x = _rand((2, Cin, H, W), 1, dev)
+    w = _rand((64, Cin, 3, 3), 2, dev, 0.3)
+    b = _rand((64,), 3, dev)
+    out, st = ops.conv2d(x, ops.pack_conv_weight(w), b, 3, stats=True)
+    assert _relerr(out, F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1)) < 1e-5
+    assert st is not None and st.shape[2] == ((H * W // 4 + 255) // 256) * 4 and not torch.isnan(st).any()
+    gamma, beta = _rand((64,), 5, dev), _rand((64,), 6, dev)
+    sc, sh = ops.groupnorm_finalize(st, gamma, beta, 32, 1e-5, H * W)
+    rsc, rsh = ops.groupnorm_stats(out, gamma, beta, 32, 1e-5)
+    assert _relerr(sc, rsc) < 1e-5 and _relerr(sh, rsh) < 1e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("Cin,Cout,H,W,use_gn,use_res", [(32, 1, 32, 128, 1, 0), (12, 3, 16, 64, 0, 1), (64, 1, 48, 192, 1, 1)])
 def test_conv_out_wide_tiles(backend, Cin, Cout, H, W, use_gn, use_res):
     """conv_out class on rows of whole 64-pixel tiles (conv_small_cout_wide_kernel): several tiles in both directions (left /
