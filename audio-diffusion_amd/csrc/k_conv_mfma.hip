@@ -97,7 +97,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], const Conv
   } while (0)
 
 template <int KS, int STRIDE, int WM, int TM>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(const ConvParams p) {
   constexpr int WN = 4 / WM;
   constexpr int TN = 4 / WN;
   constexpr int BM = 32 * WM * TM;
@@ -165,53 +165,137 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvParams p) {
 
   const int a_lane = wm * TM * 32 + l31;
 
-  for (int c0 = 0; c0 < Ct; c0 += CK) {
-    // ---- stage the activated input patch ----------------------------------------------------------
+  // STRIDE == 2 (Downsample2D: patches of 33 x 17 pixels, 3 elements per thread and channel plane — the single-element plan
+  // of conv_mfma_pf_kernel does not fit): the same loop, software-pipelined through registers — the raw patch values and the
+  // weight slab of chunk c + 1 are requested before the MFMAs of chunk c and written to LDS after them.
+  constexpr bool PF = STRIDE == 2;
+  constexpr int ROW4 = BM / 4;
+  constexpr int TOT4 = CK * KS2 * ROW4;
+  constexpr int NW4 = (TOT4 + 255) / 256;
+  constexpr int PFQ = 3;                      // patch elements per thread that travel through registers (16 x 8 outputs: 561 = 3 per
+                                              // thread); the tiny-output layers' elements 4 and 5 are loaded at stash time as before
+  float raw[PF ? PFQ : 1][CK];
+  float4 wraw[PF ? NW4 : 1];
+  auto fetch = [&](int c0) __attribute__((always_inline)) {
     const bool from1 = c0 < p.C1;
     const float* xb = from1 ? p.x1 : p.x2;
     const long xbs = from1 ? p.x1_bs : p.x2_bs;
     const int cb0 = from1 ? c0 : c0 - p.C1;
     ADM_UNROLL
-    for (int qi = 0; qi < MAXQ; ++qi) {
+    for (int qi = 0; qi < PFQ; ++qi) {
       const int q = tid + qi * 256;
       if (q < NI * IHW) {
         const int soff = q_soff[qi];
         const int n = n0 + q_img[qi];
-        float v[CK];
         ADM_UNROLL
         for (int c = 0; c < CK; ++c) {
-          v[c] = 0.f;
-          if (soff >= 0) v[c] = xb[(long)n * xbs + (long)(cb0 + c) * planeS + soff];
+          raw[PF ? qi : 0][c] = 0.f;
+          if (soff >= 0) raw[PF ? qi : 0][c] = xb[(long)n * xbs + (long)(cb0 + c) * planeS + soff];
         }
-        if (p.gn_scale != nullptr && soff >= 0) {
+      }
+    }
+    const float* wsrc = p.wp + (long)n0 * p.wp_bs + (long)c0 * KS2 * p.Cout + m0;
+    ADM_UNROLL
+    for (int i = 0; i < NW4; ++i) {
+      const int idx = tid + 256 * i;
+      wraw[PF ? i : 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < TOT4) {
+        const int row = idx / ROW4, c4 = idx - row * ROW4;
+        if (m0 + c4 * 4 < p.Cout) wraw[PF ? i : 0] = *reinterpret_cast<const float4*>(wsrc + (long)row * p.Cout + c4 * 4);
+      }
+    }
+  };
+  if (PF) fetch(0);
+  for (int c0 = 0; c0 < Ct; c0 += CK) {
+    if constexpr (PF) {
+      ADM_UNROLL
+      for (int qi = 0; qi < MAXQ; ++qi) {
+        const int q = tid + qi * 256;
+        if (q < NI * IHW) {
+          const int soff = q_soff[qi];
+          const int n = n0 + q_img[qi];
+          float v[CK];
+          if (qi < PFQ) {
+            ADM_UNROLL
+            for (int c = 0; c < CK; ++c) v[c] = raw[qi][c];
+          } else {
+            const bool f1 = c0 < p.C1;
+            const float* xs = (f1 ? p.x1 : p.x2) + (long)n * (f1 ? p.x1_bs : p.x2_bs) + (long)(f1 ? c0 : c0 - p.C1) * planeS;
+            ADM_UNROLL
+            for (int c = 0; c < CK; ++c) v[c] = soff >= 0 ? xs[(long)c * planeS + soff] : 0.f;
+          }
+          if (p.gn_scale != nullptr && soff >= 0) {
+            ADM_UNROLL
+            for (int c = 0; c < CK; ++c) {
+              const float sc = p.gn_scale[(long)n * Ct + c0 + c], sh = p.gn_shift[(long)n * Ct + c0 + c];
+              float y = v[c] * sc + sh;
+              if (p.act) y = silu_f(y);
+              v[c] = y;
+            }
+          } else if (p.act && soff >= 0) {
+            ADM_UNROLL
+            for (int c = 0; c < CK; ++c) v[c] = silu_f(v[c]);
+          }
+          ADM_UNROLL
+          for (int c = 0; c < CK; ++c) ldsX[c * p.CS + q] = v[c];
+        }
+      }
+      ADM_UNROLL
+      for (int i = 0; i < NW4; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < TOT4) {
+          const int row = idx / ROW4, c4 = idx - row * ROW4;
+          *reinterpret_cast<float4*>(ldsW + row * BM + c4 * 4) = wraw[i];
+        }
+      }
+      __syncthreads();
+      if (c0 + CK < Ct) fetch(c0 + CK);
+    } else {
+      // ---- stage the activated input patch ----------------------------------------------------------
+      const bool from1 = c0 < p.C1;
+      const float* xb = from1 ? p.x1 : p.x2;
+      const long xbs = from1 ? p.x1_bs : p.x2_bs;
+      const int cb0 = from1 ? c0 : c0 - p.C1;
+      ADM_UNROLL
+      for (int qi = 0; qi < MAXQ; ++qi) {
+        const int q = tid + qi * 256;
+        if (q < NI * IHW) {
+          const int soff = q_soff[qi];
+          const int n = n0 + q_img[qi];
+          float v[CK];
           ADM_UNROLL
           for (int c = 0; c < CK; ++c) {
-            const float sc = p.gn_scale[(long)n * Ct + c0 + c], sh = p.gn_shift[(long)n * Ct + c0 + c];
-            float y = v[c] * sc + sh;
-            if (p.act) y = silu_f(y);
-            v[c] = y;
+            v[c] = 0.f;
+            if (soff >= 0) v[c] = xb[(long)n * xbs + (long)(cb0 + c) * planeS + soff];
           }
-        } else if (p.act && soff >= 0) {
+          if (p.gn_scale != nullptr && soff >= 0) {
+            ADM_UNROLL
+            for (int c = 0; c < CK; ++c) {
+              const float sc = p.gn_scale[(long)n * Ct + c0 + c], sh = p.gn_shift[(long)n * Ct + c0 + c];
+              float y = v[c] * sc + sh;
+              if (p.act) y = silu_f(y);
+              v[c] = y;
+            }
+          } else if (p.act && soff >= 0) {
+            ADM_UNROLL
+            for (int c = 0; c < CK; ++c) v[c] = silu_f(v[c]);
+          }
           ADM_UNROLL
-          for (int c = 0; c < CK; ++c) v[c] = silu_f(v[c]);
+          for (int c = 0; c < CK; ++c) ldsX[c * p.CS + q] = v[c];
         }
-        ADM_UNROLL
-        for (int c = 0; c < CK; ++c) ldsX[c * p.CS + q] = v[c];
       }
-    }
-    // ---- stage the weight slab: rows (c, tap), BM consecutive couts each --------------------------
-    {
-      constexpr int ROW4 = BM / 4;
-      constexpr int TOT4 = CK * KS2 * ROW4;
-      const float* wsrc = p.wp + (long)n0 * p.wp_bs + (long)c0 * KS2 * p.Cout + m0;
-      for (int idx = tid; idx < TOT4; idx += 256) {
-        const int row = idx / ROW4, c4 = idx - row * ROW4;
-        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + c4 * 4 < p.Cout) w = *reinterpret_cast<const float4*>(wsrc + (long)row * p.Cout + c4 * 4);
-        *reinterpret_cast<float4*>(ldsW + row * BM + c4 * 4) = w;
+      // ---- stage the weight slab: rows (c, tap), BM consecutive couts each --------------------------
+      {
+        const float* wsrc = p.wp + (long)n0 * p.wp_bs + (long)c0 * KS2 * p.Cout + m0;
+        for (int idx = tid; idx < TOT4; idx += 256) {
+          const int row = idx / ROW4, c4 = idx - row * ROW4;
+          float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m0 + c4 * 4 < p.Cout) w = *reinterpret_cast<const float4*>(wsrc + (long)row * p.Cout + c4 * 4);
+          *reinterpret_cast<float4*>(ldsW + row * BM + c4 * 4) = w;
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
     // ---- MFMA over this chunk: 9 taps x 4 channel pairs ------------------------------------------
     ADM_UNROLL
     for (int tap = 0; tap < KS2; ++tap) {
