@@ -708,12 +708,57 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_sp8_kernel(const WgradParam
   else wgrad_sp8_body<5, 4>(p, smem);                           // waves 4..7: taps 5..8
 }
 
+// dW[i] (=|+=) sum_k part[k][i]. One workgroup per 256 consecutive elements: lane group e = tid & 63 owns one float4 column,
+// wave g = tid >> 6 sums the slabs k = g, g + 4, ... (every wave-load is one contiguous KiB; four independent chains per thread
+// keep four loads in flight), the four partial sums meet in LDS in a fixed order. The first version walked the `split` slabs of
+// an element with one thread (up to 191 dependent-latency loads): 3.7 ms per training step at 40 % of the HBM rate.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int split, long numel,
                                                            float* dW, int accumulate) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long)gridDim.x * blockDim.x) {
-    float s = accumulate ? dW[i] : 0.f;
-    for (int k = 0; k < split; ++k) s += part[(long)k * numel + i];
-    dW[i] = s;
+  __shared__ float4 red[3][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  // float4 loads need numel % 4 == 0 (slab k starts at k * numel) and an aligned workspace; dW is a slice of the flat gradient
+  // buffer at an arbitrary float offset: vector stores only when it happens to be aligned
+  const bool vec = (numel & 3) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+  const bool dvec = (reinterpret_cast<uintptr_t>(dW) & 15) == 0;
+  for (long base = (long)blockIdx.x * 256; base < numel; base += (long)gridDim.x * 256) {
+    const long i = base + 4 * e;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    if (vec && i + 3 < numel) {
+      int k = g;
+      for (; k + 12 < split; k += 16) {
+        const float4 v0 = *reinterpret_cast<const float4*>(part + (long)k * numel + i);
+        const float4 v1 = *reinterpret_cast<const float4*>(part + (long)(k + 4) * numel + i);
+        const float4 v2 = *reinterpret_cast<const float4*>(part + (long)(k + 8) * numel + i);
+        const float4 v3 = *reinterpret_cast<const float4*>(part + (long)(k + 12) * numel + i);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+      }
+      for (; k < split; k += 4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(part + (long)k * numel + i);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      }
+    } else if (i < numel) {           // ragged tail (numel % 4 != 0 never happens for the conv shapes; kept for generality)
+      for (int k = g; k < split; k += 4)
+        for (int j = 0; j < 4 && i + j < numel; ++j) (&a0.x)[j] += part[(long)k * numel + i + j];
+    }
+    float4 s = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                           (a0.w + a1.w) + (a2.w + a3.w));
+    if (g > 0) red[g - 1][e] = s;
+    __syncthreads();
+    if (g == 0 && i < numel) {
+      const float4 r0 = red[0][e], r1 = red[1][e], r2 = red[2][e];
+      s.x = (s.x + r0.x) + (r1.x + r2.x); s.y = (s.y + r0.y) + (r1.y + r2.y);
+      s.z = (s.z + r0.z) + (r1.z + r2.z); s.w = (s.w + r0.w) + (r1.w + r2.w);
+      if (dvec && i + 3 < numel) {
+        if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(dW + i); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+        *reinterpret_cast<float4*>(dW + i) = s;
+      } else {
+        for (int j = 0; j < 4 && i + j < numel; ++j) dW[i + j] = (accumulate ? dW[i + j] : 0.f) + (&s.x)[j];
+      }
+    }
+    __syncthreads();
   }
 }
 
