@@ -34,7 +34,8 @@ def group(pred):
     return {"kernel": " | ".join(sorted({k[:40] for k in ks})), "launches_per_forward": int(n), "fetch_bytes_per_forward": f,
             "write_bytes_per_forward": w, "hbm_bytes_per_launch": (f + w) / max(n, 1)}
 out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over two eager UNet forwards, B=32, 256x256 (tools/pmc_forward.sh), halved; "
-                   "FETCH_SIZE doubled (gfx950 reports 1/2 of 16 B/lane streaming reads; check: gn_stats_kernel should read ~21.2 GB per forward). "
+                   "FETCH_SIZE doubled (gfx950 reports 1/2 of 16 B/lane streaming reads; check: gn_stats_kernel reads exactly its inputs — 21.2 GB per forward "
+                   "when every GroupNorm runs the read pass (ADM_GN_FOLD=0), the inputs of the remaining read passes otherwise). "
                    "Infinity-Cache hits are counted by this counter.",
        "by_variant": {"4314": group(lambda k: "conv_wino4" in k), "4313": group(lambda k: "conv_wino3" in k)},
        "gn_stats_check_GB": group(lambda k: "gn_stats" in k)["fetch_bytes_per_forward"] / 1e9,
