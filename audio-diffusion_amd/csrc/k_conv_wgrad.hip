@@ -28,6 +28,7 @@ struct WgradParams {
   // exact reciprocals (floor(2^32 / d) + 1) of the divisors of the per-element index math: n / d == umulhi(n, m) for
   // n, d < 2^16 — a runtime integer division costs ~40 VALU instructions, and the patch loop did 5 per element and tile
   unsigned mPE, mIHW, mIW, mTX, mTXY;
+  unsigned long long* prof;   // developer aid (ADM_WGRAD_PROF=1, generic stride-2 kernel): per-phase cycle counters, else NULL
 };
 
 __device__ __forceinline__ int fdiv(int n, unsigned magic) {   // n / d for 0 <= n < 2^16; magic = floor(2^32 / d) + 1,
@@ -36,9 +37,17 @@ __device__ __forceinline__ int fdiv(int n, unsigned magic) {   // n / d for 0 <=
 
 __device__ __forceinline__ float silu_g(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
 
-template <int KS, int STRIDE>
+#if defined(ADM_EMU)
+#define WG_CLK() 0ull
+#else
+#define WG_CLK() ((unsigned long long)__builtin_readcyclecounter())
+#endif
+#define WG_LAP(slot) do { if (PROF) { const unsigned long long tn_ = WG_CLK(); pr[slot] += tn_ - tq; tq = tn_; } } while (0)
+template <int KS, int STRIDE, bool PROF = false>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p) {
   constexpr int KS2 = KS * KS;
+  unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = PROF ? WG_CLK() : 0ull;
+  const unsigned long long t_start = tq;
   constexpr int NT = KS == 3 ? 9 : 4;     // column tiles (of 32 channels) per wave
   constexpr int CB = KS == 3 ? 32 : 128;  // channels per workgroup
   constexpr int DLD = 129;
@@ -68,36 +77,66 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
   for (int pt = t_begin; pt < t_end; ++pt) {
     const int tx = pt % p.tiles_x, ty = (pt / p.tiles_x) % p.tiles_y, ig = pt / (p.tiles_x * p.tiles_y);
     const int n0 = ig * NI;
+    WG_LAP(0);
     // ---- dy tile, transposed into [px][co] --------------------------------------------------------------
-    for (int e = tid; e < 128 * 64; e += 256) {
-      const int co = e >> 6, pp = e & 63;
-      const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
-      const int oy = ty * TH + py, ox = tx * TW + px, n = n0 + img;
-      float v = 0.f;
-      if (m0 + co < p.Cout && n < p.N && oy < p.Ho && ox < p.Wo)
-        v = p.dy[((long)n * p.Cout + m0 + co) * planeO + (long)oy * p.Wo + ox];
-      ldsD[pp * DLD + co] = v;
+    // Both staging loops issue their loads in UNCONDITIONAL batches of eight (clamped address, value masked afterwards): with a
+    // per-element "load or not" branch hipcc waits vmcnt(0) after every load, and ADM_WGRAD_PROF=1 showed the stride-2 layers
+    // spending 26k + 68k cycles per tile on 32 + 37 serialized load round trips next to 25k cycles of MFMAs (31 TF/s).
+    for (int e0 = tid; e0 < 128 * 64; e0 += 256 * 8) {
+      float v[8];
+      bool okv[8];
+      ADM_UNROLL
+      for (int j = 0; j < 8; ++j) {
+        const int e = e0 + 256 * j;
+        const int co = e >> 6, pp = e & 63;
+        const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
+        const int oy = ty * TH + py, ox = tx * TW + px, n = n0 + img;
+        okv[j] = m0 + co < p.Cout && n < p.N && oy < p.Ho && ox < p.Wo;
+        const long off = okv[j] ? ((long)n * p.Cout + m0 + co) * planeO + (long)oy * p.Wo + ox : 0;
+        v[j] = p.dy[off];
+      }
+      ADM_UNROLL
+      for (int j = 0; j < 8; ++j) {
+        const int e = e0 + 256 * j;
+        ldsD[(e & 63) * DLD + (e >> 6)] = okv[j] ? v[j] : 0.f;
+      }
     }
-    // ---- activated input patch ----------------------------------------------------------------------------
-    for (int e = tid; e < CB * NI * IHW; e += 256) {
-      const int c = e / (NI * IHW), q = e - c * (NI * IHW);
+    WG_LAP(1);                // dy staging
+    // ---- activated input patch: patch element outer (its placement costs three runtime divisions), channels inner ------------
+    const bool has_gn = p.gn_scale != nullptr;
+    for (int q = tid; q < NI * IHW; q += 256) {
       const int img = q / IHW, r2 = q - img * IHW;
       const int ly = r2 / p.IW, lx = r2 - ly * p.IW;
       const int gy = ty * TH * STRIDE + ly - p.pad_lo, gx = tx * TW * STRIDE + lx - p.pad_lo;
-      const int n = n0 + img, cc = c0 + c;
-      float v = 0.f;
-      if (cc < Ct && n < p.N && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi) {
-        const int sy = p.up ? (gy >> 1) : gy, sx = p.up ? (gx >> 1) : gx;
-        v = cc < p.C1 ? p.x1[(long)n * p.x1_bs + (long)cc * planeS + sy * p.Ws + sx]
-                      : p.x2[(long)n * p.x2_bs + (long)(cc - p.C1) * planeS + sy * p.Ws + sx];
-        if (p.gn_scale != nullptr) v = v * p.gn_scale[(long)n * Ct + cc] + p.gn_shift[(long)n * Ct + cc];
-        if (p.act) v = silu_g(v);
+      const int n = n0 + img;
+      const bool ok = n < p.N && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+      const int sy = p.up ? (gy >> 1) : gy, sx = p.up ? (gx >> 1) : gx;
+      const long o1 = ok ? (long)n * p.x1_bs + sy * p.Ws + sx : 0, o2 = ok ? (long)n * p.x2_bs + sy * p.Ws + sx : 0;
+      const long gno = ok ? (long)n * Ct : 0;
+      for (int cb = 0; cb < CB; cb += 8) {
+        float v[8], sc[8], sh[8];
+        ADM_UNROLL
+        for (int j = 0; j < 8; ++j) {
+          const int cc = c0 + cb + j;                       // wave-uniform: the source select is a scalar branch
+          const int ccl = cc < Ct ? cc : 0;
+          v[j] = ccl < p.C1 ? p.x1[o1 + (long)ccl * planeS] : p.x2[o2 + (long)(ccl - p.C1) * planeS];
+          if (has_gn) { sc[j] = p.gn_scale[gno + ccl]; sh[j] = p.gn_shift[gno + ccl]; }
+        }
+        ADM_UNROLL
+        for (int j = 0; j < 8; ++j) {
+          float y = v[j];
+          if (has_gn) y = y * sc[j] + sh[j];
+          if (p.act) y = silu_g(y);
+          ldsP[(cb + j) * p.PS + q] = (ok && c0 + cb + j < Ct) ? y : 0.f;
+        }
       }
-      ldsP[c * p.PS + q] = v;
     }
+    WG_LAP(2);                // patch staging
     __syncthreads();
+    WG_LAP(3);                // barrier
     // ---- 32 k-steps (pixel pairs) x NT MFMAs -----------------------------------------------------------------
-    for (int s = 0; s < 32; ++s) {
+#pragma unroll 4
+    for (int s = 0; s < 32; ++s) {       // four steps' operand reads in flight (rolled, every step paid its LDS latency: 25k cycles for 18.4k of MFMAs)
       const int pp = 2 * s + h;
       const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
       const int poff = img * IHW + py * STRIDE * p.IW + px * STRIDE;
@@ -110,7 +149,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
       }
     }
+    WG_LAP(4);                // MFMA loop
     __syncthreads();
+    WG_LAP(5);                // barrier
   }
   // ---- partial result in (Cout,Cin,ks,ks) order --------------------------------------------------------------
   float* out = p.part + (long)sp * p.Cout * Ct * KS2;
@@ -124,6 +165,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
       const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (co < p.Cout) out[((long)co * Ct + cc) * KS2 + tap] = acc[t][r];
     }
+  }
+  if (PROF) {
+    WG_LAP(6);
+    pr[7] = WG_CLK() - t_start;
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(p.prof + i, pr[i]);
   }
 }
 
@@ -797,7 +843,7 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
   conv_out_dims(a.H, a.W, a.up, a.stride, a.ks, a.pad_lo, &p.Ho, &p.Wo);
   p.up = a.up; p.pad_lo = a.ks == 1 ? 0 : a.pad_lo;
   p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.act = a.act;
-  p.part = workspace;
+  p.part = workspace; p.prof = nullptr;
   const int TW = p.Wo >= 16 ? 16 : p.Wo, TH = p.Ho >= 4 ? 4 : p.Ho;
   ADM_REQUIRE((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "conv_wgrad: small output dims must be powers of two");
   p.lTW = ilog2w(TW); p.lTH = ilog2w(TH);
@@ -887,6 +933,24 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
   } else if (a.ks == 3 && a.stride == 1) {
     ADM_LAUNCH((conv_wgrad_kernel<3, 1>), grid, block, smem, st, p);
   } else if (a.ks == 3) {
+#if !defined(ADM_EMU)
+    static const bool want_prof = getenv("ADM_WGRAD_PROF") != nullptr;
+    if (want_prof) {        // developer aid: per-phase cycle accounting of the generic stride-2 kernel, printed after the launch
+      static unsigned long long* dprof = [] { void* q = nullptr; (void)hipMalloc(&q, 8 * sizeof(unsigned long long)); return (unsigned long long*)q; }();
+      (void)hipMemsetAsync(dprof, 0, 8 * sizeof(unsigned long long), st);
+      p.prof = dprof;
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      ADM_LAUNCH((conv_wgrad_kernel<3, 2, true>), grid, block, smem, st, p);
+      unsigned long long h[8];
+      (void)hipMemcpyAsync(h, dprof, sizeof(h), hipMemcpyDeviceToHost, st);
+      (void)hipStreamSynchronize(st);
+      const double w = 4.0 * grid.x, nt = (double)p.tiles_per_block;
+      fprintf(stderr, "[wgrad s2 prof] %d->%d out %dx%d N=%d split=%d (%d workgroups, %.0f tiles each): per wave: total %.0f | per tile: "
+              "loop head %.0f dy %.0f patch %.0f barrier %.0f mfma %.0f barrier %.0f | epilogue %.0f cycles (288 MFMAs = 18432)\n", Ct, a.Cout,
+              p.Ho, p.Wo, a.N, p.split, (int)grid.x, nt, h[7] / w, h[0] / w / nt, h[1] / w / nt, h[2] / w / nt, h[3] / w / nt, h[4] / w / nt,
+              h[5] / w / nt, h[6] / w);
+    } else
+#endif
     ADM_LAUNCH((conv_wgrad_kernel<3, 2>), grid, block, smem, st, p);
   } else {
     ADM_LAUNCH((conv_wgrad_kernel<1, 1>), grid, block, smem, st, p);
