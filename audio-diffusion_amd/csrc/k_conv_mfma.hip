@@ -330,7 +330,11 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
 //   * the raw activations (+ GroupNorm scale/shift) of chunk c+1 are prefetched into registers before the MFMAs of
 //     chunk c and normalised/activated into LDS after them.
 // Two workgroups per CU (79.5 KiB LDS each), so one workgroup's stash/barrier phase hides under the other's MFMAs.
-template <int KS, int WM, int TM>
+// KSP (split K, 3x3 at tiny spatial sizes only): two workgroups share one output tile, each walks half of the input-channel
+// chunks and adds its partial sum to the zeroed output with one fp32 atomic per element (a + b = b + a: the result does not
+// depend on which half arrives first); half 0 carries bias / per-sample term / residual. Used when the tiles alone leave CUs idle
+// (dispatch_pf).
+template <int KS, int WM, int TM, bool KSP = false>
 __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p) {
   constexpr int WN = 4 / WM;
   constexpr int TN = 4 / WN;
@@ -353,6 +357,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
     const int b = blockIdx.x, q = p.nblk >> 3, r = p.nblk & 7, xcd = b & 7;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
+  const int khalf = KSP ? (lid & 1) : 0;
+  if (KSP) lid >>= 1;
   const int ct = lid % p.n_ct, pt = lid / p.n_ct;
   const int tx = pt % p.tiles_x, ty = (pt / p.tiles_x) % p.tiles_y, ig = pt / (p.tiles_x * p.tiles_y);
   const int TW = 1 << p.lTW, TH = 1 << p.lTH, NI = 128 >> (p.lTW + p.lTH);
@@ -441,9 +447,11 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
     }
   };
 
-  const int nchunks = Ct / CKP;
-  issue(0, 0);
-  for (int ci = 0; ci < nchunks; ++ci) {
+  const int nchunks_all = Ct / CKP;
+  const int ci0 = KSP ? khalf * (nchunks_all / 2) : 0;
+  const int nchunks = KSP ? (khalf ? nchunks_all : nchunks_all / 2) : nchunks_all;
+  issue(ci0 * CKP, ci0 & 1);
+  for (int ci = ci0; ci < nchunks; ++ci) {
 #if !defined(ADM_EMU)
     __builtin_amdgcn_s_setprio(3);   // the short stash/issue phase should not queue behind the other workgroup's MFMAs
 #endif
@@ -499,7 +507,35 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
     }
     __syncthreads();
   }
-  ADM_CONV_EPILOGUE(TM, TN);
+  if constexpr (KSP) {
+    const int m_wave = m0 + wm * TM * 32;
+    const long planeO = (long)p.Ho * p.Wo;
+    ADM_UNROLL
+    for (int tn = 0; tn < TN; ++tn) {
+      const int pp = (wn * TN + tn) * 32 + l31;
+      const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
+      const int oy = ty * TH + py, ox = tx * TW + px, n = n0 + img;
+      if (n >= p.N || oy >= p.Ho || ox >= p.Wo) continue;
+      const long pix = (long)oy * p.Wo + ox;
+      ADM_UNROLL
+      for (int tm = 0; tm < TM; ++tm) {
+        ADM_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          const int co = m_wave + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const long o = ((long)n * p.Cout + co) * planeO + pix;
+          float v = acc[tm][tn][r];
+          if (khalf == 0) {
+            v += p.bias[co];
+            if (p.chan_add != nullptr) v += p.chan_add[(long)n * p.chan_add_stride + co];
+            if (p.residual != nullptr) v += p.residual[o];
+          }
+          atomicAdd(p.out + o, v);
+        }
+      }
+    }
+  } else {
+    ADM_CONV_EPILOGUE(TM, TN);
+  }
 }
 
 void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo) {
@@ -594,6 +630,20 @@ static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
     allow_big_lds(conv_mfma_pf_kernel<KS, 2, 1>, smem);
     ADM_LAUNCH((conv_mfma_pf_kernel<KS, 2, 1>), grid, block, smem, st, p);
   } else {
+    // split K over two workgroups when the tiles alone leave CUs idle (3x3 at 8x8 / 4x4 pixels at B <= 16: 119 -> 70 us per 512->512
+    // layer at B = 16). With one workgroup per CU already (B = 32: 256 tiles) it buys nothing — measured 109 us either way: a 32-cout
+    // x 128-pixel tile moves 20.7 KB per 2304 MFMA cycles, two co-resident workgroups sit at the ~10 B/clk a CU is served with
+    static const int use_ksp = [] { const char* e = getenv("ADM_CONV_KSPLIT"); return e ? atoi(e) : 1; }();
+    const int nch = (p.C1 + p.C2) / CKP;
+    if (KS == 3 && use_ksp && p.nblk < 256 && nch >= 8 && p.out != p.residual && p.wp_bs == 0) {
+      ConvParams q = p;
+      q.nblk = 2 * p.nblk;
+      g_last_variant += 5;      // 2316: the split-K instantiation of <3, 1, 1>
+      ADM_TRY(dmemset(p.out, 0, sizeof(float) * (size_t)p.N * p.Cout * p.Ho * p.Wo, st));
+      allow_big_lds(conv_mfma_pf_kernel<KS, 1, 1, true>, smem);
+      ADM_LAUNCH((conv_mfma_pf_kernel<KS, 1, 1, true>), dim3(q.nblk), block, smem, st, q);
+      return ADM_CHECK_LAUNCH();
+    }
     allow_big_lds(conv_mfma_pf_kernel<KS, 1, 1>, smem);
     ADM_LAUNCH((conv_mfma_pf_kernel<KS, 1, 1>), grid, block, smem, st, p);
   }
