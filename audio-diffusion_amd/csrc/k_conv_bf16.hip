@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
     ADM_UNROLL
     for (int r = 0; r < 16; ++r) {
       const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      out[((long)co * Ct + cc) * 9 + t] = acc[t][r];
+      out[((long)t * p.Cout + co) * Ct + cc] = acc[t][r];      // slab layout [tap][cout][cin] (k_conv_wgrad.hip: wgrad_reduce_kernel)
     }
   }
   if (PROF) {

@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
     ADM_UNROLL
     for (int r = 0; r < 16; ++r) {
       const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (co < p.Cout) out[((long)co * Ct + cc) * KS2 + tap] = acc[t][r];
+      if (co < p.Cout) out[((long)tap * p.Cout + co) * Ct + cc] = acc[t][r];      // slab layout [tap][cout][cin]: see wgrad_reduce_kernel
     }
   }
   if (PROF) {
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_pf_kernel(const WgradParams
     ADM_UNROLL
     for (int r = 0; r < 16; ++r) {
       const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (co < p.Cout) out[((long)co * Ct + cc) * KS2 + tap] = acc[t][r];
+      if (co < p.Cout) out[((long)tap * p.Cout + co) * Ct + cc] = acc[t][r];      // slab layout [tap][cout][cin]: see wgrad_reduce_kernel
     }
   }
 }
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_sp_kernel(const WgradParams
     ADM_UNROLL
     for (int r = 0; r < 16; ++r) {
       const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      out[((long)co * Ct + cc) * 9 + t] = acc[t][r];
+      out[((long)t * p.Cout + co) * Ct + cc] = acc[t][r];      // slab layout [tap][cout][cin]
     }
   }
 }
@@ -742,7 +742,7 @@ __device__ __forceinline__ void wgrad_sp8_body(const WgradParams& p, float* smem
     ADM_UNROLL
     for (int r = 0; r < 16; ++r) {
       const int co = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      out[((long)co * Ct + cc) * 9 + T0 + t] = acc[t][r];
+      out[((long)(T0 + t) * p.Cout + co) * Ct + cc] = acc[t][r];      // slab layout [tap][cout][cin]
     }
   }
 }
@@ -754,18 +754,22 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_sp8_kernel(const WgradParam
   else wgrad_sp8_body<5, 4>(p, smem);                           // waves 4..7: taps 5..8
 }
 
-// dW[i] (=|+=) sum_k part[k][i]. One workgroup per 256 consecutive elements: lane group e = tid & 63 owns one float4 column,
-// wave g = tid >> 6 sums the slabs k = g, g + 4, ... (every wave-load is one contiguous KiB; four independent chains per thread
-// keep four loads in flight), the four partial sums meet in LDS in a fixed order. The first version walked the `split` slabs of
-// an element with one thread (up to 191 dependent-latency loads): 3.7 ms per training step at 40 % of the HBM rate.
+// dW (=|+=) sum_k part[k]. The slabs are [tap][cout][cin] — a wave's 32 consecutive cins are one 128-byte run, so the kernels'
+// partial-sum epilogue touches two cache lines per store instruction; in the final (cout, cin, tap) order the same store was 32
+// words 36 bytes apart, ~18 lines, and on the small-spatial / wide layers (two 8x8 tiles per workgroup) the epilogue cost twice
+// the MFMAs (ADM_WGRAD_PROF: 72k cycles). The transposition to (cout, cin, tap) happens here, once instead of `split` times.
+// One workgroup per 256 consecutive slab elements: lane group e = tid & 63 owns one float4 column, wave g = tid >> 6 sums the
+// slabs k = g, g + 4, ... (every wave-load is one contiguous KiB; four independent chains per thread keep four loads in
+// flight), the four partial sums meet in LDS in a fixed order.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int split, long numel,
-                                                           float* dW, int accumulate) {
+                                                           float* dW, int accumulate, int taps) {
   __shared__ float4 red[3][64];
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
   // float4 loads need numel % 4 == 0 (slab k starts at k * numel) and an aligned workspace; dW is a slice of the flat gradient
-  // buffer at an arbitrary float offset: vector stores only when it happens to be aligned
+  // buffer at an arbitrary float offset: vector stores only when it happens to be aligned (and the layout is the same: taps == 1)
   const bool vec = (numel & 3) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
-  const bool dvec = (reinterpret_cast<uintptr_t>(dW) & 15) == 0;
+  const bool dvec = taps == 1 && (reinterpret_cast<uintptr_t>(dW) & 15) == 0;
+  const long M = numel / taps;                                  // cout * cin
   for (long base = (long)blockIdx.x * 256; base < numel; base += (long)gridDim.x * 256) {
     const long i = base + 4 * e;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
@@ -785,7 +789,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
         const float4 v0 = *reinterpret_cast<const float4*>(part + (long)k * numel + i);
         a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
       }
-    } else if (i < numel) {           // ragged tail (numel % 4 != 0 never happens for the conv shapes; kept for generality)
+    } else if (i < numel) {           // ragged tail / unaligned workspace (never for the conv shapes; kept for generality)
       for (int k = g; k < split; k += 4)
         for (int j = 0; j < 4 && i + j < numel; ++j) (&a0.x)[j] += part[(long)k * numel + i + j];
     }
@@ -801,7 +805,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
         if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(dW + i); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
         *reinterpret_cast<float4*>(dW + i) = s;
       } else {
-        for (int j = 0; j < 4 && i + j < numel; ++j) dW[i + j] = (accumulate ? dW[i + j] : 0.f) + (&s.x)[j];
+        for (int j = 0; j < 4 && i + j < numel; ++j) {
+          const long sj = i + j, o = taps == 1 ? sj : (sj % M) * taps + sj / M;     // slab [tap][cout*cin] -> (cout, cin, tap)
+          dW[o] = (accumulate ? dW[o] : 0.f) + (&s.x)[j];
+        }
       }
     }
     __syncthreads();
@@ -888,7 +895,7 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
     ADM_REQUIRE(slabs > 0 && slabs <= p.split, "conv1x1_wgrad_bf16: launch failed");
     long gb = (numel + 255) / 256;
     if (gb > 4096) gb = 4096;
-    ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, st, (const float*)workspace, slabs, numel, dW, accumulate);
+    ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, st, (const float*)workspace, slabs, numel, dW, accumulate, a.ks * a.ks);
     return ADM_CHECK_LAUNCH();
   }
   if (conv_bf16_enabled() && conv_wgrad_bf16_eligible(a)) {   // mixed precision: bf16 operands, fp32 partial sums
@@ -896,7 +903,7 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
     long gb = (numel + 255) / 256;
     if (gb > 4096) gb = 4096;
     ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, st, (const float*)workspace, p.split, numel, dW,
-               accumulate);
+               accumulate, a.ks * a.ks);
     return ADM_CHECK_LAUNCH();
   }
   // tile-invariant prefetch path: no upsample fold, every channel chunk inside one source tensor, full cout tiles
@@ -958,7 +965,7 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
   long g = (numel + 255) / 256;
   if (g > 4096) g = 4096;
   ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, p.split, numel, dW,
-             accumulate);
+             accumulate, a.ks * a.ks);
   return ADM_CHECK_LAUNCH();
 }
 
