@@ -815,7 +815,55 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// The same for 3x3 weights with both sides coalesced: a workgroup owns 64 consecutive (cout, cin) pairs m — in every slab one
+// contiguous 256-byte run per tap, in dW the 576 contiguous floats m * 9 + tap. Lane m of wave g sums its nine taps over the slabs
+// k = g, g + 4, ... (nine independent chains), the four waves' sums meet in LDS in a fixed order and dW is written in order. (The generic
+// kernel above writes dW[m * 9 + tap] straight from the slab order: 64 cache lines per store instruction.)
+__global__ void __launch_bounds__(256) wgrad_reduce9_kernel(const float* __restrict__ part, int split, long M,
+                                                            float* dW, int accumulate) {
+  __shared__ float tile[4][64 * 9];
+  const long numel = 9 * M;
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;         // pair m0 + e, slabs k = g, g + 4, ...
+  for (long m0 = (long)blockIdx.x * 64; m0 < M; m0 += (long)gridDim.x * 64) {
+    const long m = m0 + e;
+    float a[9];
+    ADM_UNROLL
+    for (int t = 0; t < 9; ++t) a[t] = 0.f;
+    if (m < M) {
+      for (int k = g; k < split; k += 4) {
+        const float* src = part + (long)k * numel + m;
+        ADM_UNROLL
+        for (int t = 0; t < 9; ++t) a[t] += src[(long)t * M];
+      }
+    }
+    ADM_UNROLL
+    for (int t = 0; t < 9; ++t) tile[g][e * 9 + t] = a[t];
+    __syncthreads();
+    const long o0 = m0 * 9;
+    const int cnt = (int)(M - m0 < 64 ? M - m0 : 64) * 9;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+      const float v = (tile[0][i] + tile[1][i]) + (tile[2][i] + tile[3][i]);
+      dW[o0 + i] = (accumulate ? dW[o0 + i] : 0.f) + v;
+    }
+    __syncthreads();
+  }
+}
+
 static inline int ilog2w(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+static int launch_wgrad_reduce(const float* workspace, int split, long numel, float* dW, int accumulate, int taps, hipStream_t st) {
+  if (taps == 9) {
+    const long M = numel / 9;
+    long g = (M + 63) / 64;
+    if (g > 16384) g = 16384;
+    ADM_LAUNCH(wgrad_reduce9_kernel, dim3((unsigned)g), dim3(256), 0, st, workspace, split, M, dW, accumulate);
+    return ADM_CHECK_LAUNCH();
+  }
+  long g = (numel + 255) / 256;
+  if (g > 4096) g = 4096;
+  ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, workspace, split, numel, dW, accumulate, taps);
+  return ADM_CHECK_LAUNCH();
+}
 
 // workspace floats needed by launch_conv_wgrad for this shape
 static int g_wgrad_max_split = 0;   // 0 = no cap; adm_set_option("wgrad_max_split", n) caps the split-K factor (tests use it
@@ -893,18 +941,11 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
   if (conv_bf16_mode() >= 2 && conv1x1_wgrad_bf16_eligible(a)) {   // level 2: 1x1 weight gradient on bf16 operands
     const int slabs = launch_conv1x1_wgrad_bf16(a, dy, workspace, p.split, st);
     ADM_REQUIRE(slabs > 0 && slabs <= p.split, "conv1x1_wgrad_bf16: launch failed");
-    long gb = (numel + 255) / 256;
-    if (gb > 4096) gb = 4096;
-    ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, st, (const float*)workspace, slabs, numel, dW, accumulate, a.ks * a.ks);
-    return ADM_CHECK_LAUNCH();
+    return launch_wgrad_reduce(workspace, slabs, numel, dW, accumulate, a.ks * a.ks, st);
   }
   if (conv_bf16_enabled() && conv_wgrad_bf16_eligible(a)) {   // mixed precision: bf16 operands, fp32 partial sums
     ADM_TRY(launch_conv_wgrad_bf16(a, dy, dW, accumulate, workspace, p.split, st));
-    long gb = (numel + 255) / 256;
-    if (gb > 4096) gb = 4096;
-    ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, st, (const float*)workspace, p.split, numel, dW,
-               accumulate, a.ks * a.ks);
-    return ADM_CHECK_LAUNCH();
+    return launch_wgrad_reduce(workspace, p.split, numel, dW, accumulate, a.ks * a.ks, st);
   }
   // tile-invariant prefetch path: no upsample fold, every channel chunk inside one source tensor, full cout tiles
   const bool fast = a.up == 0 && a.C1 % CB == 0 && Ct % CB == 0 && a.Cout % 128 == 0;
@@ -962,11 +1003,7 @@ int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int ac
   } else {
     ADM_LAUNCH((conv_wgrad_kernel<1, 1>), grid, block, smem, st, p);
   }
-  long g = (numel + 255) / 256;
-  if (g > 4096) g = 4096;
-  ADM_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, p.split, numel, dW,
-             accumulate, a.ks * a.ks);
-  return ADM_CHECK_LAUNCH();
+  return launch_wgrad_reduce(workspace, p.split, numel, dW, accumulate, a.ks * a.ks, st);
 }
 
 }  // namespace adm
