@@ -300,7 +300,7 @@ __device__ __forceinline__ int bdiv(int n, int d, unsigned magic) {   // n / d; 
 }
 
 // raw fp32 prefetch of one 16x4-pixel tile: 4 dy items (8 pixels each), 7 patch pixel pairs, their in-bounds bits, image
-struct Bf16WgStage { float4 d[4][2]; float xa[7], xb[7]; unsigned ok; int n; };
+struct Bf16WgStage { float4 d[8]; float xa[7], xb[7]; unsigned ok; int n; };
 
 template <bool UP, bool ACT, bool F16 = false, bool PROF = false>
 __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16WgradParams p) {
@@ -351,15 +351,18 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
     ADM_UNROLL
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // tile-invariant staging roles.  dy: item = (cout, row, half), 4 per thread, 8 pixels (two float4) each.
+  // tile-invariant staging roles.  dy: item = (cout, row, quarter of the 16-pixel row), 8 per thread, one float4 each: the four
+  // lanes of a (cout, row) read its 64 bytes with ONE instruction, a wave-load touches 16 row segments. (Round 1: item = (cout,
+  // row, half) as two float4 per lane — both instructions of an item touched the same 32 segments; the vector L1 charges per
+  // segment an instruction touches, profiles/r02_bf16_training.md.)
   // patch: item = (row, cin, pixel pair), 1728 items in 7 rounds (the last one partial).
-  unsigned dyo[4]; int ldsd[4];
+  unsigned dyo[8]; int ldsd[8];                   // ldsd: dword index of the item's 8-byte half inside the dy image
   ADM_UNROLL
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 8; ++j) {
     const int id = tid + 256 * j;
-    const int hh = id & 1, r = (id >> 1) & 3, co = id >> 3;
-    dyo[j] = (unsigned)(co * (int)planeO + r * p.Wi + 8 * hh);
-    ldsd[j] = (r * 2 + hh) * DLD + co;
+    const int qd = id & 3, r = (id >> 2) & 3, co = id >> 4;
+    dyo[j] = (unsigned)(co * (int)planeO + r * p.Wi + 4 * qd);
+    ldsd[j] = ((r * 2 + (qd >> 1)) * DLD + co) * 4 + 2 * (qd & 1);
   }
   int xcin[7], xrow[7], xq[7], ldsx[7];
   ADM_UNROLL
@@ -378,10 +381,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
     s.n = n;
     const float* dbase = p.dy + ((long)n * p.Cout + m0) * planeO + (long)(ty * 4) * p.Wi + tx * 16;   // uniform
     ADM_UNROLL
-    for (int j = 0; j < 4; ++j) {
-      s.d[j][0] = *reinterpret_cast<const float4*>(dbase + dyo[j]);
-      s.d[j][1] = *reinterpret_cast<const float4*>(dbase + dyo[j] + 4);
-    }
+    for (int j = 0; j < 8; ++j) s.d[j] = *reinterpret_cast<const float4*>(dbase + dyo[j]);
     const float* xt = xsrc + (long)n * xbs;                                                            // uniform
     const int gy0 = ty * 4 - 1, gx0 = tx * 16 - 1;
     unsigned ok = 0;
@@ -400,13 +400,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_bf16_kernel(const Bf16Wgrad
   };
   auto stash_tile = [&](const Bf16WgStage& s, u32x4* buf) __attribute__((always_inline)) {
     unsigned* bufX = reinterpret_cast<unsigned*>(buf + DFR);
+    unsigned* bufD = reinterpret_cast<unsigned*>(buf);
     ADM_UNROLL
-    for (int j = 0; j < 4; ++j) {
-      const float4 v0 = s.d[j][0], v1 = s.d[j][1];
-      u32x4 w;
-      w[0] = ADM_PK16(F16, v0.x, v0.y); w[1] = ADM_PK16(F16, v0.z, v0.w);
-      w[2] = ADM_PK16(F16, v1.x, v1.y); w[3] = ADM_PK16(F16, v1.z, v1.w);
-      buf[ldsd[j]] = w;
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = s.d[j];
+      const unsigned long long w = (unsigned long long)ADM_PK16(F16, v.x, v.y) | ((unsigned long long)ADM_PK16(F16, v.z, v.w) << 32);
+      *reinterpret_cast<unsigned long long*>(bufD + ldsd[j]) = w;              // ds_write_b64
     }
     ADM_UNROLL
     for (int j = 0; j < 7; ++j) {
