@@ -108,8 +108,8 @@ typedef struct adm_conv_args {
   /* optional: GroupNorm statistics of the OUTPUT, produced by the convolution's own epilogue instead of a separate read
    * pass: per (sample, output channel, pixel tile) the fp64 pair (sum, sum of squares) of the final output values,
    * stats_out[((n * Cout + c) * stats_tiles + tile) * 2 + {0, 1}]. stats_tiles must equal adm_conv_stats_tiles(args) (> 0
-   * only for the kernels that can do it: today the Winograd v4 kernel); adm_groupnorm_finalize turns them into
-   * scale / shift. */
+   * only for the kernels that can do it: the Winograd v4 kernel and the conv_in class kernel (Cin <= 4, W % 4 == 0));
+   * adm_groupnorm_finalize turns them into scale / shift. */
   double* stats_out; int stats_tiles;
 } adm_conv_args;
 /* number of statistic tiles per (sample, channel) the kernel chosen for these arguments would emit, 0 = it cannot. */
