@@ -39,6 +39,7 @@ struct ConvParams {
   const float* residual; float* out;
   int lTW, lTH, tiles_x, tiles_y, n_ct, IH, IW, CS, nblk;
   long x1_bs, x2_bs, wp_bs;  // batch strides (elements) of x1/x2 (channel-slice views) and of per-sample weights (0: shared)
+  int ksplit; long part_stride; // split-K instantiations: S workgroups per tile, each writes its partial sums to out + s * part_stride
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
@@ -330,10 +331,11 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
 //   * the raw activations (+ GroupNorm scale/shift) of chunk c+1 are prefetched into registers before the MFMAs of
 //     chunk c and normalised/activated into LDS after them.
 // Two workgroups per CU (79.5 KiB LDS each), so one workgroup's stash/barrier phase hides under the other's MFMAs.
-// KSP (split K, 3x3 at tiny spatial sizes only): two workgroups share one output tile, each walks half of the input-channel
-// chunks and adds its partial sum to the zeroed output with one fp32 atomic per element (a + b = b + a: the result does not
-// depend on which half arrives first); half 0 carries bias / per-sample term / residual. Used when the tiles alone leave CUs idle
-// (dispatch_pf).
+// KSP (split K, 3x3 at tiny spatial sizes only): S = p.ksplit workgroups share one output tile, each walks 1/S of the
+// input-channel chunks and stores its partial sums (no bias) to slab s of a scratch buffer; ksplit_finish_kernel adds the slabs in
+// order together with bias / per-sample term / residual. Deterministic, and the tile can be 64 couts wide: at 8x8 pixels and B = 32
+// the 32-cout tiles that fill the chip without it move 20.7 KB per 2304 MFMA cycles — two co-resident workgroups sit at the
+// ~10 B/clk a CU is served with (109 us per 512->512 layer whatever the split).
 template <int KS, int WM, int TM, bool KSP = false>
 __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p) {
   constexpr int WN = 4 / WM;
@@ -357,8 +359,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
     const int b = blockIdx.x, q = p.nblk >> 3, r = p.nblk & 7, xcd = b & 7;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
-  const int khalf = KSP ? (lid & 1) : 0;
-  if (KSP) lid >>= 1;
+  const int kpart = KSP ? lid % p.ksplit : 0;
+  if (KSP) lid /= p.ksplit;
   const int ct = lid % p.n_ct, pt = lid / p.n_ct;
   const int tx = pt % p.tiles_x, ty = (pt / p.tiles_x) % p.tiles_y, ig = pt / (p.tiles_x * p.tiles_y);
   const int TW = 1 << p.lTW, TH = 1 << p.lTH, NI = 128 >> (p.lTW + p.lTH);
@@ -448,8 +450,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
   };
 
   const int nchunks_all = Ct / CKP;
-  const int ci0 = KSP ? khalf * (nchunks_all / 2) : 0;
-  const int nchunks = KSP ? (khalf ? nchunks_all : nchunks_all / 2) : nchunks_all;
+  const int ci0 = KSP ? (int)((long)kpart * nchunks_all / p.ksplit) : 0;
+  const int nchunks = KSP ? (int)((long)(kpart + 1) * nchunks_all / p.ksplit) : nchunks_all;
   issue(ci0 * CKP, ci0 & 1);
   for (int ci = ci0; ci < nchunks; ++ci) {
 #if !defined(ADM_EMU)
@@ -510,6 +512,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
   if constexpr (KSP) {
     const int m_wave = m0 + wm * TM * 32;
     const long planeO = (long)p.Ho * p.Wo;
+    float* part = p.out + (long)kpart * p.part_stride;
     ADM_UNROLL
     for (int tn = 0; tn < TN; ++tn) {
       const int pp = (wn * TN + tn) * 32 + l31;
@@ -522,14 +525,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p
         ADM_UNROLL
         for (int r = 0; r < 16; ++r) {
           const int co = m_wave + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const long o = ((long)n * p.Cout + co) * planeO + pix;
-          float v = acc[tm][tn][r];
-          if (khalf == 0) {
-            v += p.bias[co];
-            if (p.chan_add != nullptr) v += p.chan_add[(long)n * p.chan_add_stride + co];
-            if (p.residual != nullptr) v += p.residual[o];
-          }
-          atomicAdd(p.out + o, v);
+          part[((long)n * p.Cout + co) * planeO + pix] = acc[tm][tn][r];
         }
       }
     }
@@ -618,11 +614,94 @@ static bool use_pf() {
   return v != 0;
 }
 
+// out[n][co][pix] = bias[co] + chan_add[n][co] + residual + sum_s part[s][...] (slabs in order); float4 over pixels when HW % 4 == 0
+__global__ void __launch_bounds__(256) ksplit_finish_kernel(const float* __restrict__ part, int S, long part_stride,
+                                                            const float* __restrict__ bias, const float* __restrict__ chan_add,
+                                                            int chan_add_stride, const float* residual, float* out, int Cout, int HW,
+                                                            long total4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4, nc = e / HW;
+    const int co = (int)(nc % Cout), n = (int)(nc / Cout);
+    float b = bias[co];
+    if (chan_add != nullptr) b += chan_add[(long)n * chan_add_stride + co];
+    float4 v = *reinterpret_cast<const float4*>(part + e);
+    for (int s2 = 1; s2 < S; ++s2) {
+      const float4 q = *reinterpret_cast<const float4*>(part + (long)s2 * part_stride + e);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    v.x += b; v.y += b; v.z += b; v.w += b;
+    if (residual != nullptr) {
+      const float4 q = *reinterpret_cast<const float4*>(residual + e);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    *reinterpret_cast<float4*>(out + e) = v;
+  }
+}
+
+// per-device scratch for the split-K partial slabs; grown only outside stream capture (the executors run one uncaptured forward
+// before they capture), nullptr when it cannot be provided -> the caller takes the unsplit path
+static float* ksplit_scratch(size_t floats, hipStream_t st) {
+  static float* buf[16] = {};
+  static size_t cap[16] = {};
+  const int d = const_dev_slot();
+  if (floats <= cap[d]) return buf[d];
+#if !defined(ADM_EMU)
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+#endif
+  const size_t want = floats < ((size_t)8 << 20) ? ((size_t)8 << 20) : floats;      // >= 32 MiB
+  void* q = nullptr;
+  if (dmalloc(&q, sizeof(float) * want) != 0) return nullptr;
+  buf[d] = (float*)q;   // the previous (smaller) buffer is intentionally leaked: launches may still read it
+  cap[d] = want;
+  return buf[d];
+}
+
+template <int KS>
+static int launch_ksplit(const ConvParams& p, int bm, int S, hipStream_t st) {
+  constexpr int CKP = KS == 1 ? 32 : CK;
+  const size_t smem = sizeof(float) * ((size_t)CKP * p.CS + 2 * (size_t)CKP * KS * KS * bm);
+  const long total = (long)p.N * p.Cout * p.Ho * p.Wo;
+  float* scratch = ksplit_scratch((size_t)S * total, st);
+  if (scratch == nullptr) return 1;                       // not available: unsplit path
+  ConvParams q = p;
+  q.ksplit = S; q.part_stride = total; q.out = scratch;
+  q.n_ct = p.Cout / bm;
+  q.nblk = (p.nblk / p.n_ct) * q.n_ct * S;
+  if (bm == 64) {
+    allow_big_lds(conv_mfma_pf_kernel<KS, 2, 1, true>, smem);
+    ADM_LAUNCH((conv_mfma_pf_kernel<KS, 2, 1, true>), dim3(q.nblk), dim3(256), smem, st, q);
+  } else {
+    allow_big_lds(conv_mfma_pf_kernel<KS, 1, 1, true>, smem);
+    ADM_LAUNCH((conv_mfma_pf_kernel<KS, 1, 1, true>), dim3(q.nblk), dim3(256), smem, st, q);
+  }
+  long g = (total / 4 + 255) / 256;
+  if (g > 4096) g = 4096;
+  ADM_LAUNCH(ksplit_finish_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)scratch, S, total, p.bias, p.chan_add,
+             p.chan_add_stride, p.residual, p.out, p.Cout, p.Ho * p.Wo, total / 4);
+  return ADM_CHECK_LAUNCH();
+}
+
 template <int KS>
 static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
   constexpr int CKP = KS == 1 ? 32 : CK;
   const size_t smem = sizeof(float) * ((size_t)CKP * p.CS + 2 * (size_t)CKP * KS * KS * bm);
   dim3 grid(p.nblk), block(256);
+  // 3x3 at tiny spatial sizes (the tiles alone cannot give every CU two workgroups): 64-cout tiles, K split over S workgroups
+  static const int use_ksp = [] { const char* e = getenv("ADM_CONV_KSPLIT"); return e ? atoi(e) : 1; }();
+  const int nch = (p.C1 + p.C2) / CKP;
+  const long total = (long)p.N * p.Cout * p.Ho * p.Wo;
+  if (KS == 3 && use_ksp && bm == 32 && p.nblk <= 256 && nch >= 16 && p.wp_bs == 0 && total % 4 == 0) {
+    const int bm2 = p.Cout % 64 == 0 ? 64 : 32;
+    const int tiles = (p.nblk / p.n_ct) * (p.Cout / bm2);
+    int S = (512 + tiles - 1) / tiles;
+    if (S > 8) S = 8;
+    while (S > 1 && nch / S < 4) --S;
+    if (S > 1) {
+      const int rc = launch_ksplit<KS>(p, bm2, S, st);
+      if (rc <= 0) { if (rc == 0) g_last_variant += 5; return rc; }      // 2316: the split-K instantiation
+    }
+  }
   if (bm == 128) {
     allow_big_lds(conv_mfma_pf_kernel<KS, 2, 2>, smem);
     ADM_LAUNCH((conv_mfma_pf_kernel<KS, 2, 2>), grid, block, smem, st, p);
@@ -630,20 +709,6 @@ static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
     allow_big_lds(conv_mfma_pf_kernel<KS, 2, 1>, smem);
     ADM_LAUNCH((conv_mfma_pf_kernel<KS, 2, 1>), grid, block, smem, st, p);
   } else {
-    // split K over two workgroups when the tiles alone leave CUs idle (3x3 at 8x8 / 4x4 pixels at B <= 16: 119 -> 70 us per 512->512
-    // layer at B = 16). With one workgroup per CU already (B = 32: 256 tiles) it buys nothing — measured 109 us either way: a 32-cout
-    // x 128-pixel tile moves 20.7 KB per 2304 MFMA cycles, two co-resident workgroups sit at the ~10 B/clk a CU is served with
-    static const int use_ksp = [] { const char* e = getenv("ADM_CONV_KSPLIT"); return e ? atoi(e) : 1; }();
-    const int nch = (p.C1 + p.C2) / CKP;
-    if (KS == 3 && use_ksp && p.nblk < 256 && nch >= 8 && p.out != p.residual && p.wp_bs == 0) {
-      ConvParams q = p;
-      q.nblk = 2 * p.nblk;
-      g_last_variant += 5;      // 2316: the split-K instantiation of <3, 1, 1>
-      ADM_TRY(dmemset(p.out, 0, sizeof(float) * (size_t)p.N * p.Cout * p.Ho * p.Wo, st));
-      allow_big_lds(conv_mfma_pf_kernel<KS, 1, 1, true>, smem);
-      ADM_LAUNCH((conv_mfma_pf_kernel<KS, 1, 1, true>), dim3(q.nblk), block, smem, st, q);
-      return ADM_CHECK_LAUNCH();
-    }
     allow_big_lds(conv_mfma_pf_kernel<KS, 1, 1>, smem);
     ADM_LAUNCH((conv_mfma_pf_kernel<KS, 1, 1>), grid, block, smem, st, p);
   }
@@ -704,6 +769,7 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
   p.wp_bs = a.w_bstride;
+  p.ksplit = 1; p.part_stride = 0;
   // 3x3: 16 x 8 pixel tiles (small halo); 1x1 has no halo: rows as long as the image allows (<= 128 pixels), so that the
   // pipelined kernel loads and stores whole contiguous row segments
   int TW = p.Wo >= 16 ? 16 : p.Wo, TH = p.Ho >= 8 ? 8 : p.Ho;
