@@ -20,6 +20,7 @@
 // (256^2 ... 1x1). Algorithmic bytes per launch: 4*(N*Cin*Hs*Ws + N*Cout*Ho*Wo [+ residual]) + 4*Cout*Cin*ks^2.
 #include <cstdlib>
 
+#include <mutex>
 #include <vector>
 
 #include "adm_kernels.h"
@@ -638,13 +639,21 @@ __global__ void __launch_bounds__(256) ksplit_finish_kernel(const float* __restr
   }
 }
 
-// per-device scratch for the split-K partial slabs; grown only outside stream capture (the executors run one uncaptured forward
-// before they capture), nullptr when it cannot be provided -> the caller takes the unsplit path
+// scratch for the split-K partial slabs, one buffer per (device, stream): launches on one stream are ordered, two streams must
+// not share it. Grown only outside stream capture (the executors run one uncaptured forward before they capture); nullptr when
+// it cannot be provided (capture in progress, more than 8 streams per device, out of memory) -> the caller takes the unsplit path
 static float* ksplit_scratch(size_t floats, hipStream_t st) {
-  static float* buf[16] = {};
-  static size_t cap[16] = {};
+  struct Slot { hipStream_t st; float* buf; size_t cap; bool used; };
+  static Slot slots[16][8] = {};
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   const int d = const_dev_slot();
-  if (floats <= cap[d]) return buf[d];
+  Slot* sl = nullptr;
+  for (Slot& s : slots[d]) if (s.used && s.st == st) { sl = &s; break; }
+  if (sl == nullptr)
+    for (Slot& s : slots[d]) if (!s.used) { sl = &s; sl->used = true; sl->st = st; sl->buf = nullptr; sl->cap = 0; break; }
+  if (sl == nullptr) return nullptr;
+  if (floats <= sl->cap) return sl->buf;
 #if !defined(ADM_EMU)
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
@@ -652,9 +661,9 @@ static float* ksplit_scratch(size_t floats, hipStream_t st) {
   const size_t want = floats < ((size_t)8 << 20) ? ((size_t)8 << 20) : floats;      // >= 32 MiB
   void* q = nullptr;
   if (dmalloc(&q, sizeof(float) * want) != 0) return nullptr;
-  buf[d] = (float*)q;   // the previous (smaller) buffer is intentionally leaked: launches may still read it
-  cap[d] = want;
-  return buf[d];
+  sl->buf = (float*)q;   // the previous (smaller) buffer is intentionally leaked: launches may still read it
+  sl->cap = want;
+  return sl->buf;
 }
 
 template <int KS>
