@@ -185,6 +185,37 @@ def test_conv_in_out_small(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("Cin,Cout,H,W,N", [(128, 64, 8, 8, 3), (256, 96, 8, 8, 5), (160, 128, 8, 8, 2)])
+def test_conv3x3_split_k_at_tiny_spatial_sizes(backend, Cin, Cout, H, W, N):
+    """3x3 stride-1 layers whose tiles cannot fill the chip run on 64- (or 32-) cout tiles with K split over several workgroups:
+    partial slabs + ksplit_finish_kernel (bias, per-sample term, residual added there). GroupNorm + SiLU on the load path, several
+    images per 128-pixel tile, a chunk count that does not divide by the split, and the residual aliasing the output in place."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    x = _rand((N, Cin, H, W), 1, dev)
+    w = _rand((Cout, Cin, 3, 3), 3, dev, scale=(Cin * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    gamma, beta = _rand((Cin,), 5, dev), _rand((Cin,), 6, dev)
+    gn = ops.groupnorm_stats(x, gamma, beta, 32, 1e-5)
+    temb = _rand((N, Cout), 7, dev)
+    res = _rand((N, Cout, H, W), 8, dev)
+    wp = ops.pack_conv_weight(w)
+    out = ops.conv2d(x, wp, b, 3, gn=gn, act=True, chan_add=temb, residual=res)
+    assert _native.lib().adm_last_conv_variant() == 2316, "the split-K instantiation was not selected"
+    c = lambda t: t.cpu()  # noqa: E731
+    ref = _conv_ref(c(x), None, c(w), c(b), 3, 1, 0, (c(gamma), c(beta)), True, c(temb), c(res))
+    assert _relerr(out, ref) < 1e-4, _relerr(out, ref)
+    # the residual may alias the output (the backward pass accumulates data gradients in place): out = conv + out
+    acc = res.clone()
+    import ctypes as C
+    a = ops._conv_args(x, wp, b, 3, None, False, 1, 1, gn, True, Cout)
+    a.residual, a.out = _native.ptr(acc), _native.ptr(acc)
+    a.chan_add, a.chan_add_stride = C.c_void_p(temb.data_ptr()), temb.stride(0)
+    _native.check(_native.lib().adm_conv2d(C.byref(a), _native.stream_for(x)))
+    assert _relerr(acc, ref) < 1e-4
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("Cin,H,W", [(1, 16, 32), (1, 40, 52), (3, 8, 12)])
 def test_conv_in_statistics_epilogue(backend, Cin, H, W):
     """conv_in class, four pixels per thread: the output, and the GroupNorm partial sums its epilogue writes per (sample, cout,
