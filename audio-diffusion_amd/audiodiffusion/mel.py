@@ -117,7 +117,21 @@ class Mel:
         self.last_nnls_pg = None       # max |projected gradient| of the NNLS solution the last image_to_audio returned
         self.last_nnls_pg_start = None  # ... of its start point clip(pinv(A) S, 0)
         self.last_nnls_iterations = None  # most solver iterations any column needed (0: start point returned, scipy nit = 0)
-        self.nnls_max_iter = 4000
+        self._nnls_lip = None
+        self._nnls_max_iter = 4000
+
+    @property
+    def nnls_max_iter(self):
+        """Iteration cap of the device NNLS solver (the column blocks where librosa's L-BFGS-B would iterate). Setting it
+        reaches the native handle at once. Those blocks are OUTSIDE sample parity with librosa: the minimiser of the
+        underdetermined problem is not unique — only the stopping rule (projected gradient <= pgtol) and f <= f_scipy hold."""
+        return self._nnls_max_iter
+
+    @nnls_max_iter.setter
+    def nnls_max_iter(self, v):
+        self._nnls_max_iter = int(v)
+        if getattr(self, "_handle", None) is not None:
+            N.check(N.lib().adm_mel_set_nnls_solver(self._handle, self._nnls_lip, self._nnls_max_iter))
 
     @property
     def config(self):
@@ -208,8 +222,8 @@ class Mel:
         N.check(lib.adm_mel_create(C.byref(cfg), args[0], args[1], args[2], args[3], args[4], args[5], int(len(w64)),
                                    args[6], args[7], args[8], args[9], args[10], nnls_cols, C.byref(h)))
         # NNLS solver for the blocks L-BFGS-B would iterate on: step 1 / lambda_max(A A^T)
-        lip = float(np.linalg.eigvalsh(fb64 @ fb64.T)[-1])
-        N.check(lib.adm_mel_set_nnls_solver(h, lip, self.nnls_max_iter))
+        self._nnls_lip = float(np.linalg.eigvalsh(fb64 @ fb64.T)[-1])
+        N.check(lib.adm_mel_set_nnls_solver(h, self._nnls_lip, self._nnls_max_iter))
         self._handle = h
         return h
 

@@ -64,7 +64,7 @@ def slerp_grid(x0, x1, alphas):
     """AudioDiffusionPipeline.slerp for every alpha in one launch pair: (len(alphas),) + x0.shape."""
     _f32(x0), _f32(x1)
     assert x0.shape == x1.shape
-    al = torch.as_tensor(list(alphas), dtype=torch.float32).to(x0.device)
+    al = torch.as_tensor([float(a) for a in alphas], dtype=torch.float64).to(x0.device)
     out = torch.empty((al.numel(),) + tuple(x0.shape), dtype=torch.float32, device=x0.device)
     scratch = torch.zeros(3, dtype=torch.float64, device=x0.device)
     N.check(N.lib().adm_slerp_grid(N.ptr(x0.contiguous()), N.ptr(x1.contiguous()), x0.numel(), N.ptr(al), al.numel(), N.ptr(out),

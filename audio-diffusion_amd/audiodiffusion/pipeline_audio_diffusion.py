@@ -7,6 +7,12 @@ hipGraph of {UNet forward, fused scheduler epilogue} replayed per step, csrc/une
 runs in the Mel HIP kernels. `diffusers` is not required: a minimal `DiffusionPipeline`-compatible base
 (`from_pretrained / save_pretrained / to / device / progress_bar / register_modules`) reads and writes the
 diffusers on-disk layout (`model_index.json`, `unet/`, `scheduler/`, `mel/`).
+
+Kept VERBATIM from the reference (GPL-3.0, see NOTICE.md at the repository root), because a drop-in must keep their quirks
+bit for bit and `tests/test_reference_pin.py` pins them against the reference's own program text: the `__call__` signature
+(`:72-87`), the audio-conditioned prologue (`:134-156`: slice -> image -> [-1, 1] tensor, the `images[0, 0] = add_noise(...)`
+write-through into the aliased `noise`, the `(B, steps, H, W)` mask) and the image -> tensor lines of `encode` (`:221-226`).
+Everything else in this file — the base class, the native loop call, dequantisation, batched image -> audio — is original.
 """
 import ctypes as C
 import json

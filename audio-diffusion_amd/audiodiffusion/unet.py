@@ -188,6 +188,7 @@ class UNet2DModel:
         h = C.c_void_p()
         N.check(N.lib().adm_unet_create(C.byref(nc), C.byref(h)))
         self._handle, self._handle_hw = h, hw
+        self._loss_scale = 1.0          # a fresh native handle starts at loss scale 1 (train_step caches the value it set)
         return h
 
     def _upload(self, key, t):
@@ -324,7 +325,7 @@ class UNet2DModel:
         """loss = mse(unet(noisy, t), target) and its gradient w.r.t. every parameter (into `flat_grads`). loss_scale (fp16):
         the gradients carry that factor (the returned loss does not); `training.GradScaler` un-scales them."""
         assert getattr(self, "_training", False), "call enable_training() first"
-        if loss_scale != getattr(self, "_loss_scale", 1.0):
+        if float(loss_scale) != self._loss_scale:      # _create_handle resets the cache together with the native value
             N.check(N.lib().adm_unet_set_loss_scale(self._handle, float(loss_scale)))
             self._loss_scale = float(loss_scale)
         x, tgt = noisy.contiguous(), target.contiguous()

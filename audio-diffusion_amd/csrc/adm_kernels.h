@@ -18,7 +18,7 @@ int launch_encode_step(float* x, const float* eps, const adm_sched_coef* table, 
                        hipStream_t st);
 int launch_add_noise(const float* x0, long x0_bstride, const float* noise, const float* sa, const float* sb, int cb,
                      int cn, float* out, int B, int N, long P, hipStream_t st);
-int launch_slerp_grid(const float* x0, const float* x1, long n, const float* alphas_dev, int n_alpha, float* out,
+int launch_slerp_grid(const float* x0, const float* x1, long n, const double* alphas_dev, int n_alpha, float* out,
                       double* scratch3, hipStream_t st);
 int launch_dequant(const float* x, uint8_t* out, long n, hipStream_t st);
 
@@ -49,6 +49,8 @@ int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hi
 int launch_pack_winograd_weight_T(const float* w, float* wu, int Cout, int Cin, hipStream_t st);  // data-gradient filters
 bool winograd_enabled();
 void set_wgrad_max_split(int v);  // k_conv_wgrad.hip
+void bump_dispatch_epoch();        // net_exec.hip: a process-wide option changed -> training nets re-learn which packings they read
+unsigned dispatch_epoch();
 void set_winograd_mode(int m);  // 0 off, 1 v1, 2 wave-specialised v2, 3 persistent v3 (default), -1 = default
 bool winograd_eligible(const adm_conv_args& a);
 int launch_conv_winograd(const adm_conv_args& a, hipStream_t st);

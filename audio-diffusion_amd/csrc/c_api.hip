@@ -16,6 +16,7 @@ int adm_version(void) { return 100; }
 const char* adm_last_error(void) { return adm::last_error(); }
 int adm_set_option(const char* name, int value) {
   ADM_REQUIRE(name, "set_option: null name");
+  adm::bump_dispatch_epoch();       // conv dispatch may change: Net::refresh_weights re-packs everything and re-learns its masks
   if (std::string(name) == "conv_wino") { adm::set_winograd_mode(value); return 0; }
   if (std::string(name) == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
   if (std::string(name) == "conv_bf16") { adm::set_conv_bf16(value); return 0; }
@@ -50,7 +51,7 @@ int adm_dequant_u8(const float* x, uint8_t* out, long n, void* stream) {
   return launch_dequant(x, out, n, (hipStream_t)stream);
 }
 
-int adm_slerp_grid(const float* x0, const float* x1, long n, const float* alphas_dev, int n_alpha, float* out,
+int adm_slerp_grid(const float* x0, const float* x1, long n, const double* alphas_dev, int n_alpha, float* out,
                    double* scratch3, void* stream) {
   ADM_REQUIRE(x0 && x1 && alphas_dev && out && scratch3 && n > 0 && n_alpha > 0, "slerp_grid: bad argument");
   return launch_slerp_grid(x0, x1, n, alphas_dev, n_alpha, out, scratch3, (hipStream_t)stream);

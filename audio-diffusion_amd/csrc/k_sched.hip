@@ -172,21 +172,21 @@ __global__ void __launch_bounds__(256) slerp_reduce_kernel(const float* __restri
 }
 
 __global__ void __launch_bounds__(256) slerp_blend_kernel(const float* __restrict__ x0, const float* __restrict__ x1, long n,
-                                                          const double* __restrict__ acc3, const float* __restrict__ alphas,
+                                                          const double* __restrict__ acc3, const double* __restrict__ alphas,
                                                           int n_alpha, float* __restrict__ out) {
   // torch: dot / norm / norm on float32 0-d tensors, then math.acos of the float32 quotient
   const float dotf = (float)acc3[0], n0 = (float)sqrt(acc3[1]), n1 = (float)sqrt(acc3[2]);
   const double theta = acos((double)((dotf / n0) / n1));
   const float st = (float)sin(theta);
   const int a = blockIdx.y;
-  const double al = (double)alphas[a];
+  const double al = alphas[a];   // a double, as the reference's Python float: s0, s1 are rounded to float32 once
   const float s0 = (float)sin((1.0 - al) * theta), s1 = (float)sin(al * theta);
   float* o = out + (long)a * n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     o[i] = __fadd_rn(__fdiv_rn(__fmul_rn(s0, x0[i]), st), __fdiv_rn(__fmul_rn(s1, x1[i]), st));
 }
 
-int launch_slerp_grid(const float* x0, const float* x1, long n, const float* alphas_dev, int n_alpha, float* out,
+int launch_slerp_grid(const float* x0, const float* x1, long n, const double* alphas_dev, int n_alpha, float* out,
                       double* scratch3, hipStream_t st) {
   ADM_TRY(dmemset(scratch3, 0, 3 * sizeof(double), st));
   ADM_LAUNCH(slerp_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x0, x1, n, scratch3);

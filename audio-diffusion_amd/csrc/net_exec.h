@@ -121,6 +121,16 @@ struct Net {
   bool training = false;             // keep every activation, allocate gradient buffers, maintain wpT
   bool use_known = false;            // a forward + backward pass has run on the current plan: ConvW::used is complete
   bool stale_packings = false;       // a refresh has skipped packings (see begin_inference)
+  std::vector<int> learned_B;        // batch sizes that have completed a forward + backward on this plan (masks cover them)
+  // a training pass at batch B <= planned_B is about to run inside the current plan (the partial last batch of an epoch does
+  // not re-plan): a batch size the masks have not seen yet may dispatch kernels whose packings a refresh skipped -> bring
+  // every packing up to date first, once per new size
+  int begin_training_batch(int B, hipStream_t st);
+  unsigned known_epoch = 0;          // dispatch_epoch() when use_known was set: adm_set_option invalidates the masks
+  // a pass read packing bit `pk` of `w`: record it; if a refresh has skipped that packing (the dispatch changed under a
+  // learned mask: option / environment / pointer alignment), the launch just made read weights from before the optimizer
+  // steps — fail instead of training on them
+  int note_packing(const ConvW& w, unsigned pk);
   int begin_inference(hipStream_t st, std::vector<unsigned>* saved);
   void end_inference(const std::vector<unsigned>& saved);
   const float* params_base = nullptr;  // flat master parameter buffer and the matching flat gradient buffer

@@ -211,9 +211,39 @@ void Net::mark_ready(const float* master_param, size_t numel) {
     if (lo < bk_lo[b + 1] && hi > bk_lo[b] && --bk_pending[b] == 0) bk_fn(bk_user, (int)b);
 }
 
+static unsigned g_dispatch_epoch = 1;
+void bump_dispatch_epoch() { ++g_dispatch_epoch; }
+unsigned dispatch_epoch() { return g_dispatch_epoch; }
+
+int Net::note_packing(const ConvW& w, unsigned pk) {
+  if (training && use_known && stale_packings && (pk & ~w.used) != 0)
+    ADM_FAIL("conv dispatch of layer " + w.key + " changed after the weight packings were learned (packing mask " +
+             std::to_string(pk) + " not in " + std::to_string(w.used) + "): the kernel read weights from before the last "
+             "optimizer steps; call adm_unet_refresh_weights after changing options / input alignment");
+  w.used |= pk;
+  return 0;
+}
+
+int Net::begin_training_batch(int B, hipStream_t st) {
+  for (int b : learned_B) if (b == B) return 0;
+  if (stale_packings) {
+    const bool known = use_known;
+    use_known = false;
+    for (ConvW& w : convs) ADM_TRY(pack_one(this, w, st));
+    use_known = known;
+    stale_packings = false;
+  }
+  return 0;
+}
+
 int Net::refresh_weights(hipStream_t st) {
+  if (use_known && known_epoch != dispatch_epoch()) {   // adm_set_option since the masks were learned: re-learn them
+    use_known = false;
+    learned_B.clear();
+    for (ConvW& w : convs) w.used = 0;
+  }
   for (ConvW& w : convs) ADM_TRY(pack_one(this, w, st));
-  if (training && use_known) stale_packings = true;     // the packings no training pass reads were left as they were
+  stale_packings = training && use_known;               // the packings no training pass reads were left as they were
   return 0;
 }
 // An inference entry point on a TRAINING net (evaluation samples through the live model): bring every packing up to date first,
@@ -403,6 +433,7 @@ void Net::destroy() {
 int Net::plan(int B) {
   if (planned_B == B) return 0;
   use_known = false;                       // another batch size may dispatch other kernels: re-learn which packings are read
+  learned_B.clear();
   for (ConvW& w : convs) w.used = 0;
   // the shared all-zero bias buffer is created lazily with a device allocation: do it here, outside any stream capture
   ADM_REQUIRE(conv_zero_bias(8192) != nullptr && conv_const_ones(8192) != nullptr, "plan: constant buffers");
@@ -556,7 +587,7 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
       fill_conv_args(o, B, temb_all, temb_stride, &a);
       if (tensors[o.out].stats != nullptr) { a.stats_out = tensors[o.out].stats; a.stats_tiles = tensors[o.out].stat_tiles; }
       ADM_TRY(launch_conv2d(a, st));
-      if (o.w) o.w->used |= packing_of_variant(last_conv_variant(), true);
+      if (o.w) ADM_TRY(note_packing(*o.w, packing_of_variant(last_conv_variant(), true)));
       const Tensor& to = tensors[o.out];
       const double Cin = a.C1 + a.C2, outel = (double)B * to.C * to.H * to.W;
       const int var = last_conv_variant();
@@ -733,7 +764,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
         a.out = tmp_da;
       }
       ADM_TRY(launch_conv2d(a, st));
-      o.w->used |= packing_of_variant(last_conv_variant(), false);
+      ADM_TRY(note_packing(*o.w, packing_of_variant(last_conv_variant(), false)));
       if (direct) { t1.ginit = true; continue; }
     }
     const long plane_i = (long)t1.H * t1.W;
@@ -758,6 +789,8 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       if (o.in2 >= 0) ADM_TRY(contribute(o.in2, tmp_da + (long)C1 * plane_i, (long)Ct * plane_i, C2));
     }
   }
+  known_epoch = dispatch_epoch();
+  { bool seen = false; for (int b : learned_B) seen |= b == B; if (!seen) learned_B.push_back(B); }
   use_known = true;      // a complete forward + backward has run on this plan: ConvW::used now lists every packing that is read
   return 0;
 }

@@ -499,7 +499,10 @@ int adm_unet_forward_backward(adm_unet_t* h, const float* x, const float* timest
   hipStream_t st = (hipStream_t)stream;
   Bf16Scope own(h->bf16_level, h->op16_f16);
   ADM_TRY(finalize(h));
-  ADM_TRY(plan(h, B));
+  // `drop_last=False` (train_unet.py:181): the partial last batch of an epoch runs INSIDE the full batch's plan (every buffer
+  // is sized per sample and the split-K workspace shrinks with B) instead of re-planning twice per epoch
+  if (!(h->planned_B > 0 && B <= h->planned_B)) ADM_TRY(plan(h, B));
+  ADM_TRY(h->net.begin_training_batch(B, st));
   std::vector<float> t(B);
   for (int i = 0; i < B; ++i) t[i] = timesteps_host[n_timesteps == 1 ? 0 : i];
   ADM_TRY(copy_h2d(h->t_dev, t.data(), sizeof(float) * B, st));

@@ -69,8 +69,8 @@ int adm_add_noise(const float* x0, long x0_bstride, const float* noise, const fl
 int adm_dequant_u8(const float* x, uint8_t* out, long n, void* stream);
 /* AudioDiffusionPipeline.slerp (pipeline_audio_diffusion.py:244-258) for a whole grid of interpolation weights at once:
  * out (n_alpha, n) = sin((1-alpha) theta) x0 / sin(theta) + sin(alpha theta) x1 / sin(theta), theta the angle between x0 and
- * x1 (n floats each); alphas_dev: device float[n_alpha]; scratch3: device double[3]. */
-int adm_slerp_grid(const float* x0, const float* x1, long n, const float* alphas_dev, int n_alpha, float* out,
+ * x1 (n floats each); alphas_dev: device double[n_alpha] (the reference evaluates sin((1 - alpha) * theta) on Python doubles); scratch3: device double[3]. */
+int adm_slerp_grid(const float* x0, const float* x1, long n, const double* alphas_dev, int n_alpha, float* out,
                    double* scratch3, void* stream);
 
 /* ---------------------------------------------------------------- op-level entry points (parity tests)
