@@ -68,6 +68,11 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-train-leg", action="store_true", help="skip the config-5 training sub-record")
     p.add_argument("--no-mel-leg", action="store_true", help="skip the Mel codec sub-record")
+    p.add_argument("--no-configs-leg", action="store_true", help="skip the BASELINE configs 2 / 4 sub-record")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                   help="weak (default): --batch-per-gpu spectrograms on every GPU. strong: --global-batch (config 3 as written: "
+                        "256) split over the GPUs")
+    p.add_argument("--global-batch", type=int, default=256, help="global batch of --scaling strong")
     p.add_argument("--mode", choices=["sample", "train"], default="sample",
                    help="sample (default): BASELINE.json's metric. train: config 5 (scripts/train_unet.py step) as the main line.")
     p.add_argument("--train-batch-per-gpu", type=int, default=16)
@@ -79,6 +84,21 @@ def parse():
     return p.parse_args()
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one process per GPU
+    under torch.distributed.run, rendezvous on 127.0.0.1) and hand their output through — rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 class Job:
     """Rank / device / process-group plumbing shared by every leg (one process per GPU)."""
 
@@ -86,8 +106,7 @@ class Job:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
-        assert self.world == a.gpus, (f"--gpus {a.gpus} but WORLD_SIZE={self.world}: launch with "
-                                      f"torch.distributed.run --nproc-per-node {a.gpus}")
+        assert self.world == a.gpus, f"--gpus {a.gpus} but the launcher's WORLD_SIZE is {self.world}"
         if EMU:
             from audiodiffusion import _native
             _native.load(os.path.join(ROOT, "tests", "emu", "libadm_emu.so"))
@@ -350,8 +369,61 @@ def roofline(unet, x, B):
     return out
 
 
+def configs_leg(job):
+    """BASELINE.json configs 2 and 4 on this GPU, bounded: 50 CONSECUTIVE steps of their 1000-step DDPM schedules with
+    injected per-step noise through the same native loop (per-step cost is constant, so x20 is the full sampling), config 4
+    plus its AutoencoderKL decode. Builder-side probes of the full 1000 steps: tools/config_probe.py."""
+    from audiodiffusion import AudioDiffusionPipeline, DDPMScheduler, Mel, UNet2DModel
+    from audiodiffusion.vae import AutoencoderKL
+    dev, B, n = job.dev, 16, 50
+    out = {}
+
+    def run(pipe, res, decode):
+        pipe.set_progress_bar_config(disable=True)
+        pipe.scheduler.set_timesteps(1000)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(B, 1, res, res, generator=g).to(dev)
+        step_noise = torch.randn(n, B, 1, res, res, generator=g).to(dev)
+
+        def once():
+            lat, u8 = pipe._denoise(x, 0, 0.0, None, None, 0, 0, step_noise=step_noise, stop_step=n, want_u8=not decode)
+            if decode:
+                from audiodiffusion import ops
+                u8 = ops.dequant_u8(pipe.vqvae.decode(lat, _in_scale=1 / 0.18215)["sample"])
+            return u8
+        once()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        once()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    def cfg(res):
+        c = dict(CFG256)
+        c["sample_size"] = res
+        return c
+
+    t = run(AudioDiffusionPipeline(None, UNet2DModel(**cfg(256)).init_random(0), Mel(), DDPMScheduler()).to(dev), 256, False)
+    out["config_2"] = {"workload": "teticio/audio-diffusion-256 architecture, pixel-space DDPM on the 1000-step schedule, 256x256, "
+                                   f"batch {B}: {n} consecutive steps (t = 999...{1000 - n}) with injected noise, timed; x{1000 // n} "
+                                   "extrapolation to the full sampling",
+                       "ms_per_step": round(t / n * 1e3, 3), "steps_timed": n,
+                       "spectrograms_per_s_extrapolated": round(B / (t / n * 1000), 4)}
+    vae = AutoencoderKL(sample_size=(256, 256), in_channels=1, out_channels=1, latent_channels=1, layers_per_block=2,
+                        block_out_channels=(128, 256, 512, 512), down_block_types=("DownEncoderBlock2D",) * 4,
+                        up_block_types=("UpDecoderBlock2D",) * 4).init_random(0)
+    t = run(AudioDiffusionPipeline(vae, UNet2DModel(**cfg(32)).init_random(1), Mel(), DDPMScheduler()).to(dev), 32, True)
+    pipe = None
+    out["config_4"] = {"workload": "teticio/latent-audio-diffusion-256 architecture: latent 32x32 UNet2D DDPM on the 1000-step "
+                                   f"schedule + AutoencoderKL decode to 256x256, batch {B}: {n} consecutive steps + ONE decode, timed",
+                       "ms_50_steps_plus_decode": round(t * 1e3, 2), "steps_timed": n}
+    return out
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     job = Job(a)
     world, rank, dev = job.world, job.rank, job.dev
 
@@ -373,6 +445,9 @@ def main():
     pipe = AudioDiffusionPipeline(None, unet, mel, DDIMScheduler()).to(dev)
     pipe.set_progress_bar_config(disable=True)
     B = a.batch_per_gpu
+    if a.scaling == "strong":       # config 3 as written: one global batch, split by rows
+        assert a.global_batch % world == 0, "--global-batch must divide over the GPUs"
+        B = a.global_batch // world
     # global noise from one seed, rank r takes rows [r*B, (r+1)*B): the result does not depend on the GPU count
     g = torch.Generator().manual_seed(42)
     noise = torch.randn(world * B, 1, hw, hw, generator=g)[rank * B:(rank + 1) * B].contiguous().to(dev)
@@ -394,7 +469,7 @@ def main():
         res = {
             "metric": "mel-spectrograms/sec (256x256, DDIM-50)", "value": round(value, 4), "unit": "mel-spectrograms/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"teticio/audio-diffusion-ddim-256 architecture (UNet2DModel 113.67M params, random init seed 0), "
                                    f"DDIM-{a.ddim_steps} eta=0, 256x256, batch {B}/GPU (config 3 per-GPU shard), noise -> uint8 image",
                        "global_batch": world * B, "ddim_steps": a.ddim_steps, "hipgraph": not a.no_graph,
@@ -417,6 +492,11 @@ def main():
                     res["cpu_baseline"] = cpu_baseline(unet.state_dict(), os.cpu_count() or torch.get_num_threads())
                 except Exception as e:  # noqa: BLE001
                     res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+            if not a.no_configs_leg:
+                try:
+                    res["configs"] = configs_leg(job)
+                except Exception as e:  # noqa: BLE001
+                    res["configs"] = {"error": f"{type(e).__name__}: {e}"}
         if not a.no_mel_leg:
             try:
                 res["mel"] = mel_leg(job)

@@ -13,12 +13,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(n, extra=()):
+def _run(n, extra=(), bare=False):
     from native_backend import ensure_emu_built
     ensure_emu_built()
     env = dict(os.environ, ADM_BENCH_EMU="1", ADM_EMU_THREADS="2", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
     port = 29800 + os.getpid() % 1000
-    if n == 1:
+    if n == 1 or bare:         # bare: no launcher — bench.py starts its own ranks
         cmd = [sys.executable, "bench.py"]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
@@ -65,3 +67,13 @@ def test_bench_py_reports_a_hung_training_leg_beside_the_measured_headline():
     d = _run(2, ["--no-mel-leg", "--train-leg-timeout", "0.05"])
     assert d["value"] > 0 and d["n_gpus"] == 2
     assert "timeout" in d["train"]["error"]
+
+
+def test_bare_bench_py_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it (how the driver writes its N = 1 line): bench.py re-executes itself
+    under torch.distributed.run on 127.0.0.1 and rank 0 prints the one contract line; `--scaling strong` splits one global
+    batch (config 3 as written) instead of giving every rank its own."""
+    d = _run(2, ["--no-train-leg", "--no-mel-leg", "--scaling", "strong", "--global-batch", "4"], bare=True)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 4 and d["value"] > 0
+    weak = _run(2, ["--no-train-leg", "--no-mel-leg"])
+    assert weak["gathered_checksum"] == d["gathered_checksum"] > 0          # the same 4 rows either way

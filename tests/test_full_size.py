@@ -150,6 +150,89 @@ def test_config3_ddim50_single_steps_along_the_product_trajectory_match_the_orac
     assert worst <= 1e-4, worst
 
 
+def test_config3_complete_ddim50_sampling_matches_the_oracle_on_a_briefly_trained_model(dev):
+    """BASELINE.json's headline workload END TO END (`pipeline_audio_diffusion.py:69,159-185`): a complete DDIM-50 sampling at
+    256x256 from pure noise through the captured hipGraph against 50 oracle steps on the host cores, at the path's bars
+    (<= 1e-3 float, <= 1 LSB, >= 99.5 % identical).  The denoiser is the 113.67 M-parameter model after a brief run of the
+    product's OWN trainer (bf16 operands, fp32 masters; tests/brief_training.py): a trained denoiser is contractive, whereas
+    random weights make the sampler chaotic for ANY pair of fp32 implementations — asserted below on the product against
+    itself, and recorded at every checkpoint in profiles/r03_ddim50_parity.md."""
+    import os
+    from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, Mel, UNet2DModel
+    from brief_training import train_product
+    from oracle import mel as omel
+    from oracle import pipeline as opipe
+    from oracle import schedulers as osched
+    from oracle.unet import UNet2DModel as OracleUNet
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    g = torch.Generator().manual_seed(1234)
+    noise = torch.randn(1, 1, 256, 256, generator=g)
+    both = torch.cat([noise, noise + 1e-6 * torch.randn(1, 1, 256, 256, generator=g)])
+
+    def sample(unet, x):
+        pipe = AudioDiffusionPipeline(None, unet, Mel(), DDIMScheduler()).to(dev)
+        pipe.set_progress_bar_config(disable=True)
+        return pipe(batch_size=x.shape[0], noise=x.clone().to(dev), audio=False, return_float=True)       # steps=None -> 50
+
+    # random weights: the sampler amplifies a 1e-6 perturbation of the start noise beyond the path's bar all by itself
+    _, f = sample(UNet2DModel(**CFG256).init_random(0), both)
+    chaos = float((f[0] - f[1]).abs().max())
+    assert chaos > 1e-3, chaos
+    trainee = UNet2DModel(**CFG256).init_random(0)
+    losses = train_product(trainee, (256, 256), 120, dev, batch=16, lr=1e-4)
+    assert np.isfinite(losses).all() and np.mean(losses[-10:]) < 0.5 * np.mean(losses[:3]), (losses[:3], losses[-10:])
+    sd = trainee.state_dict()
+    del trainee
+    unet = UNet2DModel(**CFG256).load_state_dict(sd)
+    mi, mf = sample(unet, both)
+    calm = float((mf[0] - mf[1]).abs().max())
+    assert calm <= 1e-4, calm                                # contractive: the perturbation does not grow any more
+    ref_unet = OracleUNet(**CFG256).eval()
+    ref_unet.load_state_dict(sd)
+    ref = opipe.AudioDiffusionPipeline(None, ref_unet, omel.Mel(), osched.DDIMScheduler())
+    ri, rf = ref(batch_size=1, noise=noise.clone(), audio=False, return_float=True)                        # 50 oracle steps
+    err = float((mf[0:1].cpu() - rf).abs().max())
+    a, b = np.asarray(mi[0]).astype(int), np.asarray(ri[0]).astype(int)
+    assert err <= 1e-3, err
+    assert np.abs(a - b).max() <= 1 and (a == b).mean() >= 0.995, (np.abs(a - b).max(), (a == b).mean())
+    assert float(rf.std()) > 0.02, "degenerate sample: the comparison would be vacuous"
+
+
+def test_config2_ddpm_1000_schedule_crosses_a_noise_staging_chunk_boundary_at_size(dev):
+    """configs[1], the part the last-4-steps test cannot reach: the DDPM noise-staging path of the native loop
+    (`_STEP_CHUNK`: per-step variance noise staged chunk by chunk, a stream sync and a rewritten staging buffer at every
+    boundary, the captured graph replayed on the next chunk).  Steps 895-905 of the 1000-step schedule at 256x256 with
+    injected noise and a 5-step chunk, so the boundary falls at step 900 — the same code a full sampling crosses nine times."""
+    import os
+    from audiodiffusion import AudioDiffusionPipeline, DDPMScheduler, Mel, UNet2DModel
+    from oracle import schedulers as osched
+    from oracle.unet import UNet2DModel as OracleUNet
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    unet = UNet2DModel(**CFG256).init_random(6)
+    ref_unet = OracleUNet(**CFG256).eval()
+    ref_unet.load_state_dict(unet.state_dict())
+    mine = AudioDiffusionPipeline(None, unet, Mel(), DDPMScheduler()).to(dev)
+    mine.set_progress_bar_config(disable=True)
+    mine.scheduler.set_timesteps(1000)
+    mine._STEP_CHUNK = 5                                     # instance override: boundary after 5 of the 10 steps
+    s = osched.DDPMScheduler()
+    s.set_timesteps(1000)
+    g = torch.Generator().manual_seed(1006)
+    x0 = 0.3 * torch.randn(1, 1, 256, 256, generator=g)      # a late-trajectory magnitude
+    step_noise = torch.randn(10, 1, 1, 256, 256, generator=g)
+    got, _ = mine._denoise(x0.to(dev), 895, 0.0, None, None, 0, 0, step_noise=step_noise.to(dev), stop_step=905)
+    whole = AudioDiffusionPipeline(None, unet, Mel(), DDPMScheduler()).to(dev)
+    whole.scheduler.set_timesteps(1000)
+    one, _ = whole._denoise(x0.to(dev), 895, 0.0, None, None, 0, 0, step_noise=step_noise.to(dev), stop_step=905)
+    assert torch.equal(got, one), "chunked and unchunked staging differ"
+    x = x0.clone()
+    with torch.no_grad():
+        for i, t in enumerate(s.timesteps[895:905]):
+            x = s.step(ref_unet(x, t)["sample"], t, x, variance_noise=step_noise[i])["prev_sample"]
+    err = float((got.cpu() - x).abs().max())
+    assert err <= 1e-3, err
+
+
 def test_config1_64x64_ddpm_10_steps_loop_matches_the_oracle(dev):
     """BASELINE.json configs[0]: audio-diffusion-64 (the train_unet.py architecture at 64x64), DDPM, 1 sample, 10 steps —
     the noise term of every DDPM step is injected so both sides consume identical draws."""

@@ -177,6 +177,55 @@ def test_gradient_accumulation_equals_one_large_batch(backend):
     assert torch.allclose(ema.shadow, shadow0 - (1 - d) * (shadow0 - flat), atol=1e-7)
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_partial_last_batch_runs_inside_the_full_batch_plan(backend):
+    """`drop_last=False` (train_unet.py:181): the short last batch of an epoch must not re-plan the arena — it runs
+    inside the full batch's plan: same workspace size before and after, gradients equal to those of a model that was planned at
+    the short size from the start, also after optimizer steps + refresh_weights (the learned packing masks cover both sizes),
+    and enable_training() called twice starts from loss scale 1 again."""
+    dev = select(backend)
+    from audiodiffusion import _native as N
+    from audiodiffusion import training as T
+    from audiodiffusion.unet import UNet2DModel
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn((3, 1, 16, 16), generator=g).to(dev)
+    tgt = torch.randn((3, 1, 16, 16), generator=g).to(dev)
+    ts = torch.tensor([10, 500, 900])
+
+    def fresh():
+        m = UNet2DModel(**TINY).init_random(0)
+        flat, grads = m.enable_training()
+        return m, flat, grads, T.AdamW(flat, lr=1e-3)
+
+    a, fa, ga, oa = fresh()           # full, partial, full, partial — one arena
+    b, fb, gb, ob = fresh()           # every batch on its own (re-planned) size: partial batches only
+    sizes = []
+    for step in range(2):
+        a.train_step(x, ts, tgt)
+        sizes.append(N.lib().adm_unet_workspace_bytes(a._handle))
+        oa.step(ga, clip=T.clip_grad_norm_(ga, 1.0)); a.refresh_weights()
+        la = a.train_step(x[:1].contiguous(), ts[:1], tgt[:1].contiguous())
+        sizes.append(N.lib().adm_unet_workspace_bytes(a._handle))
+        # b follows a's parameters exactly, then takes the partial batch in a plan of its own size
+        fb.copy_(fa)
+        if step > 0:
+            b.refresh_weights()       # (the first pass packs from the flat buffer itself)
+        lb = b.train_step(x[:1].contiguous(), ts[:1], tgt[:1].contiguous())
+        assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
+        assert float((ga - gb).abs().max()) <= 2e-6 * float(gb.abs().max())
+        oa.step(ga, clip=T.clip_grad_norm_(ga, 1.0)); a.refresh_weights()
+    assert len(set(sizes)) == 1 and sizes[0] > 0, sizes          # never re-planned
+    a.train_step(x, ts, tgt, loss_scale=8.0)
+    scaled = ga.clone()
+    a.sync_state_dict_from_flat()
+    a.enable_training()               # new native handle (same parameters): loss scale back to 1 on both sides
+    _, ga2 = a.flat.data, a.flat_grads
+    a.train_step(x, ts, tgt)
+    assert float((scaled - 8.0 * ga2).abs().max()) <= 1e-5 * float(scaled.abs().max())
+    a.train_step(x, ts, tgt, loss_scale=8.0)
+    assert float((scaled - ga2).abs().max()) <= 1e-5 * float(scaled.abs().max())
+
+
 # ---------------------------------------------------------------- --mixed_precision bf16 (train_unet.py:391-401, config 5)
 BF16CFG = dict(sample_size=16, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(128, 128),
                down_block_types=("DownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "UpBlock2D"))
