@@ -98,7 +98,13 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], const Conv
     }                                                                                                        \
   } while (0)
 
-template <int KS, int STRIDE, int WM, int TM>
+// KSP (split K; any shape whose tiles alone leave most CUs idle — the 4x4 / 2x2 / 1x1-pixel levels of a 64x64 or latent 32x32
+// model, where this kernel used to walk a 512..1024-channel K loop on Cout / 32 = 16 workgroups: 270-540 us per layer for < 1
+// GFLOP): S = p.ksplit workgroups share one output tile, each walks 1/S of the channel chunks and stores its partial sums to slab
+// s of the scratch buffer; ksplit_finish_kernel adds the slabs in order with bias / per-sample term / residual (deterministic).
+// Waves whose 32-pixel column blocks lie entirely beyond the batch skip their MFMAs (a 1x1-pixel level at B = 16 fills 16 of a
+// tile's 128 columns).
+template <int KS, int STRIDE, int WM, int TM, bool KSP = false>
 __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(const ConvParams p) {
   constexpr int WN = 4 / WM;
   constexpr int TN = 4 / WN;
@@ -120,6 +126,8 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
     const int b = blockIdx.x, q = p.nblk >> 3, r = p.nblk & 7, xcd = b & 7;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
+  const int kpart = KSP ? lid % p.ksplit : 0;
+  if (KSP) lid /= p.ksplit;
   const int ct = lid % p.n_ct, pt = lid / p.n_ct;
   const int tx = pt % p.tiles_x, ty = (pt / p.tiles_x) % p.tiles_y, ig = pt / (p.tiles_x * p.tiles_y);
   const int TW = 1 << p.lTW, TH = 1 << p.lTH, NI = 128 >> (p.lTW + p.lTH);
@@ -127,6 +135,10 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
   const int Ct = p.C1 + p.C2;
   const int planeS = p.Hs * p.Ws;
   const int IHW = p.IH * p.IW;
+  // channel range of this workgroup (KSP: chunk range kpart of p.ksplit, in chunks of CK channels)
+  const int nchunks_all = Ct / CK;
+  const int c_begin = KSP ? (int)((long)kpart * nchunks_all / p.ksplit) * CK : 0;
+  const int c_end = KSP ? (int)((long)(kpart + 1) * nchunks_all / p.ksplit) * CK : Ct;
 
   // ---- per-thread gather plan for the input patch (same for every channel plane) -------------------
   int q_soff[MAXQ];   // offset inside a source channel plane, or -1 (zero padding / out of range)
@@ -166,6 +178,10 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int a_lane = wm * TM * 32 + l31;
+  // KSP: a 32-pixel column block whose first pixel already lies beyond the batch holds no output at all (wave-uniform)
+  bool blk_on[TN];
+  ADM_UNROLL
+  for (int tn = 0; tn < TN; ++tn) blk_on[tn] = !KSP || n0 + (((ADM_UNIFORM(wn) * TN + tn) * 32) >> (p.lTW + p.lTH)) < p.N;
 
   // STRIDE == 2 (Downsample2D: patches of 33 x 17 pixels, 3 elements per thread and channel plane — the single-element plan
   // of conv_mfma_pf_kernel does not fit): the same loop, software-pipelined through registers — the raw patch values and the
@@ -207,8 +223,8 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
       }
     }
   };
-  if (PF) fetch(0);
-  for (int c0 = 0; c0 < Ct; c0 += CK) {
+  if (PF) fetch(c_begin);
+  for (int c0 = c_begin; c0 < c_end; c0 += CK) {
     if constexpr (PF) {
       ADM_UNROLL
       for (int qi = 0; qi < MAXQ; ++qi) {
@@ -251,7 +267,7 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
         }
       }
       __syncthreads();
-      if (c0 + CK < Ct) fetch(c0 + CK);
+      if (c0 + CK < c_end) fetch(c0 + CK);
     } else {
       // ---- stage the activated input patch ----------------------------------------------------------
       const bool from1 = c0 < p.C1;
@@ -314,14 +330,36 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
         for (int a = 0; a < TM; ++a)
           ADM_UNROLL
           for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            if (blk_on[b]) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
       }
     }
     __syncthreads();
   }
 
-  // ---- epilogue: bias + temb bias + residual, NCHW store ---------------------------------------------
-  ADM_CONV_EPILOGUE(TM, TN);
+  if constexpr (KSP) {       // partial sums (no bias) to slab kpart; ksplit_finish_kernel completes them
+    const int m_wave = m0 + wm * TM * 32;
+    const long planeO = (long)p.Ho * p.Wo;
+    float* part = p.out + (long)kpart * p.part_stride;
+    ADM_UNROLL
+    for (int tn = 0; tn < TN; ++tn) {
+      const int pp = (wn * TN + tn) * 32 + l31;
+      const int px = pp & (TW - 1), py = (pp >> p.lTW) & (TH - 1), img = pp >> (p.lTW + p.lTH);
+      const int oy = ty * TH + py, ox = tx * TW + px, n = n0 + img;
+      if (n >= p.N || oy >= p.Ho || ox >= p.Wo) continue;
+      const long pix = (long)oy * p.Wo + ox;
+      ADM_UNROLL
+      for (int tm = 0; tm < TM; ++tm) {
+        ADM_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          const int co = m_wave + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          part[((long)n * p.Cout + co) * planeO + pix] = acc[tm][tn][r];
+        }
+      }
+    }
+  } else {
+    // ---- epilogue: bias + temb bias + residual, NCHW store ---------------------------------------------
+    ADM_CONV_EPILOGUE(TM, TN);
+  }
 }
 
 
@@ -639,6 +677,22 @@ __global__ void __launch_bounds__(256) ksplit_finish_kernel(const float* __restr
   }
 }
 
+// the same for planes of 1 or 2 pixels (HW % 4 != 0: four consecutive elements belong to different channels)
+__global__ void __launch_bounds__(256) ksplit_finish1_kernel(const float* __restrict__ part, int S, long part_stride,
+                                                             const float* __restrict__ bias, const float* __restrict__ chan_add,
+                                                             int chan_add_stride, const float* residual, float* out, int Cout, int HW,
+                                                             long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long nc = e / HW;
+    const int co = (int)(nc % Cout), n = (int)(nc / Cout);
+    float v = part[e];
+    for (int s2 = 1; s2 < S; ++s2) v += part[(long)s2 * part_stride + e];
+    v += chan_add != nullptr ? bias[co] + chan_add[(long)n * chan_add_stride + co] : bias[co];
+    if (residual != nullptr) v += residual[e];
+    out[e] = v;
+  }
+}
+
 // scratch for the split-K partial slabs, one buffer per (device, stream): launches on one stream are ordered, two streams must
 // not share it. Grown only outside stream capture (the executors run one uncaptured forward before they capture); nullptr when
 // it cannot be provided (capture in progress, more than 8 streams per device, out of memory) -> the caller takes the unsplit path
@@ -724,8 +778,63 @@ static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
   return ADM_CHECK_LAUNCH();
 }
 
+// Split K for the generic kernel (see conv_mfma_kernel): taken when the tiles of the unsplit launch cover less than one workgroup
+// per CU and the K loop is long enough to be worth two launches. 128- (else 64- / 32-) cout tiles — every workgroup of a tile row
+// stages the same patch, so wide tiles cut the staging work — and S = as many K parts as bring the grid to ~512 workgroups with at
+// least two 8-channel chunks each. Returns 1 when not taken (the caller runs the unsplit kernel).
+template <int KS, int STRIDE>
+static int launch_ksplit_generic(const ConvParams& p, hipStream_t st) {
+  static const int use_ksp = [] { const char* e = getenv("ADM_CONV_KSPLIT"); return e ? atoi(e) : 1; }();
+  const int nch = (p.C1 + p.C2) / CK;
+  const int n_pt = p.nblk / p.n_ct;
+  if (!use_ksp || p.wp_bs != 0 || nch < 8) return 1;
+  const int bm = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
+  const int tiles = n_pt * (p.Cout / bm);
+  if (tiles >= 128) return 1;
+  int S = (512 + tiles - 1) / tiles;
+  if (S > nch / 2) S = nch / 2;
+  if (S > 64) S = 64;
+  if (S < 2) return 1;
+  const long total = (long)p.N * p.Cout * p.Ho * p.Wo;
+  float* scratch = ksplit_scratch((size_t)S * total, st);
+  if (scratch == nullptr) return 1;
+  ConvParams q = p;
+  q.ksplit = S; q.part_stride = total; q.out = scratch;
+  q.n_ct = p.Cout / bm;
+  q.nblk = n_pt * q.n_ct * S;
+  const size_t smem = sizeof(float) * ((size_t)CK * p.CS + (size_t)CK * KS * KS * bm);
+  if (bm == 128) {
+    allow_big_lds(conv_mfma_kernel<KS, STRIDE, 2, 2, true>, smem);
+    ADM_LAUNCH((conv_mfma_kernel<KS, STRIDE, 2, 2, true>), dim3(q.nblk), dim3(256), smem, st, q);
+  } else if (bm == 64) {
+    allow_big_lds(conv_mfma_kernel<KS, STRIDE, 2, 1, true>, smem);
+    ADM_LAUNCH((conv_mfma_kernel<KS, STRIDE, 2, 1, true>), dim3(q.nblk), dim3(256), smem, st, q);
+  } else {
+    allow_big_lds(conv_mfma_kernel<KS, STRIDE, 1, 1, true>, smem);
+    ADM_LAUNCH((conv_mfma_kernel<KS, STRIDE, 1, 1, true>), dim3(q.nblk), dim3(256), smem, st, q);
+  }
+  const int HW = p.Ho * p.Wo;
+  if (HW % 4 == 0) {
+    long g = (total / 4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    ADM_LAUNCH(ksplit_finish_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)scratch, S, total, p.bias, p.chan_add,
+               p.chan_add_stride, p.residual, p.out, p.Cout, HW, total / 4);
+  } else {
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    ADM_LAUNCH(ksplit_finish1_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)scratch, S, total, p.bias, p.chan_add,
+               p.chan_add_stride, p.residual, p.out, p.Cout, HW, total);
+  }
+  g_last_variant = KS * 100 + STRIDE * 10 + bm / 32 + 5;      // x16 / x26 + ...: 3x3 stride 1 -> 316 / 317 / 319 (bm 32 / 64 / 128)
+  return ADM_CHECK_LAUNCH();
+}
+
 template <int KS, int STRIDE>
 static int dispatch_bm(const ConvParams& p, int bm, size_t smem, hipStream_t st) {
+  {
+    const int rc = launch_ksplit_generic<KS, STRIDE>(p, st);
+    if (rc <= 0) return rc;
+  }
   allow_big_lds(conv_mfma_kernel<KS, STRIDE, 2, 2>, smem);
   dim3 grid(p.nblk), block(256);
   if (bm == 128) {

@@ -215,6 +215,48 @@ def test_conv3x3_split_k_at_tiny_spatial_sizes(backend, Cin, Cout, H, W, N):
     assert _relerr(acc, ref) < 1e-4
 
 
+TINY_LEVELS = [  # (N, C1, C2, H, W, Cout, ks, stride, up, use_gn, act, use_temb, use_res, expected variant)
+    (16, 128, 0, 1, 1, 128, 3, 1, 0, 1, 1, 1, 1, 319),     # 1x1-pixel level: 16 of a tile's 128 columns, HW = 1 (scalar finish)
+    (5, 64, 64, 2, 2, 64, 3, 1, 0, 1, 1, 1, 0, 317),       # 2x2, virtual concat, 64-cout tiles
+    (3, 96, 0, 4, 4, 96, 3, 1, 0, 1, 1, 0, 1, 316),        # 4x4 (CS = 288 > the pipelined kernel's plan), 32-cout tiles
+    (16, 128, 0, 1, 1, 128, 3, 1, 1, 0, 0, 0, 0, 319),     # Upsample2D 1x1 -> 2x2 folded into the load path
+    (4, 128, 0, 2, 2, 128, 3, 2, 0, 0, 0, 0, 0, 329),      # Downsample2D 2x2 -> 1x1 (stride 2)
+    (16, 160, 0, 2, 2, 128, 1, 1, 0, 0, 0, 0, 1, 119),     # 1x1 projection / shortcut on a 2x2 plane (+ residual)
+    (130, 64, 0, 1, 1, 64, 3, 1, 0, 1, 1, 1, 1, 317),      # more images than one tile holds: two tile groups, the second ragged
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", TINY_LEVELS, ids=[f"{c[4]}x{c[3]}-k{c[6]}s{c[7]}u{c[8]}-n{c[0]}" for c in TINY_LEVELS])
+def test_conv_split_k_on_the_generic_kernel_at_the_deepest_levels(backend, case):
+    """The 4x4 / 2x2 / 1x1-pixel levels of a 64x64 or latent 32x32 model (BASELINE configs 1 and 4): the generic kernel with K split
+    over up to 64 workgroups per tile + the slab reduction (float4 and scalar forms), every fusion of the load path and epilogue."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, C1, C2, H, W, Cout, ks, stride, up, use_gn, act, use_temb, use_res, want = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    w = _rand((Cout, Ct, ks, ks), 3, dev, scale=(Ct * ks * ks) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
+    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
+    Hi, Wi = (2 * H, 2 * W) if up else (H, W)
+    Ho, Wo = (Hi, Wi) if stride == 1 else (Hi // 2, Wi // 2)
+    res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
+    out = ops.conv2d(x1, ops.pack_conv_weight(w), b, ks, x2=x2, up=bool(up), stride=stride, pad_lo=1,
+                     gn=gn, act=bool(act), chan_add=temb, residual=res)
+    assert _native.lib().adm_last_conv_variant() == want, _native.lib().adm_last_conv_variant()
+    c = lambda t: None if t is None else t.cpu()  # noqa: E731
+    ref = _conv_ref(c(x1), c(x2), c(w), c(b), ks, stride, up, (c(gamma), c(beta)) if use_gn else None, act, c(temb), c(res))
+    assert out.shape == ref.shape
+    assert _relerr(out, ref) < 1e-4, _relerr(out, ref)
+    again = ops.conv2d(x1, ops.pack_conv_weight(w), b, ks, x2=x2, up=bool(up), stride=stride, pad_lo=1,
+                       gn=gn, act=bool(act), chan_add=temb, residual=res)
+    assert torch.equal(out, again), "the slab reduction must be deterministic"
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("Cin,H,W", [(1, 16, 32), (1, 40, 52), (3, 8, 12)])
 def test_conv_in_statistics_epilogue(backend, Cin, H, W):
