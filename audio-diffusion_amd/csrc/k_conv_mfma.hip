@@ -754,11 +754,13 @@ static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
   static const int use_ksp = [] { const char* e = getenv("ADM_CONV_KSPLIT"); return e ? atoi(e) : 1; }();
   const int nch = (p.C1 + p.C2) / CKP;
   const long total = (long)p.N * p.Cout * p.Ho * p.Wo;
-  if (KS == 3 && use_ksp && bm == 32 && p.nblk <= 256 && nch >= 16 && p.wp_bs == 0 && total % 4 == 0) {
+  // The decision and the number of parts depend on the LAYER only (output plane <= 8x8 pixels, channel count), never on the batch
+  // size: the partition fixes the fp32 summation order, and a sample's result must not depend on how many samples share its
+  // launch (round 2 chose S from the tile count: rows of a 32-batch and of a 256-batch then differed in the last bit, which a
+  // random-weight sampler amplifies to different images — strong scaling would not have reproduced weak scaling's pictures).
+  if (KS == 3 && use_ksp && p.Ho * p.Wo <= 64 && nch >= 16 && p.wp_bs == 0 && total % 4 == 0) {
     const int bm2 = p.Cout % 64 == 0 ? 64 : 32;
-    const int tiles = (p.nblk / p.n_ct) * (p.Cout / bm2);
-    int S = (512 + tiles - 1) / tiles;
-    if (S > 8) S = 8;
+    int S = 8;
     while (S > 1 && nch / S < 4) --S;
     if (S > 1) {
       const int rc = launch_ksplit<KS>(p, bm2, S, st);
@@ -778,22 +780,23 @@ static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
   return ADM_CHECK_LAUNCH();
 }
 
-// Split K for the generic kernel (see conv_mfma_kernel): taken when the tiles of the unsplit launch cover less than one workgroup
-// per CU and the K loop is long enough to be worth two launches. 128- (else 64- / 32-) cout tiles — every workgroup of a tile row
-// stages the same patch, so wide tiles cut the staging work — and S = as many K parts as bring the grid to ~512 workgroups with at
-// least two 8-channel chunks each. Returns 1 when not taken (the caller runs the unsplit kernel).
+// Split K for the generic kernel (see conv_mfma_kernel): taken for output planes of at most 8x8 pixels (the tiles of the unsplit
+// launch then leave most CUs idle) when the K loop is long enough to be worth two launches. 128- (else 64- / 32-) cout tiles —
+// every workgroup of a tile row stages the same patch, so wide tiles cut the staging work — and S = 64 / 32 / 8 parts for planes
+// of <= 4 / <= 16 / <= 64 pixels, at least two 8-channel chunks each. Returns 1 when not taken (the caller runs the unsplit kernel).
 template <int KS, int STRIDE>
 static int launch_ksplit_generic(const ConvParams& p, hipStream_t st) {
   static const int use_ksp = [] { const char* e = getenv("ADM_CONV_KSPLIT"); return e ? atoi(e) : 1; }();
   const int nch = (p.C1 + p.C2) / CK;
   const int n_pt = p.nblk / p.n_ct;
-  if (!use_ksp || p.wp_bs != 0 || nch < 8) return 1;
+  const int HWo = p.Ho * p.Wo;
+  // Whether and how K is split depends on the LAYER only (output plane, channel counts), never on the batch size: the partition
+  // fixes the fp32 summation order, and a sample's result must not depend on how many samples share its launch (rows sampled
+  // alone, in another batch or on another number of GPUs are bit-identical; tests/test_full_size.py, tests/test_distributed.py).
+  if (!use_ksp || p.wp_bs != 0 || nch < 8 || HWo > 64) return 1;
   const int bm = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
-  const int tiles = n_pt * (p.Cout / bm);
-  if (tiles >= 128) return 1;
-  int S = (512 + tiles - 1) / tiles;
+  int S = HWo <= 4 ? 64 : (HWo <= 16 ? 32 : 8);
   if (S > nch / 2) S = nch / 2;
-  if (S > 64) S = 64;
   if (S < 2) return 1;
   const long total = (long)p.N * p.Cout * p.Ho * p.Wo;
   float* scratch = ksplit_scratch((size_t)S * total, st);

@@ -258,6 +258,24 @@ def test_conv_split_k_on_the_generic_kernel_at_the_deepest_levels(backend, case)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("Cin,Cout,H,W,ks,stride", [(128, 128, 1, 1, 3, 1), (128, 64, 4, 4, 3, 1), (256, 64, 8, 8, 3, 1), (128, 128, 8, 8, 3, 2),
+                                                    (128, 64, 2, 2, 1, 1), (64, 64, 16, 16, 3, 1)])
+def test_a_samples_convolution_does_not_depend_on_the_batch_it_is_in(backend, Cin, Cout, H, W, ks, stride):
+    """Row r of a 70-sample launch == the same sample convolved alone, BIT FOR BIT: whether K is split, and into how many parts, is a
+    function of the layer, not of the batch (a split chosen from the tile count would change the fp32 summation order with the
+    batch size — and with it what a random-weight sampler makes of a row on 1 GPU vs 8)."""
+    dev = select(backend)
+    from audiodiffusion import ops
+    x = _rand((70, Cin, H, W), 1, dev)
+    w = _rand((Cout, Cin, ks, ks), 3, dev, scale=(Cin * ks * ks) ** -0.5)
+    wp, b = ops.pack_conv_weight(w), _rand((Cout,), 4, dev)
+    full = ops.conv2d(x, wp, b, ks, stride=stride)
+    for r in (0, 33, 69):
+        one = ops.conv2d(x[r:r + 1].contiguous(), wp, b, ks, stride=stride)
+        assert torch.equal(one[0], full[r]), r
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("Cin,H,W", [(1, 16, 32), (1, 40, 52), (3, 8, 12)])
 def test_conv_in_statistics_epilogue(backend, Cin, H, W):
     """conv_in class, four pixels per thread: the output, and the GroupNorm partial sums its epilogue writes per (sample, cout,
