@@ -760,7 +760,7 @@ static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
   // random-weight sampler amplifies to different images — strong scaling would not have reproduced weak scaling's pictures).
   if (KS == 3 && use_ksp && p.Ho * p.Wo <= 64 && nch >= 16 && p.wp_bs == 0 && total % 4 == 0) {
     const int bm2 = p.Cout % 64 == 0 ? 64 : 32;
-    int S = 8;
+    int S = 4;     // measured at B = 32 (the bench batch): 14 layers 1.54 ms with 4 parts, 1.90 ms with 8 (twice the slab traffic)
     while (S > 1 && nch / S < 4) --S;
     if (S > 1) {
       const int rc = launch_ksplit<KS>(p, bm2, S, st);
