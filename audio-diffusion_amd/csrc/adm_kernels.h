@@ -34,6 +34,15 @@ int launch_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int
 
 // k_conv_mfma.hip / k_conv_small.hip
 int launch_conv2d(const adm_conv_args& a, hipStream_t st);
+// One derived weight image to (re)write: the batched launchers below take a DEVICE array of these (blockIdx.y = item), so that
+// Net::refresh_weights after an optimizer step is a handful of launches instead of ~500 tiny ones (2.3 ms of an 85 ms step).
+// flag: transposed (data-gradient form) for the conv / Winograd / 16-bit images; element count for PACK_COPY.
+struct PackItem { const float* src; void* dst; int Cout, Cin, ks, flag; };
+int launch_pack_conv_weight_batch(const PackItem* items_dev, int n, hipStream_t st);     // k_conv_mfma.hip: wp / wpT
+int launch_pack_winograd_batch(const PackItem* items_dev, int n, hipStream_t st);        // k_conv_wino.hip: wu / wuT (v3 or v4 image)
+int winograd_pack_flag(int Cout, int Cin, int transposed);                                // PackItem::flag of a Winograd image
+int launch_pack_bf16_batch(const PackItem* items_dev, int n, hipStream_t st);            // k_conv_bf16.hip: wb / wbT
+int launch_copy_batch(const PackItem* items_dev, int n, hipStream_t st);                 // k_conv_mfma.hip: dst[0..Cout) = src[0..Cout)
 int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, hipStream_t st);
 int launch_pack_conv_weight_T(const float* w, float* wpT, int Cout, int Cin, int ks, hipStream_t st);
 void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);
@@ -130,9 +139,10 @@ int launch_scale(const float* x, float* out, float s, long n, hipStream_t st);
 int launch_time_embedding(const float* t_dev, int t_stride, const adm_sched_coef* table, const int* step_dev,
                           const float* freqs, int half_dim, int flip, const float* w1, const float* b1, const float* w2,
                           const float* b2, int dim_in, int dim_emb, float* emb, int B, hipStream_t st,
-                          float* save_sinus = nullptr, float* save_z = nullptr);
+                          float* save_sinus = nullptr, float* save_z = nullptr, float* emb_act = nullptr);
 // out[b][r] = bias[r] + sum_k W[r][k] * silu(emb[b][k])   for all resnets' time_emb_proj rows at once.
+// emb_is_activated: `emb` already holds silu(emb) (launch_time_embedding's emb_act output)
 int launch_temb_proj(const float* emb, const float* w, const float* bias, float* out, int B, int K, int R,
-                     hipStream_t st);
+                     hipStream_t st, int emb_is_activated = 0);
 
 }  // namespace adm

@@ -493,29 +493,47 @@ bool conv_bf16_enabled();
 
 // ---------------------------------------------------------------- filters: fp32 (Cout,Cin,3,3) -> bf16 [tap][Cin/8][Cout][8]
 template <bool F16>
-__global__ void pack_bf16_weight_kernel(const float* __restrict__ w, unsigned* __restrict__ wb, int Cout, int Cin,
-                                        int transposed, int taps) {
+__device__ __forceinline__ void pack_bf16_body(const float* __restrict__ w, unsigned* __restrict__ wb, int Cout, int Cin,
+                                               int transposed, int taps, long first, long step) {
   // one thread per bf16 PAIR of the packed tensor. transposed: the data-gradient filters (roles of Cout/Cin swapped, taps
   // flipped), i.e. packed "Cout" = Cin and packed "Cin" = Cout.
   const int Co = transposed ? Cin : Cout, Ci = transposed ? Cout : Cin;
   const long total = (long)taps * Ci * Co / 2;       // taps = 9 (3x3) or 1 (1x1: [Cin/8][Cout][8])
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int e2 = (int)(i & 3);
-  long r = i >> 2;
-  const int co = (int)(r % Co); r /= Co;
-  const int kg = (int)(r % (Ci >> 3));
-  const int t = (int)(r / (Ci >> 3));
-  const int ci = kg * 8 + 2 * e2;
-  float a, b;
-  if (!transposed) {
-    a = w[((long)co * Cin + ci) * taps + t];
-    b = w[((long)co * Cin + ci + 1) * taps + t];
-  } else {
-    a = w[((long)ci * Cin + co) * taps + (taps - 1 - t)];
-    b = w[((long)(ci + 1) * Cin + co) * taps + (taps - 1 - t)];
+  for (long i = first; i < total; i += step) {
+    const int e2 = (int)(i & 3);
+    long r = i >> 2;
+    const int co = (int)(r % Co); r /= Co;
+    const int kg = (int)(r % (Ci >> 3));
+    const int t = (int)(r / (Ci >> 3));
+    const int ci = kg * 8 + 2 * e2;
+    float a, b;
+    if (!transposed) {
+      a = w[((long)co * Cin + ci) * taps + t];
+      b = w[((long)co * Cin + ci + 1) * taps + t];
+    } else {
+      a = w[((long)ci * Cin + co) * taps + (taps - 1 - t)];
+      b = w[((long)(ci + 1) * Cin + co) * taps + (taps - 1 - t)];
+    }
+    wb[i] = ADM_PK16(F16, a, b);
   }
-  wb[i] = ADM_PK16(F16, a, b);
+}
+template <bool F16>
+__global__ void pack_bf16_weight_kernel(const float* __restrict__ w, unsigned* __restrict__ wb, int Cout, int Cin,
+                                        int transposed, int taps) {
+  pack_bf16_body<F16>(w, wb, Cout, Cin, transposed, taps, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+// blockIdx.y = item of a device table (Net::refresh_weights after an optimizer step); flag = transposed
+template <bool F16>
+__global__ void __launch_bounds__(256) pack_bf16_batch_kernel(const PackItem* __restrict__ items) {
+  const PackItem it = items[blockIdx.y];
+  pack_bf16_body<F16>(it.src, (unsigned*)it.dst, it.Cout, it.Cin, it.flag, it.ks * it.ks, (long)blockIdx.x * blockDim.x + threadIdx.x,
+                      (long)gridDim.x * blockDim.x);
+}
+int launch_pack_bf16_batch(const PackItem* items_dev, int n, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (conv_op16_f16()) ADM_LAUNCH(pack_bf16_batch_kernel<true>, dim3(64, (unsigned)n), dim3(256), 0, st, items_dev);
+  else ADM_LAUNCH(pack_bf16_batch_kernel<false>, dim3(64, (unsigned)n), dim3(256), 0, st, items_dev);
+  return ADM_CHECK_LAUNCH();
 }
 
 int launch_pack_bf16_weight(const float* w, void* wb, int Cout, int Cin, int transposed, hipStream_t st, int ks) {

@@ -930,26 +930,57 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
 }
 
 // (Cout,Cin,ks,ks) -> [Cin][tap][Cout]
-__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KS2) {
+__device__ __forceinline__ void pack_weight_body(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KS2,
+                                                 long first, long step) {
   const long total = (long)Cout * Cin * KS2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = first; i < total; i += step) {
     const int co = (int)(i % Cout);
     const long r = i / Cout;
     const int tap = (int)(r % KS2), c = (int)(r / KS2);
     wp[i] = w[((long)co * Cin + c) * KS2 + tap];
   }
 }
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KS2) {
+  pack_weight_body(w, wp, Cout, Cin, KS2, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
 
 // Backward-data weights: the gradient w.r.t. a conv's input is a "same" conv of dy with the channel-transposed,
 // spatially flipped kernel: (Cout,Cin,ks,ks) -> [Cout][ks*ks][Cin] with wpT[co][t][c] = w[co][c][ks*ks-1-t].
-__global__ void pack_weight_T_kernel(const float* __restrict__ w, float* __restrict__ wpT, int Cout, int Cin, int KS2) {
+__device__ __forceinline__ void pack_weight_T_body(const float* __restrict__ w, float* __restrict__ wpT, int Cout, int Cin, int KS2,
+                                                   long first, long step) {
   const long total = (long)Cout * Cin * KS2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = first; i < total; i += step) {
     const int c = (int)(i % Cin);
     const long r = i / Cin;
     const int t = (int)(r % KS2), co = (int)(r / KS2);
     wpT[i] = w[((long)co * Cin + c) * KS2 + (KS2 - 1 - t)];
   }
+}
+__global__ void pack_weight_T_kernel(const float* __restrict__ w, float* __restrict__ wpT, int Cout, int Cin, int KS2) {
+  pack_weight_T_body(w, wpT, Cout, Cin, KS2, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+// blockIdx.y = item of a device table (Net::refresh_weights after an optimizer step)
+__global__ void __launch_bounds__(256) pack_weight_batch_kernel(const PackItem* __restrict__ items) {
+  const PackItem it = items[blockIdx.y];
+  const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, step = (long)gridDim.x * blockDim.x;
+  if (it.flag) pack_weight_T_body(it.src, (float*)it.dst, it.Cout, it.Cin, it.ks * it.ks, first, step);
+  else pack_weight_body(it.src, (float*)it.dst, it.Cout, it.Cin, it.ks * it.ks, first, step);
+}
+__global__ void __launch_bounds__(256) copy_batch_kernel(const PackItem* __restrict__ items) {
+  const PackItem it = items[blockIdx.y];
+  float* d = (float*)it.dst;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < it.flag; i += (long)gridDim.x * blockDim.x) d[i] = it.src[i];
+}
+int launch_pack_conv_weight_batch(const PackItem* items_dev, int n, hipStream_t st) {
+  if (n <= 0) return 0;
+  ADM_LAUNCH(pack_weight_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, st, items_dev);
+  return ADM_CHECK_LAUNCH();
+}
+int launch_copy_batch(const PackItem* items_dev, int n, hipStream_t st) {
+  if (n <= 0) return 0;
+  ADM_LAUNCH(copy_batch_kernel, dim3(16, (unsigned)n), dim3(256), 0, st, items_dev);
+  return ADM_CHECK_LAUNCH();
 }
 
 int launch_pack_conv_weight_T(const float* w, float* wpT, int Cout, int Cin, int ks, hipStream_t st) {

@@ -12,6 +12,11 @@ namespace adm {
 
 __device__ __forceinline__ float silu_t(float v) { return v / (1.0f + __expf(-v)); }
 
+// grid (B, TE_SPLIT): every workgroup recomputes the sinusoid and linear_1 (+ SiLU) of its sample (65 k MACs) and produces a
+// 1 / TE_SPLIT slice of linear_2's rows, one WAVE per row: lanes walk the row (coalesced) and a shuffle tree adds them up — a
+// thread per row read 2 KB-strided words and made the B = 1 step wait ~50 us on one workgroup. emb_act = silu(emb) is stored
+// beside emb: temb_proj_kernel used to recompute it for each of its 9984 rows (163 M SiLUs per forward at B = 32).
+constexpr int TE_SPLIT = 8;
 __global__ void __launch_bounds__(256) time_embedding_kernel(const float* __restrict__ t_dev, int t_stride,
                                                              const adm_sched_coef* __restrict__ table,
                                                              const int* __restrict__ step_dev,
@@ -19,12 +24,14 @@ __global__ void __launch_bounds__(256) time_embedding_kernel(const float* __rest
                                                              const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
                                                              int dim_in, int dim_emb, float* __restrict__ emb,
+                                                             float* __restrict__ emb_act,
                                                              float* __restrict__ save_sinus,
                                                              float* __restrict__ save_z) {
   ADM_DYN_SMEM(float, smem);
   float* sinus = smem;          // dim_in
   float* hid = smem + dim_in;   // dim_emb
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const float t = t_dev ? t_dev[b * t_stride] : table[*step_dev].timestep;
   for (int i = tid; i < half_dim; i += blockDim.x) {
     const float arg = t * freqs[i];  // fp32 product as in diffusers; sin/cos evaluated in fp64 then rounded
@@ -33,41 +40,97 @@ __global__ void __launch_bounds__(256) time_embedding_kernel(const float* __rest
     else { sinus[i] = s; sinus[half_dim + i] = c; }
   }
   __syncthreads();
-  if (save_sinus)  // training: inputs of linear_1 kept for its weight gradient
+  if (save_sinus && part == 0)  // training: inputs of linear_1 kept for its weight gradient
     for (int i = tid; i < dim_in; i += blockDim.x) save_sinus[(long)b * dim_in + i] = sinus[i];
-  for (int j = tid; j < dim_emb; j += blockDim.x) {
-    float acc = b1[j];
+  for (int j = wave; j < dim_emb; j += 4) {          // linear_1: one wave per row
     const float* wr = w1 + (long)j * dim_in;
-    for (int k = 0; k < dim_in; ++k) acc = fmaf(wr[k], sinus[k], acc);
-    hid[j] = silu_t(acc);
-    if (save_z) save_z[(long)b * dim_emb + j] = acc;  // pre-activation of linear_1 (training)
+    float acc = 0.f;
+    for (int k = lane; k < dim_in; k += 64) acc = fmaf(wr[k], sinus[k], acc);
+    ADM_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    acc += b1[j];
+    if (lane == 0) {
+      hid[j] = silu_t(acc);
+      if (save_z && part == 0) save_z[(long)b * dim_emb + j] = acc;  // pre-activation of linear_1 (training)
+    }
   }
   __syncthreads();
-  for (int j = tid; j < dim_emb; j += blockDim.x) {
-    float acc = b2[j];
+  const int rows = (dim_emb + TE_SPLIT - 1) / TE_SPLIT;
+  const int j_end = (part + 1) * rows < dim_emb ? (part + 1) * rows : dim_emb;
+  for (int j = part * rows + wave; j < j_end; j += 4) {   // linear_2: this workgroup's slice of the rows
     const float* wr = w2 + (long)j * dim_emb;
-    for (int k = 0; k < dim_emb; ++k) acc = fmaf(wr[k], hid[k], acc);
-    emb[(long)b * dim_emb + j] = acc;
+    float acc = 0.f;
+    for (int k = lane; k < dim_emb; k += 64) acc = fmaf(wr[k], hid[k], acc);
+    ADM_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    acc += b2[j];
+    if (lane == 0) {
+      emb[(long)b * dim_emb + j] = acc;
+      if (emb_act) emb_act[(long)b * dim_emb + j] = silu_t(acc);
+    }
   }
 }
 
-// one wave per output row r; lanes split K; up to 8 batch rows per pass.
-__global__ void __launch_bounds__(256) temb_proj_kernel(const float* __restrict__ emb, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                        int K, int R) {
+// one wave per output row r; lanes split K (B < 8: at B = 1 the 2496 single-row workgroups finish in 19 us, the staged kernel
+// below in 29)
+template <bool ACTIVATED>
+__global__ void __launch_bounds__(256) temb_proj_row_kernel(const float* __restrict__ emb, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                            int K, int R) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
   const float* wr = w + (long)r * K;
-  for (int b0 = 0; b0 < B; b0 += 8) {
+  float acc[8];
+  ADM_UNROLL
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float wv = wr[k];
+    ADM_UNROLL
+    for (int i = 0; i < 8; ++i)
+      if (i < B) {
+        const float e = emb[(long)i * K + k];
+        acc[i] = fmaf(wv, ACTIVATED ? e : silu_t(e), acc[i]);
+      }
+  }
+  ADM_UNROLL
+  for (int i = 0; i < 8; ++i) {
+    float v = acc[i];
+    ADM_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0 && i < B) out[(long)i * R + r] = v + bias[r];
+  }
+}
+
+// grid (R / 16, B / 8): a workgroup stages (the SiLU of) eight samples' embeddings in LDS once and produces 16 output rows for
+// them, one wave per row at a time: lanes walk the row (coalesced, every weight read once per eight samples), the eight dot
+// products take their embedding words from LDS. ACTIVATED: emb already holds silu(emb) (emb_act above). The per-row version
+// fetched 8 embedding words per weight word straight from L2 — 1.4 M wave-level loads for 20 MB of weights (B = 16: 67 -> 38 us).
+template <bool ACTIVATED>
+__global__ void __launch_bounds__(256) temb_proj_kernel(const float* __restrict__ emb, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                        int K, int R) {
+  ADM_DYN_SMEM(float, se);     // [8][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.y * 8;
+  for (int i = tid; i < 8 * K; i += 256) {
+    const int b = i / K, k = i - b * K;
+    float e = 0.f;
+    if (b0 + b < B) { e = emb[(long)(b0 + b) * K + k]; if (!ACTIVATED) e = silu_t(e); }
+    se[i] = e;
+  }
+  __syncthreads();
+  for (int j = 0; j < 4; ++j) {
+    const int r = blockIdx.x * 16 + wave * 4 + j;
+    if (r >= R) break;
+    const float* wr = w + (long)r * K;
     float acc[8];
     ADM_UNROLL
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     for (int k = lane; k < K; k += 64) {
       const float wv = wr[k];
       ADM_UNROLL
-      for (int i = 0; i < 8; ++i)
-        if (b0 + i < B) acc[i] = fmaf(wv, silu_t(emb[(long)(b0 + i) * K + k]), acc[i]);
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(wv, se[i * K + k], acc[i]);
     }
     ADM_UNROLL
     for (int i = 0; i < 8; ++i) {
@@ -82,17 +145,26 @@ __global__ void __launch_bounds__(256) temb_proj_kernel(const float* __restrict_
 int launch_time_embedding(const float* t_dev, int t_stride, const adm_sched_coef* table, const int* step_dev,
                           const float* freqs, int half_dim, int flip, const float* w1, const float* b1, const float* w2,
                           const float* b2, int dim_in, int dim_emb, float* emb, int B, hipStream_t st,
-                          float* save_sinus, float* save_z) {
+                          float* save_sinus, float* save_z, float* emb_act) {
   ADM_REQUIRE(t_dev != nullptr || (table != nullptr && step_dev != nullptr), "time_embedding: no timestep source");
   const size_t smem = sizeof(float) * (size_t)(dim_in + dim_emb);
-  ADM_LAUNCH(time_embedding_kernel, dim3(B), dim3(256), smem, st, t_dev, t_stride, table, step_dev, freqs, half_dim,
-             flip, w1, b1, w2, b2, dim_in, dim_emb, emb, save_sinus, save_z);
+  ADM_LAUNCH(time_embedding_kernel, dim3(B, TE_SPLIT), dim3(256), smem, st, t_dev, t_stride, table, step_dev, freqs, half_dim,
+             flip, w1, b1, w2, b2, dim_in, dim_emb, emb, emb_act, save_sinus, save_z);
   return ADM_CHECK_LAUNCH();
 }
 
 int launch_temb_proj(const float* emb, const float* w, const float* bias, float* out, int B, int K, int R,
-                     hipStream_t st) {
-  ADM_LAUNCH(temb_proj_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, st, emb, w, bias, out, B, K, R);
+                     hipStream_t st, int emb_is_activated) {
+  if (B < 8) {
+    if (emb_is_activated) ADM_LAUNCH(temb_proj_row_kernel<true>, dim3(ceil_div(R, 4)), dim3(256), 0, st, emb, w, bias, out, B, K, R);
+    else ADM_LAUNCH(temb_proj_row_kernel<false>, dim3(ceil_div(R, 4)), dim3(256), 0, st, emb, w, bias, out, B, K, R);
+    return ADM_CHECK_LAUNCH();
+  }
+  ADM_REQUIRE(K <= 1536, "temb_proj: embedding width above 1536");
+  const size_t smem = sizeof(float) * 8 * (size_t)K;
+  const dim3 grid(ceil_div(R, 16), ceil_div(B, 8));
+  if (emb_is_activated) ADM_LAUNCH(temb_proj_kernel<true>, grid, dim3(256), smem, st, emb, w, bias, out, B, K, R);
+  else ADM_LAUNCH(temb_proj_kernel<false>, grid, dim3(256), smem, st, emb, w, bias, out, B, K, R);
   return ADM_CHECK_LAUNCH();
 }
 

@@ -126,6 +126,12 @@ struct Net {
   // not re-plan): a batch size the masks have not seen yet may dispatch kernels whose packings a refresh skipped -> bring
   // every packing up to date first, once per new size
   int begin_training_batch(int B, hipStream_t st);
+  // Batched re-pack (training, masks learned): device tables of PackItems, one per kernel family, rebuilt whenever a mask changes
+  std::vector<PackItem> pk_host[4];  // 0 copies (q|k|v stacks), 1 wp / wpT, 2 Winograd images, 3 16-bit images
+  PackItem* pk_dev = nullptr;
+  size_t pk_dev_cap = 0;
+  bool pk_valid = false;
+  int build_pack_tables(hipStream_t st);
   unsigned known_epoch = 0;          // dispatch_epoch() when use_known was set: adm_set_option invalidates the masks
   // a pass read packing bit `pk` of `w`: record it; if a refresh has skipped that packing (the dispatch changed under a
   // learned mask: option / environment / pointer alignment), the launch just made read weights from before the optimizer

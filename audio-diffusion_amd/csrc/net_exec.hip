@@ -220,6 +220,7 @@ int Net::note_packing(const ConvW& w, unsigned pk) {
     ADM_FAIL("conv dispatch of layer " + w.key + " changed after the weight packings were learned (packing mask " +
              std::to_string(pk) + " not in " + std::to_string(w.used) + "): the kernel read weights from before the last "
              "optimizer steps; call adm_unet_refresh_weights after changing options / input alignment");
+  if (pk & ~w.used) pk_valid = false;       // a new packing joins the mask: the batched re-pack tables are rebuilt
   w.used |= pk;
   return 0;
 }
@@ -236,11 +237,64 @@ int Net::begin_training_batch(int B, hipStream_t st) {
   return 0;
 }
 
+// The packings a learned mask asks for, as device tables for the batched kernels: the same decisions as pack_one (a packing
+// exists iff pack_one allocated it; it is written iff the mask has its bit), made once per mask change instead of per step.
+int Net::build_pack_tables(hipStream_t st) {
+  for (auto& v : pk_host) v.clear();
+  for (ConvW& w : convs) {
+    const float* src = w.stacked;
+    if (!w.qkv_prefix.empty()) {
+      const int C = w.Cin;
+      const char* names[3] = {".to_q", ".to_k", ".to_v"};
+      for (int i = 0; i < 3; ++i) {
+        pk_host[0].push_back(PackItem{ps->P(w.qkv_prefix + names[i] + ".weight"), w.stacked + (size_t)i * C * C, 0, 0, 0, C * C});
+        if (w.has_bias) pk_host[0].push_back(PackItem{ps->P(w.qkv_prefix + names[i] + ".bias"), w.bias + (size_t)i * C, 0, 0, 0, C});
+      }
+    } else {
+      src = ps->P(w.key + ".weight");
+    }
+    const unsigned need = w.used;
+    if (need & PK_WP) pk_host[1].push_back(PackItem{src, w.wp, w.Cout, w.Cin, w.ks, 0});
+    if (w.wpT && (need & PK_WPT)) pk_host[1].push_back(PackItem{src, w.wpT, w.Cout, w.Cin, w.ks, 1});
+    if (w.wu && (need & PK_WU)) pk_host[2].push_back(PackItem{src, w.wu, w.Cout, w.Cin, 3, winograd_pack_flag(w.Cout, w.Cin, 0)});
+    if (w.wuT && (need & PK_WUT)) pk_host[2].push_back(PackItem{src, w.wuT, w.Cout, w.Cin, 3, winograd_pack_flag(w.Cout, w.Cin, 1)});
+    if (w.wb && (need & PK_WB)) pk_host[3].push_back(PackItem{src, w.wb, w.Cout, w.Cin, w.ks, 0});
+    if (w.wbT && (need & PK_WBT)) pk_host[3].push_back(PackItem{src, w.wbT, w.Cout, w.Cin, w.ks, 1});
+  }
+  size_t n = 0;
+  for (auto& v : pk_host) n += v.size();
+  if (n > pk_dev_cap) {
+    ADM_TRY(dalloc((void**)&pk_dev, sizeof(PackItem) * (n + 64)));     // (a superseded smaller table stays owned until destroy)
+    pk_dev_cap = n + 64;
+  }
+  size_t off = 0;
+  for (auto& v : pk_host) {
+    if (!v.empty()) ADM_TRY(copy_h2d(pk_dev + off, v.data(), sizeof(PackItem) * v.size(), st));
+    off += v.size();
+  }
+  ADM_TRY(stream_sync(st));     // the host vectors may be rebuilt before the copies would otherwise have run
+  pk_valid = true;
+  return 0;
+}
+
 int Net::refresh_weights(hipStream_t st) {
   if (use_known && known_epoch != dispatch_epoch()) {   // adm_set_option since the masks were learned: re-learn them
     use_known = false;
     learned_B.clear();
+    pk_valid = false;
     for (ConvW& w : convs) w.used = 0;
+  }
+  static const int batched = [] { const char* e = getenv("ADM_PACK_BATCH"); return e ? atoi(e) : 1; }();
+  if (training && use_known && batched) {
+    // after an optimizer step, masks learned: ~6 launches over device tables instead of one tiny launch per (layer, packing)
+    if (!pk_valid) ADM_TRY(build_pack_tables(st));
+    const PackItem* t = pk_dev;
+    ADM_TRY(launch_copy_batch(t, (int)pk_host[0].size(), st)); t += pk_host[0].size();
+    ADM_TRY(launch_pack_conv_weight_batch(t, (int)pk_host[1].size(), st)); t += pk_host[1].size();
+    ADM_TRY(launch_pack_winograd_batch(t, (int)pk_host[2].size(), st)); t += pk_host[2].size();
+    ADM_TRY(launch_pack_bf16_batch(t, (int)pk_host[3].size(), st));
+    stale_packings = true;
+    return 0;
   }
   for (ConvW& w : convs) ADM_TRY(pack_one(this, w, st));
   stale_packings = training && use_known;               // the packings no training pass reads were left as they were
@@ -264,7 +318,10 @@ int Net::begin_inference(hipStream_t st, std::vector<unsigned>* saved) {
 void Net::end_inference(const std::vector<unsigned>& saved) {
   if (!training) return;
   size_t i = 0;
-  for (ConvW& w : convs) w.used = saved[i++];
+  for (ConvW& w : convs) {
+    if (w.used != saved[i]) pk_valid = false;
+    w.used = saved[i++];
+  }
 }
 const GNW* Net::make_gn(const std::string& p, int c) {
   GNW g;
@@ -434,6 +491,7 @@ int Net::plan(int B) {
   if (planned_B == B) return 0;
   use_known = false;                       // another batch size may dispatch other kernels: re-learn which packings are read
   learned_B.clear();
+  pk_valid = false;
   for (ConvW& w : convs) w.used = 0;
   // the shared all-zero bias buffer is created lazily with a device allocation: do it here, outside any stream capture
   ADM_REQUIRE(conv_zero_bias(8192) != nullptr && conv_const_ones(8192) != nullptr, "plan: constant buffers");

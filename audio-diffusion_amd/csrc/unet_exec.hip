@@ -34,7 +34,8 @@ struct adm_unet {
   // per-batch plan
   int planned_B = 0;
   std::vector<void*> extra;  // per-batch buffers besides the net arena
-  float *emb = nullptr, *temb_all = nullptr, *t_dev = nullptr, *eps_buf = nullptr;
+  PackItem* temb_items = nullptr; int n_temb_items = 0;   // restack_temb's device table
+  float *emb = nullptr, *emb_act = nullptr, *temb_all = nullptr, *t_dev = nullptr, *eps_buf = nullptr;
   adm_sched_coef* coef_dev = nullptr;
   int coef_cap = 0;
   int* step_dev = nullptr;
@@ -112,14 +113,24 @@ static int dalloc(adm_unet* h, void** p, size_t bytes) {
 static float* P(adm_unet* h, const std::string& k) { return h->ps.P(k); }
 
 // stacked copy of all time_emb_proj matrices (re-done after every optimizer step in training)
+// the 32 time_emb_proj matrices (+ biases) stacked row-wise: ONE batched copy launch over a device table built once (the
+// parameter pointers are stable: master parameters never move after finalize) instead of 64 copies per optimizer step
 static int restack_temb(adm_unet* h, hipStream_t st) {
-  int off = 0;
-  for (auto& r : h->net.temb_rows) {
-    ADM_TRY(copy_d2d(h->temb_w + (size_t)off * h->temb_dim, P(h, r.first + ".weight"), sizeof(float) * (size_t)r.second * h->temb_dim, st));
-    ADM_TRY(copy_d2d(h->temb_b + off, P(h, r.first + ".bias"), sizeof(float) * (size_t)r.second, st));
-    off += r.second;
+  if (h->temb_items == nullptr) {
+    std::vector<PackItem> items;
+    int off = 0;
+    for (auto& r : h->net.temb_rows) {
+      items.push_back(PackItem{P(h, r.first + ".weight"), h->temb_w + (size_t)off * h->temb_dim, 0, 0, 0, r.second * h->temb_dim});
+      items.push_back(PackItem{P(h, r.first + ".bias"), h->temb_b + off, 0, 0, 0, r.second});
+      off += r.second;
+    }
+    h->n_temb_items = (int)items.size();
+    if (items.empty()) return 0;
+    ADM_TRY(h->net.dalloc((void**)&h->temb_items, sizeof(PackItem) * items.size()));
+    ADM_TRY(copy_h2d(h->temb_items, items.data(), sizeof(PackItem) * items.size(), st));
+    ADM_TRY(stream_sync(st));
   }
-  return 0;
+  return launch_copy_batch(h->temb_items, h->n_temb_items, st);
 }
 
 // The conv dispatchers read the process-wide option conv_bf16; a model's own level is put in force only while one of ITS
@@ -257,6 +268,7 @@ static int plan(adm_unet* h, int B) {
   free_plan(h);
   ADM_TRY(h->net.plan(B));
   ADM_TRY(extra_alloc(h, (void**)&h->emb, sizeof(float) * (size_t)B * h->temb_dim));
+  ADM_TRY(extra_alloc(h, (void**)&h->emb_act, sizeof(float) * (size_t)B * h->temb_dim));
   ADM_TRY(extra_alloc(h, (void**)&h->temb_all, sizeof(float) * (size_t)B * h->temb_rows));
   ADM_TRY(extra_alloc(h, (void**)&h->t_dev, sizeof(float) * (size_t)B));
   ADM_TRY(extra_alloc(h, (void**)&h->eps_buf,
@@ -283,9 +295,9 @@ static int run_forward(adm_unet* h, const float* x, float* out, int B, const adm
                                 c.flip_sin_to_cos, P(h, "time_embedding.linear_1.weight"),
                                 P(h, "time_embedding.linear_1.bias"), P(h, "time_embedding.linear_2.weight"),
                                 P(h, "time_embedding.linear_2.bias"), dim_in, h->temb_dim, h->emb, B, st,
-                                h->training ? h->save_sinus : nullptr, h->training ? h->save_z : nullptr));
+                                h->training ? h->save_sinus : nullptr, h->training ? h->save_z : nullptr, h->emb_act));
   if (tm) { tm->st = st; tm->begin(); }
-  ADM_TRY(launch_temb_proj(h->emb, h->temb_w, h->temb_b, h->temb_all, B, h->temb_dim, h->temb_rows, st));
+  ADM_TRY(launch_temb_proj(h->emb_act, h->temb_w, h->temb_b, h->temb_all, B, h->temb_dim, h->temb_rows, st, 1));
   if (tm) tm->end(4, 0, 2.0 * B * h->temb_dim * h->temb_rows, 4.0 * h->temb_dim * h->temb_rows);
   return h->net.run(x, out, B, h->temb_all, h->temb_rows, st, tm);
 }

@@ -48,7 +48,7 @@ def test_bench_py_two_ranks_prints_one_contract_line():
     assert "error" not in d["mel"], d["mel"]
 
 
-def test_bench_py_result_is_independent_of_the_rank_count():
+def test_bench_py_result_is_independent_of_the_rank_count_and_a_bare_gpus_2_launches_its_own_ranks():
     """Same global batch on 1 rank and on 2: the gathered uint8 images (checksum) are identical — rows never interact."""
     one = _run(1, ["--batch-per-gpu", "4", "--no-train-leg", "--no-mel-leg"])
     os.environ["ADM_BENCH_FORCE_PG"] = "1"      # 1 rank but with the process group, so `gathered` exists
@@ -56,7 +56,11 @@ def test_bench_py_result_is_independent_of_the_rank_count():
         one_pg = _run(1, ["--batch-per-gpu", "4", "--no-train-leg", "--no-mel-leg"])
     finally:
         del os.environ["ADM_BENCH_FORCE_PG"]
-    two = _run(2, ["--no-train-leg", "--no-mel-leg"])
+    # the 2-rank run is BARE — `python bench.py --gpus 2` with no launcher around it, as the driver writes its N = 1 line: bench.py
+    # re-executes itself under torch.distributed.run on 127.0.0.1 and rank 0 prints the one contract line — and in `--scaling
+    # strong` mode: one global batch of 4 (config 3 as written) split by rows instead of 2 per rank; the same 4 rows either way
+    two = _run(2, ["--no-train-leg", "--no-mel-leg", "--scaling", "strong", "--global-batch", "4"], bare=True)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["global_batch"] == 4 and two["value"] > 0
     assert one["gathered_checksum"] is None
     assert one_pg["gathered_checksum"] == two["gathered_checksum"] and two["gathered_checksum"] > 0
 
@@ -68,12 +72,3 @@ def test_bench_py_reports_a_hung_training_leg_beside_the_measured_headline():
     assert d["value"] > 0 and d["n_gpus"] == 2
     assert "timeout" in d["train"]["error"]
 
-
-def test_bare_bench_py_gpus_2_launches_its_own_ranks():
-    """`python bench.py --gpus 2` with no torchrun around it (how the driver writes its N = 1 line): bench.py re-executes itself
-    under torch.distributed.run on 127.0.0.1 and rank 0 prints the one contract line; `--scaling strong` splits one global
-    batch (config 3 as written) instead of giving every rank its own."""
-    d = _run(2, ["--no-train-leg", "--no-mel-leg", "--scaling", "strong", "--global-batch", "4"], bare=True)
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 4 and d["value"] > 0
-    weak = _run(2, ["--no-train-leg", "--no-mel-leg"])
-    assert weak["gathered_checksum"] == d["gathered_checksum"] > 0          # the same 4 rows either way

@@ -154,24 +154,24 @@ def test_every_step_of_the_ddim50_schedule_matches_the_oracle_step(backend):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_complete_ddim50_sampling_matches_the_oracle_on_a_briefly_trained_model(backend):
-    """The default call — `pipe(batch_size=2)`: 50 DDIM steps from pure noise (`pipeline_audio_diffusion.py:69,159-185`) —
+    """The default call — `pipe(batch_size=1)`: 50 DDIM steps from pure noise (`pipeline_audio_diffusion.py:69,159-185`) —
     END TO END against the oracle at the path's bars.  Random weights make the sampler chaotic (asserted: the ORACLE turns a
-    1e-6 perturbation of its start noise into > 1e-3); after 100 AdamW steps of the train_unet.py objective on a structured
+    1e-6 perturbation of its start noise into > 1e-3); after 80 AdamW steps of the train_unet.py objective on a structured
     synthetic set (torch autograd on the oracle, tests/brief_training.py) the same sampler is contractive, and the product's
     50-step loop lands on the oracle's image.  Full size on the MI355X: tests/test_full_size.py."""
     from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, Mel, UNet2DModel
     from brief_training import train_oracle
     dev = select(backend)
     g = torch.Generator().manual_seed(11)
-    noise = torch.randn(2, 1, 16, 16, generator=g)
-    pert = noise + 1e-6 * torch.randn(2, 1, 16, 16, generator=g)
+    noise = torch.randn(1, 1, 16, 16, generator=g)
+    pert = noise + 1e-6 * torch.randn(1, 1, 16, 16, generator=g)
     torch.manual_seed(0)
     ref_unet = OracleUNet(**TINY).eval()
     ref = opipe.AudioDiffusionPipeline(None, ref_unet, omel.Mel(**MEL), osched.DDIMScheduler())
-    kw = dict(batch_size=2, audio=False, return_float=True)
+    kw = dict(batch_size=1, audio=False, return_float=True)
     chaos = float((ref(noise=noise.clone(), **kw)[1] - ref(noise=pert.clone(), **kw)[1]).abs().max())
     assert chaos > 1e-3, chaos
-    losses = train_oracle(ref_unet, (16, 16), 100)
+    losses = train_oracle(ref_unet, (16, 16), 80)
     assert np.mean(losses[-10:]) < 0.5 * np.mean(losses[:3])
     ri, rf = ref(noise=noise.clone(), **kw)
     calm = float((rf - ref(noise=pert.clone(), **kw)[1]).abs().max())
