@@ -1163,11 +1163,11 @@ __global__ void __launch_bounds__(512) conv_wino4_kernel(const WinoParams p) {
 // Filter image of conv_wino4_kernel: U = G g G^T as [Cin/8][Cout/16][point group q][k step ks][lane = 16 k4 + li][e]
 // holding U[xi = 4 q + e][cout = 16 cblk + li][cin = 8 chunk + 4 ks + k4]. transposed: the data-gradient filters (roles of
 // Cout / Cin swapped, taps flipped), as pack_winograd_weight_kernel.
-__global__ void pack_winograd4_weight_kernel(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin,
-                                             int transposed) {
+__device__ __forceinline__ void pack_winograd4_body(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin,
+                                                    int transposed, long first, long step) {
   const int PCo = transposed ? Cin : Cout, PCi = transposed ? Cout : Cin;      // channel counts of the packed convolution
   const long total = (long)PCo * PCi;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = first; i < total; i += step) {
     const int li = (int)(i & 15);
     long r = i >> 4;
     const int k4 = (int)(r & 3); r >>= 2;
@@ -1196,13 +1196,18 @@ __global__ void pack_winograd4_weight_kernel(const float* __restrict__ w, float*
   }
 }
 
+__global__ void pack_winograd4_weight_kernel(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin,
+                                             int transposed) {
+  pack_winograd4_body(w, wu, Cout, Cin, transposed, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
 // (Cout,Cin,3,3) -> U = G g G^T laid out [Cin][16][Cout]; G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
 // transposed != 0: filters of the DATA-GRADIENT convolution (input channels = Cout, output channels = Cin, taps flipped):
 // U' = G flip(g) G^T laid out [Cout][16][Cin].
-__global__ void pack_winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin,
-                                            int transposed) {
+__device__ __forceinline__ void pack_winograd3_body(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin,
+                                                    int transposed, long first, long step) {
   const long total = (long)Cout * Cin;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = first; i < total; i += step) {
     int co, c;
     if (transposed) { c = (int)(i % Cin); co = (int)(i / Cin); }     // consecutive threads -> consecutive destination words
     else { co = (int)(i % Cout); c = (int)(i / Cout); }
@@ -1227,6 +1232,18 @@ __global__ void pack_winograd_weight_kernel(const float* __restrict__ w, float* 
   }
 }
 
+__global__ void pack_winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin,
+                                            int transposed) {
+  pack_winograd3_body(w, wu, Cout, Cin, transposed, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+// blockIdx.y = item of a device table; flag bit 0 = transposed (data-gradient filters), bit 1 = the conv_wino4_kernel image
+__global__ void __launch_bounds__(256) pack_winograd_batch_kernel(const PackItem* __restrict__ items) {
+  const PackItem it = items[blockIdx.y];
+  const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, step = (long)gridDim.x * blockDim.x;
+  if (it.flag & 2) pack_winograd4_body(it.src, (float*)it.dst, it.Cout, it.Cin, it.flag & 1, first, step);
+  else pack_winograd3_body(it.src, (float*)it.dst, it.Cout, it.Cin, it.flag & 1, first, step);
+}
+
 static int wino_mode();
 // Which filter image a convolution with these PACKED channel counts uses — decided by the mode and the channel counts
 // alone, so that the packing (done once per layer) and every later launch agree: mode 4 and 64 | couts, 32 | cins -> the
@@ -1245,6 +1262,16 @@ static int pack_winograd(const float* w, float* wu, int Cout, int Cin, int trans
 }
 int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st) {
   return pack_winograd(w, wu, Cout, Cin, 0, st);
+}
+// PackItem::flag of a Winograd image: bit 0 = transposed, bit 1 = the conv_wino4_kernel layout — decided exactly as pack_winograd
+// decides it, so that the batched re-pack writes the image the kernels read
+int winograd_pack_flag(int Cout, int Cin, int transposed) {
+  return (transposed ? 1 : 0) | (wino4_layout(transposed ? Cin : Cout, transposed ? Cout : Cin) ? 2 : 0);
+}
+int launch_pack_winograd_batch(const PackItem* items_dev, int n, hipStream_t st) {
+  if (n <= 0) return 0;
+  ADM_LAUNCH(pack_winograd_batch_kernel, dim3(32, (unsigned)n), dim3(256), 0, st, items_dev);
+  return ADM_CHECK_LAUNCH();
 }
 int launch_pack_winograd_weight_T(const float* w, float* wu, int Cout, int Cin, hipStream_t st) {
   return pack_winograd(w, wu, Cout, Cin, 1, st);
