@@ -43,6 +43,9 @@ int launch_pack_winograd_batch(const PackItem* items_dev, int n, hipStream_t st)
 int winograd_pack_flag(int Cout, int Cin, int transposed);                                // PackItem::flag of a Winograd image
 int launch_pack_bf16_batch(const PackItem* items_dev, int n, hipStream_t st);            // k_conv_bf16.hip: wb / wbT
 int launch_copy_batch(const PackItem* items_dev, int n, hipStream_t st);                 // k_conv_mfma.hip: dst[0..Cout) = src[0..Cout)
+float* conv_ksplit_scratch(size_t floats, hipStream_t st);   // per-(device, stream) split-K slab buffer; nullptr: take the unsplit path
+int launch_ksplit_finish(const float* part, int S, long total, const float* bias, const float* chan_add, int chan_add_stride,
+                         const float* residual, float* out, int Cout, int HW, hipStream_t st);   // out = bias + ... + sum of S slabs
 int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, hipStream_t st);
 int launch_pack_conv_weight_T(const float* w, float* wpT, int Cout, int Cin, int ks, hipStream_t st);
 void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);

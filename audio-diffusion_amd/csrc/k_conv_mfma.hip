@@ -40,6 +40,7 @@ struct ConvParams {
   const float* residual; float* out;
   int lTW, lTH, tiles_x, tiles_y, n_ct, IH, IW, CS, nblk;
   long x1_bs, x2_bs, wp_bs;  // batch strides (elements) of x1/x2 (channel-slice views) and of per-sample weights (0: shared)
+  int tap_mask;                // split-K instantiations of the generic kernel: bit t set = tap t can meet a pixel inside the image (a 1-pixel-high plane only needs the middle row of taps)
   int ksplit; long part_stride; // split-K instantiations: S workgroups per tile, each writes its partial sums to out + s * part_stride
 };
 
@@ -139,6 +140,7 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
   const int nchunks_all = Ct / CK;
   const int c_begin = KSP ? (int)((long)kpart * nchunks_all / p.ksplit) * CK : 0;
   const int c_end = KSP ? (int)((long)(kpart + 1) * nchunks_all / p.ksplit) * CK : Ct;
+  const int tmask = KSP ? p.tap_mask : 0x1ff;
 
   // ---- per-thread gather plan for the input patch (same for every channel plane) -------------------
   int q_soff[MAXQ];   // offset inside a source channel plane, or -1 (zero padding / out of range)
@@ -307,6 +309,7 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
         const float* wsrc = p.wp + (long)n0 * p.wp_bs + (long)c0 * KS2 * p.Cout + m0;
         for (int idx = tid; idx < TOT4; idx += 256) {
           const int row = idx / ROW4, c4 = idx - row * ROW4;
+          if (KSP && KS2 > 1 && !((tmask >> (row % KS2)) & 1)) continue;      // a tap no pixel of this plane can use: never read
           float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
           if (m0 + c4 * 4 < p.Cout) w = *reinterpret_cast<const float4*>(wsrc + (long)row * p.Cout + c4 * 4);
           *reinterpret_cast<float4*>(ldsW + row * BM + c4 * 4) = w;
@@ -317,6 +320,7 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
     // ---- MFMA over this chunk: 9 taps x 4 channel pairs ------------------------------------------
     ADM_UNROLL
     for (int tap = 0; tap < KS2; ++tap) {
+      if (KSP && KS2 > 1 && !((tmask >> tap) & 1)) continue;     // wave-uniform (kernel argument)
       const int toff = (tap / KS) * p.IW + (tap % KS);
       ADM_UNROLL
       for (int cp = 0; cp < CK / 2; ++cp) {
@@ -720,6 +724,26 @@ static float* ksplit_scratch(size_t floats, hipStream_t st) {
   return sl->buf;
 }
 
+// the slab reduction and its scratch for other kernels' split-K paths (k_conv_small.hip: conv_out on small images)
+float* conv_ksplit_scratch(size_t floats, hipStream_t st) { return ksplit_scratch(floats, st); }
+int launch_ksplit_finish(const float* part, int S, long total, const float* bias, const float* chan_add, int chan_add_stride,
+                         const float* residual, float* out, int Cout, int HW, hipStream_t st) {
+  if (bias == nullptr) bias = zero_bias(Cout);
+  ADM_REQUIRE(bias != nullptr, "ksplit_finish: zero-bias buffer");
+  if (HW % 4 == 0) {
+    long g = (total / 4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    ADM_LAUNCH(ksplit_finish_kernel, dim3((unsigned)g), dim3(256), 0, st, part, S, total, bias, chan_add, chan_add_stride, residual,
+               out, Cout, HW, total / 4);
+  } else {
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    ADM_LAUNCH(ksplit_finish1_kernel, dim3((unsigned)g), dim3(256), 0, st, part, S, total, bias, chan_add, chan_add_stride, residual,
+               out, Cout, HW, total);
+  }
+  return ADM_CHECK_LAUNCH();
+}
+
 template <int KS>
 static int launch_ksplit(const ConvParams& p, int bm, int S, hipStream_t st) {
   constexpr int CKP = KS == 1 ? 32 : CK;
@@ -805,6 +829,24 @@ static int launch_ksplit_generic(const ConvParams& p, hipStream_t st) {
   q.ksplit = S; q.part_stride = total; q.out = scratch;
   q.n_ct = p.Cout / bm;
   q.nblk = n_pt * q.n_ct * S;
+  // taps that can meet a pixel inside the (upsampled) input for SOME output pixel: row ty is live iff an output row oy exists with
+  // 0 <= oy * STRIDE + ty - pad < Hi. At the 1x1-pixel level of the latent model that is the centre tap alone: 1 / 9 of the filter
+  // bytes these weight-streaming layers move (18.9 MB per 512 -> 512 layer); stride 2 keeps every tap (its register-pipelined
+  // staging is not masked).
+  q.tap_mask = 0x1ff;
+  if (KS == 3 && STRIDE == 1) {
+    int rows = 0, cols = 0;
+    for (int t = 0; t < 3; ++t) {
+      bool r = false, c = false;
+      for (int o = 0; o < p.Ho; ++o) r |= o + t - p.pad_lo >= 0 && o + t - p.pad_lo < p.Hi;
+      for (int o = 0; o < p.Wo; ++o) c |= o + t - p.pad_lo >= 0 && o + t - p.pad_lo < p.Wi;
+      rows |= r << t; cols |= c << t;
+    }
+    q.tap_mask = 0;
+    for (int ty = 0; ty < 3; ++ty)
+      for (int tx = 0; tx < 3; ++tx)
+        if (((rows >> ty) & 1) && ((cols >> tx) & 1)) q.tap_mask |= 1 << (ty * 3 + tx);
+  }
   const size_t smem = sizeof(float) * ((size_t)CK * p.CS + (size_t)CK * KS * KS * bm);
   if (bm == 128) {
     allow_big_lds(conv_mfma_kernel<KS, STRIDE, 2, 2, true>, smem);
@@ -890,7 +932,7 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
   p.wp_bs = a.w_bstride;
-  p.ksplit = 1; p.part_stride = 0;
+  p.ksplit = 1; p.part_stride = 0; p.tap_mask = 0x1ff;
   // 3x3: 16 x 8 pixel tiles (small halo); 1x1 has no halo: rows as long as the image allows (<= 128 pixels), so that the
   // pipelined kernel loads and stores whole contiguous row segments
   int TW = p.Wo >= 16 ? 16 : p.Wo, TH = p.Ho >= 8 ? 8 : p.Ho;

@@ -223,6 +223,8 @@ TINY_LEVELS = [  # (N, C1, C2, H, W, Cout, ks, stride, up, use_gn, act, use_temb
     (4, 128, 0, 2, 2, 128, 3, 2, 0, 0, 0, 0, 0, 329),      # Downsample2D 2x2 -> 1x1 (stride 2)
     (16, 160, 0, 2, 2, 128, 1, 1, 0, 0, 0, 0, 1, 119),     # 1x1 projection / shortcut on a 2x2 plane (+ residual)
     (130, 64, 0, 1, 1, 64, 3, 1, 0, 1, 1, 1, 1, 317),      # more images than one tile holds: two tile groups, the second ragged
+    (6, 64, 0, 1, 4, 64, 3, 1, 0, 1, 1, 0, 0, 317),        # a 1 x 4 plane: only the middle ROW of taps is live (tap mask 0b000111000)
+    (6, 64, 0, 4, 1, 64, 3, 1, 0, 0, 0, 1, 0, 317),        # a 4 x 1 plane: only the middle COLUMN of taps
 ]
 
 
@@ -273,6 +275,31 @@ def test_a_samples_convolution_does_not_depend_on_the_batch_it_is_in(backend, Ci
     for r in (0, 33, 69):
         one = ops.conv2d(x[r:r + 1].contiguous(), wp, b, ks, stride=stride)
         assert torch.equal(one[0], full[r]), r
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("Cin,Cout,H,W,N", [(128, 1, 32, 32, 3), (64, 2, 16, 24, 5), (72, 1, 8, 8, 2)])
+def test_conv_in_out_class_on_small_images(backend, Cin, Cout, H, W, N):
+    """A latent / 64x64 model's first and last layers: conv_out's channel loop split over 8 workgroups per tile (+ the slab
+    reduction with bias and residual), conv_in's output channels split over the grid; rows do not depend on the batch."""
+    dev = select(backend)
+    from audiodiffusion import ops
+    h = _rand((N, Cin, H, W), 4, dev)
+    gamma, beta = _rand((Cin,), 5, dev), _rand((Cin,), 6, dev)
+    w2, b2 = _rand((Cout, Cin, 3, 3), 7, dev, 0.1), _rand((Cout,), 8, dev)
+    res = _rand((N, Cout, H, W), 9, dev)
+    groups = 32 if Cin % 32 == 0 else 8
+    gn = ops.groupnorm_stats(h, gamma, beta, groups, 1e-5)
+    out = ops.conv2d(h, ops.pack_conv_weight(w2), b2, 3, gn=gn, act=True, residual=res)
+    ref = F.conv2d(F.silu(F.group_norm(h.cpu(), groups, gamma.cpu(), beta.cpu(), 1e-5)), w2.cpu(), b2.cpu(), padding=1) + res.cpu()
+    assert _relerr(out, ref) < 1e-4, _relerr(out, ref)
+    gn1 = (gn[0][1:2].contiguous(), gn[1][1:2].contiguous())
+    one = ops.conv2d(h[1:2].contiguous(), ops.pack_conv_weight(w2), b2, 3, gn=gn1, act=True, residual=res[1:2].contiguous())
+    assert torch.equal(one[0], out[1])
+    x = _rand((N, Cout, H, W), 1, dev)                    # conv_in class: Cout (<= 2) input channels -> 128
+    w1, b1 = _rand((128, Cout, 3, 3), 2, dev, 0.3), _rand((128,), 3, dev)
+    o1 = ops.conv2d(x, ops.pack_conv_weight(w1), b1, 3)
+    assert _relerr(o1, F.conv2d(x.cpu(), w1.cpu(), b1.cpu(), padding=1)) < 1e-5
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
