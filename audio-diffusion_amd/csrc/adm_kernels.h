@@ -63,6 +63,7 @@ bool winograd_enabled();
 void set_wgrad_max_split(int v);  // k_conv_wgrad.hip
 void bump_dispatch_epoch();        // net_exec.hip: a process-wide option changed -> training nets re-learn which packings they read
 unsigned dispatch_epoch();
+void set_winograd_pair(int v);  // conv_wino4_kernel: 1 (default) = one workgroup barrier per two chunks, 0 = one per chunk (bit-identical)
 void set_winograd_mode(int m);  // 0 off, 1 v1, 2 wave-specialised v2, 3 persistent v3 (default), -1 = default
 bool winograd_eligible(const adm_conv_args& a);
 int launch_conv_winograd(const adm_conv_args& a, hipStream_t st);

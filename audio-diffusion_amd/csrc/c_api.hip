@@ -18,6 +18,7 @@ int adm_set_option(const char* name, int value) {
   ADM_REQUIRE(name, "set_option: null name");
   adm::bump_dispatch_epoch();       // conv dispatch may change: Net::refresh_weights re-packs everything and re-learns its masks
   if (std::string(name) == "conv_wino") { adm::set_winograd_mode(value); return 0; }
+  if (std::string(name) == "wino_pair") { adm::set_winograd_pair(value); return 0; }
   if (std::string(name) == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
   if (std::string(name) == "conv_bf16") { adm::set_conv_bf16(value); return 0; }
   if (std::string(name) == "conv_op16_f16") { adm::set_conv_op16_f16(value); return 0; }

@@ -562,8 +562,14 @@ constexpr bool wino_abl_idle(int abl) { return abl == 1 || abl == 7 || abl == 9 
 // ABL (developer aid, timing only — results are wrong): 1 / 7 / 9 / 10 / 11 = this role keeps its barriers but stages nothing; 4 = stage C
 // (window gather + transform + V write) skipped; 5 = stage B (activation + patch write) skipped.
 // ACT: -1 = p.act decides at run time (v3); 0 / 1 = compiled without / with SiLU (v4: one select per element less).
-template <bool UP, bool WIDE1, bool PROF, bool V4 = false, int ABL = 0, int ACT = -1>
+// PAIR (conv_wino4_kernel only): ONE workgroup barrier per TWO chunks. The V slabs and the patch buffers become rings of four, a
+// producer interval stages V(g), V(g + 1) [stage C twice], then the patches of g + 2, g + 3 [stage B twice] and the global loads of
+// g + 6, g + 7, and only then meets the consumers — who by then have read chunks g - 2, g - 1 and go on to g, g + 1. Same arithmetic,
+// same summation order (bit-identical to the one-chunk cadence); what changes is how often the two roles wait for each other
+// (round 2's accounting: 9.5 % of the consumers' and 12 % of the producers' cycles are barrier waits at one barrier per chunk).
+template <bool UP, bool WIDE1, bool PROF, bool V4 = false, int ABL = 0, int ACT = -1, bool PAIR = false>
 __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV, float* ldsP, int tid, int b0, int bs) {
+  constexpr int RING = PAIR ? 3 : 1;          // buffer index mask: rings of four / two
   unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_start = W3_CLK();
   const int Ct = p.C1 + p.C2;
@@ -672,7 +678,7 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
     return ok ? a : 0.f;
   };
   auto stage_b = [&](const Wino3Raw& r0_, int g) {        // raw -> activation -> patch buffer g & 1
-    float* P = ldsP + (g & 1) * W3PSLAB;
+    float* P = ldsP + (g & RING) * W3PSLAB;
     Wino3Raw r = r0_;
     if (V4) {                                             // zero padding as a zeroed affine: two selects per ITEM
       r.sc0 = (r.ok & 1u) ? r.sc0 : 0.f; r.sh0 = (r.ok & 1u) ? r.sh0 : 0.f;
@@ -695,7 +701,7 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
     }
   };
   auto stage_c = [&](int g) {                // patch g & 1 -> 4x4 window -> V = B^T d B -> V buffer g & 1
-    const float* P = ldsP + (g & 1) * W3PSLAB + wbase;
+    const float* P = ldsP + (g & RING) * W3PSLAB + wbase;
     float d[16];
     ADM_UNROLL
     for (int i = 0; i < 4; ++i)
@@ -709,7 +715,7 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
       t[2][j] = d[2 * 4 + j] - d[1 * 4 + j];
       t[3][j] = d[1 * 4 + j] - d[3 * 4 + j];
     }
-    float* vdst = ldsV + (g & 1) * W3VSLAB + vofs;
+    float* vdst = ldsV + (g & RING) * W3VSLAB + vofs;
     ADM_UNROLL
     for (int i = 0; i < 4; ++i) {
       vdst[(i * 4 + 0) * (WCK * 32)] = t[i][0] - t[i][2];
@@ -723,6 +729,26 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
   r0.b = make_float4(0.f, 0.f, 0.f, 0.f); r1.b = r0.b; r0.a = r0.b; r1.a = r0.b; r0.h = 0.f; r1.h = 0.f;
   unsigned long long tq = 0, tn;
 #define W3_LAP(slot) do { if (PROF) { tn = W3_CLK(); pr[slot] += tn - tq; tq = tn; } } while (0)
+  if constexpr (V4 && PAIR) {  // one barrier per pair of chunks (see above); ABL / PROF instantiations never take this path
+    Wino3Raw r2, r3;
+    r2.b = r0.b; r3.b = r0.b; r2.a = r0.b; r3.a = r0.b; r2.h = 0.f; r3.h = 0.f;
+    stage_a(r0); stage_a(r1); stage_a(r2); stage_a(r3);            // chunks 0..3
+    stage_b(r0, 0); stage_b(r1, 1);
+    stage_a(r0); stage_a(r1);                                      // chunks 4, 5
+    ADM_BARRIER_KEEP_VMEM(63);                                     // barrier "-2": patches 0 and 1 visible to every producer wave
+    for (int g = 0; g < total; g += 4) {                           // total is a multiple of 4 (nch is)
+      stage_c(g); stage_c(g + 1);
+      stage_b(r2, g + 2); stage_b(r3, g + 3);
+      stage_a(r2); stage_a(r3);                                    // chunks g + 6, g + 7
+      ADM_BARRIER_KEEP_VMEM(63);
+      stage_c(g + 2); stage_c(g + 3);
+      stage_b(r0, g + 4); stage_b(r1, g + 5);
+      stage_a(r0); stage_a(r1);                                    // chunks g + 8, g + 9
+      ADM_BARRIER_KEEP_VMEM(63);
+    }
+    ADM_BARRIER_KEEP_VMEM(0);
+    return;
+  }
   if constexpr (V4) {          // same schedule with the global loads of g + 5 in flight: four raw-chunk register sets
     Wino3Raw r2, r3;
     r2.b = r0.b; r3.b = r0.b; r2.a = r0.b; r3.a = r0.b; r2.h = 0.f; r3.h = 0.f;
@@ -963,13 +989,15 @@ __global__ void __launch_bounds__(512, 2) conv_wino3_kernel(const WinoParams p) 
 //   * no LDS-DMA anywhere: the per-chunk barrier only hands V buffers over, and no vmcnt is ever drained at it;
 //   * LDS: V 2 x 16 KiB + patch 2 x 5.6 KiB = 43 KiB.
 constexpr int W4LDS = 2 * W3VSLAB + 2 * W3PSLAB;
+constexpr int W4LDS_PAIR = 4 * W3VSLAB + 4 * W3PSLAB;     // PAIR: rings of four (91 KiB)
 constexpr int W4ABLK = 4 * 2 * 64 * 4;      // floats of one (chunk, 16-cout block) filter image: 8 KiB
 
 // ABL (developer aid, timing only): 9 / 10 / 11 = producers idle and no filter loads / no LDS operand reads / no per-chunk barrier;
 // 2 = the MFMAs are replaced by a register dependency (operands still fetched); 6 = barriers
 // only (the producers' own pace); 7 = bare MFMA stream (no operand fetch; with idle producers: the matrix pipe's own pace).
-template <bool PROF, int ABL = 0>
+template <bool PROF, int ABL = 0, bool PAIR = false>
 __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float* ldsV, int tid, int wave, int b0, int bs) {
+  constexpr int RING = PAIR ? 3 : 1;
   unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_start = W3_CLK();
   const int lane = tid & 63;
@@ -1008,7 +1036,7 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   f32x4 acc[16][2];
   float2 rb[4][2];                         // rolling B window: 4 Winograd points ahead, running across tile boundaries
   auto read_group = [&](int slot, int gg, int xi) {
-    const float* V = ldsV + (gg & 1) * W3VSLAB + vlane;
+    const float* V = ldsV + (gg & RING) * W3VSLAB + vlane;
     rb[slot][0] = *reinterpret_cast<const float2*>(V + (xi * WCK) * 32);
     rb[slot][1] = *reinterpret_cast<const float2*>(V + (xi * WCK + 4) * 32);
   };
@@ -1075,7 +1103,9 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
           if (q == 2) W4_LOAD_A(2);
           if (q == 3) { W4_LOAD_A(3); advance_a(); }
         }
-        if (xi == 12 && ABL != 11) W3_BARRIER(63, pr, 1, 2);   // barrier g: every read of V(g) has landed, V(g + 1) is complete
+        // barrier g: every read of V(g) has landed, V(g + 1) is complete. PAIR: only behind the second chunk of a pair (its
+        // first chunk runs on into V(g + 1), which the previous pair's barrier certified)
+        if (xi == 12 && ABL != 11 && (!PAIR || (g & 1))) W3_BARRIER(63, pr, 1, 2);
         if (ABL != 10) {
           if (xi < 12) read_group(s, g, xi + 4);
           else read_group(s, g + 1, xi - 12);   // next chunk — of this tile or the next one (past the end: stale words, unused)
@@ -1143,21 +1173,21 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   }
 }
 
-template <bool UP, bool PROF, int ABL = 0, int ACT = -1>
+template <bool UP, bool PROF, int ABL = 0, int ACT = -1, bool PAIR = false>
 __global__ void __launch_bounds__(512) conv_wino4_kernel(const WinoParams p) {
   ADM_DYN_SMEM(float, smem);
   float* ldsV = smem;
-  float* ldsP = smem + 2 * W3VSLAB;
+  float* ldsP = smem + (PAIR ? 4 : 2) * W3VSLAB;
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   if (wave >= 4) {
 #if !defined(ADM_EMU)
     if (ABL != 3) __builtin_amdgcn_s_setprio(1);         // see conv_wino3_kernel (ABL 3: timing without it)
 #endif
-    if (!UP && wave == 4) wino3_producer<UP, true, PROF, true, ABL, ACT>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
-    else wino3_producer<UP, false, PROF, true, ABL, ACT>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
+    if (!UP && wave == 4) wino3_producer<UP, true, PROF, true, ABL, ACT, PAIR>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
+    else wino3_producer<UP, false, PROF, true, ABL, ACT, PAIR>(p, ldsV, ldsP, tid - 256, (int)blockIdx.x, (int)gridDim.x);
   }
-  else wino4_consumer<PROF, ABL>(p, ldsV, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+  else wino4_consumer<PROF, ABL, PAIR>(p, ldsV, tid, wave, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Filter image of conv_wino4_kernel: U = G g G^T as [Cin/8][Cout/16][point group q][k step ks][lane = 16 k4 + li][e]
@@ -1245,6 +1275,7 @@ __global__ void __launch_bounds__(256) pack_winograd_batch_kernel(const PackItem
 }
 
 static int wino_mode();
+static int wino_pair();
 // Which filter image a convolution with these PACKED channel counts uses — decided by the mode and the channel counts
 // alone, so that the packing (done once per layer) and every later launch agree: mode 4 and 64 | couts, 32 | cins -> the
 // conv_wino4_kernel image (such a layer then runs on conv_wino4_kernel or, for arguments that kernel cannot take, on the
@@ -1281,6 +1312,12 @@ int launch_pack_winograd_weight_T(const float* w, float* wu, int Cout, int Cin, 
 // kernel on the whole UNet forward) | 4 (default) v3 with the filters loaded L2 -> registers (conv_wino4_kernel: bit-identical
 // to v3, 87.7 vs 100.5 ms per B = 32 forward, profiles/r02_wino_v4.md; layers whose channel counts it cannot tile run as in
 // mode 3); shapes a mode cannot take fall back to the direct kernel.
+static int g_wino_pair = -1;   // -1: take ADM_WINO_PAIR from the environment (default 1) on first use
+void set_winograd_pair(int v) { g_wino_pair = v; }
+static int wino_pair() {
+  if (g_wino_pair < 0) { const char* e = getenv("ADM_WINO_PAIR"); g_wino_pair = e ? atoi(e) : 1; }
+  return g_wino_pair;
+}
 static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 4) on first use
 void set_winograd_mode(int m) { g_wino_mode = m; }
 static int wino_mode() {
@@ -1403,6 +1440,30 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     }
 #endif
     if (v4) {
+      // default since round 3: one workgroup barrier per TWO chunks (rings of four V slabs / patch buffers, 91 KiB of LDS). Measured on
+      // one box, alternating, bit-identical outputs: 55 launches of a B = 32 forward 67.23 / 67.08 / 67.13 ms at one barrier per chunk,
+      // 66.07 / 66.21 / 66.37 ms at one per pair; ADM_WINO_PAIR=0 restores the former.
+      if (wino_pair()) {
+        const size_t needp = sizeof(float) * W4LDS_PAIR;
+#if !defined(ADM_EMU)
+        static const bool once = [] {
+          (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<true, false, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS_PAIR));
+          (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<true, false, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS_PAIR));
+          (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, false, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS_PAIR));
+          (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, false, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS_PAIR));
+          return true;
+        }();
+        (void)once;
+#endif
+        if (a.up) {
+          if (a.act) ADM_LAUNCH((conv_wino4_kernel<true, false, 0, 1, true>), dim3(grid), dim3(512), needp, st, p);
+          else ADM_LAUNCH((conv_wino4_kernel<true, false, 0, 0, true>), dim3(grid), dim3(512), needp, st, p);
+        } else {
+          if (a.act) ADM_LAUNCH((conv_wino4_kernel<false, false, 0, 1, true>), dim3(grid), dim3(512), needp, st, p);
+          else ADM_LAUNCH((conv_wino4_kernel<false, false, 0, 0, true>), dim3(grid), dim3(512), needp, st, p);
+        }
+        return ADM_CHECK_LAUNCH();
+      }
       const size_t need4 = sizeof(float) * W4LDS;
       if (a.up) {
         if (a.act) ADM_LAUNCH((conv_wino4_kernel<true, false, 0, 1>), dim3(grid), dim3(512), need4, st, p);

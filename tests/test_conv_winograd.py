@@ -118,3 +118,39 @@ def test_groupnorm_statistics_from_the_conv_epilogue(backend):
     # a kernel without the epilogue reports 0 tiles
     _, none = ops.conv2d(x, ops.pack_conv_weight(w1[:, :, :1, :1].contiguous()), b1, 1, pad_lo=0, stats=True)
     assert none is None
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape", [(2, 64, 0, 16, 32, 64, 0), (3, 32, 32, 8, 16, 128, 0), (1, 96, 0, 8, 16, 64, 1), (5, 128, 0, 8, 16, 64, 0)],
+                         ids=["64to64", "concat-two-cout-tiles", "upsample-fold", "several-tiles-per-block"])
+def test_conv_wino4_barrier_cadence_does_not_change_a_bit(backend, shape):
+    """conv_wino4_kernel with one workgroup barrier per TWO chunks (round 3's default: rings of four V slabs / patch buffers) against one
+    barrier per chunk (`wino_pair` 0): the same arithmetic in the same order — outputs must be bit-identical, on the emulator and on
+    the MI355X, where a hand-over that came too early would show (GroupNorm + SiLU on the load path, per-sample term, residual, statistics
+    epilogue, persistent blocks walking several tiles so that the rings roll over tile boundaries)."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, C1, C2, H, W, Cout, up = shape
+    lib = _native.lib()
+    _native.check(lib.adm_set_option(b"conv_wino", 4))
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    w = _rand((Cout, C1 + C2, 3, 3), 3, dev, scale=((C1 + C2) * 9) ** -0.5)
+    b, temb = _rand((Cout,), 4, dev), _rand((Nn, Cout), 7, dev)
+    gamma, beta = _rand((C1 + C2,), 5, dev), _rand((C1 + C2,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res = _rand((Nn, Cout, Ho, Wo), 8, dev)
+    wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
+    outs = []
+    try:
+        for pair in (0, 1):
+            _native.check(lib.adm_set_option(b"wino_pair", pair))
+            o, st = ops.conv2d(x1, wp, b, 3, x2=x2, up=bool(up), gn=gn, act=True, chan_add=temb, residual=res, wino=wu, stats=True)
+            assert lib.adm_last_conv_variant() == 4314
+            outs.append((o.clone(), None if st is None else st.clone()))
+    finally:
+        _native.check(lib.adm_set_option(b"wino_pair", -1))
+        _native.check(lib.adm_set_option(b"conv_wino", -1))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert (outs[0][1] is None) == (outs[1][1] is None) and (outs[0][1] is None or torch.equal(outs[0][1], outs[1][1]))

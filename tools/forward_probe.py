@@ -17,7 +17,7 @@ N.load()
 dev = torch.device("cuda:0")
 B = int(os.environ.get("PROBE_B", "32"))
 unet = UNet2DModel(**CFG256).init_random(0)
-x = torch.randn(B, 1, 256, 256, device=dev)
+x = torch.randn(B, 1, 256, 256, generator=torch.Generator().manual_seed(0)).to(dev)
 out = torch.empty_like(x)
 recs = (N.OpProfile * 1024)()
 n = C.c_int(0)
@@ -30,3 +30,5 @@ for _ in range(int(os.environ.get("PROBE_N", "6"))):
         best = (tot, sum(r[2] for r in rows if r[1] // 100 == 43), sum(1 for r in rows if r[1] // 100 == 43))
 print(f"forward {best[0]:.3f} ms  winograd {best[1]:.3f} ms ({best[2]} launches)  env " +
       " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("ADM_")))
+if os.environ.get("PROBE_SAVE"):
+    torch.save(out.cpu(), os.environ["PROBE_SAVE"])
