@@ -729,24 +729,31 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
   r0.b = make_float4(0.f, 0.f, 0.f, 0.f); r1.b = r0.b; r0.a = r0.b; r1.a = r0.b; r0.h = 0.f; r1.h = 0.f;
   unsigned long long tq = 0, tn;
 #define W3_LAP(slot) do { if (PROF) { tn = W3_CLK(); pr[slot] += tn - tq; tq = tn; } } while (0)
-  if constexpr (V4 && PAIR) {  // one barrier per pair of chunks (see above); ABL / PROF instantiations never take this path
+  if constexpr (V4 && PAIR) {  // one barrier per pair of chunks (see above); the ABL instantiations never take this path
     Wino3Raw r2, r3;
     r2.b = r0.b; r3.b = r0.b; r2.a = r0.b; r3.a = r0.b; r2.h = 0.f; r3.h = 0.f;
     stage_a(r0); stage_a(r1); stage_a(r2); stage_a(r3);            // chunks 0..3
     stage_b(r0, 0); stage_b(r1, 1);
     stage_a(r0); stage_a(r1);                                      // chunks 4, 5
     ADM_BARRIER_KEEP_VMEM(63);                                     // barrier "-2": patches 0 and 1 visible to every producer wave
+    if (PROF) tq = W3_CLK();
     for (int g = 0; g < total; g += 4) {                           // total is a multiple of 4 (nch is)
-      stage_c(g); stage_c(g + 1);
-      stage_b(r2, g + 2); stage_b(r3, g + 3);
-      stage_a(r2); stage_a(r3);                                    // chunks g + 6, g + 7
-      ADM_BARRIER_KEEP_VMEM(63);
-      stage_c(g + 2); stage_c(g + 3);
-      stage_b(r0, g + 4); stage_b(r1, g + 5);
-      stage_a(r0); stage_a(r1);                                    // chunks g + 8, g + 9
-      ADM_BARRIER_KEEP_VMEM(63);
+      stage_c(g); stage_c(g + 1);                  W3_LAP(3);
+      stage_b(r2, g + 2); stage_b(r3, g + 3);      W3_LAP(4);
+      stage_a(r2); stage_a(r3);                    W3_LAP(5);      // chunks g + 6, g + 7
+      W3_BARRIER(63, pr, 1, 2);
+      if (PROF) tq = W3_CLK();
+      stage_c(g + 2); stage_c(g + 3);              W3_LAP(3);
+      stage_b(r0, g + 4); stage_b(r1, g + 5);      W3_LAP(4);
+      stage_a(r0); stage_a(r1);                    W3_LAP(5);      // chunks g + 8, g + 9
+      W3_BARRIER(63, pr, 1, 2);
+      if (PROF) tq = W3_CLK();
     }
     ADM_BARRIER_KEEP_VMEM(0);
+    if (PROF && tid == 0) {
+      pr[0] = W3_CLK() - t_start;
+      for (int i = 0; i < 8; ++i) atomicAdd(p.prof + 8 + i, pr[i]);
+    }
     return;
   }
   if constexpr (V4) {          // same schedule with the global loads of g + 5 in flight: four raw-chunk register sets
@@ -1409,7 +1416,14 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
       static unsigned long long* dprof = [] { void* q = nullptr; (void)hipMalloc(&q, 16 * sizeof(unsigned long long)); return (unsigned long long*)q; }();
       (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
       p.prof = dprof;
-      if (v4) ADM_LAUNCH((conv_wino4_kernel<false, true>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p);
+      if (v4 && wino_pair()) {
+        static const bool oncep = [] {
+          (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, true, 0, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS_PAIR));
+          return true;
+        }();
+        (void)oncep;
+        ADM_LAUNCH((conv_wino4_kernel<false, true, 0, -1, true>), dim3(grid), dim3(512), sizeof(float) * W4LDS_PAIR, st, p);
+      } else if (v4) ADM_LAUNCH((conv_wino4_kernel<false, true>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p);
       else ADM_LAUNCH((conv_wino3_kernel<false, true>), dim3(grid), dim3(512), need3, st, p);
       unsigned long long h[16];
       (void)hipMemcpyAsync(h, dprof, sizeof(h), hipMemcpyDeviceToHost, st);
