@@ -24,16 +24,17 @@ int adm_version(void);
 const char* adm_last_error(void);
 /* 1 if built for the device (hipcc, gfx950), 0 for the CPU-emulation test build. */
 int adm_is_device_build(void);
-/* Runtime options: "conv_wino" = 0 (direct MFMA kernel only) | 1 (Winograd F(2x2,3x3) v1) | 2 (wave-specialised v2) |
- * 3 (persistent wave-specialised v3, the default) | -1 (back to the default / ADM_CONV_WINO environment variable);
- * "wgrad_max_split" = n caps the split-K factor of adm_conv2d_wgrad (0 = heuristic; tests use it to put several pixel
- * tiles on one workgroup); "conv_bf16" = 1 runs eligible 3x3 stride-1 convolutions (forward, data gradient and weight
- * gradient) on bf16 MFMA operands with fp32 accumulation (`--mixed_precision bf16`, scripts/train_unet.py:391-401),
- * 2 = additionally the eligible 1x1 convolutions (opt-in: emulator-verified, not yet timed), 0 = fp32 everywhere
- * (default), -1 = back to the ADM_CONV_BF16 environment variable; "conv_bf16_persist" = 1 selects the persistent
- * chunk-stream variant of the 3x3 bf16 kernel, "wgrad_bf16_8w" = 1 the 8-wave variant of the bf16 3x3 weight-gradient
- * kernel, "conv_bf16_8w" = 1 the 8-wave variant of the forward / data-gradient kernel (all opt-in: ADM_BF16_PERSIST,
- * ADM_WGRAD_BF16_8W, ADM_BF16_8W; emulator-verified, not yet timed). */
+/* Runtime options (process-wide; a training net re-learns which weight images it reads after any change):
+ * "conv_wino" = 0 (direct MFMA kernel only) | 1 / 2 (earlier Winograd kernels) | 3 (persistent wave-specialised kernel of round 1) |
+ *   4 (default: conv_wino4_kernel, filters L2 -> registers; it has its own filter image, so set the mode BEFORE weights are packed) |
+ *   -1 (back to the default / ADM_CONV_WINO environment variable);
+ * "wino_pair" = 1 (default) one workgroup barrier per two chunks in conv_wino4_kernel | 0 one per chunk (bit-identical) | -1 (ADM_WINO_PAIR);
+ * "wgrad_max_split" = n caps the split-K factor of adm_conv2d_wgrad (0 = heuristic; tests use it to put several pixel tiles on
+ *   one workgroup);
+ * "conv_bf16" = 1 runs eligible 3x3 stride-1 convolutions (forward, data gradient and weight gradient) on 16-bit MFMA operands
+ *   with fp32 accumulation (`--mixed_precision bf16`, scripts/train_unet.py:391-401), 2 = additionally the eligible 1x1 convolutions
+ *   and stride-2 data gradients, 0 = fp32 everywhere (default), -1 = back to the ADM_CONV_BF16 environment variable;
+ * "conv_op16_f16" = 1 makes those kernels' operand format IEEE binary16 instead of bf16 (`--mixed_precision fp16`). */
 int adm_set_option(const char* name, int value);
 /* Kernel variant the last adm_conv2d on this thread dispatched to (see adm_op_profile.variant; 4311 = Winograd). */
 int adm_last_conv_variant(void);
