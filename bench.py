@@ -370,7 +370,7 @@ def roofline(unet, x, B):
 
 
 def configs_leg(job):
-    """BASELINE.json configs 2 and 4 on this GPU, bounded: 50 CONSECUTIVE steps of their 1000-step DDPM schedules with
+    """BASELINE.json configs 1, 2 and 4 on this GPU, bounded: config 1 in full; 50 CONSECUTIVE steps of their 1000-step DDPM schedules with
     injected per-step noise through the same native loop (per-step cost is constant, so x20 is the full sampling), config 4
     plus its AutoencoderKL decode. Builder-side probes of the full 1000 steps: tools/config_probe.py."""
     from audiodiffusion import AudioDiffusionPipeline, DDPMScheduler, Mel, UNet2DModel
@@ -410,6 +410,19 @@ def configs_leg(job):
         c["sample_size"] = res
         return c
 
+    # config 1 (the reference's own CPU-runnable case): 64x64, DDPM, ONE sample, the complete 10-step sampling
+    p1 = AudioDiffusionPipeline(None, UNet2DModel(**cfg(64)).init_random(0), Mel(x_res=64, y_res=64, hop_length=1024), DDPMScheduler()).to(dev)
+    p1.set_progress_bar_config(disable=True)
+    n1 = torch.randn(1, 1, 64, 64, generator=torch.Generator().manual_seed(6)).to(dev)
+    p1(batch_size=1, steps=10, noise=n1.clone(), audio=False)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    p1(batch_size=1, steps=10, noise=n1.clone(), audio=False)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter() - t0
+    out["config_1"] = {"workload": "audio-diffusion-64 architecture, 64x64 DDPM, 1 sample, 10 steps (complete sampling through the public "
+                                   "__call__, noise -> PIL image)", "ms_per_sample": round(t1 * 1e3, 2), "ms_per_step": round(t1 * 1e2, 3)}
+    del p1
     t, _ = run(AudioDiffusionPipeline(None, UNet2DModel(**cfg(256)).init_random(0), Mel(), DDPMScheduler()).to(dev), 256, False)
     out["config_2"] = {"workload": "teticio/audio-diffusion-256 architecture, pixel-space DDPM on the 1000-step schedule, 256x256, "
                                    f"batch {B}: {n} consecutive steps (t = 999...{1000 - n}) with injected noise, timed; x{1000 // n} "
