@@ -86,6 +86,22 @@ bool conv_wgrad_bf16_eligible(const adm_conv_args& a);
 int launch_conv_wgrad_bf16(const adm_conv_args& a, const float* dy, float* dW, int accumulate, float* workspace, int split,
                            hipStream_t st);
 
+// k_conv_bf16b.hip (round 4, level 3: blocked 16-bit operand images [n][C/8][H+2][W+2] x 16 B, zero halo; LDS-DMA fed kernels)
+size_t blk_image_bytes(int N, int C, int H, int W);
+bool blk_apply_eligible(int C1, int C2, int H, int W);
+// img = round16(act(scale * concat(x1, x2) + shift)) (scale NULL: identity); optional sums of the INPUT per (n, c) / per c (atomics)
+int launch_blk_apply(const float* x1, int C1, long x1_bs, const float* x2, int C2, long x2_bs, int N, int H, int W,
+                     const float* scale, const float* shift, int act, void* out, float* sum_nc, int nc_stride, float* sum_c,
+                     hipStream_t st);
+bool conv_bf16b_eligible(int Cin, int Cout, int H, int W);
+int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void* wb, int Cout, const float* bias,
+                      const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st);
+bool conv_wgradb_eligible(int Ct, int Cout, int H, int W);
+long conv_wgradb_workspace(int Ct, int Cout, int N, int H, int W, int* split_out);
+int launch_conv_wgradb(const void* xa, int Ct, const void* dyb, int Cout, int N, int H, int W, float* dW, int accumulate,
+                       float* workspace, hipStream_t st);
+int launch_wgrad_reduce(const float* workspace, int split, long numel, float* dW, int accumulate, int taps, hipStream_t st);
+
 // k_backward.hip / k_conv_wgrad.hip (training)
 int launch_sumpool2x2(const float* in, float* out, int H, int W, long planes, int accumulate, hipStream_t st);
 int launch_accumulate(float* dst, long dst_bs, const float* src, long src_bs, long per_sample, int N, int accumulate,

@@ -31,6 +31,14 @@
 #define ADM_MFMA_F16(a, b, c) adm_emu::mfma_f32_32x32x16_op16<true>((a), (b), (c))
 #define ADM_ALIGNBIT(hi, lo, sh) ((unsigned)((((uint64_t)(hi) << 32) | (uint64_t)(lo)) >> (sh)))
 #define ADM_OPAQUE_V(x) ((void)0)
+// round 4 (k_conv_bf16b.hip): LDS-DMA hidden from the compiler's wait-count insertion, source = wave-uniform base + per-lane
+// byte offset; ds_read_b64_tr_b16 (each lane of a 16-lane group reads 8 bytes at its own address, the 16 x 4 halfwords are
+// handed out transposed: lane l, element j <- lane (l >> 2) + 4 j, element l & 3)
+#define ADM_LDS_ADDR(ptr) ((unsigned)(reinterpret_cast<const unsigned char*>(ptr) - adm_emu::S().dyn_smem))
+#define ADM_GLDS16_ASM(gbase, off_bytes, lds_addr) \
+  memcpy(adm_emu::S().dyn_smem + (lds_addr) + (adm_emu::flat_tid() & 63) * 16, reinterpret_cast<const char*>(gbase) + (off_bytes), 16)
+#define ADM_DS_READ_TR16_B64(lds_ptr) adm_emu::ds_read_tr16_b64(lds_ptr)
+#define ADM_BARRIER_LGKM() __syncthreads()
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -54,6 +62,34 @@ typedef _Float16 adm_f16x2 __attribute__((ext_vector_type(2)));
 // makes a per-lane value opaque to the optimiser (no instruction): stops it from folding a loop-invariant lane offset into
 // dozens of pre-computed 64-bit addresses that then live in registers across the whole loop
 #define ADM_OPAQUE_V(x) asm volatile("" : "+v"(x))
+// round 4 (k_conv_bf16b.hip): LDS-DMA of 16 B per lane written as inline asm — invisible to hipcc's wait-count insertion, so
+// the kernel counts the vector-memory queue by hand (ADM_WAIT_VMEM) and nothing is drained behind its back.  Source = wave-
+// uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset; destination = wave-uniform LDS BYTE ADDRESS (ADM_LDS_ADDR of a dynamic-LDS
+// pointer, plus uniform integer offsets: no generic -> LDS pointer cast per instruction) + lane * 16.  M0 is
+// compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md §5.7).
+#define ADM_LDS_ADDR(ptr) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(ptr))
+// (the base is passed through readfirstlane: a value the compiler happens to hold in VGPRs — e.g. a subexpression it shares
+// with per-lane address arithmetic — would otherwise be substituted for the "s" operand as it is; the two s_mov + s_nop 2 in
+// front of the load are also the five wait states a VALU-written SGPR needs before a VMEM instruction reads it)
+__device__ __forceinline__ const void* adm_uniform_ptr(const void* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+#define ADM_GLDS16_ASM(gbase, off_bytes, lds_addr)                                                                   \
+  do {                                                                                                               \
+    unsigned keep_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"((unsigned)(off_bytes)), "s"(adm_uniform_ptr(gbase)),                           \
+                   "s"(__builtin_amdgcn_readfirstlane((unsigned)(lds_addr))) : "memory");                            \
+  } while (0)
+// ds_read_b64_tr_b16: 8 bytes per lane at the lane's own (8-byte aligned) LDS address, transposed inside 16-lane groups
+typedef short adm_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned adm_u32x2 __attribute__((ext_vector_type(2)));
+#define ADM_DS_READ_TR16_B64(lds_ptr) \
+  __builtin_bit_cast(adm_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) adm_s16x4*)(lds_ptr)))
+// raw workgroup barrier that drains this wave's LDS traffic only (vector memory keeps flying)
+#define ADM_BARRIER_LGKM() ADM_BARRIER_KEEP_VMEM(63)
 #define ADM_LAUNCH(kern, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), (shmem), (stream), __VA_ARGS__)
 #define ADM_DYN_SMEM(type, name)                                              \

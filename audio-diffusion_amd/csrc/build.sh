@@ -5,7 +5,7 @@
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
 root="$(cd "$here/../.." && pwd)"
-srcs=(c_api.hip k_sched.hip k_groupnorm.hip k_conv_mfma.hip k_conv_wino.hip k_conv_bf16.hip k_conv1x1_bf16.hip k_conv_small.hip k_attention.hip k_transformer.hip k_audio_encoder.hip k_temb.hip k_train.hip k_backward.hip k_conv_wgrad.hip c_api_train.hip k_vae.hip net_exec.hip unet_exec.hip vae_exec.hip)
+srcs=(c_api.hip k_sched.hip k_groupnorm.hip k_conv_mfma.hip k_conv_wino.hip k_conv_bf16.hip k_conv_bf16b.hip k_conv1x1_bf16.hip k_conv_small.hip k_attention.hip k_transformer.hip k_audio_encoder.hip k_temb.hip k_train.hip k_backward.hip k_conv_wgrad.hip c_api_train.hip k_vae.hip net_exec.hip unet_exec.hip vae_exec.hip)
 [ -f "$here/k_mel.hip" ] && srcs+=(k_mel.hip)
 cd "$here"
 if [ "${1:-hip}" = "emu" ]; then

@@ -1,0 +1,506 @@
+// k_conv_bf16b.hip — `--mixed_precision bf16` training convolutions on BLOCKED 16-bit operand images (round 4; level 3 of
+// option "conv_bf16").  scripts/train_unet.py:391-401 hands the choice to accelerate -> torch.autocast: Conv2d runs on 16-bit
+// operands with fp32 accumulation.  What round 2's phase accounting asked for (profiles/r02_bf16_training.md):
+//
+//   * the ACTIVATED convolution input (GroupNorm affine + SiLU + rounding, virtual concat resolved) is written ONCE per layer
+//     by a streaming pass (blk_apply_kernel) as  img[n][C/8][H+2][W+2] x 16 B  — one 16-byte unit = 8 consecutive channels of
+//     one pixel, a zero halo of one pixel all around (written once at allocation, never touched again) — and read by the
+//     forward kernel AND, kept like every training activation, by the weight-gradient kernel; the output gradient dy gets the
+//     same image once per layer and feeds the data-gradient and the weight-gradient kernel;
+//   * every operand byte reaches the MFMAs by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per instruction, whole
+//     cache lines, no VGPRs, no conversion or staging VALU, no bounds logic — the halo is in memory), issued as inline asm so
+//     that the kernels count the vector-memory queue themselves (ADM_WAIT_VMEM) and nothing drains the prefetch;
+//   * forward / data gradient (conv_bf16b_kernel): 128 couts x 8x32 pixels per workgroup, 4 waves x (32 couts x 256 pixels),
+//     K in chunks of 16 channels; the 10x34-pixel patch of a chunk is shared through LDS (three buffers, requested two chunks
+//     ahead), a wave's filter fragment of one tap is ONE 1-KiB DMA into its private nine-slot ring (requested a whole chunk
+//     ahead); 70.5 KiB of LDS and <= 256 registers: TWO workgroups per CU, so one's prologue / epilogue runs under the
+//     other's MFMAs;
+//   * weight gradient (conv_wgradb_kernel): k = pixels; the channel-blocked units are transposed on the way out of LDS by
+//     ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group), so the nine taps are nine base addresses into one
+//     haloed patch — no funnel shifts; 8 waves = 128 couts x 64 cins x 9 taps per workgroup, 4x32-pixel tiles double-buffered.
+//
+// Operand bits are the same as in k_conv_bf16.hip (same affine / SiLU / rounding expressions), accumulation order differs.
+#include <type_traits>
+
+#include "adm_kernels.h"
+
+namespace adm {
+
+
+__device__ __forceinline__ float silu_bb(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
+
+// ---------------------------------------------------------------------------------------------- blocked image writer
+struct BlkApplyParams {
+  const float* x1; const float* x2; int C1, C2;
+  long x1_bs, x2_bs;                 // batch strides (floats)
+  int N, H, W;
+  const float* scale; const float* shift; int nstride;   // per-(n, channel) affine rows, NULL = identity
+  int act;
+  u32x4* out; int Hp, Wp;
+  float* sum_nc; int nc_stride; float* sum_c;             // optional: per-(n, c) / per-c sums of the INPUT (bias gradients)
+};
+
+// One thread = 8 channels x 4 consecutive pixels: eight float4 row loads (a wave reads 1 KiB of ONE channel row per
+// instruction), affine + SiLU + rounding, four 16-byte units stored back to back (a wave writes 4 KiB contiguous).
+template <bool F16>
+__global__ void __launch_bounds__(256) blk_apply_kernel(const BlkApplyParams p) {
+  const int cg = blockIdx.y, n = blockIdx.z;
+  const int W4 = p.W >> 2;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int c0 = cg * 8;
+  const long HW = (long)p.H * p.W;
+  const bool live = q < p.H * W4;
+  const int y = live ? q / W4 : 0, x4 = live ? q - y * W4 : 0;
+  const float* src = c0 < p.C1 ? p.x1 + (long)n * p.x1_bs + (long)c0 * HW : p.x2 + (long)n * p.x2_bs + (long)(c0 - p.C1) * HW;
+  float4 v[8];
+  ADM_UNROLL
+  for (int e = 0; e < 8; ++e) v[e] = live ? *reinterpret_cast<const float4*>(src + (long)e * HW + (long)y * p.W + 4 * x4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.sum_c != nullptr || p.sum_nc != nullptr) {
+    // bias gradient of the producing layer folded into the pass that reads dy anyway: per-thread sums of the four pixels,
+    // 64-lane shuffle tree, one atomic per wave and channel (fp32 atomics: the order of the waves is not fixed; the fp32 path
+    // keeps adm_chan_sums for bit-reproducible sums)
+    ADM_UNROLL
+    for (int e = 0; e < 8; ++e) {
+      float s = (v[e].x + v[e].y) + (v[e].z + v[e].w);
+      ADM_UNROLL
+      for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+      if ((threadIdx.x & 63) == 0) {
+        if (p.sum_nc) atomicAdd(p.sum_nc + (long)n * p.nc_stride + c0 + e, s);
+        if (p.sum_c) atomicAdd(p.sum_c + c0 + e, s);
+      }
+    }
+  }
+  if (!live) return;
+  float o[8][4];
+  ADM_UNROLL
+  for (int e = 0; e < 8; ++e) {
+    float sc = 1.f, sh = 0.f;
+    if (p.scale) { sc = p.scale[(long)n * p.nstride + c0 + e]; sh = p.shift[(long)n * p.nstride + c0 + e]; }
+    const float in[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
+    ADM_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      float t = in[j] * sc + sh;
+      if (p.act) t = silu_bb(t);
+      o[e][j] = t;
+    }
+  }
+  u32x4* dst = p.out + (((long)n * ((p.C1 + p.C2) >> 3) + cg) * p.Hp + (y + 1)) * p.Wp + (4 * x4 + 1);
+  ADM_UNROLL
+  for (int j = 0; j < 4; ++j) {
+    u32x4 w;
+    w[0] = ADM_PK16(F16, o[0][j], o[1][j]); w[1] = ADM_PK16(F16, o[2][j], o[3][j]);
+    w[2] = ADM_PK16(F16, o[4][j], o[5][j]); w[3] = ADM_PK16(F16, o[6][j], o[7][j]);
+    dst[j] = w;
+  }
+}
+
+size_t blk_image_bytes(int N, int C, int H, int W) { return (size_t)16 * N * (C / 8) * (H + 2) * (W + 2); }
+
+bool blk_apply_eligible(int C1, int C2, int H, int W) { return C1 % 8 == 0 && C2 % 8 == 0 && W % 4 == 0 && H > 0; }
+
+int launch_blk_apply(const float* x1, int C1, long x1_bs, const float* x2, int C2, long x2_bs, int N, int H, int W,
+                     const float* scale, const float* shift, int act, void* out, float* sum_nc, int nc_stride, float* sum_c,
+                     hipStream_t st) {
+  ADM_REQUIRE(blk_apply_eligible(C1, x2 ? C2 : 0, H, W), "blk_apply: channel counts must be multiples of 8 and W of 4");
+  BlkApplyParams p;
+  p.x1 = x1; p.x2 = x2; p.C1 = C1; p.C2 = x2 ? C2 : 0;
+  p.x1_bs = x1_bs ? x1_bs : (long)C1 * H * W; p.x2_bs = x2_bs ? x2_bs : (long)p.C2 * H * W;
+  p.N = N; p.H = H; p.W = W; p.scale = scale; p.shift = shift; p.nstride = C1 + p.C2; p.act = act;
+  p.out = reinterpret_cast<u32x4*>(out); p.Hp = H + 2; p.Wp = W + 2;
+  p.sum_nc = sum_nc; p.nc_stride = nc_stride; p.sum_c = sum_c;
+  ADM_REQUIRE((scale != nullptr) == (shift != nullptr), "blk_apply: scale and shift come together");
+  ADM_REQUIRE((reinterpret_cast<uintptr_t>(x1) & 15) == 0 && (x2 == nullptr || (reinterpret_cast<uintptr_t>(x2) & 15) == 0),
+              "blk_apply: inputs must be 16-byte aligned");
+  const dim3 grid((unsigned)ceil_div(H * (W / 4), 256), (unsigned)((C1 + p.C2) / 8), (unsigned)N);
+  if (conv_op16_f16()) ADM_LAUNCH(blk_apply_kernel<true>, grid, dim3(256), 0, st, p);
+  else ADM_LAUNCH(blk_apply_kernel<false>, grid, dim3(256), 0, st, p);
+  return ADM_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------- forward / data gradient
+struct Bf16BConvParams {
+  const u32x4* img; int Cg, Hp, Wp;     // blocked input, Cg = Cin / 8
+  int N, H, W;
+  const u32x4* wb; int Cout;            // filters [tap][Cin/8][Cout] x 16 B (adm_pack_bf16_weight)
+  const float* bias; const float* chan_add; int chan_add_stride;
+  const float* residual; float* out;
+  int tiles_x, tiles_y, n_ct, nblk;
+};
+
+constexpr int FB_PW = 34, FB_PR = 10, FB_CGP = FB_PW * FB_PR;   // patch of an 8x32-pixel tile: 10 rows x 34 pixels per channel group
+constexpr int FB_UNITS = 2 * FB_CGP;                             // 680 units per 16-channel chunk
+constexpr int FB_BUF = 768;                                      // units per patch buffer: 12 DMA instructions of 64 units
+constexpr int FB_NBUF = 3;
+constexpr int FB_LDS_UNITS = FB_NBUF * FB_BUF + 4 * 9 * 64;      // + the four waves' nine-slot filter rings
+
+template <bool F16>
+__global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParams p) {
+  ADM_DYN_SMEM(u32x4, lds);
+  u32x4* const ldsP = lds;                               // [3][768] patch units: [channel group 2][row 10][pixel 34]
+  const int tid = threadIdx.x, lane = tid & 63, wave = ADM_UNIFORM(tid >> 6);
+  u32x4* const ldsA = lds + FB_NBUF * FB_BUF + wave * (9 * 64);   // this wave's ring: slot t = the fragment of tap t
+  const int l31 = lane & 31, h = lane >> 5;
+  int lid;
+  {   // all cout tiles of a pixel tile, then the neighbouring pixel tile: neighbours on one XCD share the patch in its L2
+    const int b = blockIdx.x, q = p.nblk >> 3, r = p.nblk & 7, xcd = b & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int ct = lid % p.n_ct; lid /= p.n_ct;
+  const int tx = lid % p.tiles_x; lid /= p.tiles_x;
+  const int ty = lid % p.tiles_y, n = lid / p.tiles_y;
+  const int m0 = ct * 128 + wave * 32;
+  const int n_chunks = p.Cg >> 1;
+  const long planeU = (long)p.Hp * p.Wp;
+
+  // patch DMA roles (tile- and chunk-invariant): instruction i of this wave fills units 64 (wave + 4 i) .. + 63 of a buffer
+  unsigned poff[3];
+  ADM_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    int u = 64 * (wave + 4 * i) + lane;
+    if (u > FB_UNITS - 1) u = FB_UNITS - 1;            // tail lanes re-request the last unit (they land in the buffer's pad)
+    const int cgp = u / FB_CGP, rem = u - cgp * FB_CGP;
+    const int r = rem / FB_PW, c = rem - r * FB_PW;
+    poff[i] = (unsigned)(((long)cgp * planeU + (long)r * p.Wp + c) * 16);
+  }
+  // haloed coordinates: the patch of output tile (ty, tx) starts at image pixel (8 ty - 1, 32 tx - 1) = unit (8 ty, 32 tx)
+  const u32x4* const img_t = p.img + ((long)n * p.Cg * p.Hp + (long)ty * 8) * p.Wp + (long)tx * 32;
+  const unsigned ldsP_a = ADM_LDS_ADDR(lds) + 1024u * wave;               // LDS byte addresses (wave-uniform integers)
+  const unsigned ldsA_a = ADM_LDS_ADDR(lds) + 16u * (FB_NBUF * FB_BUF + 9 * 64 * wave);
+  auto issue_patch = [&](int ch) __attribute__((always_inline)) {
+    const u32x4* src = img_t + (long)(2 * ch) * planeU;                    // wave-uniform
+    const unsigned dst = ldsP_a + 16u * FB_BUF * (unsigned)(ch % FB_NBUF);
+    ADM_UNROLL
+    for (int i = 0; i < 3; ++i) ADM_GLDS16_ASM(src, poff[i], dst + 4096u * i);
+  };
+  // filter fragment of (chunk, tap): lane (cout l31, k half h) = unit ((tap KG + 2 chunk + h) Cout + m0 + l31): two 512-byte runs
+  const unsigned aoff = (unsigned)(((long)h * p.Cout + l31) * 16);
+  auto issue_filt = [&](int ch, int t) __attribute__((always_inline)) {
+    const u32x4* src = p.wb + ((long)t * p.Cg + 2 * ch) * p.Cout + m0;     // wave-uniform
+    ADM_GLDS16_ASM(src, aoff, ldsA_a + 1024u * t);
+  };
+
+  f32x16 acc[8];
+  ADM_UNROLL
+  for (int t = 0; t < 8; ++t)
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // B fragment of pixel row pt (32 pixels), tap (dy, dx): unit h * 340 + (pt + dy) * 34 + dx + l31 — 32 consecutive units per half
+  const int bbase = h * FB_CGP + l31;
+
+  // ---- vector-memory queue of one wave (every entry is a DMA, issued in this order):
+  //   prologue: P(0) x3, P(1) x3, A(0, 0..8)
+  //   chunk c : [P(c+2) x3 if c + 2 < n] then after tap t's MFMAs A(c+1, t)            (nothing in the last chunk)
+  // vmcnt(N) = "at most N entries outstanding"; entries complete in order.
+  issue_patch(0);
+  issue_patch(1);                                        // n_chunks >= 2 (launcher)
+  ADM_UNROLL
+  for (int t = 0; t < 9; ++t) issue_filt(0, t);
+  ADM_WAIT_VMEM(12);                                     // own pieces of P(0) landed (younger: P(1) x3 + A x9)
+  ADM_BARRIER_LGKM();
+
+  // MODE 0: a chunk with P(c+2) behind it; 1: the last but one (nothing left to request but the last chunk's filters);
+  // 2: the last chunk (no requests at all) — three copies of the body so that every wait count is an immediate
+  auto chunk = [&](int c, auto mode_tag) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool LAST = MODE == 2, HASP = MODE == 0;
+    if (HASP) issue_patch(c + 2);
+    const u32x4* cur = ldsP + (c % FB_NBUF) * FB_BUF + bbase;
+    u32x4 Ac, An, Bc[8], Bn[8];
+    if (HASP) ADM_WAIT_VMEM(11); else ADM_WAIT_VMEM(8);  // A(c, 0): younger = A(c, 1..8) [+ P(c+2) x3]
+    Ac = ldsA[lane];
+    ADM_UNROLL
+    for (int pt = 0; pt < 8; ++pt) Bc[pt] = cur[pt * FB_PW];
+    ADM_UNROLL
+    for (int t = 0; t < 9; ++t) {
+      if (t < 8) {
+        // A(c, t+1): younger = A(c, t+2..8) [7 - t] [+ P(c+2) x3] + A(c+1, 0..t-1) [t, not in the last chunk]
+        if (LAST) {
+          switch (t) {
+            case 0: ADM_WAIT_VMEM(7); break; case 1: ADM_WAIT_VMEM(6); break; case 2: ADM_WAIT_VMEM(5); break;
+            case 3: ADM_WAIT_VMEM(4); break; case 4: ADM_WAIT_VMEM(3); break; case 5: ADM_WAIT_VMEM(2); break;
+            case 6: ADM_WAIT_VMEM(1); break; default: ADM_WAIT_VMEM(0); break;
+          }
+        } else if (HASP) {
+          ADM_WAIT_VMEM(10);
+        } else {
+          ADM_WAIT_VMEM(7);
+        }
+        An = ldsA[64 * (t + 1) + lane];
+        ADM_UNROLL
+        for (int pt = 0; pt < 8; ++pt) Bn[pt] = cur[(pt + (t + 1) / 3) * FB_PW + (t + 1) % 3];
+      }
+      ADM_SCHED_FENCE();
+      ADM_UNROLL
+      for (int pt = 0; pt < 8; ++pt) acc[pt] = ADM_MFMA16(F16, Ac, Bc[pt], acc[pt]);
+      ADM_SCHED_FENCE();
+      if (!LAST) issue_filt(c + 1, t);                   // slot t has been read into registers: refill it for the next chunk
+      if (t < 8) {
+        Ac = An;
+        ADM_UNROLL
+        for (int pt = 0; pt < 8; ++pt) Bc[pt] = Bn[pt];
+      }
+    }
+    // P(c+1) is older than A(c, 8), which has landed: this wave's pieces of the next patch are in LDS; the barrier makes the
+    // other waves' pieces visible and tells everybody that buffer c % 3 (refilled next by P(c+3)) is no longer read
+    ADM_BARRIER_LGKM();
+  };
+  for (int c = 0; c + 2 < n_chunks; ++c) chunk(c, std::integral_constant<int, 0>{});
+  chunk(n_chunks - 2, std::integral_constant<int, 1>{});
+  chunk(n_chunks - 1, std::integral_constant<int, 2>{});
+
+  // epilogue: D row = output channel, column = pixel; fp32 bias + per-(n, channel) term + residual.
+  // One store instruction = 2 couts x 32 consecutive pixels (two whole 128-byte lines).
+  const int planeO = p.H * p.W;
+  float* const out_n = p.out + (long)n * p.Cout * planeO;                   // wave-uniform bases, 32-bit lane offsets
+  const float* const res_n = p.residual ? p.residual + (long)n * p.Cout * planeO : nullptr;
+  const int lane_off = (m0 + 4 * h) * planeO + (ty * 8) * p.W + tx * 32 + l31;
+  float bv[16];
+  ADM_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int co = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    bv[r] = p.bias[co] + p.chan_add[(long)n * p.chan_add_stride + co];
+  }
+  ADM_UNROLL
+  for (int pt = 0; pt < 8; ++pt) {
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int o = lane_off + ((r & 3) + 8 * (r >> 2)) * planeO + pt * p.W;
+      float v = acc[pt][r] + bv[r];
+      if (res_n) v += res_n[o];
+      out_n[o] = v;
+    }
+  }
+}
+
+bool conv_bf16b_eligible(int Cin, int Cout, int H, int W) {
+  return Cin % 16 == 0 && Cin >= 32 && Cout % 128 == 0 && H % 8 == 0 && W % 32 == 0;
+}
+
+int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void* wb, int Cout, const float* bias,
+                      const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st) {
+  ADM_REQUIRE(conv_bf16b_eligible(Cin, Cout, H, W), "conv_bf16b: shape not eligible (Cin % 16, Cin >= 32, Cout % 128, H % 8, W % 32)");
+  Bf16BConvParams p;
+  p.img = reinterpret_cast<const u32x4*>(img); p.Cg = Cin / 8; p.Hp = H + 2; p.Wp = W + 2;
+  p.N = N; p.H = H; p.W = W;
+  p.wb = reinterpret_cast<const u32x4*>(wb); p.Cout = Cout;
+  p.bias = bias ? bias : conv_zero_bias(Cout);
+  p.chan_add = chan_add; p.chan_add_stride = chan_add_stride;
+  if (p.chan_add == nullptr) { p.chan_add = conv_zero_bias(Cout); p.chan_add_stride = 0; }
+  ADM_REQUIRE(p.bias && p.chan_add, "conv_bf16b: constant buffers");
+  p.residual = residual; p.out = out;
+  p.tiles_x = W / 32; p.tiles_y = H / 8; p.n_ct = Cout / 128;
+  p.nblk = p.tiles_x * p.tiles_y * N * p.n_ct;
+  const size_t smem = sizeof(u32x4) * FB_LDS_UNITS;
+#if !defined(ADM_EMU)
+  static bool once = [] {
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    return true;
+  }();
+  (void)once;
+#endif
+  set_last_conv_variant(5000 + 332);
+  if (conv_op16_f16()) ADM_LAUNCH(conv_bf16b_kernel<true>, dim3(p.nblk), dim3(256), smem, st, p);
+  else ADM_LAUNCH(conv_bf16b_kernel<false>, dim3(p.nblk), dim3(256), smem, st, p);
+  return ADM_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradient
+// dW[co][ci][tap] = sum over (n, y, x) of dy[n][co][y][x] * a[n][ci][y + dy - 1][x + dx - 1]; GEMM with k = pixels, one MFMA
+// k-step = 16 consecutive pixels of a row.  Both operands arrive channel-blocked; LDS holds them as slabs of 16 channels,
+// [slab][pixel][16 channels] = 32 B per pixel, and ds_read_b64_tr_b16 hands a lane 4 pixels of ONE channel (two reads = the
+// 8 k-values of an MFMA operand).  A 16-lane group reads 128 consecutive bytes (4 pixels); the two groups of a 32-lane half
+// read the same pixels of two slabs whose bases differ by 128 (mod 256) bytes: all 64 banks, conflict-free.
+struct Bf16BWgradParams {
+  const u32x4* xa; int CgI;             // activated input image, CgI = Ct / 8
+  const u32x4* dyb; int CgO;            // output-gradient image, CgO = Cout / 8
+  int Hp, Wp, N, H, W, Cout, Ct;
+  float* part;
+  int tiles_x, tiles_y, n_ptiles, n_ct, n_ci, split, tiles_per_block, nblk;
+  unsigned mTX, mTXY;
+};
+
+constexpr int WB_DSLAB = 264;                   // units per dy slab: 128 pixels x 2 + 8 (128 bytes) so that slab bases alternate halves
+constexpr int WB_DY = 8 * WB_DSLAB;             // 2112 units: 128 couts
+constexpr int WB_XSLAB = 6 * 34 * 2;            // 408 units = 6528 bytes = 128 (mod 256): no pad needed
+constexpr int WB_XA = 4 * WB_XSLAB;             // 1632 units: 64 cins
+constexpr int WB_BUF = WB_DY + WB_XA + 32;      // + 32 units of slack behind the half-used last DMA instruction
+constexpr int WB_NDMA = 32 + 26;                // DMA instructions per tile: 32 (dy) + 26 (patch; the last one half dummy)
+
+__device__ __forceinline__ int bdivb(int n, int d, unsigned magic) {   // n / d; exact via umulhi for n, d < 2^16
+  return magic ? (int)(((unsigned long long)(unsigned)n * magic) >> 32) : n / d;
+}
+
+template <bool F16>
+__global__ void __launch_bounds__(512, 2) conv_wgradb_kernel(const Bf16BWgradParams p) {
+  ADM_DYN_SMEM(u32x4, lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = ADM_UNIFORM(tid >> 6);
+  const int wc = wave & 3, wi = wave >> 2;          // 32-cout block, 32-cin block of this wave
+  int lid;
+  {   // the n_ci workgroups that read the same dy tiles (and the n_ct that read the same patches) are neighbours on one XCD
+    const int b = blockIdx.x, q = p.nblk >> 3, r = p.nblk & 7, xcd = b & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int cic = lid % p.n_ci; lid /= p.n_ci;
+  const int ct = lid % p.n_ct, sp = lid / p.n_ct;
+  const long planeU = (long)p.Hp * p.Wp;
+  const int t_begin = sp * p.tiles_per_block;
+  int t_end = t_begin + p.tiles_per_block;
+  if (t_end > p.n_ptiles) t_end = p.n_ptiles;
+
+  // DMA roles: instruction j = wave + 8 i (i = 0..7, j < 58); i < 4 -> dy image, i >= 4 -> patch
+  unsigned goff[8];
+  int ldst[8];
+  ADM_UNROLL
+  for (int i = 0; i < 8; ++i) {
+    const int j = wave + 8 * i;
+    if (i < 4) {
+      const int slab = j >> 2, quarter = j & 3;
+      const int u = quarter * 64 + lane, px = u >> 1, cgs = u & 1;
+      goff[i] = (unsigned)(((long)(slab * 2 + cgs) * planeU + (long)(px >> 5) * p.Wp + (px & 31)) * 16);
+      ldst[i] = slab * WB_DSLAB + quarter * 64;
+    } else {
+      const int k = j - 32;
+      int U = 64 * k + lane;
+      if (U > WB_XA - 1) U = WB_XA - 1;
+      const int slab = U / WB_XSLAB, rem = U - slab * WB_XSLAB;
+      const int pp = rem >> 1, cgs = rem & 1, prow = pp / 34, pcol = pp - prow * 34;
+      goff[i] = (unsigned)(((long)(slab * 2 + cgs) * planeU + (long)prow * p.Wp + pcol) * 16);
+      ldst[i] = WB_DY + 64 * k;
+    }
+  }
+  const unsigned lds_a = ADM_LDS_ADDR(lds);
+  const u32x4* const dy_c = p.dyb + (long)(ct * 16) * planeU;
+  const u32x4* const xa_c = p.xa + (long)(cic * 8) * planeU;
+  auto issue_tile = [&](int pt, int buf) __attribute__((always_inline)) {
+    const int nimg = bdivb(pt, p.tiles_x * p.tiles_y, p.mTXY);
+    const int rem = pt - nimg * (p.tiles_x * p.tiles_y);
+    const int ty = bdivb(rem, p.tiles_x, p.mTX), tx = rem - ty * p.tiles_x;
+    // haloed coordinates: dy pixel (4 ty, 32 tx) = unit (4 ty + 1, 32 tx + 1); the patch starts one up / left = unit (4 ty, 32 tx)
+    const u32x4* dsrc = dy_c + ((long)nimg * p.CgO * p.Hp + (long)(ty * 4 + 1)) * p.Wp + (long)(tx * 32 + 1);
+    const u32x4* xsrc = xa_c + ((long)nimg * p.CgI * p.Hp + (long)(ty * 4)) * p.Wp + (long)(tx * 32);
+    const unsigned base = lds_a + 16u * WB_BUF * (unsigned)buf;
+    ADM_UNROLL
+    for (int i = 0; i < 8; ++i) {
+      if (i < 7 || wave < WB_NDMA - 56) {                // j = wave + 56 exists for waves 0 and 1 only (wave-uniform)
+        if (i < 4) ADM_GLDS16_ASM(dsrc, goff[i], base + 16u * ldst[i]);
+        else ADM_GLDS16_ASM(xsrc, goff[i], base + 16u * ldst[i]);
+      }
+    }
+  };
+
+  f32x16 acc[9];
+  ADM_UNROLL
+  for (int t = 0; t < 9; ++t)
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // per-lane read bases (bytes inside a buffer): slab of the lane's 16-lane group, pixel 8 (lane >> 5) + ((lane & 15) >> 2),
+  // 8-byte piece lane & 3
+  const int lgrp = (lane >> 4) & 1, lpx = 8 * (lane >> 5) + ((lane & 15) >> 2), lpc = lane & 3;
+  const int abase = (2 * wc + lgrp) * (WB_DSLAB * 16) + lpx * 32 + lpc * 8;
+  const int xbase = WB_DY * 16 + (2 * wi + lgrp) * (WB_XSLAB * 16) + lpx * 32 + lpc * 8;
+
+  auto read_frag = [&](const unsigned char* b, int byte_off) __attribute__((always_inline)) -> u32x4 {
+    const adm_u32x2 lo = ADM_DS_READ_TR16_B64(b + byte_off), hi = ADM_DS_READ_TR16_B64(b + byte_off + 128);
+    u32x4 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+    return r;
+  };
+
+  issue_tile(t_begin, 0);
+  int it = 0;
+  for (int pt = t_begin; pt < t_end; ++pt, ++it) {
+    ADM_WAIT_VMEM(0);                                    // this wave's pieces of tile pt (nothing younger is in flight)
+    ADM_BARRIER_LGKM();                                  // everybody's pieces; everybody is done with the other buffer
+    if (pt + 1 < t_end) issue_tile(pt + 1, (it + 1) & 1);
+    const unsigned char* buf = reinterpret_cast<const unsigned char*>(lds + (it & 1) * WB_BUF);
+    const unsigned char* bA = buf + abase;
+    const unsigned char* bX = buf + xbase;
+    u32x4 Ac, Bc[9], An, Bn[9];
+    Ac = read_frag(bA, 0);
+    ADM_UNROLL
+    for (int t = 0; t < 9; ++t) Bc[t] = read_frag(bX, ((t / 3) * 34 + (t % 3)) * 32);
+    ADM_UNROLL
+    for (int s = 0; s < 8; ++s) {
+      if (s < 7) {
+        const int row = (s + 1) >> 1, col0 = ((s + 1) & 1) * 16;
+        An = read_frag(bA, (row * 32 + col0) * 32);
+        ADM_UNROLL
+        for (int t = 0; t < 9; ++t) Bn[t] = read_frag(bX, ((row + t / 3) * 34 + col0 + (t % 3)) * 32);
+      }
+      ADM_SCHED_FENCE();
+      ADM_UNROLL
+      for (int t = 0; t < 9; ++t) acc[t] = ADM_MFMA16(F16, Ac, Bc[t], acc[t]);
+      ADM_SCHED_FENCE();
+      if (s < 7) {
+        Ac = An;
+        ADM_UNROLL
+        for (int t = 0; t < 9; ++t) Bc[t] = Bn[t];
+      }
+    }
+  }
+
+  // partial slab [split][tap][cout][cin] (wgrad_reduce9_kernel sums the slabs and transposes to (cout, cin, tap))
+  float* out = p.part + (long)sp * p.Cout * p.Ct * 9;
+  const int cc = cic * 64 + wi * 32 + (lane & 31);
+  ADM_UNROLL
+  for (int t = 0; t < 9; ++t) {
+    ADM_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int co = ct * 128 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      out[((long)t * p.Cout + co) * p.Ct + cc] = acc[t][r];
+    }
+  }
+}
+
+bool conv_wgradb_eligible(int Ct, int Cout, int H, int W) {
+  return Ct % 64 == 0 && Cout % 128 == 0 && H % 4 == 0 && W % 32 == 0;
+}
+
+// split-K factor and workspace floats ([split][Cout * Ct * 9]) of the blocked weight-gradient kernel
+long conv_wgradb_workspace(int Ct, int Cout, int N, int H, int W, int* split_out) {
+  const int n_ptiles = (W / 32) * (H / 4) * N;
+  const int pairs = (Cout / 128) * (Ct / 64);
+  int split = ceil_div(512, pairs);              // two waves of workgroups on 256 CUs
+  if (split > n_ptiles) split = n_ptiles;
+  if (split < 1) split = 1;
+  const int tpb = ceil_div(n_ptiles, split);
+  split = ceil_div(n_ptiles, tpb);               // no empty workgroups
+  if (split_out) *split_out = split;
+  return (long)split * Cout * Ct * 9;
+}
+
+int launch_conv_wgradb(const void* xa, int Ct, const void* dyb, int Cout, int N, int H, int W, float* dW, int accumulate,
+                       float* workspace, hipStream_t st) {
+  ADM_REQUIRE(conv_wgradb_eligible(Ct, Cout, H, W), "conv_wgradb: shape not eligible (Ct % 64, Cout % 128, H % 4, W % 32)");
+  Bf16BWgradParams p;
+  p.xa = reinterpret_cast<const u32x4*>(xa); p.CgI = Ct / 8;
+  p.dyb = reinterpret_cast<const u32x4*>(dyb); p.CgO = Cout / 8;
+  p.Hp = H + 2; p.Wp = W + 2; p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.Ct = Ct;
+  p.part = workspace;
+  p.tiles_x = W / 32; p.tiles_y = H / 4;
+  p.n_ptiles = p.tiles_x * p.tiles_y * N;
+  p.n_ct = Cout / 128; p.n_ci = Ct / 64;
+  conv_wgradb_workspace(Ct, Cout, N, H, W, &p.split);
+  p.tiles_per_block = ceil_div(p.n_ptiles, p.split);
+  p.nblk = p.n_ct * p.n_ci * p.split;
+  auto magic = [&](long d) { return (d <= 1 || p.n_ptiles >= 65536) ? 0u : (unsigned)((1ULL << 32) / (unsigned long long)d + 1ULL); };
+  p.mTX = magic(p.tiles_x); p.mTXY = magic((long)p.tiles_x * p.tiles_y);
+  const size_t smem = sizeof(u32x4) * 2 * WB_BUF;
+#if !defined(ADM_EMU)
+  static bool once = [] {
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return true;
+  }();
+  (void)once;
+#endif
+  if (conv_op16_f16()) ADM_LAUNCH(conv_wgradb_kernel<true>, dim3(p.nblk), dim3(512), smem, st, p);
+  else ADM_LAUNCH(conv_wgradb_kernel<false>, dim3(p.nblk), dim3(512), smem, st, p);
+  ADM_TRY(ADM_CHECK_LAUNCH());
+  return launch_wgrad_reduce(workspace, p.split, (long)Cout * Ct * 9, dW, accumulate, 9, st);
+}
+
+}  // namespace adm

@@ -851,7 +851,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce9_kernel(const float* __restr
 
 static inline int ilog2w(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-static int launch_wgrad_reduce(const float* workspace, int split, long numel, float* dW, int accumulate, int taps, hipStream_t st) {
+int launch_wgrad_reduce(const float* workspace, int split, long numel, float* dW, int accumulate, int taps, hipStream_t st) {
   if (taps == 9) {
     const long M = numel / 9;
     long g = (M + 63) / 64;

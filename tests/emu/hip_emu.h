@@ -343,6 +343,29 @@ static inline f32x16 mfma_f32_32x32x16_op16(u32x4 a, u32x4 b, f32x16 c) {
 }
 }  // namespace adm_emu
 
+// ds_read_b64_tr_b16 (gfx950): every lane reads 8 bytes at its own LDS address; inside each 16-lane group the 16 x 4 halfwords
+// are handed out transposed: lane l (0..15), element j (0..3) receives element l & 3 of lane (l >> 2) + 4 j.  With the 16 lanes
+// on 128 consecutive bytes this is "column l of a row-major 4 x 16 matrix" (cdna_hip_programming.md §2).
+typedef unsigned adm_u32x2 __attribute__((vector_size(8)));
+namespace adm_emu {
+static inline adm_u32x2 ds_read_tr16_b64(const void* p) {
+  int lane = flat_tid() & 63;
+  Wave& w = S().waves[flat_tid() >> 6];
+  uint64_t raw;
+  memcpy(&raw, p, 8);
+  w.xch[lane] = raw;
+  wave_sync();
+  const int g = lane & ~15, l = lane & 15;
+  uint16_t e[4];
+  for (int j = 0; j < 4; ++j) e[j] = (uint16_t)(w.xch[g + (l >> 2) + 4 * j] >> (16 * (l & 3)));
+  wave_sync();
+  adm_u32x2 r;
+  r[0] = (unsigned)e[0] | ((unsigned)e[1] << 16);
+  r[1] = (unsigned)e[2] | ((unsigned)e[3] << 16);
+  return r;
+}
+}  // namespace adm_emu
+
 static inline float adm_emu_expf(float x) { return expf(x); }
 #define __expf adm_emu_expf
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

@@ -1,0 +1,143 @@
+"""Round 4: the 16-bit training convolutions on BLOCKED operand images (k_conv_bf16b.hip; option conv_bf16 = 3).
+`--mixed_precision bf16` (scripts/train_unet.py:391-401 -> accelerate -> torch.autocast: Conv2d on bf16 operands, fp32 accumulation).
+Bars as in test_conv_bf16.py: (tight) against a float64 convolution of the SAME bf16-rounded operands — only the accumulation
+order differs; (loose) against the plain fp32 convolution — the error of the mixed-precision mode itself."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from native_backend import BACKENDS, select
+from test_kernels import _rand, _relerr
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def _unblock(img):
+    """(N, C/8, H+2, W+2, 8) -> (N, C, H+2, W+2) float64"""
+    n, cg, hp, wp, _ = img.shape
+    return img.permute(0, 1, 4, 2, 3).reshape(n, cg * 8, hp, wp).to(torch.float64)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(2, 16, 8, 8, 12, True, True), (1, 8, 0, 5, 8, False, False), (1, 32, 32, 16, 64, True, False)],
+                         ids=["concat-gn-silu", "bare", "wide"])
+def test_blocked_image_is_the_rounded_activated_input_with_a_zero_halo(backend, case):
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn, C1, C2, H, W, use_gn, act = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 8, 1e-5, x2=x2) if use_gn else None
+    img, nc, c = ops.blocked_image(x1, x2, gn=gn, act=act, sums=True)
+    x = torch.cat([x1, x2], 1).cpu() if C2 else x1.cpu()
+    ref = x
+    if use_gn:
+        ref = ref * gn[0].cpu()[:, :, None, None] + gn[1].cpu()[:, :, None, None]
+    if act:
+        ref = F.silu(ref)
+    got = _unblock(img.cpu())
+    assert float(got[:, :, 0].abs().max()) == 0 and float(got[:, :, -1].abs().max()) == 0
+    assert float(got[:, :, :, 0].abs().max()) == 0 and float(got[:, :, :, -1].abs().max()) == 0
+    inner = got[:, :, 1:-1, 1:-1]
+    # bf16 rounding of an fp32 value that may differ from torch's in the last bit: at most one bf16 ulp apart, mostly identical
+    want = _bf(ref)
+    assert _relerr(inner, want) < 4e-3
+    assert float((inner == want).double().mean()) > 0.98
+    assert torch.allclose(nc.cpu().double(), x.double().sum((2, 3)), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(c.cpu().double(), x.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-4)
+
+
+FWD_CASES = [
+    # (N, C1, C2, H, W, Cout, gn, act, temb, res)
+    (1, 32, 0, 8, 32, 128, 0, 0, 0, 0),      # one tile, two chunks (the shortest K loop: no steady-state chunk)
+    (2, 64, 0, 16, 32, 128, 1, 1, 1, 1),     # four chunks, two row tiles, every epilogue term
+    (1, 48, 16, 8, 64, 256, 1, 1, 0, 1),     # virtual concat resolved by the image writer, two cout tiles, two column tiles
+    (1, 96, 0, 24, 32, 128, 1, 0, 1, 0),     # six chunks: steady state + both tail modes, three row tiles
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", FWD_CASES, ids=[str(i) for i in range(len(FWD_CASES))])
+def test_conv_bf16_blocked_forward(backend, case):
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn, C1, C2, H, W, Cout, use_gn, act, use_temb, use_res = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    w = _rand((Cout, Ct, 3, 3), 3, dev, scale=(Ct * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32 if Ct % 32 == 0 else 16, 1e-5, x2=x2) if use_gn else None
+    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
+    res = _rand((Nn, Cout, H, W), 8, dev) if use_res else None
+    img = ops.blocked_image(x1, x2, gn=gn, act=bool(act))
+    out = ops.conv2d_bf16_blocked(img, ops.pack_bf16_weight(w), Cout, bias=b, chan_add=temb, residual=res)
+    c = lambda t: None if t is None else t.cpu()  # noqa: E731
+    tail = c(b).double()[None, :, None, None]
+    if temb is not None:
+        tail = tail + c(temb).double()[:, :, None, None]
+    if res is not None:
+        tail = tail + c(res).double()
+    # tight: the kernel against a float64 convolution of ITS OWN operand image (halo cut off: the convolution pads)
+    xa = _unblock(img.cpu())[:, :, 1:-1, 1:-1]
+    exact = F.conv2d(xa, _bf(c(w)), None, padding=1) + tail
+    assert _relerr(out.double(), exact) < 2e-6, _relerr(out.double(), exact)
+    # loose: against the fp32 layer
+    x = torch.cat([c(x1), c(x2)], 1) if C2 else c(x1)
+    if use_gn:
+        x = F.group_norm(x, 32 if Ct % 32 == 0 else 16, c(gamma), c(beta), 1e-5)
+    if act:
+        x = F.silu(x)
+    full = F.conv2d(x.double(), c(w).double(), None, padding=1) + tail
+    assert _relerr(out.double(), full) < 8e-3, _relerr(out.double(), full)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv_bf16_blocked_data_gradient(backend):
+    """Backward-data pass of a 3x3 stride-1 Conv2d: the same kernel on the image of dy with transposed, flipped filters; the
+    residual port accumulates into a gradient that already holds a contribution (out aliases residual)."""
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn, Cin, Cout, H, W = 2, 128, 32, 8, 32
+    w = _rand((Cout, Cin, 3, 3), 11, dev, scale=(Cin * 9) ** -0.5)
+    dy = _rand((Nn, Cout, H, W), 12, dev)
+    acc = _rand((Nn, Cin, H, W), 13, dev)
+    img = ops.blocked_image(dy)
+    dx = ops.conv2d_bf16_blocked(img, ops.pack_bf16_weight(w, transposed=True), Cin, residual=acc)
+    exact = torch.nn.grad.conv2d_input((Nn, Cin, H, W), _bf(w.cpu()), _bf(dy.cpu()), padding=1) + acc.cpu().double()
+    assert _relerr(dx.double(), exact) < 2e-6, _relerr(dx.double(), exact)
+
+
+WGRAD_CASES = [
+    # (N, Ct, H, W, Cout, max_tiles_note)
+    (1, 64, 4, 32, 128),       # one tile
+    (2, 64, 8, 64, 128),       # 8 tiles
+    (1, 128, 16, 32, 256),     # two cin blocks x two cout tiles
+    (3, 64, 4, 32, 128),       # a workgroup walks several images when the split is capped
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[str(i) for i in range(len(WGRAD_CASES))])
+def test_conv_wgrad_bf16_blocked(backend, case):
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn, Ct, H, W, Cout = case
+    x = _rand((Nn, Ct, H, W), 1, dev)
+    dy = _rand((Nn, Cout, H, W), 2, dev)
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    gn = ops.groupnorm_stats(x, gamma, beta, 32, 1e-5)
+    x_img = ops.blocked_image(x, gn=gn, act=True)
+    dy_img = ops.blocked_image(dy)
+    dW = ops.conv2d_wgrad_bf16_blocked(x_img, dy_img)
+    xa = _unblock(x_img.cpu())[:, :, 1:-1, 1:-1]
+    exact = torch.nn.grad.conv2d_weight(xa, (Cout, Ct, 3, 3), _bf(dy.cpu()), padding=1)
+    assert _relerr(dW.double(), exact) < 2e-6, _relerr(dW.double(), exact)
+    full = torch.nn.grad.conv2d_weight(F.silu(F.group_norm(x.cpu(), 32, gamma.cpu(), beta.cpu(), 1e-5)).double(), (Cout, Ct, 3, 3),
+                                       dy.cpu().double(), padding=1)
+    assert _relerr(dW.double(), full) < 8e-3, _relerr(dW.double(), full)
