@@ -141,6 +141,11 @@ struct Net {
   void end_inference(const std::vector<unsigned>& saved);
   const float* params_base = nullptr;  // flat master parameter buffer and the matching flat gradient buffer
   float* grads_base = nullptr;
+  // level 3 of option conv_bf16 (training nets; k_conv_bf16b.hip): per 3x3 stride-1 convolution the blocked 16-bit image of
+  // its activated input (written once by the forward pass, read by the forward and the weight-gradient kernel) and the
+  // blocked image of its output gradient (one buffer per distinct (Cout, H, W): the zero halo belongs to the geometry)
+  struct BlkOp { void* xa = nullptr; void* dyb = nullptr; bool fwd = false, wg = false, dg = false; };
+  std::vector<BlkOp> blk;            // indexed like ops; empty below level 3 / for inference
   float *tmp_da = nullptr, *wgrad_ws = nullptr, *s12 = nullptr, *tmp_w = nullptr;
   size_t tmp_da_floats = 0, wgrad_ws_floats = 0, tmp_w_floats = 0;
 

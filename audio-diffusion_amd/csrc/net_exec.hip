@@ -1,6 +1,8 @@
 // net_exec.hip — implementation of the generic flat-op-list executor (see net_exec.h).
 #include <cstdlib>
 
+#include <tuple>
+
 #include "net_exec.h"
 
 #include <cmath>
@@ -569,6 +571,43 @@ int Net::plan(int B) {
       const size_t wn = (size_t)o.w->Cout * Ct * o.ks * o.ks;
       if (wn > max_w) max_w = wn;
     }
+    blk.clear();
+    if (conv_bf16_mode() >= 3) {
+      blk.resize(ops.size());
+      std::map<std::tuple<int, int, int>, void*> dy_imgs;
+      for (size_t i = 0; i < ops.size(); ++i) {
+        const Op& o = ops[i];
+        if (o.kind != Op::CONV || o.wt >= 0 || o.ks != 3 || o.stride != 1 || o.up || o.pad_lo != 1 || o.in1_C != 0) continue;
+        if (o.w == nullptr || o.w->wb == nullptr || o.w->wbT == nullptr || o.in1 == t_in) continue;
+        const Tensor& t1 = tensors[o.in1];
+        const int C1 = t1.C, C2 = o.in2 >= 0 ? tensors[o.in2].C : 0, Ct = C1 + C2, Cout = o.w->Cout, H = t1.H, W = t1.W;
+        if (!blk_apply_eligible(C1, C2, H, W) || !blk_apply_eligible(Cout, 0, H, W)) continue;
+        if (o.act && o.gn < 0) continue;
+        BlkOp& b = blk[i];
+        b.fwd = conv_bf16b_eligible(Ct, Cout, H, W);
+        b.wg = conv_wgradb_eligible(Ct, Cout, H, W);
+        b.dg = conv_bf16b_eligible(Cout, Ct, H, W);
+        if (b.fwd || b.wg) {
+          const size_t bytes = blk_image_bytes(B, Ct, H, W);
+          ADM_TRY(arena_alloc(&b.xa, bytes));
+          ADM_TRY(dmemset(b.xa, 0, bytes, nullptr));          // the halo stays zero for the life of the plan
+        }
+        if (b.wg || b.dg) {
+          void*& img = dy_imgs[std::make_tuple(Cout, H, W)];
+          if (img == nullptr) {
+            const size_t bytes = blk_image_bytes(B, Cout, H, W);
+            ADM_TRY(arena_alloc(&img, bytes));
+            ADM_TRY(dmemset(img, 0, bytes, nullptr));
+          }
+          b.dyb = img;
+          if (b.wg) {
+            const size_t ws = (size_t)conv_wgradb_workspace(Ct, Cout, B, H, W, nullptr);
+            if (ws > max_ws) max_ws = ws;
+          }
+        }
+      }
+      ADM_TRY(stream_sync(nullptr));
+    }
     ADM_TRY(arena_alloc((void**)&tmp_da, sizeof(float) * max_da)); tmp_da_floats = max_da;
     ADM_TRY(arena_alloc((void**)&wgrad_ws, sizeof(float) * (max_ws ? max_ws : 4))); wgrad_ws_floats = max_ws;
     ADM_TRY(arena_alloc((void**)&tmp_w, sizeof(float) * (max_w + 4096))); tmp_w_floats = max_w + 4096;
@@ -644,7 +683,16 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
       adm_conv_args a;
       fill_conv_args(o, B, temb_all, temb_stride, &a);
       if (tensors[o.out].stats != nullptr) { a.stats_out = tensors[o.out].stats; a.stats_tiles = tensors[o.out].stat_tiles; }
-      ADM_TRY(launch_conv2d(a, st));
+      const size_t oi = (size_t)(&o - ops.data());
+      const BlkOp* bo = (training && conv_bf16_mode() >= 3 && oi < blk.size() && blk[oi].xa != nullptr) ? &blk[oi] : nullptr;
+      if (bo)    // level 3: the activated input once as a blocked 16-bit image (kept for the weight gradient)
+        ADM_TRY(launch_blk_apply(a.x1, a.C1, a.x1_bstride, a.x2, a.C2, a.x2_bstride, B, a.H, a.W, a.gn_scale, a.gn_shift, a.act, bo->xa,
+                                 nullptr, 0, nullptr, st));
+      if (bo && bo->fwd)
+        ADM_TRY(launch_conv_bf16b(bo->xa, a.C1 + a.C2, B, a.H, a.W, o.w->wb, a.Cout, a.bias, a.chan_add, a.chan_add_stride, a.residual,
+                                  a.out, st));
+      else
+        ADM_TRY(launch_conv2d(a, st));
       if (o.w) ADM_TRY(note_packing(*o.w, packing_of_variant(last_conv_variant(), true)));
       const Tensor& to = tensors[o.out];
       const double Cin = a.C1 + a.C2, outel = (double)B * to.C * to.H * to.W;
@@ -767,6 +815,9 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
     if (qkv) ADM_TRY(dmemset(dbias, 0, sizeof(float) * Cout, st));
     ADM_TRY(launch_chan_sums(dy, B, Cout, (int)plane_o, (o.temb_off >= 0 && dtemb_all) ? dtemb_all + o.temb_off : nullptr,
                              temb_stride, 0, dbias, st));
+    const BlkOp* bo = (conv_bf16_mode() >= 3 && (size_t)i < blk.size() && (blk[i].wg || blk[i].dg)) ? &blk[i] : nullptr;
+    if (bo)      // level 3: dy once as a blocked 16-bit image for the weight-gradient and the data-gradient kernel
+      ADM_TRY(launch_blk_apply(dy, Cout, 0, nullptr, 0, 0, B, to.H, to.W, nullptr, nullptr, 0, bo->dyb, nullptr, 0, nullptr, st));
     // ---- weight gradient -----------------------------------------------------------------------------------
     const float* gsc = o.gn >= 0 ? gnbufs[o.gn].scale : nullptr;
     const float* gsh = o.gn >= 0 ? gnbufs[o.gn].shift : nullptr;
@@ -779,6 +830,8 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       ADM_REQUIRE(tmp_da_floats >= (size_t)B * Ct * Hi * Wi, "run_backward: scratch too small");
       ADM_TRY(launch_conv_small_cout_bwd(t1.ptr, Ct, B, t1.H, t1.W, gsc, gsh, o.act, ps->P(o.w->key + ".weight"), dy, Cout,
                                          tmp_da, dW, st));
+    } else if (bo && bo->wg) {
+      ADM_TRY(launch_conv_wgradb(bo->xa, Ct, bo->dyb, Cout, B, t1.H, t1.W, dW, 0, wgrad_ws, st));
     } else {
       adm_conv_args a;
       memset(&a, 0, sizeof(a));
@@ -821,7 +874,10 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
         ADM_REQUIRE(tmp_da_floats >= (size_t)B * Ct * Hi * Wi, "run_backward: scratch too small");
         a.out = tmp_da;
       }
-      ADM_TRY(launch_conv2d(a, st));
+      if (bo && bo->dg)
+        ADM_TRY(launch_conv_bf16b(bo->dyb, Cout, B, to.H, to.W, o.w->wbT, Ct, nullptr, nullptr, 0, a.residual, a.out, st));
+      else
+        ADM_TRY(launch_conv2d(a, st));
       ADM_TRY(note_packing(*o.w, packing_of_variant(last_conv_variant(), false)));
       if (direct) { t1.ginit = true; continue; }
     }

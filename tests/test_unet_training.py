@@ -320,6 +320,59 @@ def test_mixed_precision_bf16_training_step(backend):
     assert e32 < 2e-4 and abs(loss32 - float(loss_ref.detach())) <= 1e-5 * float(loss_ref.detach())
 
 
+BLKCFG = dict(sample_size=32, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(128, 128),
+              down_block_types=("DownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "UpBlock2D"))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_mixed_precision_bf16_level3_blocked_operand_images(backend, monkeypatch):
+    """Level 3 (round 4, k_conv_bf16b.hip): the 3x3 stride-1 convolutions of all three passes read blocked 16-bit operand images
+    (activated input written once per layer, dy once per layer) through LDS-DMA.  32x32 resolution so that the first level is
+    eligible (W % 32 == 0); the 16x16 level falls back to level 2's kernels inside the same step.  Bars: the toy model's (1) and (3)
+    against fp32 autograd, no worse than torch.autocast, and the same gradient as level 2 up to accumulation order / rounding flips."""
+    dev = select(backend)
+    from audiodiffusion import _native
+    from audiodiffusion.unet import UNet2DModel
+    torch.manual_seed(0)
+    ref = OracleUNet(**BLKCFG)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "norm" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(1)
+    x, tgt = torch.randn((2, 1, 32, 32), generator=g), torch.randn((2, 1, 32, 32), generator=g)
+    ts = torch.tensor([5, 700])
+    loss_ref = F.mse_loss(ref(x, ts)["sample"], tgt)
+    loss_ref.backward()
+    g32 = torch.cat([p.grad.flatten() for _, p in ref.named_parameters()])
+    ref.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        loss_ac = F.mse_loss(ref(x, ts)["sample"].float(), tgt)
+    loss_ac.backward()
+    gac = torch.cat([p.grad.float().flatten() for _, p in ref.named_parameters()])
+
+    def native(level):
+        monkeypatch.setenv("ADM_BF16_LEVEL", str(level))
+        m = UNet2DModel(**BLKCFG).load_state_dict(ref.state_dict())
+        _, grads = m.enable_training(mixed_precision="bf16")
+        loss = float(m.train_step(x.to(dev), ts, tgt.to(dev)))
+        flat = torch.cat([grads[m.flat.offsets[n][0]:m.flat.offsets[n][0] + p.numel()].cpu() for n, p in ref.named_parameters()])
+        return loss, flat
+
+    rel = lambda a, b: float((a - b).double().norm() / b.double().norm())  # noqa: E731
+    try:
+        l3, g3 = native(3)
+        l2, g2 = native(2)
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+    assert abs(l3 - float(loss_ref.detach())) <= 5e-3 * float(loss_ref.detach())
+    e3, e2, eac = rel(g3, g32), rel(g2, g32), rel(gac, g32)
+    assert 1e-4 < e3 < 1.5e-2, e3
+    assert e3 <= eac, (e3, eac)
+    assert rel(g3, g2) < 5e-3 and abs(e3 - e2) < 3e-3, (rel(g3, g2), e3, e2)
+    assert float((g3 - g2).abs().max()) > 0          # another kernel family really ran
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_mixed_precision_fp16_training_step_and_grad_scaler(backend):
     """`--mixed_precision fp16` (train_unet.py:391-395): the 16-bit-operand kernels on IEEE binary16 + GradScaler semantics.
