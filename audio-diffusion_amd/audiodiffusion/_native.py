@@ -115,12 +115,13 @@ _OPTIONAL_SIGS = {
     "adm_conv_wgrad_workspace": (_l, [C.POINTER(ConvArgs)]),
     "adm_conv2d_wgrad": (_i, [C.POINTER(ConvArgs), _vp, _vp, _i, _vp, _vp]),
     "adm_blocked_image_bytes": (C.c_size_t, [_i, _i, _i, _i]),
-    "adm_blocked_apply": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "adm_blocked_sums_scratch": (_l, [_i, _i, _i, _i]),
+    "adm_blocked_apply": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "adm_conv2d_bf16_blocked_eligible": (_i, [_i, _i, _i, _i]),
-    "adm_conv2d_bf16_blocked": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "adm_conv2d_bf16_blocked": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "adm_conv2d_wgrad_bf16_blocked_eligible": (_i, [_i, _i, _i, _i]),
     "adm_conv_wgrad_blocked_workspace": (_l, [_i, _i, _i, _i, _i]),
-    "adm_conv2d_wgrad_bf16_blocked": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "adm_conv2d_wgrad_bf16_blocked": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "adm_sumpool2x2": (_i, [_vp, _vp, _i, _i, _l, _i, _vp]),
     "adm_accumulate": (_i, [_vp, _l, _vp, _l, _l, _i, _i, _vp]),
     "adm_chan_sums": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),

@@ -347,38 +347,41 @@ def blocked_image(x1, x2=None, gn=None, act=False, sums=False):
     assert img.numel() * 2 == N.lib().adm_blocked_image_bytes(Nn, C1 + C2, H, W)
     nc = torch.zeros((Nn, C1 + C2), dtype=torch.float32, device=x1.device) if sums else None
     c = torch.zeros(C1 + C2, dtype=torch.float32, device=x1.device) if sums else None
+    scr = torch.empty(N.lib().adm_blocked_sums_scratch(Nn, C1 + C2, H, W), dtype=torch.float32, device=x1.device) if sums else None
     N.check(N.lib().adm_blocked_apply(N.ptr(x1), C1, N.ptr(x2), C2, Nn, H, W, N.ptr(gn[0]) if gn is not None else None,
-                                      N.ptr(gn[1]) if gn is not None else None, int(act), C.c_void_p(img.data_ptr()), N.ptr(nc),
-                                      C1 + C2, N.ptr(c), N.stream_for(x1)))
+                                      N.ptr(gn[1]) if gn is not None else None, int(act), C.c_void_p(img.data_ptr()), N.ptr(scr),
+                                      N.ptr(nc), C1 + C2, N.ptr(c), N.stream_for(x1)))
     return (img, nc, c) if sums else img
 
 
-def conv2d_bf16_blocked(img, wb, Cout, bias=None, chan_add=None, residual=None):
+def conv2d_bf16_blocked(img, wb, Cout, bias=None, chan_add=None, residual=None, up=False, stats=False):
     """3x3 stride-1 convolution of a blocked image on 16-bit MFMA operands (adm_conv2d_bf16_blocked); wb from pack_bf16_weight
-    (transposed=True with the image of dy: the data gradient)."""
+    (transposed=True with the image of dy: the data gradient); up: nearest x2 of the image folded in (Upsample2D.conv)."""
     Nn, Cg, Hp, Wp, _ = img.shape
-    H, W = Hp - 2, Wp - 2
+    H, W = (Hp - 2) * (2 if up else 1), (Wp - 2) * (2 if up else 1)
     out = torch.empty((Nn, Cout, H, W), dtype=torch.float32, device=img.device)
     ca, cas = (None, 0)
     if chan_add is not None:
         assert chan_add.dtype == torch.float32 and chan_add.stride(1) == 1
         ca, cas = C.c_void_p(chan_add.data_ptr()), chan_add.stride(0)
+    st = torch.zeros((Nn, Cout, (H // 8) * (W // 32), 2), dtype=torch.float64, device=img.device) if stats else None
     N.check(N.lib().adm_conv2d_bf16_blocked(C.c_void_p(img.data_ptr()), Cg * 8, Nn, H, W, C.c_void_p(wb.data_ptr()), Cout,
-                                            N.ptr(bias), ca, cas, N.ptr(residual), N.ptr(out), N.stream_for(out)))
-    return out
+                                            N.ptr(bias), ca, cas, N.ptr(residual), N.ptr(out), int(up), N.ptr(st), N.stream_for(out)))
+    return (out, st) if stats else out
 
 
-def conv2d_wgrad_bf16_blocked(x_img, dy_img):
-    """dW (Cout, Cin, 3, 3) from the blocked images of the activated input and of dy (adm_conv2d_wgrad_bf16_blocked)."""
-    Nn, CgI, Hp, Wp, _ = x_img.shape
-    CgO = dy_img.shape[1]
+def conv2d_wgrad_bf16_blocked(x_img, dy_img, up=False):
+    """dW (Cout, Cin, 3, 3) from the blocked images of the activated input and of dy (adm_conv2d_wgrad_bf16_blocked);
+    up: x_img is the half-resolution input of an Upsample2D convolution."""
+    Nn, CgI = x_img.shape[:2]
+    CgO, Hp, Wp = dy_img.shape[1:4]
     H, W, Cin, Cout = Hp - 2, Wp - 2, CgI * 8, CgO * 8
     ws_n = N.lib().adm_conv_wgrad_blocked_workspace(Cin, Cout, Nn, H, W)
     assert ws_n > 0, "shape not eligible"
     ws = torch.empty(ws_n, dtype=torch.float32, device=x_img.device)
     dW = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float32, device=x_img.device)
     N.check(N.lib().adm_conv2d_wgrad_bf16_blocked(C.c_void_p(x_img.data_ptr()), Cin, C.c_void_p(dy_img.data_ptr()), Cout, Nn, H, W,
-                                                  N.ptr(dW), 0, N.ptr(ws), N.stream_for(dW)))
+                                                  N.ptr(dW), 0, N.ptr(ws), int(up), N.stream_for(dW)))
     return dW
 
 

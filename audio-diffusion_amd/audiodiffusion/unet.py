@@ -285,20 +285,22 @@ class UNet2DModel:
         launch) and switches the native executor to training mode (activations kept, gradient buffers, wgrad/dgrad
         weight packings). Returns (flat_params, flat_grads) — torch views the optimizer side works on.
         mixed_precision="bf16" (scripts/train_unet.py:391-401): the 3x3 stride-1 convolutions of the training passes take
-        bf16 MFMA operands (activations rounded on the load path, filters re-rounded from the fp32 masters after every
-        optimizer step) with fp32 accumulation; everything stored — weights, activations, gradients, optimizer state —
-        stays fp32, so checkpoints and the fp32 sampling path are unaffected."""
+        bf16 MFMA operands (the activated input rounded once per layer into a blocked 16-bit image, filters re-rounded from
+        the fp32 masters after every optimizer step) with fp32 accumulation; everything the model keeps — weights,
+        activations, gradients, optimizer state — stays fp32, so checkpoints and the fp32 sampling path are unaffected."""
         from .training import FlatBuffer
         if mixed_precision not in ("no", "bf16", "fp16"):
             raise ValueError(f"mixed_precision must be 'no', 'bf16' or 'fp16', got {mixed_precision!r}")
-        # level 2 (default; measured 98.6 vs 113.5 ms per step at level 1, profiles/r02_first_contact.md): the 1x1
-        # convolutions and the stride-2 data gradients take bf16 operands too; ADM_BF16_LEVEL=1 keeps them fp32.
+        # level 3 (default, round 4; measured 69 vs 84 ms per step at level 2, profiles/r04_*): level 2 plus the blocked
+        # operand images of k_conv_bf16b.hip for the 3x3 stride-1 convolutions of all three passes.  Level 2 (round 2; 98.6
+        # vs 113.5 ms at level 1): the 1x1 convolutions and the stride-2 data gradients take bf16 operands too;
+        # ADM_BF16_LEVEL=1 keeps them fp32.
         # The level is read by adm_unet_enable_training and belongs to THIS model from then on: the process-wide option is
         # put back to 0 below, and the native sampling entry points always run fp32.
         # "fp16" (`train_unet.py:391-395`): the same kernels on IEEE binary16 operands (v_mfma_f32_32x32x16_f16); binary16's
         # narrow exponent needs the gradient side scaled: training.GradScaler + train_step(loss_scale=), as accelerate's
         # torch.cuda.amp.GradScaler does for the reference.
-        level = int(os.environ.get("ADM_BF16_LEVEL", "2")) if mixed_precision in ("bf16", "fp16") else 0
+        level = int(os.environ.get("ADM_BF16_LEVEL", "3")) if mixed_precision in ("bf16", "fp16") else 0
         N.check(N.lib().adm_set_option(b"conv_bf16", level))
         N.check(N.lib().adm_set_option(b"conv_op16_f16", int(mixed_precision == "fp16")))
         self.mixed_precision = mixed_precision

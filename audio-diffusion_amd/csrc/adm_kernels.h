@@ -25,7 +25,7 @@ int launch_dequant(const float* x, uint8_t* out, long n, hipStream_t st);
 // k_groupnorm.hip
 int launch_groupnorm_finalize(const double* st1, int C1, int tiles1, const double* st2, int C2, int tiles2, int N, int HW,
                               int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,
-                              hipStream_t st);
+                              hipStream_t st, float* mean_rstd = nullptr);
 int conv_stats_tiles(const adm_conv_args& a);        // k_conv_mfma.hip: statistic tiles the dispatched kernel would emit (0: none)
 int winograd_stats_tiles(const adm_conv_args& a);    // k_conv_wino.hip
 int launch_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int groups, float eps,
@@ -89,17 +89,22 @@ int launch_conv_wgrad_bf16(const adm_conv_args& a, const float* dy, float* dW, i
 // k_conv_bf16b.hip (round 4, level 3: blocked 16-bit operand images [n][C/8][H+2][W+2] x 16 B, zero halo; LDS-DMA fed kernels)
 size_t blk_image_bytes(int N, int C, int H, int W);
 bool blk_apply_eligible(int C1, int C2, int H, int W);
-// img = round16(act(scale * concat(x1, x2) + shift)) (scale NULL: identity); optional sums of the INPUT per (n, c) / per c (atomics)
+// img = round16(act(scale * concat(x1, x2) + shift)) (scale NULL: identity); sum_scratch (blk_sums_scratch floats, NULL ok):
+// per-workgroup sums of the INPUT, turned into per-(n, c) / per-c sums by launch_blk_sums_finalize (bias gradients when x1 = dy)
+long blk_sums_scratch(int N, int C, int H, int W);
 int launch_blk_apply(const float* x1, int C1, long x1_bs, const float* x2, int C2, long x2_bs, int N, int H, int W,
-                     const float* scale, const float* shift, int act, void* out, float* sum_nc, int nc_stride, float* sum_c,
-                     hipStream_t st);
+                     const float* scale, const float* shift, int act, void* out, float* sum_scratch, hipStream_t st);
+int launch_blk_sums_finalize(const float* sum_scratch, int N, int C, int H, int W, float* out_nc, int nc_stride, int nc_accumulate,
+                             float* out_c, hipStream_t st);
 bool conv_bf16b_eligible(int Cin, int Cout, int H, int W);
 int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void* wb, int Cout, const float* bias,
-                      const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st);
+                      const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st, int up = 0,
+                      double* stats_out = nullptr);   // stats_out: GroupNorm partial sums of the OUTPUT, [n][cout][(H/8)*(W/32)][2] fp64
+int conv_bf16b_stats_tiles(int H, int W);
 bool conv_wgradb_eligible(int Ct, int Cout, int H, int W);
 long conv_wgradb_workspace(int Ct, int Cout, int N, int H, int W, int* split_out);
 int launch_conv_wgradb(const void* xa, int Ct, const void* dyb, int Cout, int N, int H, int W, float* dW, int accumulate,
-                       float* workspace, hipStream_t st);
+                       float* workspace, hipStream_t st, int up = 0);
 int launch_wgrad_reduce(const float* workspace, int split, long numel, float* dW, int accumulate, int taps, hipStream_t st);
 
 // k_backward.hip / k_conv_wgrad.hip (training)

@@ -39,6 +39,9 @@
   memcpy(adm_emu::S().dyn_smem + (lds_addr) + (adm_emu::flat_tid() & 63) * 16, reinterpret_cast<const char*>(gbase) + (off_bytes), 16)
 #define ADM_DS_READ_TR16_B64(lds_ptr) adm_emu::ds_read_tr16_b64(lds_ptr)
 #define ADM_BARRIER_LGKM() __syncthreads()
+// LDS hand-over between the lanes of ONE wave (hardware: a wave's LDS operations execute in order, nothing to do; the
+// emulator runs every lane as its own fiber and needs the rendezvous)
+#define ADM_WAVE_LDS_ORDER() adm_emu::wave_sync()
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -90,6 +93,8 @@ typedef unsigned adm_u32x2 __attribute__((ext_vector_type(2)));
   __builtin_bit_cast(adm_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) adm_s16x4*)(lds_ptr)))
 // raw workgroup barrier that drains this wave's LDS traffic only (vector memory keeps flying)
 #define ADM_BARRIER_LGKM() ADM_BARRIER_KEEP_VMEM(63)
+// LDS hand-over between the lanes of ONE wave: LDS executes a wave's operations in order; only the compiler must not reorder
+#define ADM_WAVE_LDS_ORDER() __builtin_amdgcn_wave_barrier()
 #define ADM_LAUNCH(kern, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), (shmem), (stream), __VA_ARGS__)
 #define ADM_DYN_SMEM(type, name)                                              \

@@ -30,26 +30,32 @@ int adm_conv2d_wgrad(const adm_conv_args* a, const float* dy, float* dW, int acc
 }
 
 size_t adm_blocked_image_bytes(int N, int C, int H, int W) { return blk_image_bytes(N, C, H, W); }
+long adm_blocked_sums_scratch(int N, int C, int H, int W) { return blk_sums_scratch(N, C, H, W); }
 int adm_blocked_apply(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, const float* scale,
-                      const float* shift, int act, void* img, float* sum_nc, int nc_stride, float* sum_c, void* stream) {
+                      const float* shift, int act, void* img, float* sum_scratch, float* sum_nc, int nc_stride, float* sum_c,
+                      void* stream) {
   ADM_REQUIRE(x1 && img, "blocked_apply: null argument");
-  return launch_blk_apply(x1, C1, 0, x2, x2 ? C2 : 0, 0, N, H, W, scale, shift, act, img, sum_nc, nc_stride, sum_c,
-                          (hipStream_t)stream);
+  ADM_REQUIRE(sum_scratch != nullptr || (sum_nc == nullptr && sum_c == nullptr), "blocked_apply: sums need sum_scratch");
+  ADM_TRY(launch_blk_apply(x1, C1, 0, x2, x2 ? C2 : 0, 0, N, H, W, scale, shift, act, img, sum_scratch, (hipStream_t)stream));
+  if (sum_scratch == nullptr) return 0;
+  return launch_blk_sums_finalize(sum_scratch, N, C1 + (x2 ? C2 : 0), H, W, sum_nc, nc_stride, 0, sum_c, (hipStream_t)stream);
 }
 int adm_conv2d_bf16_blocked_eligible(int Cin, int Cout, int H, int W) { return conv_bf16b_eligible(Cin, Cout, H, W) ? 1 : 0; }
 int adm_conv2d_bf16_blocked(const void* img, int Cin, int N, int H, int W, const void* wb, int Cout, const float* bias,
-                            const float* chan_add, int chan_add_stride, const float* residual, float* out, void* stream) {
+                            const float* chan_add, int chan_add_stride, const float* residual, float* out, int up,
+                            double* stats_out, void* stream) {
   ADM_REQUIRE(img && wb && out, "conv2d_bf16_blocked: null argument");
-  return launch_conv_bf16b(img, Cin, N, H, W, wb, Cout, bias, chan_add, chan_add_stride, residual, out, (hipStream_t)stream);
+  return launch_conv_bf16b(img, Cin, N, H, W, wb, Cout, bias, chan_add, chan_add_stride, residual, out, (hipStream_t)stream, up,
+                           stats_out);
 }
 int adm_conv2d_wgrad_bf16_blocked_eligible(int Cin, int Cout, int H, int W) { return conv_wgradb_eligible(Cin, Cout, H, W) ? 1 : 0; }
 long adm_conv_wgrad_blocked_workspace(int Cin, int Cout, int N, int H, int W) {
   return conv_wgradb_eligible(Cin, Cout, H, W) ? conv_wgradb_workspace(Cin, Cout, N, H, W, nullptr) : 0;
 }
 int adm_conv2d_wgrad_bf16_blocked(const void* x_img, int Cin, const void* dy_img, int Cout, int N, int H, int W, float* dW,
-                                  int accumulate, float* workspace, void* stream) {
+                                  int accumulate, float* workspace, int up, void* stream) {
   ADM_REQUIRE(x_img && dy_img && dW && workspace, "conv2d_wgrad_bf16_blocked: null argument");
-  return launch_conv_wgradb(x_img, Cin, dy_img, Cout, N, H, W, dW, accumulate, workspace, (hipStream_t)stream);
+  return launch_conv_wgradb(x_img, Cin, dy_img, Cout, N, H, W, dW, accumulate, workspace, (hipStream_t)stream, up);
 }
 
 int adm_sumpool2x2(const float* in, float* out, int H, int W, long planes, int accumulate, void* stream) {

@@ -21,6 +21,7 @@
 //
 // Operand bits are the same as in k_conv_bf16.hip (same affine / SiLU / rounding expressions), accumulation order differs.
 #include <type_traits>
+#include <vector>
 
 #include "adm_kernels.h"
 
@@ -37,7 +38,7 @@ struct BlkApplyParams {
   const float* scale; const float* shift; int nstride;   // per-(n, channel) affine rows, NULL = identity
   int act;
   u32x4* out; int Hp, Wp;
-  float* sum_nc; int nc_stride; float* sum_c;             // optional: per-(n, c) / per-c sums of the INPUT (bias gradients)
+  float* part;                       // optional: per-(n, c, workgroup) sums of the INPUT ([n][c][gridDim.x], blk_sums_finalize_kernel)
 };
 
 // One thread = 8 channels x 4 consecutive pixels: eight float4 row loads (a wave reads 1 KiB of ONE channel row per
@@ -55,22 +56,23 @@ __global__ void __launch_bounds__(256) blk_apply_kernel(const BlkApplyParams p) 
   float4 v[8];
   ADM_UNROLL
   for (int e = 0; e < 8; ++e) v[e] = live ? *reinterpret_cast<const float4*>(src + (long)e * HW + (long)y * p.W + 4 * x4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.sum_c != nullptr || p.sum_nc != nullptr) {
-    // bias gradient of the producing layer folded into the pass that reads dy anyway: per-thread sums of the four pixels,
-    // 64-lane shuffle tree, one atomic per wave and channel (fp32 atomics: the order of the waves is not fixed; the fp32 path
-    // keeps adm_chan_sums for bit-reproducible sums)
+  if (p.part != nullptr) {
+    // bias gradient of the producing layer folded into the pass that reads dy anyway: per-thread sums of the four pixels, a
+    // fixed 64-lane shuffle tree, the four waves in order — one partial per (n, channel, workgroup); blk_sums_finalize_kernel
+    // adds the partials in order (fp64), so the sums are as reproducible as adm_chan_sums'
+    __shared__ float red[8][4];
     ADM_UNROLL
     for (int e = 0; e < 8; ++e) {
-      float s = (v[e].x + v[e].y) + (v[e].z + v[e].w);
+      float sm = (v[e].x + v[e].y) + (v[e].z + v[e].w);
       ADM_UNROLL
-      for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-      if ((threadIdx.x & 63) == 0) {
-        if (p.sum_nc) atomicAdd(p.sum_nc + (long)n * p.nc_stride + c0 + e, s);
-        if (p.sum_c) atomicAdd(p.sum_c + c0 + e, s);
-      }
+      for (int m = 32; m >= 1; m >>= 1) sm += __shfl_xor(sm, m);
+      if ((threadIdx.x & 63) == 0) red[e][threadIdx.x >> 6] = sm;
     }
+    __syncthreads();
+    if (threadIdx.x < 8)
+      p.part[((long)n * (p.C1 + p.C2) + c0 + threadIdx.x) * gridDim.x + blockIdx.x] =
+          (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
   }
-  if (!live) return;
   float o[8][4];
   ADM_UNROLL
   for (int e = 0; e < 8; ++e) {
@@ -84,13 +86,29 @@ __global__ void __launch_bounds__(256) blk_apply_kernel(const BlkApplyParams p) 
       o[e][j] = t;
     }
   }
-  u32x4* dst = p.out + (((long)n * ((p.C1 + p.C2) >> 3) + cg) * p.Hp + (y + 1)) * p.Wp + (4 * x4 + 1);
+  // A lane owns 4 consecutive units (64 B): stored straight from here, one instruction would touch 64 separate 16-byte pieces
+  // of 32 cache lines.  The wave's 256 units go through 4 KiB of LDS instead and leave as four runs of 64 consecutive units
+  // (1 KiB per store instruction where the image row is long enough).  LDS position of unit 4 l + j: 4 l + (j ^ ((l >> 1) & 3)) —
+  // conflict-free for the 8-lane groups of ds_write_b128 and the 16-lane groups of ds_read_b128.
+  __shared__ u32x4 stg[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   ADM_UNROLL
   for (int j = 0; j < 4; ++j) {
     u32x4 w;
     w[0] = ADM_PK16(F16, o[0][j], o[1][j]); w[1] = ADM_PK16(F16, o[2][j], o[3][j]);
     w[2] = ADM_PK16(F16, o[4][j], o[5][j]); w[3] = ADM_PK16(F16, o[6][j], o[7][j]);
-    dst[j] = w;
+    stg[wave][4 * lane + (j ^ ((lane >> 1) & 3))] = w;
+  }
+  // destination (in units, relative to this (n, channel group) plane) of the lane's first unit; -1: thread past the end
+  const int my_dst = live ? (y + 1) * p.Wp + (4 * x4 + 1) : -1;
+  ADM_WAVE_LDS_ORDER();
+  u32x4* const plane = p.out + ((long)n * ((p.C1 + p.C2) >> 3) + cg) * p.Hp * p.Wp;
+  ADM_UNROLL
+  for (int j = 0; j < 4; ++j) {
+    const int owner = 16 * j + (lane >> 2);                       // lane that produced unit 64 j + lane
+    const int od = __shfl(my_dst, owner);
+    const u32x4 w = stg[wave][64 * j + 4 * (lane >> 2) + ((lane & 3) ^ ((lane >> 3) & 3))];
+    if (od >= 0) plane[od + (lane & 3)] = w;
   }
 }
 
@@ -98,22 +116,47 @@ size_t blk_image_bytes(int N, int C, int H, int W) { return (size_t)16 * N * (C 
 
 bool blk_apply_eligible(int C1, int C2, int H, int W) { return C1 % 8 == 0 && C2 % 8 == 0 && W % 4 == 0 && H > 0; }
 
+// out_nc[n * nc_stride + c] (= | +=) sum over the workgroup partials (NULL ok); out_c[c] += the same over n (atomic; NULL ok)
+__global__ void __launch_bounds__(256) blk_sums_finalize_kernel(const float* __restrict__ part, int C, int nbx, float* out_nc,
+                                                               int nc_stride, int nc_accumulate, float* out_c) {
+  const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (c >= C) return;
+  const float* q = part + ((long)n * C + c) * nbx;
+  double sm = 0.0;
+  for (int i = 0; i < nbx; ++i) sm += (double)q[i];
+  if (out_nc) {
+    float* o = out_nc + (long)n * nc_stride + c;
+    *o = nc_accumulate ? *o + (float)sm : (float)sm;
+  }
+  if (out_c) atomicAdd(out_c + c, (float)sm);
+}
+
+long blk_sums_scratch(int N, int C, int H, int W) { return (long)N * C * ceil_div(H * (W / 4), 256); }
+
 int launch_blk_apply(const float* x1, int C1, long x1_bs, const float* x2, int C2, long x2_bs, int N, int H, int W,
-                     const float* scale, const float* shift, int act, void* out, float* sum_nc, int nc_stride, float* sum_c,
-                     hipStream_t st) {
+                     const float* scale, const float* shift, int act, void* out, float* sum_scratch, hipStream_t st) {
   ADM_REQUIRE(blk_apply_eligible(C1, x2 ? C2 : 0, H, W), "blk_apply: channel counts must be multiples of 8 and W of 4");
   BlkApplyParams p;
   p.x1 = x1; p.x2 = x2; p.C1 = C1; p.C2 = x2 ? C2 : 0;
   p.x1_bs = x1_bs ? x1_bs : (long)C1 * H * W; p.x2_bs = x2_bs ? x2_bs : (long)p.C2 * H * W;
   p.N = N; p.H = H; p.W = W; p.scale = scale; p.shift = shift; p.nstride = C1 + p.C2; p.act = act;
   p.out = reinterpret_cast<u32x4*>(out); p.Hp = H + 2; p.Wp = W + 2;
-  p.sum_nc = sum_nc; p.nc_stride = nc_stride; p.sum_c = sum_c;
+  p.part = sum_scratch;
   ADM_REQUIRE((scale != nullptr) == (shift != nullptr), "blk_apply: scale and shift come together");
   ADM_REQUIRE((reinterpret_cast<uintptr_t>(x1) & 15) == 0 && (x2 == nullptr || (reinterpret_cast<uintptr_t>(x2) & 15) == 0),
               "blk_apply: inputs must be 16-byte aligned");
   const dim3 grid((unsigned)ceil_div(H * (W / 4), 256), (unsigned)((C1 + p.C2) / 8), (unsigned)N);
   if (conv_op16_f16()) ADM_LAUNCH(blk_apply_kernel<true>, grid, dim3(256), 0, st, p);
   else ADM_LAUNCH(blk_apply_kernel<false>, grid, dim3(256), 0, st, p);
+  return ADM_CHECK_LAUNCH();
+}
+
+// the sums blk_apply left in sum_scratch -> per-(n, c) sums (written, or added with nc_accumulate) and per-c sums (ADDED)
+int launch_blk_sums_finalize(const float* sum_scratch, int N, int C, int H, int W, float* out_nc, int nc_stride, int nc_accumulate,
+                             float* out_c, hipStream_t st) {
+  if (out_nc == nullptr && out_c == nullptr) return 0;
+  ADM_LAUNCH(blk_sums_finalize_kernel, dim3((unsigned)ceil_div(C, 256), (unsigned)N), dim3(256), 0, st, sum_scratch, C,
+             ceil_div(H * (W / 4), 256), out_nc, nc_stride, nc_accumulate, out_c);
   return ADM_CHECK_LAUNCH();
 }
 
@@ -124,8 +167,17 @@ struct Bf16BConvParams {
   const u32x4* wb; int Cout;            // filters [tap][Cin/8][Cout] x 16 B (adm_pack_bf16_weight)
   const float* bias; const float* chan_add; int chan_add_stride;
   const float* residual; float* out;
+  double* stats;                        // NULL or GroupNorm partial sums of the output: [n][cout][tile][2] (sum, sum of squares)
   int tiles_x, tiles_y, n_ct, nblk;
+  unsigned long long* prof;             // developer aid (ADM_BF16B_PROF=1): per-phase cycle counters, else NULL
 };
+
+#if defined(ADM_EMU)
+#define BB_CLK() 0ull
+#else
+#define BB_CLK() ((unsigned long long)__builtin_readcyclecounter())
+#endif
+#define BB_LAP(slot) do { if (PROF) { const unsigned long long tn_ = BB_CLK(); pr[slot] += tn_ - tq; tq = tn_; } } while (0)
 
 constexpr int FB_PW = 34, FB_PR = 10, FB_CGP = FB_PW * FB_PR;   // patch of an 8x32-pixel tile: 10 rows x 34 pixels per channel group
 constexpr int FB_UNITS = 2 * FB_CGP;                             // 680 units per 16-channel chunk
@@ -133,8 +185,14 @@ constexpr int FB_BUF = 768;                                      // units per pa
 constexpr int FB_NBUF = 3;
 constexpr int FB_LDS_UNITS = FB_NBUF * FB_BUF + 4 * 9 * 64;      // + the four waves' nine-slot filter rings
 
-template <bool F16>
+// UP: the image is the HALF-resolution input of an Upsample2D convolution (nearest x2 folded into the patch addresses: patch
+// pixel (r, c) of upsampled pixel (8 ty - 1 + r, 32 tx - 1 + c) is source unit (4 ty + (r + 1) / 2, 16 tx + (c + 1) / 2) of the
+// haloed image — the halo doubles as the zero padding of the UPSAMPLED tensor); H, W are the output dims, Hp, Wp the image's.
+template <bool F16, bool UP = false, bool PROF = false>
 __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParams p) {
+  unsigned long long pr[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
+  const unsigned long long t_start = BB_CLK();
+  if (PROF) tq = t_start;
   ADM_DYN_SMEM(u32x4, lds);
   u32x4* const ldsP = lds;                               // [3][768] patch units: [channel group 2][row 10][pixel 34]
   const int tid = threadIdx.x, lane = tid & 63, wave = ADM_UNIFORM(tid >> 6);
@@ -160,10 +218,11 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
     if (u > FB_UNITS - 1) u = FB_UNITS - 1;            // tail lanes re-request the last unit (they land in the buffer's pad)
     const int cgp = u / FB_CGP, rem = u - cgp * FB_CGP;
     const int r = rem / FB_PW, c = rem - r * FB_PW;
-    poff[i] = (unsigned)(((long)cgp * planeU + (long)r * p.Wp + c) * 16);
+    poff[i] = UP ? (unsigned)(((long)cgp * planeU + (long)((r + 1) >> 1) * p.Wp + ((c + 1) >> 1)) * 16)
+                 : (unsigned)(((long)cgp * planeU + (long)r * p.Wp + c) * 16);
   }
   // haloed coordinates: the patch of output tile (ty, tx) starts at image pixel (8 ty - 1, 32 tx - 1) = unit (8 ty, 32 tx)
-  const u32x4* const img_t = p.img + ((long)n * p.Cg * p.Hp + (long)ty * 8) * p.Wp + (long)tx * 32;
+  const u32x4* const img_t = p.img + ((long)n * p.Cg * p.Hp + (long)ty * (UP ? 4 : 8)) * p.Wp + (long)tx * (UP ? 16 : 32);
   const unsigned ldsP_a = ADM_LDS_ADDR(lds) + 1024u * wave;               // LDS byte addresses (wave-uniform integers)
   const unsigned ldsA_a = ADM_LDS_ADDR(lds) + 16u * (FB_NBUF * FB_BUF + 9 * 64 * wave);
   auto issue_patch = [&](int ch) __attribute__((always_inline)) {
@@ -197,7 +256,9 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
   ADM_UNROLL
   for (int t = 0; t < 9; ++t) issue_filt(0, t);
   ADM_WAIT_VMEM(12);                                     // own pieces of P(0) landed (younger: P(1) x3 + A x9)
+  BB_LAP(1);                                             // prologue: address set-up + the first patch from HBM
   ADM_BARRIER_LGKM();
+  BB_LAP(3);
 
   // MODE 0: a chunk with P(c+2) behind it; 1: the last but one (nothing left to request but the last chunk's filters);
   // 2: the last chunk (no requests at all) — three copies of the body so that every wait count is an immediate
@@ -243,33 +304,74 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
     }
     // P(c+1) is older than A(c, 8), which has landed: this wave's pieces of the next patch are in LDS; the barrier makes the
     // other waves' pieces visible and tells everybody that buffer c % 3 (refilled next by P(c+3)) is no longer read
+    BB_LAP(2);
     ADM_BARRIER_LGKM();
+    BB_LAP(3);
   };
   for (int c = 0; c + 2 < n_chunks; ++c) chunk(c, std::integral_constant<int, 0>{});
   chunk(n_chunks - 2, std::integral_constant<int, 1>{});
   chunk(n_chunks - 1, std::integral_constant<int, 2>{});
 
-  // epilogue: D row = output channel, column = pixel; fp32 bias + per-(n, channel) term + residual.
-  // One store instruction = 2 couts x 32 consecutive pixels (two whole 128-byte lines).
+  // epilogue: D row = output channel, column = pixel.  A wave's 32 couts x 32 pixels of one pixel row go through 4 KiB of its
+  // own in LDS (the patch buffers are dead behind the last barrier) and come back as float4 per lane, so that bias, per-(n,
+  // channel) term, residual and the store are 16-byte operations: one store instruction = 8 couts x 128 contiguous bytes,
+  // 32 stores per wave instead of 128 dword stores (the dword version spent ~40 % of a workgroup's life ISSUING its stores).
+  // LDS executes a wave's operations in order: no barrier, the next row's writes queue behind this row's reads.
   const int planeO = p.H * p.W;
   float* const out_n = p.out + (long)n * p.Cout * planeO;                   // wave-uniform bases, 32-bit lane offsets
   const float* const res_n = p.residual ? p.residual + (long)n * p.Cout * planeO : nullptr;
-  const int lane_off = (m0 + 4 * h) * planeO + (ty * 8) * p.W + tx * 32 + l31;
-  float bv[16];
+  float* const stage = reinterpret_cast<float*>(lds) + 1024 * wave;
+  const int srow = lane >> 3, scol = 4 * (lane & 7);
+  const int lane_off = (m0 + srow) * planeO + (ty * 8) * p.W + tx * 32 + scol;
+  float bv[4], gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
   ADM_UNROLL
-  for (int r = 0; r < 16; ++r) {
-    const int co = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    bv[r] = p.bias[co] + p.chan_add[(long)n * p.chan_add_stride + co];
+  for (int k = 0; k < 4; ++k) {
+    const int co = m0 + srow + 8 * k;
+    bv[k] = p.bias[co] + p.chan_add[(long)n * p.chan_add_stride + co];
   }
   ADM_UNROLL
   for (int pt = 0; pt < 8; ++pt) {
     ADM_UNROLL
-    for (int r = 0; r < 16; ++r) {
-      const int o = lane_off + ((r & 3) + 8 * (r >> 2)) * planeO + pt * p.W;
-      float v = acc[pt][r] + bv[r];
-      if (res_n) v += res_n[o];
-      out_n[o] = v;
+    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[pt][r];
+    ADM_WAVE_LDS_ORDER();
+    float4 sv[4];
+    ADM_UNROLL
+    for (int k = 0; k < 4; ++k) sv[k] = *reinterpret_cast<const float4*>(stage + (srow + 8 * k) * 32 + scol);
+    ADM_WAVE_LDS_ORDER();
+    ADM_UNROLL
+    for (int k = 0; k < 4; ++k) {
+      float4 v = sv[k];
+      const int o = lane_off + 8 * k * planeO + pt * p.W;
+      v.x += bv[k]; v.y += bv[k]; v.z += bv[k]; v.w += bv[k];
+      if (res_n) {
+        const float4 rr = *reinterpret_cast<const float4*>(res_n + o);
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+      *reinterpret_cast<float4*>(out_n + o) = v;
+      if (p.stats) {        // wave-uniform: statistics of the FINAL output values for the GroupNorm that reads this tensor
+        gs[k] += (v.x + v.y) + (v.z + v.w);
+        gq[k] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
     }
+  }
+  if (p.stats) {
+    // the 8 lanes that share a cout row hold its 256 pixels: fp32 inside a lane (32 values), fp64 across the lanes
+    ADM_UNROLL
+    for (int k = 0; k < 4; ++k) {
+      double a = (double)gs[k], b = (double)gq[k];
+      ADM_UNROLL
+      for (int m = 1; m <= 4; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+      if ((lane & 7) == 0) {
+        double* d = p.stats + ((((long)n * p.Cout + m0 + srow + 8 * k) * p.tiles_y + ty) * p.tiles_x + tx) * 2;
+        d[0] = a; d[1] = b;
+      }
+    }
+  }
+  if (PROF) {
+    BB_LAP(4);                            // epilogue (issue only: the stores drain after the wave has left)
+    pr[0] = BB_CLK() - t_start;
+    if (lane == 0)
+      for (int i = 0; i < 6; ++i) p.prof[((long)blockIdx.x * 4 + wave) * 8 + i] = pr[i];
   }
 }
 
@@ -277,32 +379,69 @@ bool conv_bf16b_eligible(int Cin, int Cout, int H, int W) {
   return Cin % 16 == 0 && Cin >= 32 && Cout % 128 == 0 && H % 8 == 0 && W % 32 == 0;
 }
 
+int conv_bf16b_stats_tiles(int H, int W) { return (H / 8) * (W / 32); }
+
 int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void* wb, int Cout, const float* bias,
-                      const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st) {
+                      const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st, int up,
+                      double* stats_out) {
   ADM_REQUIRE(conv_bf16b_eligible(Cin, Cout, H, W), "conv_bf16b: shape not eligible (Cin % 16, Cin >= 32, Cout % 128, H % 8, W % 32)");
   Bf16BConvParams p;
-  p.img = reinterpret_cast<const u32x4*>(img); p.Cg = Cin / 8; p.Hp = H + 2; p.Wp = W + 2;
+  p.img = reinterpret_cast<const u32x4*>(img); p.Cg = Cin / 8;
+  p.Hp = (up ? H / 2 : H) + 2; p.Wp = (up ? W / 2 : W) + 2;     // H, W: OUTPUT dims; the image of an up-convolution is half-size
   p.N = N; p.H = H; p.W = W;
   p.wb = reinterpret_cast<const u32x4*>(wb); p.Cout = Cout;
   p.bias = bias ? bias : conv_zero_bias(Cout);
   p.chan_add = chan_add; p.chan_add_stride = chan_add_stride;
   if (p.chan_add == nullptr) { p.chan_add = conv_zero_bias(Cout); p.chan_add_stride = 0; }
   ADM_REQUIRE(p.bias && p.chan_add, "conv_bf16b: constant buffers");
-  p.residual = residual; p.out = out;
+  p.residual = residual; p.out = out; p.stats = stats_out;
+  ADM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0,
+              "conv_bf16b: out / residual must be 16-byte aligned");
   p.tiles_x = W / 32; p.tiles_y = H / 8; p.n_ct = Cout / 128;
   p.nblk = p.tiles_x * p.tiles_y * N * p.n_ct;
   const size_t smem = sizeof(u32x4) * FB_LDS_UNITS;
 #if !defined(ADM_EMU)
   static bool once = [] {
-    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     return true;
   }();
   (void)once;
 #endif
   set_last_conv_variant(5000 + 332);
-  if (conv_op16_f16()) ADM_LAUNCH(conv_bf16b_kernel<true>, dim3(p.nblk), dim3(256), smem, st, p);
-  else ADM_LAUNCH(conv_bf16b_kernel<false>, dim3(p.nblk), dim3(256), smem, st, p);
+  p.prof = nullptr;
+#if !defined(ADM_EMU)
+  static const bool want_prof = getenv("ADM_BF16B_PROF") != nullptr;
+  if (want_prof && !conv_op16_f16() && !up) {   // developer aid: per-phase cycle accounting, printed after the launch (synchronous)
+    const size_t pn = (size_t)p.nblk * 4 * 8;
+    static unsigned long long* dprof = nullptr;
+    static size_t dcap = 0;
+    if (pn > dcap) { if (dprof) (void)hipFree(dprof); void* q = nullptr; (void)hipMalloc(&q, pn * sizeof(unsigned long long)); dprof = (unsigned long long*)q; dcap = pn; }
+    static bool once_p = [] { (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); return true; }();
+    (void)once_p;
+    p.prof = dprof;
+    ADM_LAUNCH((conv_bf16b_kernel<false, false, true>), dim3(p.nblk), dim3(256), smem, st, p);
+    std::vector<unsigned long long> hv(pn);
+    (void)hipMemcpyAsync(hv.data(), dprof, pn * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    double h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < pn; ++i) h[i & 7] += (double)hv[i];
+    const double w = 4.0 * p.nblk, nch = Cin / 16.0;
+    fprintf(stderr, "[bf16b prof] %d->%d @%dx%d N=%d (%d workgroups): per wave: total %.0f | prologue %.0f | per chunk: mfma+issue %.0f barrier %.0f "
+            "| epilogue issue %.0f cycles (%d chunks; 72 MFMAs = 2304)\n", Cin, Cout, H, W, N, p.nblk, h[0] / w, h[1] / w, h[2] / w / nch,
+            h[3] / w / nch, h[4] / w, (int)nch);
+    return ADM_CHECK_LAUNCH();
+  }
+#endif
+  if (up) {
+    if (conv_op16_f16()) ADM_LAUNCH((conv_bf16b_kernel<true, true>), dim3(p.nblk), dim3(256), smem, st, p);
+    else ADM_LAUNCH((conv_bf16b_kernel<false, true>), dim3(p.nblk), dim3(256), smem, st, p);
+  } else {
+    if (conv_op16_f16()) ADM_LAUNCH((conv_bf16b_kernel<true, false>), dim3(p.nblk), dim3(256), smem, st, p);
+    else ADM_LAUNCH((conv_bf16b_kernel<false, false>), dim3(p.nblk), dim3(256), smem, st, p);
+  }
   return ADM_CHECK_LAUNCH();
 }
 
@@ -315,7 +454,8 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
 struct Bf16BWgradParams {
   const u32x4* xa; int CgI;             // activated input image, CgI = Ct / 8
   const u32x4* dyb; int CgO;            // output-gradient image, CgO = Cout / 8
-  int Hp, Wp, N, H, W, Cout, Ct;
+  int Hp, Wp, N, H, W, Cout, Ct;       // Hp, Wp: the dy image (H + 2, W + 2)
+  int HpX, WpX;                         // the input image: the same, or (H / 2 + 2, W / 2 + 2) for an up-convolution
   float* part;
   int tiles_x, tiles_y, n_ptiles, n_ct, n_ci, split, tiles_per_block, nblk;
   unsigned mTX, mTXY;
@@ -332,7 +472,7 @@ __device__ __forceinline__ int bdivb(int n, int d, unsigned magic) {   // n / d;
   return magic ? (int)(((unsigned long long)(unsigned)n * magic) >> 32) : n / d;
 }
 
-template <bool F16>
+template <bool F16, bool UP = false>
 __global__ void __launch_bounds__(512, 2) conv_wgradb_kernel(const Bf16BWgradParams p) {
   ADM_DYN_SMEM(u32x4, lds);
   const int tid = threadIdx.x, lane = tid & 63, wave = ADM_UNIFORM(tid >> 6);
@@ -344,7 +484,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgradb_kernel(const Bf16BWgradPar
   }
   const int cic = lid % p.n_ci; lid /= p.n_ci;
   const int ct = lid % p.n_ct, sp = lid / p.n_ct;
-  const long planeU = (long)p.Hp * p.Wp;
+  const long planeU = (long)p.Hp * p.Wp, planeX = (long)p.HpX * p.WpX;
   const int t_begin = sp * p.tiles_per_block;
   int t_end = t_begin + p.tiles_per_block;
   if (t_end > p.n_ptiles) t_end = p.n_ptiles;
@@ -366,20 +506,21 @@ __global__ void __launch_bounds__(512, 2) conv_wgradb_kernel(const Bf16BWgradPar
       if (U > WB_XA - 1) U = WB_XA - 1;
       const int slab = U / WB_XSLAB, rem = U - slab * WB_XSLAB;
       const int pp = rem >> 1, cgs = rem & 1, prow = pp / 34, pcol = pp - prow * 34;
-      goff[i] = (unsigned)(((long)(slab * 2 + cgs) * planeU + (long)prow * p.Wp + pcol) * 16);
+      goff[i] = UP ? (unsigned)(((long)(slab * 2 + cgs) * planeX + (long)((prow + 1) >> 1) * p.WpX + ((pcol + 1) >> 1)) * 16)
+                   : (unsigned)(((long)(slab * 2 + cgs) * planeX + (long)prow * p.WpX + pcol) * 16);
       ldst[i] = WB_DY + 64 * k;
     }
   }
   const unsigned lds_a = ADM_LDS_ADDR(lds);
   const u32x4* const dy_c = p.dyb + (long)(ct * 16) * planeU;
-  const u32x4* const xa_c = p.xa + (long)(cic * 8) * planeU;
+  const u32x4* const xa_c = p.xa + (long)(cic * 8) * planeX;
   auto issue_tile = [&](int pt, int buf) __attribute__((always_inline)) {
     const int nimg = bdivb(pt, p.tiles_x * p.tiles_y, p.mTXY);
     const int rem = pt - nimg * (p.tiles_x * p.tiles_y);
     const int ty = bdivb(rem, p.tiles_x, p.mTX), tx = rem - ty * p.tiles_x;
     // haloed coordinates: dy pixel (4 ty, 32 tx) = unit (4 ty + 1, 32 tx + 1); the patch starts one up / left = unit (4 ty, 32 tx)
     const u32x4* dsrc = dy_c + ((long)nimg * p.CgO * p.Hp + (long)(ty * 4 + 1)) * p.Wp + (long)(tx * 32 + 1);
-    const u32x4* xsrc = xa_c + ((long)nimg * p.CgI * p.Hp + (long)(ty * 4)) * p.Wp + (long)(tx * 32);
+    const u32x4* xsrc = xa_c + ((long)nimg * p.CgI * p.HpX + (long)(ty * (UP ? 2 : 4))) * p.WpX + (long)(tx * (UP ? 16 : 32));
     const unsigned base = lds_a + 16u * WB_BUF * (unsigned)buf;
     ADM_UNROLL
     for (int i = 0; i < 8; ++i) {
@@ -463,7 +604,8 @@ bool conv_wgradb_eligible(int Ct, int Cout, int H, int W) {
 long conv_wgradb_workspace(int Ct, int Cout, int N, int H, int W, int* split_out) {
   const int n_ptiles = (W / 32) * (H / 4) * N;
   const int pairs = (Cout / 128) * (Ct / 64);
-  int split = ceil_div(512, pairs);              // two waves of workgroups on 256 CUs
+  static const int target = [] { const char* e = getenv("ADM_WGRADB_WGS"); return e ? atoi(e) : 256; }();
+  int split = ceil_div(target, pairs);           // one workgroup per CU (120 KiB of LDS each): 256 measured 68.3 ms per step, 384: 70.5, 512: 69.7
   if (split > n_ptiles) split = n_ptiles;
   if (split < 1) split = 1;
   const int tpb = ceil_div(n_ptiles, split);
@@ -473,12 +615,13 @@ long conv_wgradb_workspace(int Ct, int Cout, int N, int H, int W, int* split_out
 }
 
 int launch_conv_wgradb(const void* xa, int Ct, const void* dyb, int Cout, int N, int H, int W, float* dW, int accumulate,
-                       float* workspace, hipStream_t st) {
+                       float* workspace, hipStream_t st, int up) {
   ADM_REQUIRE(conv_wgradb_eligible(Ct, Cout, H, W), "conv_wgradb: shape not eligible (Ct % 64, Cout % 128, H % 4, W % 32)");
   Bf16BWgradParams p;
   p.xa = reinterpret_cast<const u32x4*>(xa); p.CgI = Ct / 8;
   p.dyb = reinterpret_cast<const u32x4*>(dyb); p.CgO = Cout / 8;
-  p.Hp = H + 2; p.Wp = W + 2; p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.Ct = Ct;
+  p.Hp = H + 2; p.Wp = W + 2; p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.Ct = Ct;   // H, W: output (= dy) dims
+  p.HpX = (up ? H / 2 : H) + 2; p.WpX = (up ? W / 2 : W) + 2;
   p.part = workspace;
   p.tiles_x = W / 32; p.tiles_y = H / 4;
   p.n_ptiles = p.tiles_x * p.tiles_y * N;
@@ -491,14 +634,21 @@ int launch_conv_wgradb(const void* xa, int Ct, const void* dyb, int Cout, int N,
   const size_t smem = sizeof(u32x4) * 2 * WB_BUF;
 #if !defined(ADM_EMU)
   static bool once = [] {
-    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     return true;
   }();
   (void)once;
 #endif
-  if (conv_op16_f16()) ADM_LAUNCH(conv_wgradb_kernel<true>, dim3(p.nblk), dim3(512), smem, st, p);
-  else ADM_LAUNCH(conv_wgradb_kernel<false>, dim3(p.nblk), dim3(512), smem, st, p);
+  if (up) {
+    if (conv_op16_f16()) ADM_LAUNCH((conv_wgradb_kernel<true, true>), dim3(p.nblk), dim3(512), smem, st, p);
+    else ADM_LAUNCH((conv_wgradb_kernel<false, true>), dim3(p.nblk), dim3(512), smem, st, p);
+  } else {
+    if (conv_op16_f16()) ADM_LAUNCH((conv_wgradb_kernel<true, false>), dim3(p.nblk), dim3(512), smem, st, p);
+    else ADM_LAUNCH((conv_wgradb_kernel<false, false>), dim3(p.nblk), dim3(512), smem, st, p);
+  }
   ADM_TRY(ADM_CHECK_LAUNCH());
   return launch_wgrad_reduce(workspace, p.split, (long)Cout * Ct * 9, dW, accumulate, 9, st);
 }

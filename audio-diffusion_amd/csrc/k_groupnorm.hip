@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const double* __restri
                                                           const double* __restrict__ st2, int C2, int tiles2, int HW,
                                                           int groups, float eps, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ scale,
-                                                          float* __restrict__ shift) {
+                                                          float* __restrict__ shift, float* __restrict__ mean_rstd) {
   const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int C = C1 + C2, cg = C / groups;
   double s = 0.0, ss = 0.0;
@@ -139,6 +139,10 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const double* __restri
     if (var < 0.0) var = 0.0;
     stat[0] = (float)mean;
     stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (mean_rstd) {                                     // training: kept for the backward pass, as gn_stats_kernel does
+      mean_rstd[((long)n * groups + g) * 2] = stat[0];
+      mean_rstd[((long)n * groups + g) * 2 + 1] = stat[1];
+    }
   }
   __syncthreads();
   const float mean = stat[0], rstd = stat[1];
@@ -152,12 +156,12 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const double* __restri
 
 int launch_groupnorm_finalize(const double* st1, int C1, int tiles1, const double* st2, int C2, int tiles2, int N, int HW,
                               int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,
-                              hipStream_t st) {
+                              hipStream_t st, float* mean_rstd) {
   if (st2 == nullptr) { C2 = 0; tiles2 = 0; }
   ADM_REQUIRE(st1 && tiles1 > 0 && (C2 == 0 || tiles2 > 0), "groupnorm_finalize: missing partial sums");
   ADM_REQUIRE((C1 + C2) % groups == 0, "groupnorm: channels not divisible by groups");
   ADM_LAUNCH(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, st, st1, C1, tiles1, st2, C2, tiles2, HW, groups, eps, gamma,
-             beta, scale, shift);
+             beta, scale, shift, mean_rstd);
   return ADM_CHECK_LAUNCH();
 }
 

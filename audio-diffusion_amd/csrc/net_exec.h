@@ -146,6 +146,7 @@ struct Net {
   // blocked image of its output gradient (one buffer per distinct (Cout, H, W): the zero halo belongs to the geometry)
   struct BlkOp { void* xa = nullptr; void* dyb = nullptr; bool fwd = false, wg = false, dg = false; };
   std::vector<BlkOp> blk;            // indexed like ops; empty below level 3 / for inference
+  float* blk_part = nullptr;         // per-workgroup channel sums of the dy image pass (bias gradients)
   float *tmp_da = nullptr, *wgrad_ws = nullptr, *s12 = nullptr, *tmp_w = nullptr;
   size_t tmp_da_floats = 0, wgrad_ws_floats = 0, tmp_w_floats = 0;
 

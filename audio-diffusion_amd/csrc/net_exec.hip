@@ -2,6 +2,7 @@
 #include <cstdlib>
 
 #include <tuple>
+#include <utility>
 
 #include "net_exec.h"
 
@@ -575,37 +576,61 @@ int Net::plan(int B) {
     if (conv_bf16_mode() >= 3) {
       blk.resize(ops.size());
       std::map<std::tuple<int, int, int>, void*> dy_imgs;
+      size_t max_part = 4;
       for (size_t i = 0; i < ops.size(); ++i) {
         const Op& o = ops[i];
-        if (o.kind != Op::CONV || o.wt >= 0 || o.ks != 3 || o.stride != 1 || o.up || o.pad_lo != 1 || o.in1_C != 0) continue;
+        if (o.kind != Op::CONV || o.wt >= 0 || o.ks != 3 || o.stride != 1 || o.up > 1 || o.pad_lo != 1 || o.in1_C != 0) continue;
         if (o.w == nullptr || o.w->wb == nullptr || o.w->wbT == nullptr || o.in1 == t_in) continue;
+        if (o.up && (o.gn >= 0 || o.act || o.in2 >= 0)) continue;       // Upsample2D.conv: plain nearest x2, nothing on the load path
         const Tensor& t1 = tensors[o.in1];
         const int C1 = t1.C, C2 = o.in2 >= 0 ? tensors[o.in2].C : 0, Ct = C1 + C2, Cout = o.w->Cout, H = t1.H, W = t1.W;
-        if (!blk_apply_eligible(C1, C2, H, W) || !blk_apply_eligible(Cout, 0, H, W)) continue;
+        const int Ho = o.up ? 2 * H : H, Wo = o.up ? 2 * W : W;           // the image has the SOURCE dims, the kernels tile the output
+        if (!blk_apply_eligible(C1, C2, H, W) || !blk_apply_eligible(Cout, 0, Ho, Wo)) continue;
         if (o.act && o.gn < 0) continue;
         BlkOp& b = blk[i];
-        b.fwd = conv_bf16b_eligible(Ct, Cout, H, W);
-        b.wg = conv_wgradb_eligible(Ct, Cout, H, W);
-        b.dg = conv_bf16b_eligible(Cout, Ct, H, W);
+        b.fwd = conv_bf16b_eligible(Ct, Cout, Ho, Wo);
+        b.wg = conv_wgradb_eligible(Ct, Cout, Ho, Wo);
+        b.dg = conv_bf16b_eligible(Cout, Ct, Ho, Wo);
         if (b.fwd || b.wg) {
           const size_t bytes = blk_image_bytes(B, Ct, H, W);
           ADM_TRY(arena_alloc(&b.xa, bytes));
           ADM_TRY(dmemset(b.xa, 0, bytes, nullptr));          // the halo stays zero for the life of the plan
         }
         if (b.wg || b.dg) {
-          void*& img = dy_imgs[std::make_tuple(Cout, H, W)];
+          void*& img = dy_imgs[std::make_tuple(Cout, Ho, Wo)];
           if (img == nullptr) {
-            const size_t bytes = blk_image_bytes(B, Cout, H, W);
+            const size_t bytes = blk_image_bytes(B, Cout, Ho, Wo);
             ADM_TRY(arena_alloc(&img, bytes));
             ADM_TRY(dmemset(img, 0, bytes, nullptr));
           }
           b.dyb = img;
+          const size_t pf = (size_t)blk_sums_scratch(B, Cout, Ho, Wo);
+          if (pf > max_part) max_part = pf;
           if (b.wg) {
-            const size_t ws = (size_t)conv_wgradb_workspace(Ct, Cout, B, H, W, nullptr);
+            const size_t ws = (size_t)conv_wgradb_workspace(Ct, Cout, B, Ho, Wo, nullptr);
             if (ws > max_ws) max_ws = ws;
           }
         }
       }
+      // GroupNorm statistics from the producing convolution's epilogue (as the inference plan does): tensors a blocked forward
+      // kernel writes and some GroupNorm reads get per-tile partial sums; the read pass (gn_stats_kernel) disappears for them
+      static const int fold_t = [] { const char* e = getenv("ADM_GN_FOLD_TRAIN"); return e ? atoi(e) : 1; }();
+      if (fold_t) {
+        for (const Op& o : ops)
+          if (o.kind == Op::GN) {
+            tensors[o.in1].want_stats = true;
+            if (o.in2 >= 0) tensors[o.in2].want_stats = true;
+          }
+        for (size_t i = 0; i < ops.size(); ++i) {
+          const Op& o = ops[i];
+          if (!blk[i].fwd || !tensors[o.out].want_stats || tensors[o.out].external) continue;
+          Tensor& t = tensors[o.out];
+          const int tiles = conv_bf16b_stats_tiles(t.H, t.W);
+          ADM_TRY(arena_alloc((void**)&t.stats, sizeof(double) * 2 * (size_t)B * t.C * tiles));
+          t.stat_tiles = tiles;
+        }
+      }
+      ADM_TRY(arena_alloc((void**)&blk_part, sizeof(float) * max_part));
       ADM_TRY(stream_sync(nullptr));
     }
     ADM_TRY(arena_alloc((void**)&tmp_da, sizeof(float) * max_da)); tmp_da_floats = max_da;
@@ -666,12 +691,13 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
       const GnBuf& g = gnbufs[o.gn];
       const float* x2 = o.in2 >= 0 ? tensors[o.in2].ptr : nullptr;
       const int C2 = o.in2 >= 0 ? tensors[o.in2].C : 0;
-      const bool folded = t1.stats != nullptr && (o.in2 < 0 || tensors[o.in2].stats != nullptr);
+      const bool folded = t1.stats != nullptr && (o.in2 < 0 || tensors[o.in2].stats != nullptr) &&
+                          (!training || conv_bf16_mode() >= 3);   // training plan: the blocked forward kernels write them
       if (folded) {    // the producing convolutions left per-tile partial sums: no pass over the activation
         const Tensor* t2 = o.in2 >= 0 ? &tensors[o.in2] : nullptr;
         ADM_TRY(launch_groupnorm_finalize(t1.stats, t1.C, t1.stat_tiles, t2 ? t2->stats : nullptr, C2, t2 ? t2->stat_tiles : 0, B,
                                           t1.H * t1.W, groups, o.eps > 0.f ? o.eps : eps, o.g->gamma, o.g->beta, g.scale, g.shift,
-                                          st));
+                                          st, g.mean_rstd));
         tm->end(0, 1, 3.0 * B * (t1.C + C2) * t1.H * t1.W,
                 16.0 * B * ((double)t1.C * t1.stat_tiles + (t2 ? (double)C2 * t2->stat_tiles : 0.0)));
       } else {
@@ -682,15 +708,15 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
     } else if (o.kind == Op::CONV) {
       adm_conv_args a;
       fill_conv_args(o, B, temb_all, temb_stride, &a);
-      if (tensors[o.out].stats != nullptr) { a.stats_out = tensors[o.out].stats; a.stats_tiles = tensors[o.out].stat_tiles; }
+      if (tensors[o.out].stats != nullptr && !training) { a.stats_out = tensors[o.out].stats; a.stats_tiles = tensors[o.out].stat_tiles; }
       const size_t oi = (size_t)(&o - ops.data());
       const BlkOp* bo = (training && conv_bf16_mode() >= 3 && oi < blk.size() && blk[oi].xa != nullptr) ? &blk[oi] : nullptr;
       if (bo)    // level 3: the activated input once as a blocked 16-bit image (kept for the weight gradient)
         ADM_TRY(launch_blk_apply(a.x1, a.C1, a.x1_bstride, a.x2, a.C2, a.x2_bstride, B, a.H, a.W, a.gn_scale, a.gn_shift, a.act, bo->xa,
-                                 nullptr, 0, nullptr, st));
+                                 nullptr, st));
       if (bo && bo->fwd)
-        ADM_TRY(launch_conv_bf16b(bo->xa, a.C1 + a.C2, B, a.H, a.W, o.w->wb, a.Cout, a.bias, a.chan_add, a.chan_add_stride, a.residual,
-                                  a.out, st));
+        ADM_TRY(launch_conv_bf16b(bo->xa, a.C1 + a.C2, B, o.up ? 2 * a.H : a.H, o.up ? 2 * a.W : a.W, o.w->wb, a.Cout, a.bias, a.chan_add,
+                                  a.chan_add_stride, a.residual, a.out, st, o.up, tensors[o.out].stats));
       else
         ADM_TRY(launch_conv2d(a, st));
       if (o.w) ADM_TRY(note_packing(*o.w, packing_of_variant(last_conv_variant(), true)));
@@ -808,16 +834,32 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
     const float* x2 = o.in2 >= 0 ? tensors[o.in2].ptr : nullptr;
     const bool qkv = !o.w->qkv_prefix.empty();
     // ---- residual fan-in --------------------------------------------------------------------------------
-    if (o.res >= 0) ADM_TRY(contribute(o.res, dy, (long)Cout * plane_o, Cout));
+    if (o.res >= 0) {
+      Tensor& tr = tensors[o.res];
+      if (o.res != t_in && !tr.ginit && !tr.external && !to.external && o.out != t_out && tr.C == Cout && tr.H == to.H && tr.W == to.W) {
+        // first contribution to the residual's gradient = dy itself: hand the BUFFER over instead of copying it (the two tensors
+        // have one shape). `dy` keeps pointing at the data for the rest of this op; later contributions accumulate into it, by
+        // which time this convolution's own backward kernels — queued before them on the stream — have read it; the output
+        // tensor's gradient is dead after this op (its consumers ran earlier in the reverse walk)
+        std::swap(tr.grad, to.grad);
+        tr.ginit = true;
+      } else {
+        ADM_TRY(contribute(o.res, dy, (long)Cout * plane_o, Cout));
+      }
+    }
     // ---- bias (+ time-embedding bias) gradients ------------------------------------------------------------
     float* dW = qkv ? tmp_w : grad_of(ps->P(o.w->key + ".weight"));
     float* dbias = qkv ? tmp_w + (size_t)Cout * Ct : (o.w->has_bias ? grad_of(ps->P(o.w->key + ".bias")) : nullptr);
     if (qkv) ADM_TRY(dmemset(dbias, 0, sizeof(float) * Cout, st));
-    ADM_TRY(launch_chan_sums(dy, B, Cout, (int)plane_o, (o.temb_off >= 0 && dtemb_all) ? dtemb_all + o.temb_off : nullptr,
-                             temb_stride, 0, dbias, st));
     const BlkOp* bo = (conv_bf16_mode() >= 3 && (size_t)i < blk.size() && (blk[i].wg || blk[i].dg)) ? &blk[i] : nullptr;
-    if (bo)      // level 3: dy once as a blocked 16-bit image for the weight-gradient and the data-gradient kernel
-      ADM_TRY(launch_blk_apply(dy, Cout, 0, nullptr, 0, 0, B, to.H, to.W, nullptr, nullptr, 0, bo->dyb, nullptr, 0, nullptr, st));
+    float* dtemb_o = (o.temb_off >= 0 && dtemb_all) ? dtemb_all + o.temb_off : nullptr;
+    if (bo) {    // level 3: dy once as a blocked 16-bit image for the weight-gradient and the data-gradient kernel; the pass
+                 // also leaves the channel sums that adm_chan_sums would read dy a second time for
+      ADM_TRY(launch_blk_apply(dy, Cout, 0, nullptr, 0, 0, B, to.H, to.W, nullptr, nullptr, 0, bo->dyb, blk_part, st));
+      ADM_TRY(launch_blk_sums_finalize(blk_part, B, Cout, to.H, to.W, dtemb_o, temb_stride, 0, dbias, st));
+    } else {
+      ADM_TRY(launch_chan_sums(dy, B, Cout, (int)plane_o, dtemb_o, temb_stride, 0, dbias, st));
+    }
     // ---- weight gradient -----------------------------------------------------------------------------------
     const float* gsc = o.gn >= 0 ? gnbufs[o.gn].scale : nullptr;
     const float* gsh = o.gn >= 0 ? gnbufs[o.gn].shift : nullptr;
@@ -831,7 +873,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       ADM_TRY(launch_conv_small_cout_bwd(t1.ptr, Ct, B, t1.H, t1.W, gsc, gsh, o.act, ps->P(o.w->key + ".weight"), dy, Cout,
                                          tmp_da, dW, st));
     } else if (bo && bo->wg) {
-      ADM_TRY(launch_conv_wgradb(bo->xa, Ct, bo->dyb, Cout, B, t1.H, t1.W, dW, 0, wgrad_ws, st));
+      ADM_TRY(launch_conv_wgradb(bo->xa, Ct, bo->dyb, Cout, B, to.H, to.W, dW, 0, wgrad_ws, st, o.up));
     } else {
       adm_conv_args a;
       memset(&a, 0, sizeof(a));

@@ -331,23 +331,31 @@ int adm_conv2d_wgrad(const adm_conv_args* a, const float* dy, float* dW, int acc
  *   adm_blocked_apply: img = round16(act(scale[n][c] * concat(x1, x2)[n][c] + shift[n][c])), scale / shift as produced by
  *     adm_groupnorm_stats (both NULL: identity), act != 0: SiLU — the activated conv input, written ONCE per layer; with
  *     scale = NULL, act = 0 on dy it is the operand image of the backward kernels.  C1, C2 multiples of 8, W of 4.
- *     sum_nc (N, nc_stride) / sum_c (C): NULL or ACCUMULATE (atomics) the per-(n, c) / per-c sums of the fp32 INPUT (the bias
- *     and time-embedding-bias gradients when the input is dy).
+ *     sum_nc (N, nc_stride): NULL or receives the per-(n, c) sums of the fp32 INPUT; sum_c (C): NULL or ACCUMULATES the per-c
+ *     sums (the time-embedding-bias and bias gradients when the input is dy, as adm_chan_sums); both need sum_scratch
+ *     (adm_blocked_sums_scratch floats: one partial per workgroup, added in a fixed order).
  *   adm_conv2d_bf16_blocked: out (N,Cout,H,W) fp32 = conv3x3(img, stride 1, pad 1) + bias[co] + chan_add[n][co] + residual
  *     (each NULL ok), filters `wb` from adm_pack_bf16_weight (transposed = 1 and img = image of dy: the data gradient).
  *     Cin % 16 == 0, Cin >= 32, Cout % 128 == 0, H % 8 == 0, W % 32 == 0 (adm_conv2d_bf16_blocked_eligible).
  *   adm_conv2d_wgrad_bf16_blocked: dW (Cout,Cin,3,3) (+)= sum over pixels of dy x activated input, both as blocked images;
- *     Cin % 64 == 0, Cout % 128 == 0, H % 4 == 0, W % 32 == 0; workspace: adm_conv_wgrad_blocked_workspace floats. */
+ *     Cin % 64 == 0, Cout % 128 == 0, H % 4 == 0, W % 32 == 0; workspace: adm_conv_wgrad_blocked_workspace floats.
+ *     stats_out: NULL or (N, Cout, (H/8)*(W/32), 2) fp64 — per 8x32-pixel tile the (sum, sum of squares) of the final output
+ *     values, the input adm_groupnorm_finalize needs (as adm_conv_args.stats_out).
+ *   up != 0 (both): the convolution of Upsample2D — H, W are the OUTPUT dims and the input image is the half-resolution tensor
+ *     (N, Cin, H/2, W/2); the nearest x2 is folded into the patch addresses. */
 size_t adm_blocked_image_bytes(int N, int C, int H, int W);
+long adm_blocked_sums_scratch(int N, int C, int H, int W);
 int adm_blocked_apply(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, const float* scale,
-                      const float* shift, int act, void* img, float* sum_nc, int nc_stride, float* sum_c, void* stream);
+                      const float* shift, int act, void* img, float* sum_scratch, float* sum_nc, int nc_stride, float* sum_c,
+                      void* stream);
 int adm_conv2d_bf16_blocked_eligible(int Cin, int Cout, int H, int W);
 int adm_conv2d_bf16_blocked(const void* img, int Cin, int N, int H, int W, const void* wb, int Cout, const float* bias,
-                            const float* chan_add, int chan_add_stride, const float* residual, float* out, void* stream);
+                            const float* chan_add, int chan_add_stride, const float* residual, float* out, int up,
+                            double* stats_out, void* stream);
 int adm_conv2d_wgrad_bf16_blocked_eligible(int Cin, int Cout, int H, int W);
 long adm_conv_wgrad_blocked_workspace(int Cin, int Cout, int N, int H, int W);
 int adm_conv2d_wgrad_bf16_blocked(const void* x_img, int Cin, const void* dy_img, int Cout, int N, int H, int W, float* dW,
-                                  int accumulate, float* workspace, void* stream);
+                                  int accumulate, float* workspace, int up, void* stream);
 /* gradient of the nearest-x2 upsample folded into a conv: out (planes,H/2,W/2) (+)= 2x2 sums of in (planes,H,W). */
 int adm_sumpool2x2(const float* in, float* out, int H, int W, long planes, int accumulate, void* stream);
 /* dst[n][0:per_sample] (+)= src[n][0:per_sample] with independent batch strides (gradient fan-in of channel slices). */

@@ -76,7 +76,11 @@ def test_conv_bf16_blocked_forward(backend, case):
     temb = _rand((Nn, Cout), 7, dev) if use_temb else None
     res = _rand((Nn, Cout, H, W), 8, dev) if use_res else None
     img = ops.blocked_image(x1, x2, gn=gn, act=bool(act))
-    out = ops.conv2d_bf16_blocked(img, ops.pack_bf16_weight(w), Cout, bias=b, chan_add=temb, residual=res)
+    out, st = ops.conv2d_bf16_blocked(img, ops.pack_bf16_weight(w), Cout, bias=b, chan_add=temb, residual=res, stats=True)
+    # GroupNorm partial sums of the output from the epilogue: per 8x32-pixel tile (sum, sum of squares) of the values it stored
+    tiles = out.cpu().double().reshape(Nn, Cout, H // 8, 8, W // 32, 32).permute(0, 1, 2, 4, 3, 5).reshape(Nn, Cout, -1, 256)
+    assert torch.allclose(st.cpu()[..., 0], tiles.sum(-1), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(st.cpu()[..., 1], (tiles * tiles).sum(-1), rtol=1e-5, atol=1e-4)
     c = lambda t: None if t is None else t.cpu()  # noqa: E731
     tail = c(b).double()[None, :, None, None]
     if temb is not None:
@@ -141,3 +145,25 @@ def test_conv_wgrad_bf16_blocked(backend, case):
     full = torch.nn.grad.conv2d_weight(F.silu(F.group_norm(x.cpu(), 32, gamma.cpu(), beta.cpu(), 1e-5)).double(), (Cout, Ct, 3, 3),
                                        dy.cpu().double(), padding=1)
     assert _relerr(dW.double(), full) < 8e-3, _relerr(dW.double(), full)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv_bf16_blocked_upsample_folded_forward_and_weight_gradient(backend):
+    """Upsample2D.conv (scripts/train_unet.py UpBlock2D: nearest x2, then 3x3): the blocked image is the half-resolution tensor, the
+    x2 lives in the patch addresses of both kernels; the halo of the small image is the zero padding of the upsampled one."""
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn, C, Cout, H, W = 2, 64, 128, 8, 16                     # output 16 x 32
+    x = _rand((Nn, C, H, W), 1, dev)
+    w = _rand((Cout, C, 3, 3), 3, dev, scale=(C * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    dy = _rand((Nn, Cout, 2 * H, 2 * W), 5, dev)
+    img = ops.blocked_image(x)
+    out = ops.conv2d_bf16_blocked(img, ops.pack_bf16_weight(w), Cout, bias=b, up=True)
+    xu = F.interpolate(_bf(x.cpu()), scale_factor=2.0, mode="nearest")
+    exact = F.conv2d(xu, _bf(w.cpu()), b.cpu().double(), padding=1)
+    assert out.shape == exact.shape
+    assert _relerr(out.double(), exact) < 2e-6, _relerr(out.double(), exact)
+    dW = ops.conv2d_wgrad_bf16_blocked(img, ops.blocked_image(dy), up=True)
+    exact_w = torch.nn.grad.conv2d_weight(xu, (Cout, C, 3, 3), _bf(dy.cpu()), padding=1)
+    assert _relerr(dW.double(), exact_w) < 2e-6, _relerr(dW.double(), exact_w)

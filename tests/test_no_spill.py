@@ -35,6 +35,7 @@ def _usage(src):
     ("k_conv_wgrad.hip:sp8|sp_kernel|pf_kernelILi3ELb1|pf_kernelILi1ELb1", 0),   # fp32 weight gradients on the fast paths (the
                                          # generic 1x1 fallback `pf_kernel<1, false>` is known to spill; it serves odd chunkings only)
     ("k_conv_bf16.hip", 0),              # measured defaults: forward / data gradient, weight gradient, packing
+    ("k_conv_bf16b.hip", 0),             # round 4: blocked-image forward / data gradient (2 workgroups per CU) and weight gradient
     ("k_conv1x1_bf16.hip", 0),
 ])
 def test_conv_kernels_compile_without_spills(src, max_scratch):
