@@ -58,6 +58,7 @@ _SIGS = {
     "adm_last_error": (C.c_char_p, []),
     "adm_is_device_build": (C.c_int, []),
     "adm_last_conv_variant": (C.c_int, []),
+    "adm_has_experiments": (C.c_int, []),
     "adm_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "adm_sched_step": (C.c_int, [C.c_void_p] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
     "adm_add_noise": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
@@ -116,7 +117,7 @@ _OPTIONAL_SIGS = {
     "adm_conv2d_wgrad": (_i, [C.POINTER(ConvArgs), _vp, _vp, _i, _vp, _vp]),
     "adm_blocked_image_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "adm_blocked_sums_scratch": (_l, [_i, _i, _i, _i]),
-    "adm_blocked_apply": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "adm_blocked_apply": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "adm_conv2d_bf16_blocked_eligible": (_i, [_i, _i, _i, _i]),
     "adm_conv2d_bf16_blocked": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "adm_conv2d_wgrad_bf16_blocked_eligible": (_i, [_i, _i, _i, _i]),

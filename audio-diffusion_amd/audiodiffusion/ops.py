@@ -336,20 +336,21 @@ def conv2d_wgrad(x1, dy, Cout, ks, x2=None, up=False, stride=1, pad_lo=1, gn=Non
     return dW
 
 
-def blocked_image(x1, x2=None, gn=None, act=False, sums=False):
+def blocked_image(x1, x2=None, gn=None, act=False, sums=False, zero_insert=False):
     """Blocked 16-bit operand image [n][C/8][H+2][W+2][8] (zero halo) of act(gn(concat(x1, x2))) — include/adm.h
     adm_blocked_apply.  Returns a (N, C/8, H+2, W+2, 8) bf16 tensor (binary16 bits under option conv_op16_f16);
     sums=True: also the per-(n, c) and per-c sums of the fp32 input."""
     _f32(x1)
     Nn, C1, H, W = x1.shape
     C2 = x2.shape[1] if x2 is not None else 0
-    img = torch.zeros((Nn, (C1 + C2) // 8, H + 2, W + 2, 8), dtype=torch.bfloat16, device=x1.device)
-    assert img.numel() * 2 == N.lib().adm_blocked_image_bytes(Nn, C1 + C2, H, W)
+    zi = 2 if zero_insert else 1        # zero_insert 1 / 2: the (2H, 2W) image with x(y, x) on pixel (2y + 1, 2x + 1) / (2y, 2x) (stride-2 backward)
+    img = torch.zeros((Nn, (C1 + C2) // 8, zi * H + 2, zi * W + 2, 8), dtype=torch.bfloat16, device=x1.device)
+    assert img.numel() * 2 == N.lib().adm_blocked_image_bytes(Nn, C1 + C2, zi * H, zi * W)
     nc = torch.zeros((Nn, C1 + C2), dtype=torch.float32, device=x1.device) if sums else None
     c = torch.zeros(C1 + C2, dtype=torch.float32, device=x1.device) if sums else None
     scr = torch.empty(N.lib().adm_blocked_sums_scratch(Nn, C1 + C2, H, W), dtype=torch.float32, device=x1.device) if sums else None
     N.check(N.lib().adm_blocked_apply(N.ptr(x1), C1, N.ptr(x2), C2, Nn, H, W, N.ptr(gn[0]) if gn is not None else None,
-                                      N.ptr(gn[1]) if gn is not None else None, int(act), C.c_void_p(img.data_ptr()), N.ptr(scr),
+                                      N.ptr(gn[1]) if gn is not None else None, int(act), int(zero_insert), C.c_void_p(img.data_ptr()), N.ptr(scr),
                                       N.ptr(nc), C1 + C2, N.ptr(c), N.stream_for(x1)))
     return (img, nc, c) if sums else img
 
@@ -358,13 +359,15 @@ def conv2d_bf16_blocked(img, wb, Cout, bias=None, chan_add=None, residual=None, 
     """3x3 stride-1 convolution of a blocked image on 16-bit MFMA operands (adm_conv2d_bf16_blocked); wb from pack_bf16_weight
     (transposed=True with the image of dy: the data gradient); up: nearest x2 of the image folded in (Upsample2D.conv)."""
     Nn, Cg, Hp, Wp, _ = img.shape
-    H, W = (Hp - 2) * (2 if up else 1), (Wp - 2) * (2 if up else 1)
-    out = torch.empty((Nn, Cout, H, W), dtype=torch.float32, device=img.device)
+    up = int(up)                        # 0 stride 1, 1 nearest x2 of the image folded in, 2 / 3 stride-2 output (pad (0,1,0,1) / padding 1)
+    H, W = (Hp - 2) * (2 if up == 1 else 1), (Wp - 2) * (2 if up == 1 else 1)
+    out = torch.empty((Nn, Cout, H // 2, W // 2) if up >= 2 else (Nn, Cout, H, W), dtype=torch.float32, device=img.device)
     ca, cas = (None, 0)
     if chan_add is not None:
         assert chan_add.dtype == torch.float32 and chan_add.stride(1) == 1
         ca, cas = C.c_void_p(chan_add.data_ptr()), chan_add.stride(0)
     st = torch.zeros((Nn, Cout, (H // 8) * (W // 32), 2), dtype=torch.float64, device=img.device) if stats else None
+    assert not (stats and up >= 2)
     N.check(N.lib().adm_conv2d_bf16_blocked(C.c_void_p(img.data_ptr()), Cg * 8, Nn, H, W, C.c_void_p(wb.data_ptr()), Cout,
                                             N.ptr(bias), ca, cas, N.ptr(residual), N.ptr(out), int(up), N.ptr(st), N.stream_for(out)))
     return (out, st) if stats else out

@@ -57,6 +57,8 @@ void set_last_conv_variant(int v);
 // k_conv_wino.hip
 const float* conv_zero_bias(int n);  // shared all-zero device buffer of >= n floats (k_conv_mfma.hip)
 const float* conv_const_ones(int n); // shared all-ones device buffer of >= n floats
+int conv_dev_slot();                 // current HIP device as an index 0..15 (per-device static state: constant buffers, LDS attributes)
+bool winograd_mode_available(int m); // k_conv_wino.hip: modes 1-3 (earlier kernel generations) exist only in -DADM_EXPERIMENTS builds
 int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st);
 int launch_pack_winograd_weight_T(const float* w, float* wu, int Cout, int Cin, hipStream_t st);  // data-gradient filters
 bool winograd_enabled();
@@ -93,12 +95,12 @@ bool blk_apply_eligible(int C1, int C2, int H, int W);
 // per-workgroup sums of the INPUT, turned into per-(n, c) / per-c sums by launch_blk_sums_finalize (bias gradients when x1 = dy)
 long blk_sums_scratch(int N, int C, int H, int W);
 int launch_blk_apply(const float* x1, int C1, long x1_bs, const float* x2, int C2, long x2_bs, int N, int H, int W,
-                     const float* scale, const float* shift, int act, void* out, float* sum_scratch, hipStream_t st);
+                     const float* scale, const float* shift, int act, void* out, float* sum_scratch, hipStream_t st, int zins = 0);
 int launch_blk_sums_finalize(const float* sum_scratch, int N, int C, int H, int W, float* out_nc, int nc_stride, int nc_accumulate,
                              float* out_c, hipStream_t st);
 bool conv_bf16b_eligible(int Cin, int Cout, int H, int W);
 int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void* wb, int Cout, const float* bias,
-                      const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st, int up = 0,
+                      const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st, int mode = 0,
                       double* stats_out = nullptr);   // stats_out: GroupNorm partial sums of the OUTPUT, [n][cout][(H/8)*(W/32)][2] fp64
 int conv_bf16b_stats_tiles(int H, int W);
 bool conv_wgradb_eligible(int Ct, int Cout, int H, int W);

@@ -1,5 +1,8 @@
 // c_api.hip — error state + op-level C-ABI entry points (include/adm.h). The UNet executor and the
 // sampling loop export their own entry points from unet_exec.hip.
+#include <map>
+#include <mutex>
+
 #include "adm_kernels.h"
 
 namespace adm {
@@ -12,19 +15,46 @@ using namespace adm;
 
 extern "C" {
 
-int adm_version(void) { return 100; }
+int adm_version(void) { return 101; }   // 101 (round 4): adm_slerp_grid takes double weights (round 3), blocked-image entry points
 const char* adm_last_error(void) { return adm::last_error(); }
 int adm_set_option(const char* name, int value) {
   ADM_REQUIRE(name, "set_option: null name");
-  adm::bump_dispatch_epoch();       // conv dispatch may change: Net::refresh_weights re-packs everything and re-learns its masks
-  if (std::string(name) == "conv_wino") { adm::set_winograd_mode(value); return 0; }
-  if (std::string(name) == "wino_pair") { adm::set_winograd_pair(value); return 0; }
-  if (std::string(name) == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
-  if (std::string(name) == "conv_bf16") { adm::set_conv_bf16(value); return 0; }
-  if (std::string(name) == "conv_op16_f16") { adm::set_conv_op16_f16(value); return 0; }
-  ADM_FAIL(std::string("set_option: unknown option ") + name);
+  const std::string nm(name);
+  static const char* known[] = {"conv_wino", "wino_pair", "wgrad_max_split", "conv_bf16", "conv_op16_f16"};
+  bool ok = false;
+  for (const char* k : known) ok |= nm == k;
+  if (!ok) ADM_FAIL(std::string("set_option: unknown option ") + name);
+  // the dispatch epoch (training nets re-learn which weight images they read: a full re-pack) moves only when a value really
+  // changes — a model that sets the options it already runs under (every enable_training does) leaves other nets alone
+  static std::mutex mu;
+  static std::map<std::string, int> last;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = last.find(nm);
+    const bool same = it != last.end() && it->second == value;
+    last[nm] = value;
+    if (!same) adm::bump_dispatch_epoch();
+  }
+  if (nm == "conv_wino") {
+    ADM_REQUIRE(adm::winograd_mode_available(value), "set_option: conv_wino modes 1-3 are earlier kernel generations, built only with "
+                "-DADM_EXPERIMENTS (audio-diffusion_amd/csrc/build.sh hip exp); this library has 0 (direct MFMA kernel) and 4");
+    adm::set_winograd_mode(value);
+    return 0;
+  }
+  if (nm == "wino_pair") { adm::set_winograd_pair(value); return 0; }
+  if (nm == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
+  if (nm == "conv_bf16") { adm::set_conv_bf16(value); return 0; }
+  adm::set_conv_op16_f16(value);
+  return 0;
 }
 int adm_last_conv_variant(void) { return adm::last_conv_variant(); }
+int adm_has_experiments(void) {
+#if defined(ADM_EXPERIMENTS)
+  return 1;
+#else
+  return 0;
+#endif
+}
 int adm_is_device_build(void) {
 #if defined(ADM_EMU)
   return 0;

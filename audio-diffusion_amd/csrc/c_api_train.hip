@@ -32,11 +32,13 @@ int adm_conv2d_wgrad(const adm_conv_args* a, const float* dy, float* dW, int acc
 size_t adm_blocked_image_bytes(int N, int C, int H, int W) { return blk_image_bytes(N, C, H, W); }
 long adm_blocked_sums_scratch(int N, int C, int H, int W) { return blk_sums_scratch(N, C, H, W); }
 int adm_blocked_apply(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, const float* scale,
-                      const float* shift, int act, void* img, float* sum_scratch, float* sum_nc, int nc_stride, float* sum_c,
-                      void* stream) {
+                      const float* shift, int act, int zero_insert, void* img, float* sum_scratch, float* sum_nc, int nc_stride,
+                      float* sum_c, void* stream) {
   ADM_REQUIRE(x1 && img, "blocked_apply: null argument");
   ADM_REQUIRE(sum_scratch != nullptr || (sum_nc == nullptr && sum_c == nullptr), "blocked_apply: sums need sum_scratch");
-  ADM_TRY(launch_blk_apply(x1, C1, 0, x2, x2 ? C2 : 0, 0, N, H, W, scale, shift, act, img, sum_scratch, (hipStream_t)stream));
+  ADM_REQUIRE(zero_insert >= 0 && zero_insert <= 2, "blocked_apply: zero_insert is 0, 1 (odd pixels) or 2 (even pixels)");
+  ADM_TRY(launch_blk_apply(x1, C1, 0, x2, x2 ? C2 : 0, 0, N, H, W, scale, shift, act, img, sum_scratch, (hipStream_t)stream,
+                           zero_insert));
   if (sum_scratch == nullptr) return 0;
   return launch_blk_sums_finalize(sum_scratch, N, C1 + (x2 ? C2 : 0), H, W, sum_nc, nc_stride, 0, sum_c, (hipStream_t)stream);
 }

@@ -39,6 +39,8 @@ struct BlkApplyParams {
   int act;
   u32x4* out; int Hp, Wp;
   float* part;                       // optional: per-(n, c, workgroup) sums of the INPUT ([n][c][gridDim.x], blk_sums_finalize_kernel)
+  int zins;                          // 1 / 2: the image has (2H, 2W) pixels and source pixel (y, x) lands on pixel (2y + 1, 2x + 1) / (2y, 2x), the
+                                     // rest stays zero (the zero-inserted dy of a stride-2 convolution with pad (0,1,0,1) / pad 1, see below)
 };
 
 // One thread = 8 channels x 4 consecutive pixels: eight float4 row loads (a wave reads 1 KiB of ONE channel row per
@@ -90,6 +92,19 @@ __global__ void __launch_bounds__(256) blk_apply_kernel(const BlkApplyParams p) 
   // of 32 cache lines.  The wave's 256 units go through 4 KiB of LDS instead and leave as four runs of 64 consecutive units
   // (1 KiB per store instruction where the image row is long enough).  LDS position of unit 4 l + j: 4 l + (j ^ ((l >> 1) & 3)) —
   // conflict-free for the 8-lane groups of ds_write_b128 and the 16-lane groups of ds_read_b128.
+  if (p.zins) {      // scattered units (every other pixel of every other row): stored straight from the lane
+    if (!live) return;
+    const int zo = p.zins == 1 ? 2 : 1;                  // haloed coordinate of source pixel 0: odd pixels (pad 0) / even pixels (pad 1)
+    u32x4* const zrow = p.out + (((long)n * ((p.C1 + p.C2) >> 3) + cg) * p.Hp + (2 * y + zo)) * p.Wp + (8 * x4 + zo);
+    ADM_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      u32x4 w;
+      w[0] = ADM_PK16(F16, o[0][j], o[1][j]); w[1] = ADM_PK16(F16, o[2][j], o[3][j]);
+      w[2] = ADM_PK16(F16, o[4][j], o[5][j]); w[3] = ADM_PK16(F16, o[6][j], o[7][j]);
+      zrow[2 * j] = w;
+    }
+    return;
+  }
   __shared__ u32x4 stg[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   ADM_UNROLL
@@ -134,14 +149,14 @@ __global__ void __launch_bounds__(256) blk_sums_finalize_kernel(const float* __r
 long blk_sums_scratch(int N, int C, int H, int W) { return (long)N * C * ceil_div(H * (W / 4), 256); }
 
 int launch_blk_apply(const float* x1, int C1, long x1_bs, const float* x2, int C2, long x2_bs, int N, int H, int W,
-                     const float* scale, const float* shift, int act, void* out, float* sum_scratch, hipStream_t st) {
+                     const float* scale, const float* shift, int act, void* out, float* sum_scratch, hipStream_t st, int zins) {
   ADM_REQUIRE(blk_apply_eligible(C1, x2 ? C2 : 0, H, W), "blk_apply: channel counts must be multiples of 8 and W of 4");
   BlkApplyParams p;
   p.x1 = x1; p.x2 = x2; p.C1 = C1; p.C2 = x2 ? C2 : 0;
   p.x1_bs = x1_bs ? x1_bs : (long)C1 * H * W; p.x2_bs = x2_bs ? x2_bs : (long)p.C2 * H * W;
   p.N = N; p.H = H; p.W = W; p.scale = scale; p.shift = shift; p.nstride = C1 + p.C2; p.act = act;
-  p.out = reinterpret_cast<u32x4*>(out); p.Hp = H + 2; p.Wp = W + 2;
-  p.part = sum_scratch;
+  p.out = reinterpret_cast<u32x4*>(out); p.Hp = (zins ? 2 * H : H) + 2; p.Wp = (zins ? 2 * W : W) + 2;
+  p.part = sum_scratch; p.zins = zins;
   ADM_REQUIRE((scale != nullptr) == (shift != nullptr), "blk_apply: scale and shift come together");
   ADM_REQUIRE((reinterpret_cast<uintptr_t>(x1) & 15) == 0 && (x2 == nullptr || (reinterpret_cast<uintptr_t>(x2) & 15) == 0),
               "blk_apply: inputs must be 16-byte aligned");
@@ -188,8 +203,15 @@ constexpr int FB_LDS_UNITS = FB_NBUF * FB_BUF + 4 * 9 * 64;      // + the four w
 // UP: the image is the HALF-resolution input of an Upsample2D convolution (nearest x2 folded into the patch addresses: patch
 // pixel (r, c) of upsampled pixel (8 ty - 1 + r, 32 tx - 1 + c) is source unit (4 ty + (r + 1) / 2, 16 tx + (c + 1) / 2) of the
 // haloed image — the halo doubles as the zero padding of the UPSAMPLED tensor); H, W are the output dims, Hp, Wp the image's.
-template <bool F16, bool UP = false, bool PROF = false>
+// S2: the stride-2 3x3 convolutions of Downsample2D as every other pixel of the stride-1 "same" convolution o of the same image (the
+// halo is the zero padding): S2 = 1, padding 1 (UNet2DModel's DownBlock2D): out(y, x) = o(2y, 2x); S2 = 2, pad (0, 1, 0, 1) then no
+// padding (the AutoencoderKL encoder): out(y, x) = o(2y + 1, 2x + 1).  The tile is still 8 x 32 pixels of o, but only its four rows of
+// that parity get accumulators (64 registers, half the MFMAs), and the epilogue stores the columns of that parity: H, W are the
+// dims of the INPUT image, out is (N, Cout, H / 2, W / 2).
+template <bool F16, bool UP = false, bool PROF = false, int S2 = 0>
 __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParams p) {
+  constexpr int NPT = S2 ? 4 : 8;                        // pixel rows (32-pixel N tiles) per wave
+#define FB_ROW(q) (S2 ? 2 * (q) + (S2 - 1) : (q))
   unsigned long long pr[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
   const unsigned long long t_start = BB_CLK();
   if (PROF) tq = t_start;
@@ -238,9 +260,9 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
     ADM_GLDS16_ASM(src, aoff, ldsA_a + 1024u * t);
   };
 
-  f32x16 acc[8];
+  f32x16 acc[NPT];
   ADM_UNROLL
-  for (int t = 0; t < 8; ++t)
+  for (int t = 0; t < NPT; ++t)
     ADM_UNROLL
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -267,11 +289,11 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
     constexpr bool LAST = MODE == 2, HASP = MODE == 0;
     if (HASP) issue_patch(c + 2);
     const u32x4* cur = ldsP + (c % FB_NBUF) * FB_BUF + bbase;
-    u32x4 Ac, An, Bc[8], Bn[8];
+    u32x4 Ac, An, Bc[NPT], Bn[NPT];
     if (HASP) ADM_WAIT_VMEM(11); else ADM_WAIT_VMEM(8);  // A(c, 0): younger = A(c, 1..8) [+ P(c+2) x3]
     Ac = ldsA[lane];
     ADM_UNROLL
-    for (int pt = 0; pt < 8; ++pt) Bc[pt] = cur[pt * FB_PW];
+    for (int pt = 0; pt < NPT; ++pt) Bc[pt] = cur[FB_ROW(pt) * FB_PW];
     ADM_UNROLL
     for (int t = 0; t < 9; ++t) {
       if (t < 8) {
@@ -289,17 +311,17 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
         }
         An = ldsA[64 * (t + 1) + lane];
         ADM_UNROLL
-        for (int pt = 0; pt < 8; ++pt) Bn[pt] = cur[(pt + (t + 1) / 3) * FB_PW + (t + 1) % 3];
+        for (int pt = 0; pt < NPT; ++pt) Bn[pt] = cur[(FB_ROW(pt) + (t + 1) / 3) * FB_PW + (t + 1) % 3];
       }
       ADM_SCHED_FENCE();
       ADM_UNROLL
-      for (int pt = 0; pt < 8; ++pt) acc[pt] = ADM_MFMA16(F16, Ac, Bc[pt], acc[pt]);
+      for (int pt = 0; pt < NPT; ++pt) acc[pt] = ADM_MFMA16(F16, Ac, Bc[pt], acc[pt]);
       ADM_SCHED_FENCE();
       if (!LAST) issue_filt(c + 1, t);                   // slot t has been read into registers: refill it for the next chunk
       if (t < 8) {
         Ac = An;
         ADM_UNROLL
-        for (int pt = 0; pt < 8; ++pt) Bc[pt] = Bn[pt];
+        for (int pt = 0; pt < NPT; ++pt) Bc[pt] = Bn[pt];
       }
     }
     // P(c+1) is older than A(c, 8), which has landed: this wave's pieces of the next patch are in LDS; the barrier makes the
@@ -317,12 +339,14 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
   // channel) term, residual and the store are 16-byte operations: one store instruction = 8 couts x 128 contiguous bytes,
   // 32 stores per wave instead of 128 dword stores (the dword version spent ~40 % of a workgroup's life ISSUING its stores).
   // LDS executes a wave's operations in order: no barrier, the next row's writes queue behind this row's reads.
-  const int planeO = p.H * p.W;
+  const int planeO = S2 ? (p.H >> 1) * (p.W >> 1) : p.H * p.W;
   float* const out_n = p.out + (long)n * p.Cout * planeO;                   // wave-uniform bases, 32-bit lane offsets
   const float* const res_n = p.residual ? p.residual + (long)n * p.Cout * planeO : nullptr;
   float* const stage = reinterpret_cast<float*>(lds) + 1024 * wave;
   const int srow = lane >> 3, scol = 4 * (lane & 7);
-  const int lane_off = (m0 + srow) * planeO + (ty * 8) * p.W + tx * 32 + scol;
+  // S2: row 2 q (+ 1) of the tile is output row 4 ty + q, the lane's columns scol (+ 1), scol + 2 (+ 1) are output columns 16 tx + scol / 2 + {0, 1}
+  const int lane_off = S2 ? (m0 + srow) * planeO + (ty * 4) * (p.W >> 1) + tx * 16 + (scol >> 1)
+                          : (m0 + srow) * planeO + (ty * 8) * p.W + tx * 32 + scol;
   float bv[4], gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
   ADM_UNROLL
   for (int k = 0; k < 4; ++k) {
@@ -330,7 +354,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
     bv[k] = p.bias[co] + p.chan_add[(long)n * p.chan_add_stride + co];
   }
   ADM_UNROLL
-  for (int pt = 0; pt < 8; ++pt) {
+  for (int pt = 0; pt < NPT; ++pt) {
     ADM_UNROLL
     for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[pt][r];
     ADM_WAVE_LDS_ORDER();
@@ -338,6 +362,15 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
     ADM_UNROLL
     for (int k = 0; k < 4; ++k) sv[k] = *reinterpret_cast<const float4*>(stage + (srow + 8 * k) * 32 + scol);
     ADM_WAVE_LDS_ORDER();
+    if (S2) {          // bias only (Downsample2D.conv has no per-sample term; the launcher refuses a residual): two odd columns per lane
+      ADM_UNROLL
+      for (int k = 0; k < 4; ++k) {
+        const int o = lane_off + 8 * k * planeO + pt * (p.W >> 1);
+        *reinterpret_cast<float2*>(out_n + o) = S2 == 2 ? make_float2(sv[k].y + bv[k], sv[k].w + bv[k])
+                                                         : make_float2(sv[k].x + bv[k], sv[k].z + bv[k]);
+      }
+      continue;
+    }
     ADM_UNROLL
     for (int k = 0; k < 4; ++k) {
       float4 v = sv[k];
@@ -375,6 +408,8 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
   }
 }
 
+#undef FB_ROW
+
 bool conv_bf16b_eligible(int Cin, int Cout, int H, int W) {
   return Cin % 16 == 0 && Cin >= 32 && Cout % 128 == 0 && H % 8 == 0 && W % 32 == 0;
 }
@@ -382,8 +417,12 @@ bool conv_bf16b_eligible(int Cin, int Cout, int H, int W) {
 int conv_bf16b_stats_tiles(int H, int W) { return (H / 8) * (W / 32); }
 
 int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void* wb, int Cout, const float* bias,
-                      const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st, int up,
+                      const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st, int mode,
                       double* stats_out) {
+  // 1: nearest x2 of the image folded in; 2 / 3: stride-2 output (H, W = INPUT dims) of a pad-(0,1,0,1) / padding-1 convolution
+  const int up = mode == 1, s2 = mode == 2 || mode == 3;
+  ADM_REQUIRE(mode >= 0 && mode <= 3, "conv_bf16b: mode is 0 (stride 1), 1 (nearest x2 folded), 2 (stride 2, pad (0,1,0,1)) or 3 (stride 2, padding 1)");
+  ADM_REQUIRE(!s2 || (residual == nullptr && chan_add == nullptr && stats_out == nullptr), "conv_bf16b: the stride-2 variant has a bias only");
   ADM_REQUIRE(conv_bf16b_eligible(Cin, Cout, H, W), "conv_bf16b: shape not eligible (Cin % 16, Cin >= 32, Cout % 128, H % 8, W % 32)");
   Bf16BConvParams p;
   p.img = reinterpret_cast<const u32x4*>(img); p.Cg = Cin / 8;
@@ -406,6 +445,10 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
     (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     return true;
   }();
   (void)once;
@@ -414,7 +457,7 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
   p.prof = nullptr;
 #if !defined(ADM_EMU)
   static const bool want_prof = getenv("ADM_BF16B_PROF") != nullptr;
-  if (want_prof && !conv_op16_f16() && !up) {   // developer aid: per-phase cycle accounting, printed after the launch (synchronous)
+  if (want_prof && !conv_op16_f16() && mode == 0) {   // developer aid: per-phase cycle accounting, printed after the launch (synchronous)
     const size_t pn = (size_t)p.nblk * 4 * 8;
     static unsigned long long* dprof = nullptr;
     static size_t dcap = 0;
@@ -435,7 +478,13 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
     return ADM_CHECK_LAUNCH();
   }
 #endif
-  if (up) {
+  if (mode == 2) {
+    if (conv_op16_f16()) ADM_LAUNCH((conv_bf16b_kernel<true, false, false, 2>), dim3(p.nblk), dim3(256), smem, st, p);
+    else ADM_LAUNCH((conv_bf16b_kernel<false, false, false, 2>), dim3(p.nblk), dim3(256), smem, st, p);
+  } else if (mode == 3) {
+    if (conv_op16_f16()) ADM_LAUNCH((conv_bf16b_kernel<true, false, false, 1>), dim3(p.nblk), dim3(256), smem, st, p);
+    else ADM_LAUNCH((conv_bf16b_kernel<false, false, false, 1>), dim3(p.nblk), dim3(256), smem, st, p);
+  } else if (up) {
     if (conv_op16_f16()) ADM_LAUNCH((conv_bf16b_kernel<true, true>), dim3(p.nblk), dim3(256), smem, st, p);
     else ADM_LAUNCH((conv_bf16b_kernel<false, true>), dim3(p.nblk), dim3(256), smem, st, p);
   } else {

@@ -611,7 +611,7 @@ const float* conv_zero_bias(int n);
 static const float* zero_bias(int n) { return conv_zero_bias(n); }
 // Both constant buffers are keyed by the current HIP device (a process normally owns one GPU, but nothing here assumes
 // it) and grown outside any stream capture: the executors call them from finalize()/their uncaptured warm-up forward.
-static int const_dev_slot() {
+int conv_dev_slot() {
   int dev = 0;
 #if !defined(ADM_EMU)
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
@@ -621,7 +621,7 @@ static int const_dev_slot() {
 const float* conv_zero_bias(int n) {
   static float* z[16] = {};
   static int cap[16] = {};
-  const int d = const_dev_slot();
+  const int d = conv_dev_slot();
   if (n > cap[d]) {
     void* pz = nullptr;
     const int want = n < 8192 ? 8192 : n;
@@ -638,7 +638,7 @@ const float* conv_zero_bias(int n) {
 const float* conv_const_ones(int n) {
   static float* z[16] = {};
   static int cap[16] = {};
-  const int d = const_dev_slot();
+  const int d = conv_dev_slot();
   if (n > cap[d]) {
     const int want = n < 8192 ? 8192 : n;
     std::vector<float> h((size_t)want, 1.0f);
@@ -698,28 +698,38 @@ __global__ void __launch_bounds__(256) ksplit_finish1_kernel(const float* __rest
 }
 
 // scratch for the split-K partial slabs, one buffer per (device, stream): launches on one stream are ordered, two streams must
-// not share it. Grown only outside stream capture (the executors run one uncaptured forward before they capture); nullptr when
-// it cannot be provided (capture in progress, more than 8 streams per device, out of memory) -> the caller takes the unsplit path
+// not share it. Grown only outside stream capture (the executors run one uncaptured forward before they capture), geometrically,
+// and the superseded buffer is freed once the stream has drained (it used to be leaked on every growth).
+// nullptr = it cannot be provided (capture in progress and the buffer too small, more than 8 streams per device, out of memory):
+// the callers FAIL the launch — the unsplit kernel sums in another fp32 order, and a row's bits must not depend on such things.
 static float* ksplit_scratch(size_t floats, hipStream_t st) {
   struct Slot { hipStream_t st; float* buf; size_t cap; bool used; };
   static Slot slots[16][8] = {};
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
-  const int d = const_dev_slot();
+  const int d = conv_dev_slot();
   Slot* sl = nullptr;
   for (Slot& s : slots[d]) if (s.used && s.st == st) { sl = &s; break; }
   if (sl == nullptr)
     for (Slot& s : slots[d]) if (!s.used) { sl = &s; sl->used = true; sl->st = st; sl->buf = nullptr; sl->cap = 0; break; }
-  if (sl == nullptr) return nullptr;
+  if (sl == nullptr) { set_error("split-K scratch: more than 8 streams on one device"); return nullptr; }
   if (floats <= sl->cap) return sl->buf;
 #if !defined(ADM_EMU)
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    set_error("split-K scratch must grow during stream capture: run one uncaptured pass at this batch size first");
+    return nullptr;
+  }
 #endif
-  const size_t want = floats < ((size_t)8 << 20) ? ((size_t)8 << 20) : floats;      // >= 32 MiB
+  size_t want = floats < ((size_t)8 << 20) ? ((size_t)8 << 20) : floats;      // >= 32 MiB
+  if (want < 2 * sl->cap) want = 2 * sl->cap;
   void* q = nullptr;
-  if (dmalloc(&q, sizeof(float) * want) != 0) return nullptr;
-  sl->buf = (float*)q;   // the previous (smaller) buffer is intentionally leaked: launches may still read it
+  if (dmalloc(&q, sizeof(float) * want) != 0) { set_error("split-K scratch: out of device memory"); return nullptr; }
+  if (sl->buf != nullptr) {              // launches queued on this stream may still read the old slabs: drain, then free
+    (void)stream_sync(st);
+    dfree(sl->buf);
+  }
+  sl->buf = (float*)q;
   sl->cap = want;
   return sl->buf;
 }
@@ -750,7 +760,7 @@ static int launch_ksplit(const ConvParams& p, int bm, int S, hipStream_t st) {
   const size_t smem = sizeof(float) * ((size_t)CKP * p.CS + 2 * (size_t)CKP * KS * KS * bm);
   const long total = (long)p.N * p.Cout * p.Ho * p.Wo;
   float* scratch = ksplit_scratch((size_t)S * total, st);
-  if (scratch == nullptr) return 1;                       // not available: unsplit path
+  if (scratch == nullptr) return -1;                      // (error recorded) never fall back silently: another summation order
   ConvParams q = p;
   q.ksplit = S; q.part_stride = total; q.out = scratch;
   q.n_ct = p.Cout / bm;
@@ -824,7 +834,7 @@ static int launch_ksplit_generic(const ConvParams& p, hipStream_t st) {
   if (S < 2) return 1;
   const long total = (long)p.N * p.Cout * p.Ho * p.Wo;
   float* scratch = ksplit_scratch((size_t)S * total, st);
-  if (scratch == nullptr) return 1;
+  if (scratch == nullptr) return -1;
   ConvParams q = p;
   q.ksplit = S; q.part_stride = total; q.out = scratch;
   q.n_ct = p.Cout / bm;

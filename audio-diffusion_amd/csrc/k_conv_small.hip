@@ -415,7 +415,8 @@ int launch_conv_small(const adm_conv_args& a, hipStream_t st) {
   static const int use_ksp = [] { const char* e = getenv("ADM_CONV_KSPLIT"); return e ? atoi(e) : 1; }();
   if (use_ksp && (long)a.H * a.W <= 1024 && a.C1 >= 64) {
     part = conv_ksplit_scratch((size_t)8 * total, st);
-    if (part != nullptr) S = 8;
+    if (part == nullptr) return -1;       // (error recorded) the unsplit kernel sums in another order
+    S = 8;
   }
 #define ADM_COUT_CASE(CO)                                                                                          \
   if (a.Cout == CO) {                                                                                              \

@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 #include "adm_kernels.h"
 
@@ -45,6 +46,7 @@ constexpr int WBM = 32;           // couts per workgroup
 constexpr int WUSLAB = WCK * 16 * WBM;   // 4096 floats = 16 KiB
 constexpr int WVSLAB = 16 * WCK * 32;    // 4096 floats
 
+#if defined(ADM_EXPERIMENTS)   // superseded kernel generations (modes 1 and 2): built only with -DADM_EXPERIMENTS (build.sh ... exp)
 template <bool HAS_CHAN, bool HAS_RES>
 __device__ __forceinline__ void wino_store(const WinoParams& p, const float* ldsM, int tid, int m0, int n, int ty0,
                                            int tx0) {
@@ -483,6 +485,7 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_kernel(const WinoParams p) 
 }
 
 
+#endif  // ADM_EXPERIMENTS (v1, v2)
 // ---------------------------------------------------------------------------------------------------------------------
 // v3 — persistent, wave-specialised Winograd kernel (mode 3). What v2's measurements asked for:
 //   * the producers' per-thread 4x4 window gathers (16 dword loads, every input pixel fetched 4x, GN+SiLU applied 4x)
@@ -819,6 +822,7 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
   }
 }
 
+#if defined(ADM_EXPERIMENTS)   // v3 (mode 3): the producer role above is shared with v4, this consumer and the kernel are not
 // ---- consumer role: 256 threads (waves 0..3) ------------------------------------------------------------------------
 template <bool PROF>
 __device__ __forceinline__ void wino3_consumer(const WinoParams& p, const float* ldsV, float* ldsU, int tid, int wave,
@@ -981,6 +985,7 @@ __global__ void __launch_bounds__(512, 2) conv_wino3_kernel(const WinoParams p) 
   else wino3_consumer<PROF>(p, ldsV, ldsU, tid, wave, (int)blockIdx.x, (int)gridDim.x);
 }
 
+#endif  // ADM_EXPERIMENTS (v3 consumer + kernel)
 // =====================================================================================================================
 // v4 (mode 4) — v3 with the FILTER operand taken out of LDS. What v3's measurements asked for (profiles/r01_pmc_wino.md):
 // its consumer stream alone needs 3200 cycles per chunk against 2048 of MFMA — 550 of them are the eight LDS-DMA pieces
@@ -1326,9 +1331,20 @@ static int wino_pair() {
   return g_wino_pair;
 }
 static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 4) on first use
-void set_winograd_mode(int m) { g_wino_mode = m; }
+bool winograd_mode_available(int m) {
+#if defined(ADM_EXPERIMENTS)
+  return m >= -1 && m <= 4;
+#else
+  return m == -1 || m == 0 || m == 4;      // modes 1-3 (earlier kernel generations) exist only in -DADM_EXPERIMENTS builds
+#endif
+}
+void set_winograd_mode(int m) { g_wino_mode = winograd_mode_available(m) ? m : 4; }
 static int wino_mode() {
-  if (g_wino_mode < 0) { const char* e = getenv("ADM_CONV_WINO"); g_wino_mode = e ? atoi(e) : 4; }
+  if (g_wino_mode < 0) {
+    const char* e = getenv("ADM_CONV_WINO");
+    g_wino_mode = e ? atoi(e) : 4;
+    if (!winograd_mode_available(g_wino_mode) || g_wino_mode < 0) g_wino_mode = 4;
+  }
   return g_wino_mode;
 }
 bool winograd_enabled() { return wino_mode() != 0; }
@@ -1350,7 +1366,11 @@ bool winograd_eligible(const adm_conv_args& a) {
   if (!(Wi % 16 == 0 && Hi % 8 == 0 && (a.C1 + C2) % 8 == 0 && a.C1 % 8 == 0 && a.Cout % 32 == 0)) return false;
   if (wino4_layout(a.Cout, a.C1 + C2))     // filters are in the v4 image: conv_wino4_kernel or nothing (-> direct kernel)
     return wino_persistent_args_ok(a) && aligned16(a.out) && (a.residual == nullptr || aligned16(a.residual));
-  return true;
+#if defined(ADM_EXPERIMENTS)
+  return true;                             // modes 1-3
+#else
+  return false;                            // shapes conv_wino4_kernel cannot tile take the direct MFMA kernel: the only fallback
+#endif
 }
 
 const float* conv_zero_bias(int n);  // k_conv_mfma.hip
@@ -1381,6 +1401,9 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * a.H * a.W;
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
   const bool v4 = wino4_layout(a.Cout, a.C1 + C2);             // (winograd_eligible has checked the kernel's other needs)
+#if !defined(ADM_EXPERIMENTS)
+  ADM_REQUIRE(v4, "conv_winograd: shape outside conv_wino4_kernel's tiling (winograd_eligible should have said no)");
+#endif
   if (v4 || (wino_mode() >= 3 && a.Cout % W3BM == 0 && (a.C1 + C2) % (2 * WCK) == 0 && wino_persistent_args_ok(a))) {
     // persistent wave-specialised kernels
     p.n_ct = a.Cout / W3BM;
@@ -1392,39 +1415,56 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     }
     if (p.chan_add == nullptr) { p.chan_add = conv_zero_bias(a.Cout); p.chan_add_stride = 0; }
     ADM_REQUIRE(p.chan_add != nullptr, "conv_winograd: zero-bias buffer");
-    const size_t need3 = sizeof(float) * W3LDS;
 #if !defined(ADM_EMU)
-    static int n_cu = [] {
-      (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS));
-      (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
-      (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
-      (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
-      int dev = 0, n = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      return n > 0 ? n : 256;
-    }();
+    // Per device (a function-local `static once` ran for the device that happened to be current on first use only):
+    // the CU count, and the permission for the PAIR kernels' 91 KiB of dynamic LDS — checked; where the runtime refuses it the
+    // bit-identical one-barrier-per-chunk instantiation (43 KiB, no attribute needed) runs instead.
+    struct DevInfo { int n_cu = 0; bool pair_ok = false; };
+    static DevInfo info[16];
+    static std::mutex info_mu;
+    const int dslot = conv_dev_slot() & 15;
+    {
+      std::lock_guard<std::mutex> lk(info_mu);
+      if (info[dslot].n_cu == 0) {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        info[dslot].n_cu = n > 0 ? n : 256;
+        const int by = (int)(sizeof(float) * W4LDS_PAIR);
+        bool ok = true;
+        ok &= hipFuncSetAttribute((const void*)conv_wino4_kernel<true, false, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)conv_wino4_kernel<true, false, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)conv_wino4_kernel<false, false, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)conv_wino4_kernel<false, false, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        info[dslot].pair_ok = ok;
+#if defined(ADM_EXPERIMENTS)
+        (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS));
+        (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, true, 0, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, by);
+        (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
+        (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
+        (void)hipFuncSetAttribute((const void*)conv_wino3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W3LDS));
+#endif
+      }
+    }
+    const int n_cu = info[dslot].n_cu;
+    const bool pair_ok = info[dslot].pair_ok;
 #else
     const int n_cu = 3;                                          // exercise persistence (several tiles per block) on the emulator
+    const bool pair_ok = true;
 #endif
     const int grid = p.nblk < n_cu ? p.nblk : n_cu;
     set_last_conv_variant(4000 + (v4 ? 314 : 313));
     p.prof = nullptr;
     p.stats = v4 ? a.stats_out : nullptr;
-#if !defined(ADM_EMU)
+#if !defined(ADM_EMU) && defined(ADM_EXPERIMENTS)
     static const bool want_prof = getenv("ADM_WINO_PROF") != nullptr;
     if (want_prof && !a.up) {   // developer aid: per-role cycle accounting, printed after every launch (synchronous)
       static unsigned long long* dprof = [] { void* q = nullptr; (void)hipMalloc(&q, 16 * sizeof(unsigned long long)); return (unsigned long long*)q; }();
       (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
       p.prof = dprof;
-      if (v4 && wino_pair()) {
-        static const bool oncep = [] {
-          (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, true, 0, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS_PAIR));
-          return true;
-        }();
-        (void)oncep;
-        ADM_LAUNCH((conv_wino4_kernel<false, true, 0, -1, true>), dim3(grid), dim3(512), sizeof(float) * W4LDS_PAIR, st, p);
-      } else if (v4) ADM_LAUNCH((conv_wino4_kernel<false, true>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p);
-      else ADM_LAUNCH((conv_wino3_kernel<false, true>), dim3(grid), dim3(512), need3, st, p);
+      if (v4 && wino_pair()) ADM_LAUNCH((conv_wino4_kernel<false, true, 0, -1, true>), dim3(grid), dim3(512), sizeof(float) * W4LDS_PAIR, st, p);
+      else if (v4) ADM_LAUNCH((conv_wino4_kernel<false, true>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p);
+      else ADM_LAUNCH((conv_wino3_kernel<false, true>), dim3(grid), dim3(512), sizeof(float) * W3LDS, st, p);
       unsigned long long h[16];
       (void)hipMemcpyAsync(h, dprof, sizeof(h), hipMemcpyDeviceToHost, st);
       (void)hipStreamSynchronize(st);
@@ -1433,8 +1473,6 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
               h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[8] / nb, h[9] / nb, h[10] / nb, h[11] / nb, h[12] / nb, h[13] / nb);
       return ADM_CHECK_LAUNCH();
     }
-#endif
-#if !defined(ADM_EMU)
     static const int abl = [] { const char* e = getenv("ADM_WINO_ABL"); return e ? atoi(e) : 0; }();
     if (v4 && !a.up && abl) {   // developer aid: role ablations of conv_wino4_kernel (TIMING ONLY, wrong results)
       switch (abl) {
@@ -1457,18 +1495,8 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
       // default since round 3: one workgroup barrier per TWO chunks (rings of four V slabs / patch buffers, 91 KiB of LDS). Measured on
       // one box, alternating, bit-identical outputs: 55 launches of a B = 32 forward 67.23 / 67.08 / 67.13 ms at one barrier per chunk,
       // 66.07 / 66.21 / 66.37 ms at one per pair; ADM_WINO_PAIR=0 restores the former.
-      if (wino_pair()) {
+      if (wino_pair() && pair_ok) {
         const size_t needp = sizeof(float) * W4LDS_PAIR;
-#if !defined(ADM_EMU)
-        static const bool once = [] {
-          (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<true, false, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS_PAIR));
-          (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<true, false, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS_PAIR));
-          (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, false, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS_PAIR));
-          (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, false, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS_PAIR));
-          return true;
-        }();
-        (void)once;
-#endif
         if (a.up) {
           if (a.act) ADM_LAUNCH((conv_wino4_kernel<true, false, 0, 1, true>), dim3(grid), dim3(512), needp, st, p);
           else ADM_LAUNCH((conv_wino4_kernel<true, false, 0, 0, true>), dim3(grid), dim3(512), needp, st, p);
@@ -1488,10 +1516,13 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
       }
       return ADM_CHECK_LAUNCH();
     }
-    if (a.up) ADM_LAUNCH((conv_wino3_kernel<true, false>), dim3(grid), dim3(512), need3, st, p);
-    else ADM_LAUNCH((conv_wino3_kernel<false, false>), dim3(grid), dim3(512), need3, st, p);
+#if defined(ADM_EXPERIMENTS)
+    if (a.up) ADM_LAUNCH((conv_wino3_kernel<true, false>), dim3(grid), dim3(512), sizeof(float) * W3LDS, st, p);
+    else ADM_LAUNCH((conv_wino3_kernel<false, false>), dim3(grid), dim3(512), sizeof(float) * W3LDS, st, p);
     return ADM_CHECK_LAUNCH();
+#endif
   }
+#if defined(ADM_EXPERIMENTS)
   if (wino_mode() == 2 && a.Cout % W2BM == 0 && (a.C1 + C2) % (2 * WCK) == 0) {   // wave-specialised kernel (even chunk count)
     p.n_ct = a.Cout / W2BM;
     p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
@@ -1520,6 +1551,9 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
   set_last_conv_variant(4000 + 311);
   ADM_LAUNCH(conv_wino_kernel, dim3(p.nblk), dim3(256), need, st, p);
   return ADM_CHECK_LAUNCH();
+#else
+  ADM_FAIL("conv_winograd: no kernel for this shape in a build without ADM_EXPERIMENTS");
+#endif
 }
 
 }  // namespace adm

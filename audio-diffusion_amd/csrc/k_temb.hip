@@ -42,22 +42,64 @@ __global__ void __launch_bounds__(256) time_embedding_kernel(const float* __rest
   __syncthreads();
   if (save_sinus && part == 0)  // training: inputs of linear_1 kept for its weight gradient
     for (int i = tid; i < dim_in; i += blockDim.x) save_sinus[(long)b * dim_in + i] = sinus[i];
-  for (int j = wave; j < dim_emb; j += 4) {          // linear_1: one wave per row
-    const float* wr = w1 + (long)j * dim_in;
+  // Both GEMVs: EIGHT rows per wave at a time — lane l works on row l / 8 and the k values congruent to l % 8 (mod 8) in float4
+  // units, so a wave's load is 8 rows x 128 contiguous bytes, several independent row groups are in flight, and the reduction is
+  // 3 shuffle steps.  (One row per wave and iteration — 2 loads, a 6-step shuffle tree, an LDS store, 128 times in a row per wave —
+  // made this launch 186 us at ANY batch: a serial chain of L2 round trips)
+  const int rl = lane >> 3, kq = lane & 7;
+  auto gemv8 = [&](const float* __restrict__ w, const float* __restrict__ x, int K, int j0) __attribute__((always_inline)) -> float {
+    const float* wr = w + (long)(j0 + rl) * K;
     float acc = 0.f;
-    for (int k = lane; k < dim_in; k += 64) acc = fmaf(wr[k], sinus[k], acc);
-    ADM_UNROLL
-    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    acc += b1[j];
-    if (lane == 0) {
-      hid[j] = silu_t(acc);
-      if (save_z && part == 0) save_z[(long)b * dim_emb + j] = acc;  // pre-activation of linear_1 (training)
+    for (int k = 4 * kq; k < K; k += 32) {
+      const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+      acc = fmaf(wv.x, x[k], acc); acc = fmaf(wv.y, x[k + 1], acc); acc = fmaf(wv.z, x[k + 2], acc); acc = fmaf(wv.w, x[k + 3], acc);
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+    return acc;
+  };
+  const bool vec = (dim_in % 32 == 0) && (dim_emb % 32 == 0) && ((reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2)) & 15) == 0;
+  if (vec) {
+    for (int j0 = 8 * wave; j0 < dim_emb; j0 += 32) {          // linear_1 (every workgroup of a sample recomputes it: 65 k MACs)
+      const int j = j0 + rl;
+      float acc = 0.f;
+      if (j < dim_emb) acc = gemv8(w1, sinus, dim_in, j0);
+      if (kq == 0 && j < dim_emb) {
+        acc += b1[j];
+        hid[j] = silu_t(acc);
+        if (save_z && part == 0) save_z[(long)b * dim_emb + j] = acc;  // pre-activation of linear_1 (training)
+      }
+    }
+  } else {
+    for (int j = wave; j < dim_emb; j += 4) {          // generic shapes: one wave per row
+      const float* wr = w1 + (long)j * dim_in;
+      float acc = 0.f;
+      for (int k = lane; k < dim_in; k += 64) acc = fmaf(wr[k], sinus[k], acc);
+      ADM_UNROLL
+      for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+      acc += b1[j];
+      if (lane == 0) {
+        hid[j] = silu_t(acc);
+        if (save_z && part == 0) save_z[(long)b * dim_emb + j] = acc;
+      }
     }
   }
   __syncthreads();
   const int rows = (dim_emb + TE_SPLIT - 1) / TE_SPLIT;
   const int j_end = (part + 1) * rows < dim_emb ? (part + 1) * rows : dim_emb;
-  for (int j = part * rows + wave; j < j_end; j += 4) {   // linear_2: this workgroup's slice of the rows
+  if (vec && rows % 8 == 0) {
+    for (int j0 = part * rows + 8 * wave; j0 < j_end; j0 += 32) {   // linear_2: this workgroup's slice of the rows
+      const int j = j0 + rl;
+      float acc = 0.f;
+      if (j < j_end) acc = gemv8(w2, hid, dim_emb, j0);
+      if (kq == 0 && j < j_end) {
+        acc += b2[j];
+        emb[(long)b * dim_emb + j] = acc;
+        if (emb_act) emb_act[(long)b * dim_emb + j] = silu_t(acc);
+      }
+    }
+    return;
+  }
+  for (int j = part * rows + wave; j < j_end; j += 4) {
     const float* wr = w2 + (long)j * dim_emb;
     float acc = 0.f;
     for (int k = lane; k < dim_emb; k += 64) acc = fmaf(wr[k], hid[k], acc);

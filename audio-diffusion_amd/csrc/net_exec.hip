@@ -1,6 +1,7 @@
 // net_exec.hip — implementation of the generic flat-op-list executor (see net_exec.h).
 #include <cstdlib>
 
+#include <atomic>
 #include <tuple>
 #include <utility>
 
@@ -214,9 +215,9 @@ void Net::mark_ready(const float* master_param, size_t numel) {
     if (lo < bk_lo[b + 1] && hi > bk_lo[b] && --bk_pending[b] == 0) bk_fn(bk_user, (int)b);
 }
 
-static unsigned g_dispatch_epoch = 1;
-void bump_dispatch_epoch() { ++g_dispatch_epoch; }
-unsigned dispatch_epoch() { return g_dispatch_epoch; }
+static std::atomic<unsigned> g_dispatch_epoch{1};
+void bump_dispatch_epoch() { g_dispatch_epoch.fetch_add(1); }
+unsigned dispatch_epoch() { return g_dispatch_epoch.load(); }
 
 int Net::note_packing(const ConvW& w, unsigned pk) {
   if (training && use_known && stale_packings && (pk & ~w.used) != 0)
@@ -579,32 +580,40 @@ int Net::plan(int B) {
       size_t max_part = 4;
       for (size_t i = 0; i < ops.size(); ++i) {
         const Op& o = ops[i];
-        if (o.kind != Op::CONV || o.wt >= 0 || o.ks != 3 || o.stride != 1 || o.up > 1 || o.pad_lo != 1 || o.in1_C != 0) continue;
+        if (o.kind != Op::CONV || o.wt >= 0 || o.ks != 3 || o.up > 1 || o.in1_C != 0) continue;
+        // stride 1 "same", or Downsample2D.conv (stride 2: every other pixel of the stride-1 convolution; padding 1 -> the even
+        // pixels, pad (0, 1, 0, 1) -> the odd ones)
+        const bool s2 = o.stride == 2 && (o.pad_lo == 0 || o.pad_lo == 1) && !o.up && o.gn < 0 && !o.act && o.in2 < 0 && o.res < 0 && o.temb_off < 0;
+        if (!s2 && (o.stride != 1 || o.pad_lo != 1)) continue;
         if (o.w == nullptr || o.w->wb == nullptr || o.w->wbT == nullptr || o.in1 == t_in) continue;
         if (o.up && (o.gn >= 0 || o.act || o.in2 >= 0)) continue;       // Upsample2D.conv: plain nearest x2, nothing on the load path
         const Tensor& t1 = tensors[o.in1];
         const int C1 = t1.C, C2 = o.in2 >= 0 ? tensors[o.in2].C : 0, Ct = C1 + C2, Cout = o.w->Cout, H = t1.H, W = t1.W;
-        const int Ho = o.up ? 2 * H : H, Wo = o.up ? 2 * W : W;           // the image has the SOURCE dims, the kernels tile the output
-        if (!blk_apply_eligible(C1, C2, H, W) || !blk_apply_eligible(Cout, 0, Ho, Wo)) continue;
+        if (s2 && ((H | W) & 1)) continue;
+        // the image has the SOURCE dims; the kernels tile Ho x Wo: the output (stride 1, up) or, for stride 2, the input plane again
+        const int Ho = o.up ? 2 * H : H, Wo = o.up ? 2 * W : W;
+        if (!blk_apply_eligible(C1, C2, H, W) || !blk_apply_eligible(Cout, 0, s2 ? H / 2 : Ho, s2 ? W / 2 : Wo)) continue;
         if (o.act && o.gn < 0) continue;
         BlkOp& b = blk[i];
+        b.s2 = s2;
         b.fwd = conv_bf16b_eligible(Ct, Cout, Ho, Wo);
         b.wg = conv_wgradb_eligible(Ct, Cout, Ho, Wo);
         b.dg = conv_bf16b_eligible(Cout, Ct, Ho, Wo);
+        if (s2 && !(b.fwd && b.wg && b.dg)) { b = BlkOp(); continue; }      // all three passes or none (one zero-inserted dy image)
         if (b.fwd || b.wg) {
           const size_t bytes = blk_image_bytes(B, Ct, H, W);
           ADM_TRY(arena_alloc(&b.xa, bytes));
           ADM_TRY(dmemset(b.xa, 0, bytes, nullptr));          // the halo stays zero for the life of the plan
         }
         if (b.wg || b.dg) {
-          void*& img = dy_imgs[std::make_tuple(Cout, Ho, Wo)];
+          void*& img = dy_imgs[std::make_tuple(s2 ? -Cout : Cout, Ho, Wo)];   // (a zero-inserted image keeps its own zeros)
           if (img == nullptr) {
             const size_t bytes = blk_image_bytes(B, Cout, Ho, Wo);
             ADM_TRY(arena_alloc(&img, bytes));
             ADM_TRY(dmemset(img, 0, bytes, nullptr));
           }
           b.dyb = img;
-          const size_t pf = (size_t)blk_sums_scratch(B, Cout, Ho, Wo);
+          const size_t pf = (size_t)blk_sums_scratch(B, Cout, s2 ? H / 2 : Ho, s2 ? W / 2 : Wo);
           if (pf > max_part) max_part = pf;
           if (b.wg) {
             const size_t ws = (size_t)conv_wgradb_workspace(Ct, Cout, B, Ho, Wo, nullptr);
@@ -623,7 +632,7 @@ int Net::plan(int B) {
           }
         for (size_t i = 0; i < ops.size(); ++i) {
           const Op& o = ops[i];
-          if (!blk[i].fwd || !tensors[o.out].want_stats || tensors[o.out].external) continue;
+          if (!blk[i].fwd || blk[i].s2 || !tensors[o.out].want_stats || tensors[o.out].external) continue;
           Tensor& t = tensors[o.out];
           const int tiles = conv_bf16b_stats_tiles(t.H, t.W);
           ADM_TRY(arena_alloc((void**)&t.stats, sizeof(double) * 2 * (size_t)B * t.C * tiles));
@@ -716,7 +725,7 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
                                  nullptr, st));
       if (bo && bo->fwd)
         ADM_TRY(launch_conv_bf16b(bo->xa, a.C1 + a.C2, B, o.up ? 2 * a.H : a.H, o.up ? 2 * a.W : a.W, o.w->wb, a.Cout, a.bias, a.chan_add,
-                                  a.chan_add_stride, a.residual, a.out, st, o.up, tensors[o.out].stats));
+                                  a.chan_add_stride, a.residual, a.out, st, bo->s2 ? (o.pad_lo ? 3 : 2) : o.up, bo->s2 ? nullptr : tensors[o.out].stats));
       else
         ADM_TRY(launch_conv2d(a, st));
       if (o.w) ADM_TRY(note_packing(*o.w, packing_of_variant(last_conv_variant(), true)));
@@ -855,7 +864,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
     float* dtemb_o = (o.temb_off >= 0 && dtemb_all) ? dtemb_all + o.temb_off : nullptr;
     if (bo) {    // level 3: dy once as a blocked 16-bit image for the weight-gradient and the data-gradient kernel; the pass
                  // also leaves the channel sums that adm_chan_sums would read dy a second time for
-      ADM_TRY(launch_blk_apply(dy, Cout, 0, nullptr, 0, 0, B, to.H, to.W, nullptr, nullptr, 0, bo->dyb, blk_part, st));
+      ADM_TRY(launch_blk_apply(dy, Cout, 0, nullptr, 0, 0, B, to.H, to.W, nullptr, nullptr, 0, bo->dyb, blk_part, st, bo->s2 ? (o.pad_lo ? 2 : 1) : 0));
       ADM_TRY(launch_blk_sums_finalize(blk_part, B, Cout, to.H, to.W, dtemb_o, temb_stride, 0, dbias, st));
     } else {
       ADM_TRY(launch_chan_sums(dy, B, Cout, (int)plane_o, dtemb_o, temb_stride, 0, dbias, st));
@@ -873,7 +882,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       ADM_TRY(launch_conv_small_cout_bwd(t1.ptr, Ct, B, t1.H, t1.W, gsc, gsh, o.act, ps->P(o.w->key + ".weight"), dy, Cout,
                                          tmp_da, dW, st));
     } else if (bo && bo->wg) {
-      ADM_TRY(launch_conv_wgradb(bo->xa, Ct, bo->dyb, Cout, B, to.H, to.W, dW, 0, wgrad_ws, st, o.up));
+      ADM_TRY(launch_conv_wgradb(bo->xa, Ct, bo->dyb, Cout, B, bo->s2 ? t1.H : to.H, bo->s2 ? t1.W : to.W, dW, 0, wgrad_ws, st, o.up));
     } else {
       adm_conv_args a;
       memset(&a, 0, sizeof(a));
@@ -916,8 +925,9 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
         ADM_REQUIRE(tmp_da_floats >= (size_t)B * Ct * Hi * Wi, "run_backward: scratch too small");
         a.out = tmp_da;
       }
-      if (bo && bo->dg)
-        ADM_TRY(launch_conv_bf16b(bo->dyb, Cout, B, to.H, to.W, o.w->wbT, Ct, nullptr, nullptr, 0, a.residual, a.out, st));
+      if (bo && bo->dg)      // (stride 2: the zero-inserted dy image has the INPUT's dims; the kernel is the plain stride-1 one)
+        ADM_TRY(launch_conv_bf16b(bo->dyb, Cout, B, bo->s2 ? t1.H : to.H, bo->s2 ? t1.W : to.W, o.w->wbT, Ct, nullptr, nullptr, 0, a.residual,
+                                  a.out, st));
       else
         ADM_TRY(launch_conv2d(a, st));
       ADM_TRY(note_packing(*o.w, packing_of_variant(last_conv_variant(), false)));

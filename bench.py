@@ -286,12 +286,112 @@ def cpu_baseline(sd, cores):
         tried[nt] = run(s.timesteps[:2])[1]
     nt = min(tried, key=tried.get)
     torch.set_num_threads(nt)
+    full = tried[nt] * 50 <= 60.0          # the complete 50-step sampling when it fits a minute of CPU work
+    if full:
+        x = torch.randn(1, 1, 256, 256, generator=torch.Generator().manual_seed(42))
+        times = run(s.timesteps)
+        total = sum(times)
+        return {"value": 1.0 / total, "unit": "mel-spectrograms/s", "cores": nt, "kind": "port",
+                "sample": f"the COMPLETE DDIM-50 sampling at B=1, 256x256 fp32 (torch-CPU oracle: 50 x {{UNet fwd + DDIM step}}, "
+                          f"{total:.1f} s on {nt} threads; thread-count probe: " + ", ".join(f"{k}: {v:.2f} s" for k, v in tried.items()) + ")"}
     times = run(s.timesteps[2:12])
     per_step = sum(times) / len(times)
     return {"value": 1.0 / (50 * per_step), "unit": "mel-spectrograms/s", "cores": nt, "kind": "port",
             "sample": f"{len(times)} consecutive {{UNet fwd + DDIM step}} of the 50 at B=1, 256x256 fp32 (torch-CPU oracle, "
                       f"{per_step:.2f} s/step on {nt} threads, {sum(times):.1f} s of CPU work; thread-count probe: " +
                       ", ".join(f"{k}: {v:.2f} s" for k, v in tried.items()) + "), linear extrapolation to 50 steps"}
+
+
+def side_cpu_baselines(nt):
+    """BASELINE.md §3's CPU protocol for the SIDE legs (the oracle on `nt` host threads, outside every timed region, bounded to about a
+    minute in total): config 1 in full (64x64 DDPM-10, B = 1), config 4 (20 latent 32x32 UNet steps + one AutoencoderKL decode at B = 1),
+    config 5 (optimizer steps at B = 2, fp32: forward + backward + clip + AdamW), and the Mel codec single-threaded as the reference
+    calls it per image (pipeline_audio_diffusion.py:201; the only wall-clock claim in the reference tree is app.py:20-22)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from oracle import mel as omel
+    from oracle.schedulers import DDPMScheduler
+    from oracle.unet import UNet2DModel
+    from oracle.vae import AutoencoderKL
+    out = {}
+    torch.set_num_threads(nt)
+
+    def cfg(res):
+        c = dict(CFG256)
+        c["sample_size"] = res
+        return c
+
+    def ddpm_steps(m, res, n, B=1):
+        s = DDPMScheduler()
+        s.set_timesteps(1000 if n != 10 else 10)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(B, 1, res, res, generator=g)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for t in s.timesteps[:n]:
+                x = s.step(m(x, t)["sample"], t, x, generator=g)["prev_sample"]
+        return time.perf_counter() - t0
+
+    torch.manual_seed(0)
+    m64 = UNet2DModel(**cfg(64)).eval()
+    ddpm_steps(m64, 64, 1)
+    t = ddpm_steps(m64, 64, 10)
+    out["config_1"] = {"s_per_sample": round(t, 3), "ms_per_step": round(t * 100, 1), "cores": nt, "kind": "port",
+                       "sample": "the complete 10-step 64x64 DDPM sampling at B = 1 (oracle UNet + scheduler)"}
+    del m64
+    m32 = UNet2DModel(**cfg(32)).eval()
+    ddpm_steps(m32, 32, 1)
+    t = ddpm_steps(m32, 32, 20)
+    vae = AutoencoderKL(sample_size=(256, 256), in_channels=1, out_channels=1, latent_channels=1, layers_per_block=2,
+                        block_out_channels=(128, 256, 512, 512), down_block_types=("DownEncoderBlock2D",) * 4,
+                        up_block_types=("UpDecoderBlock2D",) * 4).eval()
+    z = torch.randn(1, 1, 32, 32, generator=torch.Generator().manual_seed(6))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        vae.decode(z / 0.18215)
+    td = time.perf_counter() - t0
+    out["config_4"] = {"ms_per_step": round(t / 20 * 1e3, 1), "s_vae_decode": round(td, 3), "cores": nt, "kind": "port",
+                       "spectrograms_per_s_extrapolated": round(1.0 / (t / 20 * 1000 + td), 5),
+                       "sample": "20 latent 32x32 DDPM steps + ONE AutoencoderKL decode to 256x256 at B = 1, x50 extrapolation of the loop"}
+    del m32, vae
+    m = UNet2DModel(**CFG256)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
+    g = torch.Generator().manual_seed(7)
+    x, tgt = torch.randn(2, 1, 256, 256, generator=g), torch.randn(2, 1, 256, 256, generator=g)
+    ts = torch.randint(0, 1000, (2,), generator=g)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        loss = F.mse_loss(m(x, ts)["sample"], tgt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        times.append(time.perf_counter() - t0)
+        if sum(times) > 45:
+            break
+    per = min(times)
+    out["train"] = {"samples_per_s": round(2 / per, 4), "s_per_step": round(per, 2), "cores": nt, "kind": "port", "dtype": "f32",
+                    "sample": f"{len(times)} optimizer steps at B = 2, 256x256 fp32 (oracle forward + torch autograd + clip + AdamW), best step"}
+    del m, opt
+    torch.set_num_threads(1)
+    om = omel.Mel()
+    rng = np.random.default_rng(3)
+    om.load_audio(raw_audio=(0.3 * rng.standard_normal(om.slice_size)).astype(np.float32))
+    om.audio_slice_to_image(0)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        img = om.audio_slice_to_image(0)
+    tf = (time.perf_counter() - t0) / 10
+    t0 = time.perf_counter()
+    for _ in range(3):
+        om.image_to_audio(img)
+    ti = (time.perf_counter() - t0) / 3
+    out["mel"] = {"forward_ms_per_call": round(tf * 1e3, 2), "inverse_ms_per_call": round(ti * 1e3, 1), "cores": 1, "kind": "port",
+                  "sample": "oracle Mel.audio_slice_to_image x10 and Mel.image_to_audio x3 (NNLS start point + 32 Griffin-Lim iterations), "
+                            "one 5.9 s clip, single thread"}
+    torch.set_num_threads(nt)
+    return out
 
 
 def roofline(unet, x, B):
@@ -518,11 +618,26 @@ def main():
                     res["configs"] = configs_leg(job)
                 except Exception as e:  # noqa: BLE001
                     res["configs"] = {"error": f"{type(e).__name__}: {e}"}
+            if not a.no_cpu_baseline and world == 1:      # the side legs' CPU figures (attached to their sub-records below)
+                try:
+                    nt_side = res.get("cpu_baseline", {}).get("cores") or min(16, os.cpu_count() or 1)
+                    side_cpu = side_cpu_baselines(int(nt_side))
+                except Exception as e:  # noqa: BLE001
+                    side_cpu = {"error": f"{type(e).__name__}: {e}"}
+                if "error" in side_cpu:
+                    res["side_cpu_baselines"] = side_cpu
+                if isinstance(res.get("configs"), dict):
+                    for k in ("config_1", "config_4"):
+                        if k in side_cpu and k in res["configs"]:
+                            res["configs"][k]["cpu_baseline"] = side_cpu[k]
+                res["_side_cpu"] = side_cpu
         if not a.no_mel_leg:
             try:
                 res["mel"] = mel_leg(job)
             except Exception as e:  # noqa: BLE001 - a failing side leg must not cost the headline line
                 res["mel"] = {"error": f"{type(e).__name__}: {e}"}
+            if isinstance(res.get("_side_cpu"), dict) and "mel" in res["_side_cpu"]:
+                res["mel"]["cpu_baseline"] = res["_side_cpu"]["mel"]
     del pipe
     # config 5 beside the headline: every rank takes part (the gradient all-reduce is a collective)
     if not a.no_train_leg:
@@ -544,8 +659,12 @@ def main():
             tr = {"error": f"{type(e).__name__}: {e}"}
         dog.cancel()
         if rank == 0:
+            side = res.pop("_side_cpu", None) if isinstance(res, dict) else None
+            if isinstance(side, dict) and "train" in side and isinstance(tr, dict):
+                tr["cpu_baseline"] = side["train"]
             res["train"] = tr
     if rank == 0:
+        res.pop("_side_cpu", None)
         print(json.dumps(res), flush=True)
     job.close()
 

@@ -24,17 +24,24 @@ int adm_version(void);
 const char* adm_last_error(void);
 /* 1 if built for the device (hipcc, gfx950), 0 for the CPU-emulation test build. */
 int adm_is_device_build(void);
+/* 1 if built with -DADM_EXPERIMENTS: the superseded Winograd kernel generations ("conv_wino" = 1 / 2 / 3) and the developer-aid
+ * ablation / profiling instantiations of conv_wino4_kernel are present; 0 (the product build) otherwise. */
+int adm_has_experiments(void);
 /* Runtime options (process-wide; a training net re-learns which weight images it reads after any change):
- * "conv_wino" = 0 (direct MFMA kernel only) | 1 / 2 (earlier Winograd kernels) | 3 (persistent wave-specialised kernel of round 1) |
- *   4 (default: conv_wino4_kernel, filters L2 -> registers; it has its own filter image, so set the mode BEFORE weights are packed) |
- *   -1 (back to the default / ADM_CONV_WINO environment variable);
+ * "conv_wino" = 0 (direct MFMA kernel only) | 4 (default: conv_wino4_kernel, filters L2 -> registers; it has its own filter image,
+ *   so set the mode BEFORE weights are packed) | -1 (back to the default / ADM_CONV_WINO environment variable) | 1 / 2 / 3 (earlier
+ *   Winograd kernel generations: only in a library built with -DADM_EXPERIMENTS, see adm_has_experiments; an error otherwise);
  * "wino_pair" = 1 (default) one workgroup barrier per two chunks in conv_wino4_kernel | 0 one per chunk (bit-identical) | -1 (ADM_WINO_PAIR);
  * "wgrad_max_split" = n caps the split-K factor of adm_conv2d_wgrad (0 = heuristic; tests use it to put several pixel tiles on
  *   one workgroup);
  * "conv_bf16" = 1 runs eligible 3x3 stride-1 convolutions (forward, data gradient and weight gradient) on 16-bit MFMA operands
  *   with fp32 accumulation (`--mixed_precision bf16`, scripts/train_unet.py:391-401), 2 = additionally the eligible 1x1 convolutions
  *   and stride-2 data gradients, 0 = fp32 everywhere (default), -1 = back to the ADM_CONV_BF16 environment variable;
- * "conv_op16_f16" = 1 makes those kernels' operand format IEEE binary16 instead of bf16 (`--mixed_precision fp16`). */
+ *   3 (round 4; what `enable_training(mixed_precision=...)` selects) = 2, with the 3x3 stride-1 convolutions of all three passes on
+ *   blocked 16-bit operand images (adm_blocked_apply / adm_conv2d_bf16_blocked / adm_conv2d_wgrad_bf16_blocked below);
+ * "conv_op16_f16" = 1 makes those kernels' operand format IEEE binary16 instead of bf16 (`--mixed_precision fp16`).
+ * The dispatch epoch moves only when a value really changes; set options BEFORE adm_unet_refresh_weights / the next train step.
+ * adm_version() = 101 since round 4 (adm_slerp_grid takes DOUBLE weights since round 3; blocked-image entry points). */
 int adm_set_option(const char* name, int value);
 /* Kernel variant the last adm_conv2d on this thread dispatched to (see adm_op_profile.variant; 4311 = Winograd). */
 int adm_last_conv_variant(void);
@@ -341,13 +348,20 @@ int adm_conv2d_wgrad(const adm_conv_args* a, const float* dy, float* dW, int acc
  *     Cin % 64 == 0, Cout % 128 == 0, H % 4 == 0, W % 32 == 0; workspace: adm_conv_wgrad_blocked_workspace floats.
  *     stats_out: NULL or (N, Cout, (H/8)*(W/32), 2) fp64 — per 8x32-pixel tile the (sum, sum of squares) of the final output
  *     values, the input adm_groupnorm_finalize needs (as adm_conv_args.stats_out).
- *   up != 0 (both): the convolution of Upsample2D — H, W are the OUTPUT dims and the input image is the half-resolution tensor
- *     (N, Cin, H/2, W/2); the nearest x2 is folded into the patch addresses. */
+ *   up = 1 (both): the convolution of Upsample2D — H, W are the OUTPUT dims and the input image is the half-resolution tensor
+ *     (N, Cin, H/2, W/2); the nearest x2 is folded into the patch addresses.
+ *   Stride 2 (Downsample2D.conv) = every other pixel of the stride-1 "same" convolution o of the same image: adm_conv2d_bf16_blocked
+ *     with up = 2 for pad (0, 1, 0, 1) + 3x3 stride 2 without padding (AutoencoderKL encoder; out(y, x) = o(2y + 1, 2x + 1)) or up = 3
+ *     for 3x3 stride 2 padding 1 (UNet2DModel; out(y, x) = o(2y, 2x)) — H, W are the INPUT dims, out is (N, Cout, H/2, W/2), bias only.
+ *     Its backward passes take the ZERO-INSERTED image of dy: adm_blocked_apply(zero_insert = 1 / 2 for up = 2 / 3) on dy
+ *     (N, Cout, H/2, W/2) writes an image of (H, W) pixels (adm_blocked_image_bytes(N, Cout, H, W), zeroed once) with dy(y, x) on pixel
+ *     (2y + 1, 2x + 1) / (2y, 2x); the data gradient is then the plain stride-1 call with the transposed filters, the weight gradient
+ *     the plain call with the input's image. */
 size_t adm_blocked_image_bytes(int N, int C, int H, int W);
 long adm_blocked_sums_scratch(int N, int C, int H, int W);
 int adm_blocked_apply(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, const float* scale,
-                      const float* shift, int act, void* img, float* sum_scratch, float* sum_nc, int nc_stride, float* sum_c,
-                      void* stream);
+                      const float* shift, int act, int zero_insert, void* img, float* sum_scratch, float* sum_nc, int nc_stride,
+                      float* sum_c, void* stream);
 int adm_conv2d_bf16_blocked_eligible(int Cin, int Cout, int H, int W);
 int adm_conv2d_bf16_blocked(const void* img, int Cin, int N, int H, int W, const void* wb, int Cout, const float* bias,
                             const float* chan_add, int chan_add_stride, const float* residual, float* out, int up,

@@ -167,3 +167,42 @@ def test_conv_bf16_blocked_upsample_folded_forward_and_weight_gradient(backend):
     dW = ops.conv2d_wgrad_bf16_blocked(img, ops.blocked_image(dy), up=True)
     exact_w = torch.nn.grad.conv2d_weight(xu, (Cout, C, 3, 3), _bf(dy.cpu()), padding=1)
     assert _relerr(dW.double(), exact_w) < 2e-6, _relerr(dW.double(), exact_w)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("pad", [1, 0], ids=["padding-1-unet", "pad-0101-vae"])
+def test_conv_bf16_blocked_stride_2_all_three_passes(backend, pad):
+    """Downsample2D.conv — 3x3 stride 2 with padding 1 (UNet2DModel's DownBlock2D) or after pad (0, 1, 0, 1) without padding (the
+    AutoencoderKL encoder): forward = every other pixel (even / odd) of the stride-1 convolution of the same blocked image; backward =
+    the plain stride-1 kernels on the zero-inserted image of dy (dy(y, x) on pixel (2y, 2x) / (2y + 1, 2x + 1))."""
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn, C, Cout, H, W = 2, 128, 128, 16, 64                    # output 8 x 32
+    x = _rand((Nn, C, H, W), 1, dev)
+    w = _rand((Cout, C, 3, 3), 3, dev, scale=(C * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    dy = _rand((Nn, Cout, H // 2, W // 2), 5, dev)
+    img = ops.blocked_image(x)
+    out = ops.conv2d_bf16_blocked(img, ops.pack_bf16_weight(w), Cout, bias=b, up=3 if pad else 2)
+    # both as an unpadded stride-2 convolution of an explicitly padded input: (1, 0, 1, 0)-padded on the top / left for padding 1 (its
+    # bottom / right padding row is never read at even sizes), (0, 1, 0, 1) for the other
+    xp = F.pad(_bf(x.cpu()), (1, 0, 1, 0) if pad else (0, 1, 0, 1))
+    exact = F.conv2d(xp, _bf(w.cpu()), b.cpu().double(), stride=2)
+    assert torch.allclose(exact, F.conv2d(_bf(x.cpu()), _bf(w.cpu()), b.cpu().double(), stride=2, padding=1)) or not pad
+    assert out.shape == exact.shape
+    assert _relerr(out.double(), exact) < 2e-6, _relerr(out.double(), exact)
+    dimg, nc, c = ops.blocked_image(dy, zero_insert=2 if pad else 1, sums=True)
+    assert tuple(dimg.shape) == (Nn, Cout // 8, H + 2, W + 2, 8)
+    z = _unblock(dimg.cpu())[:, :, 1:-1, 1:-1]
+    o = 0 if pad else 1
+    assert torch.equal(z[:, :, o::2, o::2], _bf(dy.cpu()))
+    assert float(z[:, :, 1 - o::2, :].abs().max()) == 0 and float(z[:, :, :, 1 - o::2].abs().max()) == 0
+    assert torch.allclose(c.cpu().double(), dy.cpu().double().sum((0, 2, 3)), rtol=1e-5, atol=1e-4)
+    # data gradient: autograd of the explicitly padded stride-2 convolution, cropped back to the input
+    dx = ops.conv2d_bf16_blocked(dimg, ops.pack_bf16_weight(w, transposed=True), C)
+    full = torch.nn.grad.conv2d_input((Nn, C, H + 1, W + 1), _bf(w.cpu()), _bf(dy.cpu()), stride=2)
+    want = full[:, :, 1:, 1:] if pad else full[:, :, :H, :W]
+    assert _relerr(dx.double(), want) < 2e-6, _relerr(dx.double(), want)
+    dW = ops.conv2d_wgrad_bf16_blocked(img, dimg)
+    want_w = torch.nn.grad.conv2d_weight(xp, (Cout, C, 3, 3), _bf(dy.cpu()), stride=2)
+    assert _relerr(dW.double(), want_w) < 2e-6, _relerr(dW.double(), want_w)

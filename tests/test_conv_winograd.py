@@ -25,6 +25,8 @@ CASES = [
 def test_conv_winograd(backend, case, mode):
     dev = select(backend)
     from audiodiffusion import _native, ops
+    if mode < 4 and not _native.lib().adm_has_experiments():
+        pytest.skip("modes 1-3 are superseded kernel generations: built only with -DADM_EXPERIMENTS (build.sh ... exp)")
     if mode >= 2 and case[5] % 64 != 0:
         pytest.skip("v2/v3 tile 64 output channels")
     if mode >= 3 and ((case[8] and not case[7]) or (case[1] + case[2]) % 16 != 0):
@@ -68,6 +70,8 @@ def test_conv_winograd_data_gradient(backend, mode, Cin, Cout, variant):
     (the data-gradient convolution maps Cout -> Cin channels, so ITS output-channel count is the forward's Cin)."""
     dev = select(backend)
     from audiodiffusion import _native, ops
+    if mode < 4 and not _native.lib().adm_has_experiments():
+        pytest.skip("mode 3 is a superseded kernel generation: built only with -DADM_EXPERIMENTS")
     Nn, H, W = 2, 16, 32
     w = _rand((Cout, Cin, 3, 3), 11, dev, scale=(Cin * 9) ** -0.5)
     dy = _rand((Nn, Cout, H, W), 12, dev)

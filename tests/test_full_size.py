@@ -51,6 +51,28 @@ def test_unet_256_samples_do_not_interact(dev, unet):
     assert torch.equal(unet(x, ts)["sample"], full), "the forward is not deterministic"
 
 
+def test_bench_batch_rows_are_bit_identical_to_single_sample_runs(dev, unet):
+    """The bench batch (B = 32, config 3's per-GPU shard) against single-sample runs, BIT FOR BIT (SURVEY §8(c) anchor 7):
+    rows 0 / 17 / 31 of one forward equal forwards of those samples alone, and row 5 of a complete DDIM-50 sampling at B = 32 (captured
+    hipGraph) equals the same start noise sampled alone.  This is what lets the single B = 1 comparison against the oracle speak for the
+    bench batch and for every multi-GPU shard: no kernel's summation order, split or tile walk depends on the batch it runs in."""
+    from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, Mel
+    B = 32
+    x = torch.randn(B, 1, 256, 256, generator=torch.Generator().manual_seed(11)).to(dev)
+    ts = torch.tensor([(37 * i) % 1000 for i in range(B)])
+    full = unet(x, ts)["sample"]
+    for r in (0, 17, 31):
+        one = unet(x[r:r + 1].contiguous(), ts[r:r + 1])["sample"]
+        assert torch.equal(one[0], full[r]), (r, float((one[0] - full[r]).abs().max()))
+    pipe = AudioDiffusionPipeline(None, unet, Mel(), DDIMScheduler())
+    pipe.set_progress_bar_config(disable=True)
+    noise = torch.randn(B, 1, 256, 256, generator=torch.Generator().manual_seed(12)).to(dev)
+    imgs, flt = pipe(batch_size=B, noise=noise.clone(), audio=False, return_float=True)          # 50 steps at the bench batch
+    i1, f1 = pipe(batch_size=1, noise=noise[5:6].clone(), audio=False, return_float=True)
+    assert torch.equal(f1[0], flt[5]), float((f1[0] - flt[5]).abs().max())
+    assert np.array_equal(np.asarray(i1[0]), np.asarray(imgs[5]))
+
+
 def test_ddim50_loop_is_deterministic_shardable_and_quantises_as_documented(dev, unet):
     from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, Mel
     pipe = AudioDiffusionPipeline(None, unet, Mel(), DDIMScheduler())

