@@ -65,6 +65,7 @@ bool winograd_enabled();
 void set_wgrad_max_split(int v);  // k_conv_wgrad.hip
 void bump_dispatch_epoch();        // net_exec.hip: a process-wide option changed -> training nets re-learn which packings they read
 unsigned dispatch_epoch();
+void set_blk_direct_dy(int v);     // net_exec.hip: option "blk_direct_dy" (read when a training plan is made)
 void set_winograd_pair(int v);  // conv_wino4_kernel: 1 (default) = one workgroup barrier per two chunks, 0 = one per chunk (bit-identical)
 void set_winograd_mode(int m);  // 0 off, 1 v1, 2 wave-specialised v2, 3 persistent v3 (default), -1 = default
 bool winograd_eligible(const adm_conv_args& a);
@@ -80,6 +81,7 @@ bool conv_op16_f16();
 // k_conv1x1_bf16.hip (mode 2)
 bool conv1x1_bf16_eligible(const adm_conv_args& a);
 int launch_conv1x1_bf16(const adm_conv_args& a, hipStream_t st);
+int launch_conv1x1_bf16_split(const adm_conv_args& a, int split_c, float* out2, const float* residual2, hipStream_t st);
 bool conv1x1_wgrad_bf16_eligible(const adm_conv_args& a);
 int launch_conv1x1_wgrad_bf16(const adm_conv_args& a, const float* dy, float* workspace, int split, hipStream_t st);
 bool conv_bf16_eligible(const adm_conv_args& a);
@@ -96,6 +98,12 @@ bool blk_apply_eligible(int C1, int C2, int H, int W);
 long blk_sums_scratch(int N, int C, int H, int W);
 int launch_blk_apply(const float* x1, int C1, long x1_bs, const float* x2, int C2, long x2_bs, int N, int H, int W,
                      const float* scale, const float* shift, int act, void* out, float* sum_scratch, hipStream_t st, int zins = 0);
+int launch_blk_gn_bwd_image(const float* x, int C, const float* da, int N, int H, int W, int groups, const float* mean_rstd,
+                            const float* gamma, const float* beta, int act, const float* s12, void* out, float* sum_scratch,
+                            hipStream_t st);
+int launch_gn_backward_stats(const float* x1, int C1, const float* x2, int C2, const float* da, int N, int HW, int groups,
+                             const float* mean_rstd, const float* gamma, const float* beta, int act, float* s12_scratch,
+                             float* dgamma, float* dbeta, hipStream_t st);   // k_backward.hip: pass 1 of launch_gn_backward alone
 int launch_blk_sums_finalize(const float* sum_scratch, int N, int C, int H, int W, float* out_nc, int nc_stride, int nc_accumulate,
                              float* out_c, hipStream_t st);
 bool conv_bf16b_eligible(int Cin, int Cout, int H, int W);

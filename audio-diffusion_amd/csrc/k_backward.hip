@@ -559,6 +559,14 @@ int launch_gn_backward(const float* x1, int C1, const float* x2, int C2, const f
              gamma, beta, act, (const float*)s12_scratch, dx1, acc1, dx2, acc2);
   return ADM_CHECK_LAUNCH();
 }
+int launch_gn_backward_stats(const float* x1, int C1, const float* x2, int C2, const float* da, int N, int HW, int groups,
+                             const float* mean_rstd, const float* gamma, const float* beta, int act, float* s12_scratch,
+                             float* dgamma, float* dbeta, hipStream_t st) {
+  if (x2 == nullptr) C2 = 0;
+  ADM_LAUNCH(gn_bwd_stats_kernel, dim3(groups, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd, gamma,
+             beta, act, s12_scratch, dgamma, dbeta);
+  return ADM_CHECK_LAUNCH();
+}
 int launch_attention_bwd(const float* qkv, const float* dout, float* dqkv, int N, int C, int T, int head_dim,
                          hipStream_t st) {
   ADM_REQUIRE(C % head_dim == 0, "attention_bwd: C not divisible by head_dim");

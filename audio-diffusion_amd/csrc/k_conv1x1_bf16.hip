@@ -23,6 +23,9 @@ struct Bf16PwParams {
   const u32x4* wb; const float* bias; int Cout;
   const float* chan_add; int chan_add_stride;
   const float* residual; float* out;
+  // split output (the data gradient of a convolution over a virtual concat): couts [0, split_c) go to out / residual (a tensor of
+  // split_c channels), couts [split_c, Cout) to out2 / residual2 (a tensor of Cout - split_c channels); split_c == Cout: one output
+  const float* residual2; float* out2; int split_c;
   int tiles, n_ct, nblk;
   long x1_bs, x2_bs;
 };
@@ -130,24 +133,44 @@ __global__ void __launch_bounds__(256, 1) conv1x1_bf16_kernel(const Bf16PwParams
     issue(X, ch + 4);
     __syncthreads();
   }
+  // epilogue: a wave's 32 couts x 32 pixels go through 4 KiB of its own in LDS (the operand buffers are dead behind the last
+  // barrier) and come back as float4 per lane — bias, per-sample term, residual and the store are 16-byte operations, one store
+  // instruction = 8 couts x 128 contiguous bytes (round 4: the dword version issued 128 stores per wave; k_conv_bf16b.hip).
+  float* const stage = reinterpret_cast<float*>(lds) + 1024 * wave;
+  const int srow = lane >> 3, scol = 4 * (lane & 7);
   ADM_UNROLL
   for (int a = 0; a < 2; ++a) {
-    float bv[16];
+    const int cb = m0 + 32 * a;                                    // the 32 couts of this sub-tile lie inside one output (launcher)
+    const bool second = cb >= p.split_c;
+    const int Cs = second ? p.Cout - p.split_c : p.split_c;
+    float* const ob = (second ? p.out2 : p.out) + ((long)n * Cs + (cb - (second ? p.split_c : 0))) * T + p0 + 128 * wn + scol;
+    const float* const rb0 = second ? p.residual2 : p.residual;
+    const float* const rb = rb0 ? rb0 + ((long)n * Cs + (cb - (second ? p.split_c : 0))) * T + p0 + 128 * wn + scol : nullptr;
+    float bv[4];
     ADM_UNROLL
-    for (int r = 0; r < 16; ++r) {
-      const int co = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-      bv[r] = p.bias[co] + p.chan_add[(long)n * p.chan_add_stride + co];
+    for (int k = 0; k < 4; ++k) {
+      const int co = cb + srow + 8 * k;
+      bv[k] = p.bias[co] + p.chan_add[(long)n * p.chan_add_stride + co];
     }
     ADM_UNROLL
     for (int pt = 0; pt < 4; ++pt) {
-      const long pix = p0 + 128 * wn + 32 * pt + l31;
       ADM_UNROLL
-      for (int r = 0; r < 16; ++r) {
-        const int co = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const long o = ((long)n * p.Cout + co) * T + pix;
-        float v = acc[a][pt][r] + bv[r];
-        if (p.residual) v += p.residual[o];
-        p.out[o] = v;
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[a][pt][r];
+      ADM_WAVE_LDS_ORDER();
+      float4 sv[4];
+      ADM_UNROLL
+      for (int k = 0; k < 4; ++k) sv[k] = *reinterpret_cast<const float4*>(stage + (srow + 8 * k) * 32 + scol);
+      ADM_WAVE_LDS_ORDER();
+      ADM_UNROLL
+      for (int k = 0; k < 4; ++k) {
+        const long o = (long)(srow + 8 * k) * T + 32 * pt;
+        float4 v = sv[k];
+        v.x += bv[k]; v.y += bv[k]; v.z += bv[k]; v.w += bv[k];
+        if (rb) {
+          const float4 rr = *reinterpret_cast<const float4*>(rb + o);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        *reinterpret_cast<float4*>(ob + o) = v;
       }
     }
   }
@@ -161,7 +184,14 @@ bool conv1x1_bf16_eligible(const adm_conv_args& a) {
          (a.gn_scale != nullptr || !a.act);
 }
 
-int launch_conv1x1_bf16(const adm_conv_args& a, hipStream_t st) {
+int launch_conv1x1_bf16(const adm_conv_args& a, hipStream_t st) { return launch_conv1x1_bf16_split(a, a.Cout, nullptr, nullptr, st); }
+
+// couts [0, split_c) -> a.out (+ a.residual), couts [split_c, Cout) -> out2 (+ residual2): two tensors of split_c and Cout - split_c
+// channels (the two halves of a virtual concat whose gradient this convolution produces); split_c == Cout: the plain call
+int launch_conv1x1_bf16_split(const adm_conv_args& a, int split_c, float* out2, const float* residual2, hipStream_t st) {
+  ADM_REQUIRE(split_c == a.Cout || (out2 != nullptr && split_c > 0 && split_c < a.Cout && split_c % 32 == 0), "conv1x1_bf16: split output");
+  ADM_REQUIRE(((reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.residual) | reinterpret_cast<uintptr_t>(out2) |
+                reinterpret_cast<uintptr_t>(residual2)) & 15) == 0, "conv1x1_bf16: outputs / residuals must be 16-byte aligned");
   Bf16PwParams p;
   const int C2 = a.x2 ? a.C2 : 0, Ct = a.C1 + C2;
   p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2; p.N = a.N; p.T = (long)a.H * a.W;
@@ -173,6 +203,7 @@ int launch_conv1x1_bf16(const adm_conv_args& a, hipStream_t st) {
   if (p.chan_add == nullptr) { p.chan_add = conv_zero_bias(a.Cout); p.chan_add_stride = 0; }
   ADM_REQUIRE(p.gn_scale && p.gn_shift && p.bias && p.chan_add, "conv1x1_bf16: constant buffers");
   p.residual = a.residual; p.out = a.out;
+  p.residual2 = residual2; p.out2 = out2; p.split_c = split_c;
   p.tiles = (int)(p.T / 256); p.n_ct = a.Cout / 128;
   p.nblk = p.tiles * a.N * p.n_ct;
   p.x1_bs = a.x1_bstride ? a.x1_bstride : (long)a.C1 * p.T;

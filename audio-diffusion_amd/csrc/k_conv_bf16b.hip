@@ -39,13 +39,19 @@ struct BlkApplyParams {
   int act;
   u32x4* out; int Hp, Wp;
   float* part;                       // optional: per-(n, c, workgroup) sums of the INPUT ([n][c][gridDim.x], blk_sums_finalize_kernel)
+  // GNBWD kernels: the "input" of the pass is computed, not loaded — dx of GroupNorm (+ SiLU) backward, pass 2 (k_backward.hip
+  // gn_bwd_apply_kernel): x1 = the GroupNorm input, gda = dL/d(activated tensor), per-(n, group) mean / rstd and s1 / s2
+  const float* gda; const float* g_mean_rstd; const float* g_gamma; const float* g_beta; const float* g_s12; int g_groups, g_act;
   int zins;                          // 1 / 2: the image has (2H, 2W) pixels and source pixel (y, x) lands on pixel (2y + 1, 2x + 1) / (2y, 2x), the
                                      // rest stays zero (the zero-inserted dy of a stride-2 convolution with pad (0,1,0,1) / pad 1, see below)
 };
 
 // One thread = 8 channels x 4 consecutive pixels: eight float4 row loads (a wave reads 1 KiB of ONE channel row per
 // instruction), affine + SiLU + rounding, four 16-byte units stored back to back (a wave writes 4 KiB contiguous).
-template <bool F16>
+// GNBWD: the image of dy for a convolution whose OUTPUT is read by nothing but a GroupNorm (+ SiLU) + convolution (conv1 of a resnet):
+// its dy IS the dx of that GroupNorm's backward, so pass 2 of the backward writes the 16-bit image (and the channel sums) directly —
+// the fp32 dx tensor and the image pass over it disappear.  Same arithmetic as gn_bwd_apply_kernel: rstd * (g * gamma - s1 - xhat * s2).
+template <bool F16, bool GNBWD = false>
 __global__ void __launch_bounds__(256) blk_apply_kernel(const BlkApplyParams p) {
   const int cg = blockIdx.y, n = blockIdx.z;
   const int W4 = p.W >> 2;
@@ -58,6 +64,28 @@ __global__ void __launch_bounds__(256) blk_apply_kernel(const BlkApplyParams p) 
   float4 v[8];
   ADM_UNROLL
   for (int e = 0; e < 8; ++e) v[e] = live ? *reinterpret_cast<const float4*>(src + (long)e * HW + (long)y * p.W + 4 * x4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (GNBWD) {
+    const float* dsrc = p.gda + ((long)n * p.C1 + c0) * HW;
+    const int cpg = p.C1 / p.g_groups;
+    ADM_UNROLL
+    for (int e = 0; e < 8; ++e) {
+      const float4 dv = live ? *reinterpret_cast<const float4*>(dsrc + (long)e * HW + (long)y * p.W + 4 * x4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int g = (c0 + e) / cpg;
+      const float mean = p.g_mean_rstd[((long)n * p.g_groups + g) * 2], rstd = p.g_mean_rstd[((long)n * p.g_groups + g) * 2 + 1];
+      const float s1 = p.g_s12[((long)n * p.g_groups + g) * 2], s2 = p.g_s12[((long)n * p.g_groups + g) * 2 + 1];
+      const float gm = p.g_gamma[c0 + e], bt = p.g_beta[c0 + e];
+      const float xe[4] = {v[e].x, v[e].y, v[e].z, v[e].w}, de[4] = {dv.x, dv.y, dv.z, dv.w};
+      float r[4];
+      ADM_UNROLL
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (xe[k] - mean) * rstd;
+        float gy = de[k];
+        if (p.g_act) { const float yv = xh * gm + bt, sg = ADM_RCP(1.0f + __expf(-yv)); gy *= sg * (1.0f + yv * (1.0f - sg)); }
+        r[k] = live ? rstd * (gy * gm - s1 - xh * s2) : 0.f;
+      }
+      v[e] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+  }
   if (p.part != nullptr) {
     // bias gradient of the producing layer folded into the pass that reads dy anyway: per-thread sums of the four pixels, a
     // fixed 64-lane shuffle tree, the four waves in order — one partial per (n, channel, workgroup); blk_sums_finalize_kernel
@@ -157,12 +185,30 @@ int launch_blk_apply(const float* x1, int C1, long x1_bs, const float* x2, int C
   p.N = N; p.H = H; p.W = W; p.scale = scale; p.shift = shift; p.nstride = C1 + p.C2; p.act = act;
   p.out = reinterpret_cast<u32x4*>(out); p.Hp = (zins ? 2 * H : H) + 2; p.Wp = (zins ? 2 * W : W) + 2;
   p.part = sum_scratch; p.zins = zins;
+  p.gda = nullptr; p.g_mean_rstd = p.g_gamma = p.g_beta = p.g_s12 = nullptr; p.g_groups = 1; p.g_act = 0;
   ADM_REQUIRE((scale != nullptr) == (shift != nullptr), "blk_apply: scale and shift come together");
   ADM_REQUIRE((reinterpret_cast<uintptr_t>(x1) & 15) == 0 && (x2 == nullptr || (reinterpret_cast<uintptr_t>(x2) & 15) == 0),
               "blk_apply: inputs must be 16-byte aligned");
   const dim3 grid((unsigned)ceil_div(H * (W / 4), 256), (unsigned)((C1 + p.C2) / 8), (unsigned)N);
-  if (conv_op16_f16()) ADM_LAUNCH(blk_apply_kernel<true>, grid, dim3(256), 0, st, p);
-  else ADM_LAUNCH(blk_apply_kernel<false>, grid, dim3(256), 0, st, p);
+  if (conv_op16_f16()) ADM_LAUNCH((blk_apply_kernel<true, false>), grid, dim3(256), 0, st, p);
+  else ADM_LAUNCH((blk_apply_kernel<false, false>), grid, dim3(256), 0, st, p);
+  return ADM_CHECK_LAUNCH();
+}
+
+// pass 2 of GroupNorm (+ SiLU) backward writing the blocked 16-bit image of dx (and its channel sums) instead of the fp32 tensor
+int launch_blk_gn_bwd_image(const float* x, int C, const float* da, int N, int H, int W, int groups, const float* mean_rstd,
+                            const float* gamma, const float* beta, int act, const float* s12, void* out, float* sum_scratch,
+                            hipStream_t st) {
+  ADM_REQUIRE(blk_apply_eligible(C, 0, H, W) && C % groups == 0, "blk_gn_bwd_image: C % 8, W % 4, C % groups");
+  ADM_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(da)) & 15) == 0, "blk_gn_bwd_image: inputs must be 16-byte aligned");
+  BlkApplyParams p;
+  p.x1 = x; p.x2 = nullptr; p.C1 = C; p.C2 = 0; p.x1_bs = (long)C * H * W; p.x2_bs = 0;
+  p.N = N; p.H = H; p.W = W; p.scale = p.shift = nullptr; p.nstride = C; p.act = 0;
+  p.out = reinterpret_cast<u32x4*>(out); p.Hp = H + 2; p.Wp = W + 2; p.part = sum_scratch; p.zins = 0;
+  p.gda = da; p.g_mean_rstd = mean_rstd; p.g_gamma = gamma; p.g_beta = beta; p.g_s12 = s12; p.g_groups = groups; p.g_act = act;
+  const dim3 grid((unsigned)ceil_div(H * (W / 4), 256), (unsigned)(C / 8), (unsigned)N);
+  if (conv_op16_f16()) ADM_LAUNCH((blk_apply_kernel<true, true>), grid, dim3(256), 0, st, p);
+  else ADM_LAUNCH((blk_apply_kernel<false, true>), grid, dim3(256), 0, st, p);
   return ADM_CHECK_LAUNCH();
 }
 

@@ -144,7 +144,9 @@ struct Net {
   // level 3 of option conv_bf16 (training nets; k_conv_bf16b.hip): per 3x3 stride-1 convolution the blocked 16-bit image of
   // its activated input (written once by the forward pass, read by the forward and the weight-gradient kernel) and the
   // blocked image of its output gradient (one buffer per distinct (Cout, H, W): the zero halo belongs to the geometry)
-  struct BlkOp { void* xa = nullptr; void* dyb = nullptr; bool fwd = false, wg = false, dg = false, s2 = false; };   // s2: Downsample2D.conv
+  // s2: Downsample2D.conv; img_for: this op's GroupNorm backward writes the dy image of op `img_for` directly (its input is that
+  // convolution's output and nothing else reads it), -1: none; img_done: set by that pass for the producer during a reverse walk
+  struct BlkOp { void* xa = nullptr; void* dyb = nullptr; bool fwd = false, wg = false, dg = false, s2 = false; int img_for = -1; bool img_done = false; };
   std::vector<BlkOp> blk;            // indexed like ops; empty below level 3 / for inference
   float* blk_part = nullptr;         // per-workgroup channel sums of the dy image pass (bias gradients)
   float *tmp_da = nullptr, *wgrad_ws = nullptr, *s12 = nullptr, *tmp_w = nullptr;

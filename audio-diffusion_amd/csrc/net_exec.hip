@@ -215,6 +215,12 @@ void Net::mark_ready(const float* master_param, size_t numel) {
     if (lo < bk_lo[b + 1] && hi > bk_lo[b] && --bk_pending[b] == 0) bk_fn(bk_user, (int)b);
 }
 
+static int g_blk_direct_dy = -1;    // -1: ADM_BLK_DIRECT_DY from the environment (default 1); read at plan time
+void set_blk_direct_dy(int v) { g_blk_direct_dy = v; }
+static bool blk_direct_dy() {
+  if (g_blk_direct_dy < 0) { const char* e = getenv("ADM_BLK_DIRECT_DY"); g_blk_direct_dy = e ? atoi(e) : 1; }
+  return g_blk_direct_dy != 0;
+}
 static std::atomic<unsigned> g_dispatch_epoch{1};
 void bump_dispatch_epoch() { g_dispatch_epoch.fetch_add(1); }
 unsigned dispatch_epoch() { return g_dispatch_epoch.load(); }
@@ -621,6 +627,28 @@ int Net::plan(int B) {
           }
         }
       }
+      // conv1 of a resnet: its output feeds one GroupNorm (+ SiLU) + convolution and nothing else, so its dy is that GroupNorm's dx —
+      // the consumer's backward writes the 16-bit image (and the channel sums) straight away (launch_blk_gn_bwd_image)
+      if (blk_direct_dy()) {
+        std::vector<int> producer(tensors.size(), -1), readers(tensors.size(), 0);
+        for (size_t i = 0; i < ops.size(); ++i) {
+          const Op& o = ops[i];
+          if (o.out >= 0) producer[o.out] = (int)i;
+          if (o.kind == Op::GN) continue;                       // the statistics op of the consuming convolution is not a reader of its own
+          for (int t : {o.in1, o.in2, o.res, o.wt}) if (t >= 0) ++readers[t];
+        }
+        for (size_t i = 0; i < ops.size(); ++i) {
+          const Op& o = ops[i];
+          if (o.kind != Op::CONV || o.gn < 0 || o.in2 >= 0 || o.up || o.in1_C != 0 || o.wt >= 0) continue;
+          const int t = o.in1, pi = producer[t];
+          if (pi < 0 || readers[t] != 1 || tensors[t].external || t == t_in || t == t_out) continue;
+          const Op& po = ops[pi];
+          const BlkOp& pb = blk[pi];
+          if (po.kind != Op::CONV || !pb.wg || !pb.dg || pb.s2 || po.up || po.res >= 0 || po.w == nullptr || !po.w->qkv_prefix.empty()) continue;
+          if (tensors[t].C % groups != 0 || tensors[t].C <= 4) continue;
+          blk[i].img_for = pi;
+        }
+      }
       // GroupNorm statistics from the producing convolution's epilogue (as the inference plan does): tensors a blocked forward
       // kernel writes and some GroupNorm reads get per-tile partial sums; the read pass (gn_stats_kernel) disappears for them
       static const int fold_t = [] { const char* e = getenv("ADM_GN_FOLD_TRAIN"); return e ? atoi(e) : 1; }();
@@ -777,6 +805,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
   ADM_REQUIRE(training && params_base && grads_base, "run_backward: training mode is not enabled");
   for (Tensor& t : tensors) t.ginit = false;
   tensors[t_out].ginit = true;
+  for (BlkOp& b : blk) b.img_done = false;
   auto contribute = [&](int t, const float* src, long src_bs, int C) -> int {
     Tensor& tt = tensors[t];
     if (t == t_in) return 0;
@@ -862,7 +891,9 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
     if (qkv) ADM_TRY(dmemset(dbias, 0, sizeof(float) * Cout, st));
     const BlkOp* bo = (conv_bf16_mode() >= 3 && (size_t)i < blk.size() && (blk[i].wg || blk[i].dg)) ? &blk[i] : nullptr;
     float* dtemb_o = (o.temb_off >= 0 && dtemb_all) ? dtemb_all + o.temb_off : nullptr;
-    if (bo) {    // level 3: dy once as a blocked 16-bit image for the weight-gradient and the data-gradient kernel; the pass
+    if (bo && bo->img_done) {
+      // the consumer's GroupNorm backward has written this convolution's dy image and its channel sums already
+    } else if (bo) {    // level 3: dy once as a blocked 16-bit image for the weight-gradient and the data-gradient kernel; the pass
                  // also leaves the channel sums that adm_chan_sums would read dy a second time for
       ADM_TRY(launch_blk_apply(dy, Cout, 0, nullptr, 0, 0, B, to.H, to.W, nullptr, nullptr, 0, bo->dyb, blk_part, st, bo->s2 ? (o.pad_lo ? 2 : 1) : 0));
       ADM_TRY(launch_blk_sums_finalize(blk_part, B, Cout, to.H, to.W, dtemb_o, temb_stride, 0, dbias, st));
@@ -925,6 +956,19 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
         ADM_REQUIRE(tmp_da_floats >= (size_t)B * Ct * Hi * Wi, "run_backward: scratch too small");
         a.out = tmp_da;
       }
+      if (o.ks == 1 && o.in2 >= 0 && o.gn < 0 && !o.up && conv_bf16_mode() >= 2 && C1 % 32 == 0 && a.bf16_packed != nullptr) {
+        // 1x1 convolution over a virtual concat (the shortcuts of the up blocks): its data gradient goes straight into the two source
+        // tensors' gradient buffers (each written or accumulated in the epilogue) instead of a scratch tensor + two fan-in passes
+        adm_conv_args a2 = a;
+        Tensor& t2 = tensors[o.in2];
+        a2.out = t1.grad; a2.residual = t1.ginit ? t1.grad : nullptr;
+        if (conv1x1_bf16_eligible(a2) && o.in1 != t_in && o.in2 != t_in) {
+          ADM_TRY(launch_conv1x1_bf16_split(a2, C1, t2.grad, t2.ginit ? t2.grad : nullptr, st));
+          ADM_TRY(note_packing(*o.w, PK_WBT));
+          t1.ginit = true; t2.ginit = true;
+          continue;
+        }
+      }
       if (bo && bo->dg)      // (stride 2: the zero-inserted dy image has the INPUT's dims; the kernel is the plain stride-1 one)
         ADM_TRY(launch_conv_bf16b(bo->dyb, Cout, B, bo->s2 ? t1.H : to.H, bo->s2 ? t1.W : to.W, o.w->wbT, Ct, nullptr, nullptr, 0, a.residual,
                                   a.out, st));
@@ -938,6 +982,18 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       ADM_REQUIRE(!o.up, "run_backward: GroupNorm + upsample in one conv is not supported");
       const GnBuf& gb = gnbufs[o.gn];
       Tensor* t2 = o.in2 >= 0 ? &tensors[o.in2] : nullptr;
+      const int pi = (conv_bf16_mode() >= 3 && (size_t)i < blk.size()) ? blk[i].img_for : -1;
+      if (pi >= 0 && !t1.ginit) {
+        const Op& po = ops[pi];
+        ADM_TRY(launch_gn_backward_stats(t1.ptr, C1, nullptr, 0, tmp_da, B, (int)plane_i, groups, gb.mean_rstd, gb.g->gamma, gb.g->beta, o.act,
+                                         s12, grad_of(gb.g->gamma), grad_of(gb.g->beta), st));
+        ADM_TRY(launch_blk_gn_bwd_image(t1.ptr, C1, tmp_da, B, t1.H, t1.W, groups, gb.mean_rstd, gb.g->gamma, gb.g->beta, o.act, s12,
+                                        blk[pi].dyb, blk_part, st));
+        float* pdb = po.w->has_bias ? grad_of(ps->P(po.w->key + ".bias")) : nullptr;
+        ADM_TRY(launch_blk_sums_finalize(blk_part, B, C1, t1.H, t1.W, (po.temb_off >= 0 && dtemb_all) ? dtemb_all + po.temb_off : nullptr,
+                                         temb_stride, 0, pdb, st));
+        blk[pi].img_done = true;
+      } else
       ADM_TRY(launch_gn_backward(t1.ptr, C1, x2, C2, tmp_da, B, (int)plane_i, groups, gb.mean_rstd, gb.g->gamma, gb.g->beta,
                                  o.act, s12, grad_of(gb.g->gamma), grad_of(gb.g->beta), t1.grad, t1.ginit ? 1 : 0,
                                  t2 ? t2->grad : nullptr, (t2 && t2->ginit) ? 1 : 0, st));

@@ -39,7 +39,9 @@ int adm_has_experiments(void);
  *   and stride-2 data gradients, 0 = fp32 everywhere (default), -1 = back to the ADM_CONV_BF16 environment variable;
  *   3 (round 4; what `enable_training(mixed_precision=...)` selects) = 2, with the 3x3 stride-1 convolutions of all three passes on
  *   blocked 16-bit operand images (adm_blocked_apply / adm_conv2d_bf16_blocked / adm_conv2d_wgrad_bf16_blocked below);
- * "conv_op16_f16" = 1 makes those kernels' operand format IEEE binary16 instead of bf16 (`--mixed_precision fp16`).
+ * "conv_op16_f16" = 1 makes those kernels' operand format IEEE binary16 instead of bf16 (`--mixed_precision fp16`);
+ * "blk_direct_dy" = 1 (default; level 3, read when a training plan is made) the backward of a GroupNorm whose input is read by nothing
+ *   else writes the producing convolution's dy image directly | 0 fp32 dx tensor + image pass (bit-identical results) | -1 ADM_BLK_DIRECT_DY.
  * The dispatch epoch moves only when a value really changes; set options BEFORE adm_unet_refresh_weights / the next train step.
  * adm_version() = 101 since round 4 (adm_slerp_grid takes DOUBLE weights since round 3; blocked-image entry points). */
 int adm_set_option(const char* name, int value);

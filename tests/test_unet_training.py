@@ -372,6 +372,14 @@ def test_mixed_precision_bf16_level3_blocked_operand_images(backend, monkeypatch
     # (level 3 also puts the stride-2 forward and weight gradient on 16-bit operands, which level 2 keeps fp32: 6e-3 apart, measured)
     assert rel(g3, g2) < 1e-2 and abs(e3 - e2) < 3e-3, (rel(g3, g2), e3, e2)
     assert float((g3 - g2).abs().max()) > 0          # another kernel family really ran
+    # conv1's dy image written directly by the GroupNorm backward of its only reader vs the fp32 dx tensor + image pass: the same bits
+    _native.check(_native.lib().adm_set_option(b"blk_direct_dy", 0))
+    try:
+        l3t, g3t = native(3)
+    finally:
+        _native.check(_native.lib().adm_set_option(b"blk_direct_dy", -1))
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+    assert l3t == l3 and torch.equal(g3, g3t)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
