@@ -161,7 +161,7 @@ bool blk_apply_eligible(int C1, int C2, int H, int W) { return C1 % 8 == 0 && C2
 
 // out_nc[n * nc_stride + c] (= | +=) sum over the workgroup partials (NULL ok); out_c[c] += the same over n (atomic; NULL ok)
 __global__ void __launch_bounds__(256) blk_sums_finalize_kernel(const float* __restrict__ part, int C, int nbx, float* out_nc,
-                                                               int nc_stride, int nc_accumulate, float* out_c) {
+                                                               int nc_stride, int nc_accumulate, float* out_c, float* out_c2) {
   const int c = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
   if (c >= C) return;
   const float* q = part + ((long)n * C + c) * nbx;
@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(256) blk_sums_finalize_kernel(const float* __r
     *o = nc_accumulate ? *o + (float)sm : (float)sm;
   }
   if (out_c) atomicAdd(out_c + c, (float)sm);
+  if (out_c2) atomicAdd(out_c2 + c, (float)sm);      // a second bias that sees the same dy (the shortcut convolution of a resnet)
 }
 
 long blk_sums_scratch(int N, int C, int H, int W) { return (long)N * C * ceil_div(H * (W / 4), 256); }
@@ -214,10 +215,10 @@ int launch_blk_gn_bwd_image(const float* x, int C, const float* da, int N, int H
 
 // the sums blk_apply left in sum_scratch -> per-(n, c) sums (written, or added with nc_accumulate) and per-c sums (ADDED)
 int launch_blk_sums_finalize(const float* sum_scratch, int N, int C, int H, int W, float* out_nc, int nc_stride, int nc_accumulate,
-                             float* out_c, hipStream_t st) {
-  if (out_nc == nullptr && out_c == nullptr) return 0;
+                             float* out_c, hipStream_t st, float* out_c2) {
+  if (out_nc == nullptr && out_c == nullptr && out_c2 == nullptr) return 0;
   ADM_LAUNCH(blk_sums_finalize_kernel, dim3((unsigned)ceil_div(C, 256), (unsigned)N), dim3(256), 0, st, sum_scratch, C,
-             ceil_div(H * (W / 4), 256), out_nc, nc_stride, nc_accumulate, out_c);
+             ceil_div(H * (W / 4), 256), out_nc, nc_stride, nc_accumulate, out_c, out_c2);
   return ADM_CHECK_LAUNCH();
 }
 

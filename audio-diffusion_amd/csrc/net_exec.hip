@@ -629,6 +629,9 @@ int Net::plan(int B) {
       }
       // conv1 of a resnet: its output feeds one GroupNorm (+ SiLU) + convolution and nothing else, so its dy is that GroupNorm's dx —
       // the consumer's backward writes the 16-bit image (and the channel sums) straight away (launch_blk_gn_bwd_image)
+      producer_of.assign(tensors.size(), -1);
+      for (size_t i = 0; i < ops.size(); ++i)
+        if (ops[i].out >= 0) producer_of[ops[i].out] = (int)i;
       if (blk_direct_dy()) {
         std::vector<int> producer(tensors.size(), -1), readers(tensors.size(), 0);
         for (size_t i = 0; i < ops.size(); ++i) {
@@ -806,6 +809,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
   for (Tensor& t : tensors) t.ginit = false;
   tensors[t_out].ginit = true;
   for (BlkOp& b : blk) b.img_done = false;
+  bias_done.assign(ops.size(), 0);
   auto contribute = [&](int t, const float* src, long src_bs, int C) -> int {
     Tensor& tt = tensors[t];
     if (t == t_in) return 0;
@@ -872,6 +876,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
     const float* x2 = o.in2 >= 0 ? tensors[o.in2].ptr : nullptr;
     const bool qkv = !o.w->qkv_prefix.empty();
     // ---- residual fan-in --------------------------------------------------------------------------------
+    bool res_swapped = false;
     if (o.res >= 0) {
       Tensor& tr = tensors[o.res];
       if (o.res != t_in && !tr.ginit && !tr.external && !to.external && o.out != t_out && tr.C == Cout && tr.H == to.H && tr.W == to.W) {
@@ -881,6 +886,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
         // tensor's gradient is dead after this op (its consumers ran earlier in the reverse walk)
         std::swap(tr.grad, to.grad);
         tr.ginit = true;
+        res_swapped = true;
       } else {
         ADM_TRY(contribute(o.res, dy, (long)Cout * plane_o, Cout));
       }
@@ -891,12 +897,28 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
     if (qkv) ADM_TRY(dmemset(dbias, 0, sizeof(float) * Cout, st));
     const BlkOp* bo = (conv_bf16_mode() >= 3 && (size_t)i < blk.size() && (blk[i].wg || blk[i].dg)) ? &blk[i] : nullptr;
     float* dtemb_o = (o.temb_off >= 0 && dtemb_all) ? dtemb_all + o.temb_off : nullptr;
-    if (bo && bo->img_done) {
+    // the shortcut convolution of this resnet (the producer of the residual) sees the SAME dy — the buffer has just been handed to
+    // its output's gradient and nothing else adds to it — so its bias gradient is this convolution's channel sums: second target
+    float* dbias_sc = nullptr;
+    if (res_swapped && (size_t)o.res < producer_of.size() && producer_of[o.res] >= 0) {
+      const int ri = producer_of[o.res];
+      const Op& ro = ops[ri];
+      const bool r_blocked = (size_t)ri < blk.size() && (blk[ri].wg || blk[ri].dg);
+      if (ro.kind == Op::CONV && ro.wt < 0 && ro.w && ro.w->has_bias && ro.w->qkv_prefix.empty() && ro.temb_off < 0 && !r_blocked &&
+          ro.w->Cout == Cout && ri < i) {
+        dbias_sc = grad_of(ps->P(ro.w->key + ".bias"));
+        if (!(conv_bf16_mode() >= 3 && (size_t)i < blk.size() && (blk[i].wg || blk[i].dg) && !blk[i].img_done)) dbias_sc = nullptr;
+        if (dbias_sc) bias_done[ri] = 1;
+      }
+    }
+    if (bias_done[i]) {
+      // (this convolution's bias gradient has been added with its resnet's conv2 channel sums)
+    } else if (bo && bo->img_done) {
       // the consumer's GroupNorm backward has written this convolution's dy image and its channel sums already
     } else if (bo) {    // level 3: dy once as a blocked 16-bit image for the weight-gradient and the data-gradient kernel; the pass
                  // also leaves the channel sums that adm_chan_sums would read dy a second time for
       ADM_TRY(launch_blk_apply(dy, Cout, 0, nullptr, 0, 0, B, to.H, to.W, nullptr, nullptr, 0, bo->dyb, blk_part, st, bo->s2 ? (o.pad_lo ? 2 : 1) : 0));
-      ADM_TRY(launch_blk_sums_finalize(blk_part, B, Cout, to.H, to.W, dtemb_o, temb_stride, 0, dbias, st));
+      ADM_TRY(launch_blk_sums_finalize(blk_part, B, Cout, to.H, to.W, dtemb_o, temb_stride, 0, dbias, st, dbias_sc));
     } else {
       ADM_TRY(launch_chan_sums(dy, B, Cout, (int)plane_o, dtemb_o, temb_stride, 0, dbias, st));
     }
