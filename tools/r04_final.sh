@@ -15,5 +15,5 @@ find $R/$O -name "*.db" -delete
 cd $R
 bash tools/pmc_forward.sh $T/pmc r04 2>&1 | tail -25 > $O/pmc.txt
 PROBE_MP=bf16 bash tools/profile_train_trace.sh $T/train > $O/train_trace.txt 2>&1
-sed -i "s#^O=r04b#O=$T/blk#" tools/r04_trace.sh 2>/dev/null
-cat $O/pytest_gpu.txt; tail -1 $O/smoke.txt; cut -c1-300 $O/bench_line.json; tail -3 $O/bench_err.txt; tail -3 $O/train_trace.txt
+SKIP_TRACE=1 bash tools/r04_trace.sh $T/blk > $O/blk_pmc.txt 2>&1
+cat $O/pytest_gpu.txt; tail -1 $O/smoke.txt; tail -12 $O/blk_pmc.txt; cut -c1-300 $O/bench_line.json; tail -3 $O/bench_err.txt; tail -3 $O/train_trace.txt

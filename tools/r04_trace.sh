@@ -1,9 +1,11 @@
 # Round 4: kernel trace of the level-3 bf16 training step + PMC passes on the blocked-image kernels (128->128 @256^2, B = 16)
 R=$GRAFT_REPO_ROOT
-O=r04b
+O=${1:-r04b}
 mkdir -p $R/gpurun_out/$O
+if [ "${SKIP_TRACE:-0}" != "1" ]; then
 ADM_BF16_LEVEL=3 PROBE_MP=bf16 bash $R/tools/profile_train_trace.sh $O/trace > $R/gpurun_out/$O/trace_head.txt 2>&1
 head -45 $R/gpurun_out/$O/trace/train_kernel_stats.txt | cut -c1-170
+fi
 cd /tmp && export TMPDIR=/tmp
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE" "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
   tag=$(echo $pass | cut -d' ' -f1)
