@@ -700,27 +700,44 @@ __global__ void __launch_bounds__(256) ksplit_finish1_kernel(const float* __rest
 // scratch for the split-K partial slabs, one buffer per (device, stream): launches on one stream are ordered, two streams must
 // not share it. Grown only outside stream capture (the executors run one uncaptured forward before they capture), geometrically,
 // and the superseded buffer is freed once the stream has drained (it used to be leaked on every growth).
-// nullptr = it cannot be provided (capture in progress and the buffer too small, more than 8 streams per device, out of memory):
+// When more than 8 streams have used one device the least recently used slot is taken over (after a device sync).
+// nullptr = it cannot be provided (capture in progress and the buffer too small / no slot, out of memory):
 // the callers FAIL the launch — the unsplit kernel sums in another fp32 order, and a row's bits must not depend on such things.
 static float* ksplit_scratch(size_t floats, hipStream_t st) {
-  struct Slot { hipStream_t st; float* buf; size_t cap; bool used; };
+  struct Slot { hipStream_t st; float* buf; size_t cap; bool used; unsigned long long tick; };
   static Slot slots[16][8] = {};
+  static unsigned long long clock_ = 0;
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
   const int d = conv_dev_slot();
+  bool capturing = false;
+#if !defined(ADM_EMU)
+  {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+  }
+#endif
   Slot* sl = nullptr;
   for (Slot& s : slots[d]) if (s.used && s.st == st) { sl = &s; break; }
   if (sl == nullptr)
     for (Slot& s : slots[d]) if (!s.used) { sl = &s; sl->used = true; sl->st = st; sl->buf = nullptr; sl->cap = 0; break; }
-  if (sl == nullptr) { set_error("split-K scratch: more than 8 streams on one device"); return nullptr; }
-  if (floats <= sl->cap) return sl->buf;
+  if (sl == nullptr) {
+    // every slot belongs to some other stream (a long-lived process that has used many streams: their handles may be long gone):
+    // take over the least recently used one. Its buffer may still be read by launches queued on its stream -> drain the device first.
+    if (capturing) { set_error("split-K scratch: no free slot for this stream during stream capture (run one uncaptured pass first)"); return nullptr; }
+    for (Slot& s : slots[d]) if (sl == nullptr || s.tick < sl->tick) sl = &s;
 #if !defined(ADM_EMU)
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipDeviceSynchronize();
+#endif
+    if (sl->buf) dfree(sl->buf);
+    sl->st = st; sl->buf = nullptr; sl->cap = 0;
+  }
+  sl->tick = ++clock_;
+  if (floats <= sl->cap) return sl->buf;
+  if (capturing) {
     set_error("split-K scratch must grow during stream capture: run one uncaptured pass at this batch size first");
     return nullptr;
   }
-#endif
   size_t want = floats < ((size_t)8 << 20) ? ((size_t)8 << 20) : floats;      // >= 32 MiB
   if (want < 2 * sl->cap) want = 2 * sl->cap;
   void* q = nullptr;
