@@ -53,6 +53,16 @@ void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho
 // 1000 + ... for the direct small-channel kernels (profiling only).
 int last_conv_variant();
 void set_last_conv_variant(int v);
+// GroupNorm of a convolution's OUTPUT folded into its split-K finish pass (k_groupnorm.hip: ksplit_finish_gn_kernel). The executor
+// announces the GroupNorm that reads the tensor before launch_conv2d (request), the split-K launchers honour it when they can
+// (pending -> launch_ksplit_finish_gn) and the executor then skips its statistics launch (taken). Thread-local like the variant.
+struct GnFuse { const float* gamma; const float* beta; float eps; int groups; float* scale; float* shift; float* mean_rstd; };
+void conv_gn_fuse_request(const GnFuse* f);            // nullptr clears
+bool conv_gn_fuse_taken();
+void set_gn_fuse_finish(int v);                         // option "gn_fuse_finish" (c_api.hip)
+const GnFuse* conv_gn_fuse_pending(int Cout);          // the request if this output (Cout channels) can take it, else nullptr
+int launch_ksplit_finish_gn(const float* part, int S, long part_stride, const float* bias, const float* chan_add, int chan_add_stride,
+                            const float* residual, float* out, int N, int Cout, int HW, const GnFuse& f, hipStream_t st);
 
 // k_conv_wino.hip
 const float* conv_zero_bias(int n);  // shared all-zero device buffer of >= n floats (k_conv_mfma.hip)

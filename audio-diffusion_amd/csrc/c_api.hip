@@ -20,7 +20,7 @@ const char* adm_last_error(void) { return adm::last_error(); }
 int adm_set_option(const char* name, int value) {
   ADM_REQUIRE(name, "set_option: null name");
   const std::string nm(name);
-  static const char* known[] = {"conv_wino", "wino_pair", "wgrad_max_split", "conv_bf16", "conv_op16_f16", "blk_direct_dy"};
+  static const char* known[] = {"conv_wino", "wino_pair", "wgrad_max_split", "conv_bf16", "conv_op16_f16", "blk_direct_dy", "gn_fuse_finish"};
   bool ok = false;
   for (const char* k : known) ok |= nm == k;
   if (!ok) ADM_FAIL(std::string("set_option: unknown option ") + name);
@@ -45,6 +45,7 @@ int adm_set_option(const char* name, int value) {
   if (nm == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
   if (nm == "conv_bf16") { adm::set_conv_bf16(value); return 0; }
   if (nm == "conv_op16_f16") { adm::set_conv_op16_f16(value); return 0; }
+  if (nm == "gn_fuse_finish") { adm::set_gn_fuse_finish(value); return 0; }
   adm::set_blk_direct_dy(value);
   return 0;
 }

@@ -668,6 +668,7 @@ __global__ void __launch_bounds__(256) ksplit_finish_kernel(const float* __restr
     float b = bias[co];
     if (chan_add != nullptr) b += chan_add[(long)n * chan_add_stride + co];
     float4 v = *reinterpret_cast<const float4*>(part + e);
+#pragma unroll 8
     for (int s2 = 1; s2 < S; ++s2) {
       const float4 q = *reinterpret_cast<const float4*>(part + (long)s2 * part_stride + e);
       v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
@@ -690,6 +691,7 @@ __global__ void __launch_bounds__(256) ksplit_finish1_kernel(const float* __rest
     const long nc = e / HW;
     const int co = (int)(nc % Cout), n = (int)(nc / Cout);
     float v = part[e];
+#pragma unroll 8
     for (int s2 = 1; s2 < S; ++s2) v += part[(long)s2 * part_stride + e];
     v += chan_add != nullptr ? bias[co] + chan_add[(long)n * chan_add_stride + co] : bias[co];
     if (residual != nullptr) v += residual[e];
@@ -789,6 +791,8 @@ static int launch_ksplit(const ConvParams& p, int bm, int S, hipStream_t st) {
     allow_big_lds(conv_mfma_pf_kernel<KS, 1, 1, true>, smem);
     ADM_LAUNCH((conv_mfma_pf_kernel<KS, 1, 1, true>), dim3(q.nblk), dim3(256), smem, st, q);
   }
+  if (const GnFuse* f = conv_gn_fuse_pending(p.Cout))
+    return launch_ksplit_finish_gn(scratch, S, total, p.bias, p.chan_add, p.chan_add_stride, p.residual, p.out, p.N, p.Cout, p.Ho * p.Wo, *f, st);
   long g = (total / 4 + 255) / 256;
   if (g > 4096) g = 4096;
   ADM_LAUNCH(ksplit_finish_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)scratch, S, total, p.bias, p.chan_add,
@@ -811,7 +815,10 @@ static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
   // random-weight sampler amplifies to different images — strong scaling would not have reproduced weak scaling's pictures).
   if (KS == 3 && use_ksp && p.Ho * p.Wo <= 64 && nch >= 16 && p.wp_bs == 0 && total % 4 == 0) {
     const int bm2 = p.Cout % 64 == 0 ? 64 : 32;
-    int S = 4;     // measured at B = 32 (the bench batch): 14 layers 1.54 ms with 4 parts, 1.90 ms with 8 (twice the slab traffic)
+    // 512+ input channels (the 8x8 level of the 256x256 model), measured at B = 32 (the bench batch): 14 layers 1.54 ms with 4
+    // parts, 1.90 ms with 8 (twice the slab traffic). Up to 384 channels (the 8x8 levels of the 64x64 and latent 32x32 models, whose
+    // batches are 1..16 images: 16..128 workgroups with 4 parts): 8 parts, -85 us per config-4 step, -70 us per config-1 step.
+    int S = nch <= 48 ? 8 : 4;
     while (S > 1 && nch / S < 4) --S;
     if (S > 1) {
       const int rc = launch_ksplit<KS>(p, bm2, S, st);
@@ -845,6 +852,8 @@ static int launch_ksplit_generic(const ConvParams& p, hipStream_t st) {
   // fixes the fp32 summation order, and a sample's result must not depend on how many samples share its launch (rows sampled
   // alone, in another batch or on another number of GPUs are bit-identical; tests/test_full_size.py, tests/test_distributed.py).
   if (!use_ksp || p.wp_bs != 0 || nch < 8 || HWo > 64) return 1;
+  // (64-cout tiles = twice the workgroups, two per CU: measured SLOWER in the latency regime, 3.85 vs 3.50 ms per config-4 step —
+  // every workgroup of a tile row stages the same patch)
   const int bm = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
   int S = HWo <= 4 ? 64 : (HWo <= 16 ? 32 : 8);
   if (S > nch / 2) S = nch / 2;
@@ -886,6 +895,9 @@ static int launch_ksplit_generic(const ConvParams& p, hipStream_t st) {
     ADM_LAUNCH((conv_mfma_kernel<KS, STRIDE, 1, 1, true>), dim3(q.nblk), dim3(256), smem, st, q);
   }
   const int HW = p.Ho * p.Wo;
+  g_last_variant = KS * 100 + STRIDE * 10 + bm / 32 + 5;      // x16 / x26 + ...: 3x3 stride 1 -> 316 / 317 / 319 (bm 32 / 64 / 128)
+  if (const GnFuse* f = conv_gn_fuse_pending(p.Cout))
+    return launch_ksplit_finish_gn(scratch, S, total, p.bias, p.chan_add, p.chan_add_stride, p.residual, p.out, p.N, p.Cout, HW, *f, st);
   if (HW % 4 == 0) {
     long g = (total / 4 + 255) / 256;
     if (g > 4096) g = 4096;
@@ -897,7 +909,6 @@ static int launch_ksplit_generic(const ConvParams& p, hipStream_t st) {
     ADM_LAUNCH(ksplit_finish1_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)scratch, S, total, p.bias, p.chan_add,
                p.chan_add_stride, p.residual, p.out, p.Cout, HW, total);
   }
-  g_last_variant = KS * 100 + STRIDE * 10 + bm / 32 + 5;      // x16 / x26 + ...: 3x3 stride 1 -> 316 / 317 / 319 (bm 32 / 64 / 128)
   return ADM_CHECK_LAUNCH();
 }
 

@@ -6,6 +6,7 @@
 // One workgroup per (n, group); fp64 accumulation; wavefront shuffles (64 lanes) then LDS across the 4 waves.
 // Algorithmic bytes: 4 B per input element.
 #include "adm_kernels.h"
+#include <atomic>
 
 namespace adm {
 
@@ -162,6 +163,113 @@ int launch_groupnorm_finalize(const double* st1, int C1, int tiles1, const doubl
   ADM_REQUIRE((C1 + C2) % groups == 0, "groupnorm: channels not divisible by groups");
   ADM_LAUNCH(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, st, st1, C1, tiles1, st2, C2, tiles2, HW, groups, eps, gamma,
              beta, scale, shift, mean_rstd);
+  return ADM_CHECK_LAUNCH();
+}
+
+// Split-K finish + GroupNorm statistics in one pass (the latency regime: planes of <= 8x8 pixels, where a forward is a chain of
+// ~5 us launches): workgroup (group, sample) completes ITS slice of the split convolution's output — slabs added in order with
+// bias / per-sample term / residual, the arithmetic of ksplit_finish_kernel, so the tensor is bit-identical to the two-launch
+// path — and, holding every value of the group, leaves the scale / shift of the GroupNorm that reads the tensor next
+// (gn_stats_kernel's formulas).  Replaces ksplit_finish + gn_stats: one launch instead of two, (group, sample) workgroups instead
+// of total / 1024, slab loads eight at a time.
+__global__ void __launch_bounds__(256) ksplit_finish_gn_kernel(const float* __restrict__ part, int S, long part_stride,
+                                                               const float* __restrict__ bias, const float* __restrict__ chan_add,
+                                                               int chan_add_stride, const float* residual, float* out, int Cout,
+                                                               int HW, int groups, float eps, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ scale,
+                                                               float* __restrict__ shift, float* __restrict__ mean_rstd) {
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int cg = Cout / groups;
+  const int total = cg * HW;
+  const long base = ((long)n * Cout + (long)g * cg) * HW;
+  double s = 0.0, ss = 0.0;
+  if ((HW & 3) == 0) {
+    for (int e4 = tid * 4; e4 < total; e4 += 256 * 4) {
+      const long e = base + e4;
+      const int co = g * cg + e4 / HW;
+      float b = bias[co];
+      if (chan_add != nullptr) b += chan_add[(long)n * chan_add_stride + co];
+      float4 v = *reinterpret_cast<const float4*>(part + e);
+#pragma unroll 8
+      for (int s2 = 1; s2 < S; ++s2) {
+        const float4 q = *reinterpret_cast<const float4*>(part + (long)s2 * part_stride + e);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      v.x += b; v.y += b; v.z += b; v.w += b;
+      if (residual != nullptr) {
+        const float4 q = *reinterpret_cast<const float4*>(residual + e);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      *reinterpret_cast<float4*>(out + e) = v;
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    for (int el = tid; el < total; el += 256) {
+      const long e = base + el;
+      const int co = g * cg + el / HW;
+      float v = part[e];
+#pragma unroll 8
+      for (int s2 = 1; s2 < S; ++s2) v += part[(long)s2 * part_stride + e];
+      v += chan_add != nullptr ? bias[co] + chan_add[(long)n * chan_add_stride + co] : bias[co];
+      if (residual != nullptr) v += residual[e];
+      out[e] = v;
+      s += (double)v;
+      ss += (double)v * v;
+    }
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  __shared__ double red[2][4];
+  __shared__ float stat[2];
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+  __syncthreads();
+  if (tid == 0) {
+    const double Sm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const double SS = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double mean = Sm / (double)total;
+    double var = SS / (double)total - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[0] = (float)mean;
+    stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (mean_rstd) {
+      mean_rstd[((long)n * groups + g) * 2] = stat[0];
+      mean_rstd[((long)n * groups + g) * 2 + 1] = stat[1];
+    }
+  }
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+  for (int cl = tid; cl < cg; cl += 256) {
+    const int c = g * cg + cl;
+    const float sc = rstd * gamma[c];
+    scale[(long)n * Cout + c] = sc;
+    shift[(long)n * Cout + c] = -sc * mean + beta[c];
+  }
+}
+
+// the request a caller (the executor) leaves for the NEXT launch_conv2d on this thread: "the tensor you write is read by this
+// GroupNorm"; a split-K launch that can honour it (finish pass = one workgroup per (group, sample)) takes it and says so
+static thread_local const GnFuse* g_gn_request = nullptr;
+static thread_local bool g_gn_taken = false;
+void conv_gn_fuse_request(const GnFuse* f) { g_gn_request = f; g_gn_taken = false; }
+bool conv_gn_fuse_taken() { return g_gn_taken; }
+static std::atomic<int> g_gn_fuse_finish{-1};     // option "gn_fuse_finish": -1 = ADM_GN_FUSE_FINISH from the environment (default 1)
+void set_gn_fuse_finish(int v) { g_gn_fuse_finish.store(v); }
+const GnFuse* conv_gn_fuse_pending(int Cout) {
+  static const int env = [] { const char* e = getenv("ADM_GN_FUSE_FINISH"); return e ? atoi(e) : 1; }();
+  const int opt = g_gn_fuse_finish.load();
+  const bool on = (opt < 0 ? env : opt) != 0;
+  const GnFuse* f = g_gn_request;
+  return (on && f != nullptr && f->groups > 0 && Cout % f->groups == 0) ? f : nullptr;
+}
+
+int launch_ksplit_finish_gn(const float* part, int S, long part_stride, const float* bias, const float* chan_add, int chan_add_stride,
+                            const float* residual, float* out, int N, int Cout, int HW, const GnFuse& f, hipStream_t st) {
+  ADM_REQUIRE(bias != nullptr && Cout % f.groups == 0 && f.scale && f.shift && f.gamma && f.beta, "ksplit_finish_gn: arguments");
+  ADM_LAUNCH(ksplit_finish_gn_kernel, dim3(f.groups, N), dim3(256), 0, st, part, S, part_stride, bias, chan_add, chan_add_stride,
+             residual, out, Cout, HW, f.groups, f.eps, f.gamma, f.beta, f.scale, f.shift, f.mean_rstd);
+  g_gn_taken = true;
   return ADM_CHECK_LAUNCH();
 }
 

@@ -150,6 +150,8 @@ struct Net {
   std::vector<BlkOp> blk;            // indexed like ops; empty below level 3 / for inference
   float* blk_part = nullptr;         // per-workgroup channel sums of the dy image pass (bias gradients)
   std::vector<int> producer_of;      // tensor -> index of the op that writes it (-1: none), level-3 training plans
+  std::vector<int> gn_fuse_of;       // per op: the GroupNorm op whose statistics this convolution's split-K finish may leave (-1: none)
+  std::vector<char> gn_skip;         // per op, during a forward walk: this GroupNorm's scale / shift have been written already
   std::vector<char> bias_done;       // per op, during a reverse walk: its bias gradient came with another convolution's channel sums
   float *tmp_da = nullptr, *wgrad_ws = nullptr, *s12 = nullptr, *tmp_w = nullptr;
   size_t tmp_da_floats = 0, wgrad_ws_floats = 0, tmp_w_floats = 0;

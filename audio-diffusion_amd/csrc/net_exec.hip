@@ -554,6 +554,25 @@ int Net::plan(int B) {
       t.stat_tiles = tiles;
     }
   }
+  // GroupNorm statistics folded into the split-K finish pass of the producing convolution (planes of <= 8x8 pixels; both modes):
+  // the FIRST single-input GroupNorm that reads a convolution's output is announced to that convolution's launch (run()); when
+  // the launch took the request, the statistics op is skipped. Which launches split K is the kernels' business, decided per call.
+  gn_fuse_of.assign(ops.size(), -1);
+  {
+    std::vector<int> prod(tensors.size(), -1);
+    for (size_t i = 0; i < ops.size(); ++i) {
+      const Op& o = ops[i];
+      if (o.kind == Op::GN) {
+        const int t = o.in1, pi = t >= 0 ? prod[t] : -1;
+        if (o.in2 >= 0 || pi < 0 || tensors[t].external || t == t_in || tensors[t].C % groups != 0) continue;
+        const Op& po = ops[pi];
+        if (po.kind != Op::CONV || po.wt >= 0 || po.w == nullptr || po.w->Cout != tensors[t].C || gn_fuse_of[pi] >= 0) continue;
+        gn_fuse_of[pi] = (int)i;
+      } else if (o.out >= 0) {
+        prod[o.out] = (int)i;
+      }
+    }
+  }
   if (training) {
     // gradient buffer for every tensor except the network input; scratch sized for the largest layer
     size_t max_da = 0, max_ws = 0, max_w = 0;
@@ -724,10 +743,13 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
   tm->st = st;
   tensors[t_in].ptr = const_cast<float*>(x);
   tensors[t_out].ptr = out;
+  gn_skip.assign(ops.size(), 0);
   for (const Op& o : ops) {
     const Tensor& t1 = tensors[o.in1];
     tm->begin();
-    if (o.kind == Op::GN) {
+    if (o.kind == Op::GN && gn_skip[(size_t)(&o - ops.data())]) {
+      tm->end(0, 2, 0.0, 0.0);           // its scale / shift came with the producing convolution's split-K finish pass
+    } else if (o.kind == Op::GN) {
       const GnBuf& g = gnbufs[o.gn];
       const float* x2 = o.in2 >= 0 ? tensors[o.in2].ptr : nullptr;
       const int C2 = o.in2 >= 0 ? tensors[o.in2].C : 0;
@@ -757,8 +779,24 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
       if (bo && bo->fwd)
         ADM_TRY(launch_conv_bf16b(bo->xa, a.C1 + a.C2, B, o.up ? 2 * a.H : a.H, o.up ? 2 * a.W : a.W, o.w->wb, a.Cout, a.bias, a.chan_add,
                                   a.chan_add_stride, a.residual, a.out, st, bo->s2 ? (o.pad_lo ? 3 : 2) : o.up, bo->s2 ? nullptr : tensors[o.out].stats));
-      else
-        ADM_TRY(launch_conv2d(a, st));
+      else {
+        GnFuse gf;
+        const int gk = oi < gn_fuse_of.size() ? gn_fuse_of[oi] : -1;
+        const bool ask = gk >= 0 && tensors[o.out].stats == nullptr;
+        if (ask) {
+          const Op& go = ops[gk];
+          const GnBuf& gb = gnbufs[go.gn];
+          gf.gamma = go.g->gamma; gf.beta = go.g->beta; gf.eps = go.eps > 0.f ? go.eps : eps; gf.groups = groups;
+          gf.scale = gb.scale; gf.shift = gb.shift; gf.mean_rstd = gb.mean_rstd;
+          conv_gn_fuse_request(&gf);
+        }
+        const int rc = launch_conv2d(a, st);
+        if (ask) {
+          if (rc == 0 && conv_gn_fuse_taken()) gn_skip[gk] = 1;
+          conv_gn_fuse_request(nullptr);
+        }
+        ADM_TRY(rc);
+      }
       if (o.w) ADM_TRY(note_packing(*o.w, packing_of_variant(last_conv_variant(), true)));
       const Tensor& to = tensors[o.out];
       const double Cin = a.C1 + a.C2, outel = (double)B * to.C * to.H * to.W;

@@ -42,6 +42,9 @@ int adm_has_experiments(void);
  * "conv_op16_f16" = 1 makes those kernels' operand format IEEE binary16 instead of bf16 (`--mixed_precision fp16`);
  * "blk_direct_dy" = 1 (default; level 3, read when a training plan is made) the backward of a GroupNorm whose input is read by nothing
  *   else writes the producing convolution's dy image directly | 0 fp32 dx tensor + image pass (bit-identical results) | -1 ADM_BLK_DIRECT_DY.
+ * "gn_fuse_finish" = 1 (default) a split-K convolution (output planes of <= 8x8 pixels) whose output a GroupNorm reads next leaves
+ *   that GroupNorm's scale / shift from its finish pass (one launch instead of finish + statistics; the tensor is bit-identical) |
+ *   0 separate launches | -1 ADM_GN_FUSE_FINISH.
  * The dispatch epoch moves only when a value really changes; set options BEFORE adm_unet_refresh_weights / the next train step.
  * adm_version() = 101 since round 4 (adm_slerp_grid takes DOUBLE weights since round 3; blocked-image entry points). */
 int adm_set_option(const char* name, int value);

@@ -75,3 +75,43 @@ def test_deprecated_attention_names_and_unknown_blocks():
     mine.load_state_dict(old)
     with pytest.raises(NotImplementedError):
         UNet2DModel(down_block_types=("CrossAttnDownBlock2D",), up_block_types=("UpBlock2D",), block_out_channels=(32,))
+
+
+SMALL_PLANES = dict(sample_size=8, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(64, 128),
+                    down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_groupnorm_from_the_split_k_finish_pass(backend):
+    """Option gn_fuse_finish (default 1): on planes of <= 8x8 pixels a split-K convolution's finish pass leaves the scale / shift
+    of the GroupNorm that reads its output (one launch instead of two). The statistics ops it replaces show up as (kind 0,
+    variant 2) zero-cost records in the op profile; the forward stays inside the oracle tolerance and agrees with the two-launch path
+    (the tensors are bit-identical, the statistics sum the same values in another fp64 order)."""
+    import ctypes as C
+    from audiodiffusion import _native as N
+    dev = select(backend)
+    ref, mine = _pair(SMALL_PLANES, seed=3)
+    mine = mine.to(dev)
+    B = 3
+    x = torch.randn(B, 1, 8, 8, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        r = ref(x, 37)["sample"]
+    outs, fused = {}, {}
+    try:
+        for on in (0, 1):
+            N.check(N.lib().adm_set_option(b"gn_fuse_finish", on))
+            o = mine(x.to(dev), 37)["sample"]
+            xd = x.to(dev)
+            out = torch.empty_like(xd)
+            recs = (N.OpProfile * 512)()
+            n = C.c_int(0)
+            N.check(N.lib().adm_unet_profile(mine._ensure_handle(), N.ptr(xd), 37.0, N.ptr(out), B, recs, 512, C.byref(n), N.stream_for(xd)))
+            fused[on] = sum(1 for q in recs[: n.value] if q.kind == 0 and q.variant == 2)
+            assert torch.equal(out, o)
+            outs[on] = o.cpu()
+    finally:
+        N.check(N.lib().adm_set_option(b"gn_fuse_finish", -1))
+    assert fused[0] == 0 and fused[1] >= 4, fused
+    for o in outs.values():
+        assert float((o - r).abs().max()) < 1e-3 * max(1.0, float(r.abs().max()))
+    assert float((outs[0] - outs[1]).abs().max()) < 1e-5 * max(1.0, float(r.abs().max()))
