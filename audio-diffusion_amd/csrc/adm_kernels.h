@@ -116,7 +116,7 @@ int launch_gn_backward_stats(const float* x1, int C1, const float* x2, int C2, c
                              float* dgamma, float* dbeta, hipStream_t st);   // k_backward.hip: pass 1 of launch_gn_backward alone
 int launch_blk_sums_finalize(const float* sum_scratch, int N, int C, int H, int W, float* out_nc, int nc_stride, int nc_accumulate,
                              float* out_c, hipStream_t st, float* out_c2 = nullptr);
-bool conv_bf16b_eligible(int Cin, int Cout, int H, int W);
+bool conv_bf16b_eligible(int Cin, int Cout, int H, int W, int N = 0);   // N > 0: also rows of 16 / 8 pixels when N % 2 / 4 == 0
 int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void* wb, int Cout, const float* bias,
                       const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st, int mode = 0,
                       double* stats_out = nullptr);   // stats_out: GroupNorm partial sums of the OUTPUT, [n][cout][(H/8)*(W/32)][2] fp64

@@ -231,6 +231,7 @@ struct Bf16BConvParams {
   const float* residual; float* out;
   double* stats;                        // NULL or GroupNorm partial sums of the output: [n][cout][tile][2] (sum, sum of squares)
   int tiles_x, tiles_y, n_ct, nblk;
+  int ksplit; float* part; long part_stride;   // > 1: K split over `ksplit` workgroups per tile, raw partial sums to slab kpart of `part`
   unsigned long long* prof;             // developer aid (ADM_BF16B_PROF=1): per-phase cycle counters, else NULL
 };
 
@@ -241,8 +242,7 @@ struct Bf16BConvParams {
 #endif
 #define BB_LAP(slot) do { if (PROF) { const unsigned long long tn_ = BB_CLK(); pr[slot] += tn_ - tq; tq = tn_; } } while (0)
 
-constexpr int FB_PW = 34, FB_PR = 10, FB_CGP = FB_PW * FB_PR;   // patch of an 8x32-pixel tile: 10 rows x 34 pixels per channel group
-constexpr int FB_UNITS = 2 * FB_CGP;                             // 680 units per 16-channel chunk
+constexpr int FB_PR = 10;                                        // patch of an 8x32-pixel tile: 10 rows x 34 pixels per channel group (680 units per chunk)
 constexpr int FB_BUF = 768;                                      // units per patch buffer: 12 DMA instructions of 64 units
 constexpr int FB_NBUF = 3;
 constexpr int FB_LDS_UNITS = FB_NBUF * FB_BUF + 4 * 9 * 64;      // + the four waves' nine-slot filter rings
@@ -255,8 +255,18 @@ constexpr int FB_LDS_UNITS = FB_NBUF * FB_BUF + 4 * 9 * 64;      // + the four w
 // padding (the AutoencoderKL encoder): out(y, x) = o(2y + 1, 2x + 1).  The tile is still 8 x 32 pixels of o, but only its four rows of
 // that parity get accumulators (64 registers, half the MFMAs), and the epilogue stores the columns of that parity: H, W are the
 // dims of the INPUT image, out is (N, Cout, H / 2, W / 2).
-template <bool F16, bool UP = false, bool PROF = false, int S2 = 0>
+// LW < 5: planes of 16 (LW = 4) / 8 (LW = 3) pixels per row — the 16x16 and 8x8 levels of the 256x256 model.  The 32 columns of a tile
+// are GI = 2 / 4 IMAGES side by side (tile "n" = a group of GI consecutive samples); neighbouring images share one zero column of
+// the patch (the right halo of one is the left halo of the next: both are zero), so a patch row is 1 + GI (W + 1) = 35 / 37 units.
+// K may be split over p.ksplit workgroups per tile (16..64 tiles cannot fill 256 CUs): raw partial sums to slab kpart, finished by
+// ksplit_finish_kernel in slab order.
+template <bool F16, bool UP = false, bool PROF = false, int S2 = 0, int LW = 5>
 __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParams p) {
+  static_assert(LW == 5 || S2 == 0, "the stride-2 variant tiles 32-pixel rows only");
+  constexpr int WI = 1 << LW, GI = 32 >> LW;             // image width the tile is cut for, images per tile
+  constexpr int FB_PW = LW == 5 ? 34 : 1 + GI * (WI + 1);
+  constexpr int FB_CGP = FB_PW * FB_PR, FB_UNITS = 2 * FB_CGP;
+  static_assert(FB_UNITS <= FB_BUF, "patch does not fit its buffer");
   constexpr int NPT = S2 ? 4 : 8;                        // pixel rows (32-pixel N tiles) per wave
 #define FB_ROW(q) (S2 ? 2 * (q) + (S2 - 1) : (q))
   unsigned long long pr[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
@@ -273,10 +283,13 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   const int ct = lid % p.n_ct; lid /= p.n_ct;
+  int kpart = 0;
+  if (p.ksplit > 1) { kpart = lid % p.ksplit; lid /= p.ksplit; }
   const int tx = lid % p.tiles_x; lid /= p.tiles_x;
-  const int ty = lid % p.tiles_y, n = lid / p.tiles_y;
+  const int ty = lid % p.tiles_y, n = lid / p.tiles_y;   // LW < 5: n = group of GI images
   const int m0 = ct * 128 + wave * 32;
-  const int n_chunks = p.Cg >> 1;
+  const int c_begin = (int)((long)kpart * (p.Cg >> 1) / p.ksplit);
+  const int n_chunks = (int)((long)(kpart + 1) * (p.Cg >> 1) / p.ksplit) - c_begin;     // >= 2 (launcher)
   const long planeU = (long)p.Hp * p.Wp;
 
   // patch DMA roles (tile- and chunk-invariant): instruction i of this wave fills units 64 (wave + 4 i) .. + 63 of a buffer
@@ -286,12 +299,21 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
     int u = 64 * (wave + 4 * i) + lane;
     if (u > FB_UNITS - 1) u = FB_UNITS - 1;            // tail lanes re-request the last unit (they land in the buffer's pad)
     const int cgp = u / FB_CGP, rem = u - cgp * FB_CGP;
-    const int r = rem / FB_PW, c = rem - r * FB_PW;
-    poff[i] = UP ? (unsigned)(((long)cgp * planeU + (long)((r + 1) >> 1) * p.Wp + ((c + 1) >> 1)) * 16)
-                 : (unsigned)(((long)cgp * planeU + (long)r * p.Wp + c) * 16);
+    const int r = rem / FB_PW;
+    int c = rem - r * FB_PW;
+    long img_off = 0;
+    if (LW < 5) {      // patch column c = image j, haloed column c - j (W + 1); the last column is the right halo of the last image
+      int j = c / (WI + 1);
+      if (j > GI - 1) j = GI - 1;
+      c -= j * (WI + 1);
+      img_off = (long)j * p.Cg * planeU;
+    }
+    poff[i] = UP ? (unsigned)((img_off + (long)cgp * planeU + (long)((r + 1) >> 1) * p.Wp + ((c + 1) >> 1)) * 16)
+                 : (unsigned)((img_off + (long)cgp * planeU + (long)r * p.Wp + c) * 16);
   }
   // haloed coordinates: the patch of output tile (ty, tx) starts at image pixel (8 ty - 1, 32 tx - 1) = unit (8 ty, 32 tx)
-  const u32x4* const img_t = p.img + ((long)n * p.Cg * p.Hp + (long)ty * (UP ? 4 : 8)) * p.Wp + (long)tx * (UP ? 16 : 32);
+  const u32x4* const img_t = p.img + ((long)(LW < 5 ? n * GI : n) * p.Cg * p.Hp + (long)ty * (UP ? 4 : 8)) * p.Wp + (long)tx * (UP ? 16 : 32) +
+                             (long)(2 * c_begin) * planeU;      // (chunk indices below are relative to this workgroup's first)
   const unsigned ldsP_a = ADM_LDS_ADDR(lds) + 1024u * wave;               // LDS byte addresses (wave-uniform integers)
   const unsigned ldsA_a = ADM_LDS_ADDR(lds) + 16u * (FB_NBUF * FB_BUF + 9 * 64 * wave);
   auto issue_patch = [&](int ch) __attribute__((always_inline)) {
@@ -303,7 +325,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
   // filter fragment of (chunk, tap): lane (cout l31, k half h) = unit ((tap KG + 2 chunk + h) Cout + m0 + l31): two 512-byte runs
   const unsigned aoff = (unsigned)(((long)h * p.Cout + l31) * 16);
   auto issue_filt = [&](int ch, int t) __attribute__((always_inline)) {
-    const u32x4* src = p.wb + ((long)t * p.Cg + 2 * ch) * p.Cout + m0;     // wave-uniform
+    const u32x4* src = p.wb + ((long)t * p.Cg + 2 * (c_begin + ch)) * p.Cout + m0;     // wave-uniform
     ADM_GLDS16_ASM(src, aoff, ldsA_a + 1024u * t);
   };
 
@@ -314,7 +336,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   // B fragment of pixel row pt (32 pixels), tap (dy, dx): unit h * 340 + (pt + dy) * 34 + dx + l31 — 32 consecutive units per half
-  const int bbase = h * FB_CGP + l31;
+  const int bbase = h * FB_CGP + l31 + (LW < 5 ? (l31 >> LW) : 0);      // LW < 5: image j = l31 / W starts at patch column j (W + 1)
 
   // ---- vector-memory queue of one wave (every entry is a DMA, issued in this order):
   //   prologue: P(0) x3, P(1) x3, A(0, 0..8)
@@ -387,18 +409,22 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
   // 32 stores per wave instead of 128 dword stores (the dword version spent ~40 % of a workgroup's life ISSUING its stores).
   // LDS executes a wave's operations in order: no barrier, the next row's writes queue behind this row's reads.
   const int planeO = S2 ? (p.H >> 1) * (p.W >> 1) : p.H * p.W;
-  float* const out_n = p.out + (long)n * p.Cout * planeO;                   // wave-uniform bases, 32-bit lane offsets
-  const float* const res_n = p.residual ? p.residual + (long)n * p.Cout * planeO : nullptr;
+  const int n_img = LW < 5 ? n * GI : n;                                    // first image of the tile
+  const bool split = p.ksplit > 1;                                          // raw partial sums to slab kpart (no bias / residual)
+  float* const out_n = (split ? p.part + (long)kpart * p.part_stride : p.out) + (long)n_img * p.Cout * planeO;   // wave-uniform bases, 32-bit lane offsets
+  const float* const res_n = (p.residual && !split) ? p.residual + (long)n_img * p.Cout * planeO : nullptr;
   float* const stage = reinterpret_cast<float*>(lds) + 1024 * wave;
   const int srow = lane >> 3, scol = 4 * (lane & 7);
+  const int jimg = LW < 5 ? scol >> LW : 0;                                 // LW < 5: the lane's four columns lie in image jimg of the tile
   // S2: row 2 q (+ 1) of the tile is output row 4 ty + q, the lane's columns scol (+ 1), scol + 2 (+ 1) are output columns 16 tx + scol / 2 + {0, 1}
   const int lane_off = S2 ? (m0 + srow) * planeO + (ty * 4) * (p.W >> 1) + tx * 16 + (scol >> 1)
-                          : (m0 + srow) * planeO + (ty * 8) * p.W + tx * 32 + scol;
+                     : LW < 5 ? (jimg * p.Cout + m0 + srow) * planeO + (ty * 8) * p.W + (scol & (WI - 1))
+                              : (m0 + srow) * planeO + (ty * 8) * p.W + tx * 32 + scol;
   float bv[4], gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
   ADM_UNROLL
   for (int k = 0; k < 4; ++k) {
     const int co = m0 + srow + 8 * k;
-    bv[k] = p.bias[co] + p.chan_add[(long)n * p.chan_add_stride + co];
+    bv[k] = split ? 0.f : p.bias[co] + p.chan_add[(long)(n_img + jimg) * p.chan_add_stride + co];
   }
   ADM_UNROLL
   for (int pt = 0; pt < NPT; ++pt) {
@@ -457,11 +483,23 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
 
 #undef FB_ROW
 
-bool conv_bf16b_eligible(int Cin, int Cout, int H, int W) {
-  return Cin % 16 == 0 && Cin >= 32 && Cout % 128 == 0 && H % 8 == 0 && W % 32 == 0;
+// N = 0: the 32-pixel-row tiling only. N > 0 additionally admits rows of 16 / 8 pixels when the batch fills whole tiles of 2 / 4 images.
+bool conv_bf16b_eligible(int Cin, int Cout, int H, int W, int N) {
+  if (!(Cin % 16 == 0 && Cin >= 32 && Cout % 128 == 0 && H % 8 == 0)) return false;
+  if (W % 32 == 0) return true;
+  return N > 0 && (W == 16 || W == 8) && N % (32 / W) == 0 && Cin >= 64;
 }
 
 int conv_bf16b_stats_tiles(int H, int W) { return (H / 8) * (W / 32); }
+
+// parts of the K split of the narrow-row tilings: a function of the layer only (see k_conv_mfma.hip launch_ksplit_generic), at least two
+// 16-channel chunks each. 16-pixel rows: 4 (B = 16: 64 tiles -> 256 workgroups of 8 chunks at 512 channels; the slabs are 4 x the
+// output), 8-pixel rows: 16 (16 tiles -> 256 workgroups of 2 chunks).
+static int conv_bf16b_parts(int Cin, int W) {
+  int S = W == 16 ? 4 : (W == 8 ? 16 : 1);
+  while (S > 1 && (Cin / 16) / S < 2) S >>= 1;
+  return S;
+}
 
 int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void* wb, int Cout, const float* bias,
                       const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st, int mode,
@@ -470,7 +508,9 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
   const int up = mode == 1, s2 = mode == 2 || mode == 3;
   ADM_REQUIRE(mode >= 0 && mode <= 3, "conv_bf16b: mode is 0 (stride 1), 1 (nearest x2 folded), 2 (stride 2, pad (0,1,0,1)) or 3 (stride 2, padding 1)");
   ADM_REQUIRE(!s2 || (residual == nullptr && chan_add == nullptr && stats_out == nullptr), "conv_bf16b: the stride-2 variant has a bias only");
-  ADM_REQUIRE(conv_bf16b_eligible(Cin, Cout, H, W), "conv_bf16b: shape not eligible (Cin % 16, Cin >= 32, Cout % 128, H % 8, W % 32)");
+  ADM_REQUIRE(conv_bf16b_eligible(Cin, Cout, H, W, N), "conv_bf16b: shape not eligible (Cin % 16, Cin >= 32, Cout % 128, H % 8, W % 32 — or W = 16 / 8 with N % 2 / 4 == 0)");
+  const int lw = W % 32 == 0 ? 5 : (W == 16 ? 4 : 3), gi = 32 >> lw;
+  ADM_REQUIRE(lw == 5 || (!s2 && stats_out == nullptr), "conv_bf16b: the 16- / 8-pixel-row tilings have no stride-2 variant and no statistics epilogue");
   Bf16BConvParams p;
   p.img = reinterpret_cast<const u32x4*>(img); p.Cg = Cin / 8;
   p.Hp = (up ? H / 2 : H) + 2; p.Wp = (up ? W / 2 : W) + 2;     // H, W: OUTPUT dims; the image of an up-convolution is half-size
@@ -483,8 +523,14 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
   p.residual = residual; p.out = out; p.stats = stats_out;
   ADM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0,
               "conv_bf16b: out / residual must be 16-byte aligned");
-  p.tiles_x = W / 32; p.tiles_y = H / 8; p.n_ct = Cout / 128;
-  p.nblk = p.tiles_x * p.tiles_y * N * p.n_ct;
+  p.tiles_x = lw == 5 ? W / 32 : 1; p.tiles_y = H / 8; p.n_ct = Cout / 128;
+  p.ksplit = lw == 5 ? 1 : conv_bf16b_parts(Cin, W);
+  p.part = nullptr; p.part_stride = (long)N * Cout * H * W;
+  if (p.ksplit > 1) {
+    p.part = conv_ksplit_scratch((size_t)p.ksplit * p.part_stride, st);
+    if (p.part == nullptr) return -1;
+  }
+  p.nblk = p.tiles_x * p.tiles_y * (N / gi) * p.n_ct * p.ksplit;
   const size_t smem = sizeof(u32x4) * FB_LDS_UNITS;
 #if !defined(ADM_EMU)
   static bool once = [] {
@@ -496,6 +542,12 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
     (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false, false, false, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true, false, false, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false, true, false, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true, true, false, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<false, false, false, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16b_kernel<true, false, false, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     return true;
   }();
   (void)once;
@@ -504,7 +556,7 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
   p.prof = nullptr;
 #if !defined(ADM_EMU)
   static const bool want_prof = getenv("ADM_BF16B_PROF") != nullptr;
-  if (want_prof && !conv_op16_f16() && mode == 0) {   // developer aid: per-phase cycle accounting, printed after the launch (synchronous)
+  if (want_prof && !conv_op16_f16() && mode == 0 && lw == 5) {   // developer aid: per-phase cycle accounting, printed after the launch (synchronous)
     const size_t pn = (size_t)p.nblk * 4 * 8;
     static unsigned long long* dprof = nullptr;
     static size_t dcap = 0;
@@ -525,6 +577,24 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
     return ADM_CHECK_LAUNCH();
   }
 #endif
+  if (lw < 5) {
+    ADM_REQUIRE(lw == 4 || !up, "conv_bf16b: no nearest-x2 variant for 8-pixel rows");
+    const bool f16 = conv_op16_f16();
+    if (lw == 3) {
+      if (f16) ADM_LAUNCH((conv_bf16b_kernel<true, false, false, 0, 3>), dim3(p.nblk), dim3(256), smem, st, p);
+      else ADM_LAUNCH((conv_bf16b_kernel<false, false, false, 0, 3>), dim3(p.nblk), dim3(256), smem, st, p);
+    } else if (up) {
+      if (f16) ADM_LAUNCH((conv_bf16b_kernel<true, true, false, 0, 4>), dim3(p.nblk), dim3(256), smem, st, p);
+      else ADM_LAUNCH((conv_bf16b_kernel<false, true, false, 0, 4>), dim3(p.nblk), dim3(256), smem, st, p);
+    } else {
+      if (f16) ADM_LAUNCH((conv_bf16b_kernel<true, false, false, 0, 4>), dim3(p.nblk), dim3(256), smem, st, p);
+      else ADM_LAUNCH((conv_bf16b_kernel<false, false, false, 0, 4>), dim3(p.nblk), dim3(256), smem, st, p);
+    }
+    if (ADM_CHECK_LAUNCH() != 0) return -1;
+    if (p.ksplit > 1)
+      return launch_ksplit_finish(p.part, p.ksplit, p.part_stride, bias, chan_add, chan_add_stride, residual, out, Cout, H * W, st);
+    return 0;
+  }
   if (mode == 2) {
     if (conv_op16_f16()) ADM_LAUNCH((conv_bf16b_kernel<true, false, false, 2>), dim3(p.nblk), dim3(256), smem, st, p);
     else ADM_LAUNCH((conv_bf16b_kernel<false, false, false, 2>), dim3(p.nblk), dim3(256), smem, st, p);

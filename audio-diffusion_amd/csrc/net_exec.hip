@@ -621,9 +621,9 @@ int Net::plan(int B) {
         if (o.act && o.gn < 0) continue;
         BlkOp& b = blk[i];
         b.s2 = s2;
-        b.fwd = conv_bf16b_eligible(Ct, Cout, Ho, Wo);
+        b.fwd = conv_bf16b_eligible(Ct, Cout, Ho, Wo, s2 ? 0 : B);      // (B: rows of 16 / 8 pixels tile 2 / 4 images side by side)
         b.wg = conv_wgradb_eligible(Ct, Cout, Ho, Wo);
-        b.dg = conv_bf16b_eligible(Cout, Ct, Ho, Wo);
+        b.dg = conv_bf16b_eligible(Cout, Ct, Ho, Wo, s2 ? 0 : B);
         if (s2 && !(b.fwd && b.wg && b.dg)) { b = BlkOp(); continue; }      // all three passes or none (one zero-inserted dy image)
         if (b.fwd || b.wg) {
           const size_t bytes = blk_image_bytes(B, Ct, H, W);
@@ -685,6 +685,7 @@ int Net::plan(int B) {
           if (!blk[i].fwd || blk[i].s2 || !tensors[o.out].want_stats || tensors[o.out].external) continue;
           Tensor& t = tensors[o.out];
           const int tiles = conv_bf16b_stats_tiles(t.H, t.W);
+          if (tiles <= 0) continue;                              // rows of 16 / 8 pixels: no statistics epilogue
           ADM_TRY(arena_alloc((void**)&t.stats, sizeof(double) * 2 * (size_t)B * t.C * tiles));
           t.stat_tiles = tiles;
         }
@@ -776,7 +777,7 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
       if (bo)    // level 3: the activated input once as a blocked 16-bit image (kept for the weight gradient)
         ADM_TRY(launch_blk_apply(a.x1, a.C1, a.x1_bstride, a.x2, a.C2, a.x2_bstride, B, a.H, a.W, a.gn_scale, a.gn_shift, a.act, bo->xa,
                                  nullptr, st));
-      if (bo && bo->fwd)
+      if (bo && bo->fwd && conv_bf16b_eligible(a.C1 + a.C2, a.Cout, o.up ? 2 * a.H : a.H, o.up ? 2 * a.W : a.W, bo->s2 ? 0 : B))
         ADM_TRY(launch_conv_bf16b(bo->xa, a.C1 + a.C2, B, o.up ? 2 * a.H : a.H, o.up ? 2 * a.W : a.W, o.w->wb, a.Cout, a.bias, a.chan_add,
                                   a.chan_add_stride, a.residual, a.out, st, bo->s2 ? (o.pad_lo ? 3 : 2) : o.up, bo->s2 ? nullptr : tensors[o.out].stats));
       else {
@@ -1029,7 +1030,8 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
           continue;
         }
       }
-      if (bo && bo->dg)      // (stride 2: the zero-inserted dy image has the INPUT's dims; the kernel is the plain stride-1 one)
+      if (bo && bo->dg && conv_bf16b_eligible(Cout, Ct, bo->s2 ? t1.H : to.H, bo->s2 ? t1.W : to.W, bo->s2 ? 0 : B))
+                             // (stride 2: the zero-inserted dy image has the INPUT's dims; the kernel is the plain stride-1 one)
         ADM_TRY(launch_conv_bf16b(bo->dyb, Cout, B, bo->s2 ? t1.H : to.H, bo->s2 ? t1.W : to.W, o.w->wbT, Ct, nullptr, nullptr, 0, a.residual,
                                   a.out, st));
       else

@@ -206,3 +206,51 @@ def test_conv_bf16_blocked_stride_2_all_three_passes(backend, pad):
     dW = ops.conv2d_wgrad_bf16_blocked(img, dimg)
     want_w = torch.nn.grad.conv2d_weight(xp, (Cout, C, 3, 3), _bf(dy.cpu()), stride=2)
     assert _relerr(dW.double(), want_w) < 2e-6, _relerr(dW.double(), want_w)
+
+
+NARROW_CASES = [
+    # (N, Cin, H, W, Cout, temb, res, up)        rows of 16 / 8 pixels: 2 / 4 images side by side in one 32-column tile, K split
+    (2, 64, 16, 16, 128, 1, 1, 0),      # one pair, two row tiles, 4 chunks -> 2 parts
+    (4, 128, 8, 16, 128, 0, 0, 0),      # two pairs, 8 chunks -> 4 parts
+    (4, 64, 8, 8, 128, 1, 1, 0),        # one group of four 8x8 images, 4 chunks -> 2 parts
+    (8, 256, 8, 8, 256, 0, 1, 0),       # two groups, two cout tiles, 16 chunks -> 8 parts
+    (2, 64, 16, 16, 128, 0, 0, 1),      # Upsample2D.conv 8x8 -> 16x16: nearest x2 folded into the patch addresses of each image
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", NARROW_CASES, ids=[str(i) for i in range(len(NARROW_CASES))])
+def test_conv_bf16_blocked_narrow_rows_tile_images_side_by_side(backend, case):
+    """The 16x16 and 8x8 levels of the 256x256 model (round 4): the same kernel, a tile's 32 columns = 2 / 4 images that share their
+    zero halo columns; K split over a layer-determined number of workgroups, slabs added in order by the split-K finish pass with
+    bias / per-sample term / residual. Row-independence: a sample's result does not depend on which images share its tile."""
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn, Cin, H, W, Cout, use_temb, use_res, up = case
+    Hs, Ws = (H // 2, W // 2) if up else (H, W)
+    x = _rand((Nn, Cin, Hs, Ws), 1, dev)
+    w = _rand((Cout, Cin, 3, 3), 3, dev, scale=(Cin * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
+    res = _rand((Nn, Cout, H, W), 8, dev) if use_res else None
+    img = ops.blocked_image(x)
+    wb = ops.pack_bf16_weight(w)
+    out = ops.conv2d_bf16_blocked(img, wb, Cout, bias=b, chan_add=temb, residual=res, up=bool(up))
+    c = lambda t: None if t is None else t.cpu()  # noqa: E731
+    tail = c(b).double()[None, :, None, None]
+    if temb is not None:
+        tail = tail + c(temb).double()[:, :, None, None]
+    if res is not None:
+        tail = tail + c(res).double()
+    xa = _unblock(img.cpu())[:, :, 1:-1, 1:-1]
+    if up:
+        xa = F.interpolate(xa, scale_factor=2, mode="nearest")
+    exact = F.conv2d(xa, _bf(c(w)), None, padding=1) + tail
+    assert out.shape == exact.shape
+    assert _relerr(out.double(), exact) < 2e-6, _relerr(out.double(), exact)
+    # the same samples in another order land in other tile slots: bit-identical rows
+    perm = torch.arange(Nn - 1, -1, -1)
+    out_p = ops.conv2d_bf16_blocked(ops.blocked_image(x[perm.to(x.device)]), wb, Cout, bias=b,
+                                    chan_add=None if temb is None else temb[perm.to(x.device)],
+                                    residual=None if res is None else res[perm.to(x.device)], up=bool(up))
+    assert torch.equal(out_p.cpu()[perm], out.cpu())

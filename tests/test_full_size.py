@@ -337,13 +337,15 @@ def _oracle_bf16_step(m):
     return _BF16_ORACLE["v"]
 
 
-@pytest.mark.parametrize("level", [3, 2])
-def test_training_step_256_bf16_gradients_within_the_autocast_bars(dev, level, monkeypatch):
+@pytest.mark.parametrize("level,batch", [(3, 1), (3, 4), (2, 1)], ids=["3", "3-batch4", "2"])
+def test_training_step_256_bf16_gradients_within_the_autocast_bars(dev, level, batch, monkeypatch):
     """BASELINE config 5 as written — 256x256, `--mixed_precision bf16` (scripts/train_unet.py:250-267, 391-401) — at size: ONE
     training step of the 113.67 M-parameter model at B = 1 against fp32 autograd of the oracle and against the reference's own
     mixed-precision mode (torch.autocast(bfloat16) on the oracle, what accelerate applies).  The toy model's three bars
     (tests/test_unet_training.py: global relative L2 error of the whole gradient < 1.5e-2, worst per-tensor error < 2e-2,
-    no less accurate than autocast), for level 3 (blocked operand images, round 4) and level 2 (round 2's kernels)."""
+    no less accurate than autocast), for level 3 (blocked operand images, round 4) and level 2 (round 2's kernels).
+    batch 4 = the same sample four times (the mean loss and its gradient are those of B = 1): the 16x16 and 8x8 levels then run the
+    narrow-row tilings of the blocked kernels (2 / 4 images per tile, K split), which a single sample cannot fill."""
     from audiodiffusion import UNet2DModel, _native
     monkeypatch.setenv("ADM_BF16_LEVEL", str(level))
     m = UNet2DModel(**CFG256).init_random(0)
@@ -361,12 +363,13 @@ def test_training_step_256_bf16_gradients_within_the_autocast_bars(dev, level, m
 
     try:
         flat, grads = m.enable_training(mixed_precision="bf16")
-        lm = float(m.train_step(x.to(dev), ts, tgt.to(dev)))
+        rep = lambda t: t.repeat((batch,) + (1,) * (t.dim() - 1))  # noqa: E731
+        lm = float(m.train_step(rep(x).to(dev), rep(ts), rep(tgt).to(dev)))
         mine = errs(lambda n: grads[m.flat.offsets[n][0]:m.flat.offsets[n][0] + g32[n].numel()].view(g32[n].shape).cpu())
     finally:
         _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
     auto = errs(lambda n: gac[n])
-    print(f"bf16 level {level} at 256x256: loss {lm:.6f} (fp32 {float(lr):.6f}, autocast {float(lac):.6f}); "
+    print(f"bf16 level {level} (B = {batch}) at 256x256: loss {lm:.6f} (fp32 {float(lr):.6f}, autocast {float(lac):.6f}); "
           f"gradient error global / worst tensor: product {mine[0]:.3e} / {mine[1]:.3e}, autocast {auto[0]:.3e} / {auto[1]:.3e}")
     assert abs(lm - float(lr)) <= 5e-3 * float(lr)
     assert mine[0] < 1.5e-2 and mine[1] < 2e-2, mine

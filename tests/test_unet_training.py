@@ -327,8 +327,8 @@ BLKCFG = dict(sample_size=32, in_channels=1, out_channels=1, layers_per_block=1,
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_mixed_precision_bf16_level3_blocked_operand_images(backend, monkeypatch):
     """Level 3 (round 4, k_conv_bf16b.hip): the 3x3 stride-1 convolutions of all three passes read blocked 16-bit operand images
-    (activated input written once per layer, dy once per layer) through LDS-DMA.  32x32 resolution so that the first level is
-    eligible (W % 32 == 0); the 16x16 level falls back to level 2's kernels inside the same step.  Bars: the toy model's (1) and (3)
+    (activated input written once per layer, dy once per layer) through LDS-DMA.  32x32 resolution: the first level takes the
+    32-pixel-row tiling, the 16x16 level (B = 2: one pair of images per tile) the narrow-row tiling with split K.  Bars: the toy model's (1) and (3)
     against fp32 autograd, no worse than torch.autocast, and the same gradient as level 2 up to accumulation order / rounding flips."""
     dev = select(backend)
     from audiodiffusion import _native
