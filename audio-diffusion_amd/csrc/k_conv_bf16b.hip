@@ -487,7 +487,8 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
 bool conv_bf16b_eligible(int Cin, int Cout, int H, int W, int N) {
   if (!(Cin % 16 == 0 && Cin >= 32 && Cout % 128 == 0 && H % 8 == 0)) return false;
   if (W % 32 == 0) return true;
-  return N > 0 && (W == 16 || W == 8) && N % (32 / W) == 0 && Cin >= 64;
+  static const int narrow = [] { const char* e = getenv("ADM_BF16B_NARROW"); return e ? atoi(e) : 1; }();     // developer A/B
+  return narrow && N > 0 && (W == 16 || W == 8) && N % (32 / W) == 0 && Cin >= 64;
 }
 
 int conv_bf16b_stats_tiles(int H, int W) { return (H / 8) * (W / 32); }
