@@ -121,7 +121,7 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
                       const float* chan_add, int chan_add_stride, const float* residual, float* out, hipStream_t st, int mode = 0,
                       double* stats_out = nullptr);   // stats_out: GroupNorm partial sums of the OUTPUT, [n][cout][(H/8)*(W/32)][2] fp64
 int conv_bf16b_stats_tiles(int H, int W);
-bool conv_wgradb_eligible(int Ct, int Cout, int H, int W);
+bool conv_wgradb_eligible(int Ct, int Cout, int H, int W, int N = 0);
 long conv_wgradb_workspace(int Ct, int Cout, int N, int H, int W, int* split_out);
 int launch_conv_wgradb(const void* xa, int Ct, const void* dyb, int Cout, int N, int H, int W, float* dW, int accumulate,
                        float* workspace, hipStream_t st, int up = 0);

@@ -52,7 +52,7 @@ int adm_conv2d_bf16_blocked(const void* img, int Cin, int N, int H, int W, const
 }
 int adm_conv2d_wgrad_bf16_blocked_eligible(int Cin, int Cout, int H, int W) { return conv_wgradb_eligible(Cin, Cout, H, W) ? 1 : 0; }
 long adm_conv_wgrad_blocked_workspace(int Cin, int Cout, int N, int H, int W) {
-  return conv_wgradb_eligible(Cin, Cout, H, W) ? conv_wgradb_workspace(Cin, Cout, N, H, W, nullptr) : 0;
+  return conv_wgradb_eligible(Cin, Cout, H, W, N) ? conv_wgradb_workspace(Cin, Cout, N, H, W, nullptr) : 0;
 }
 int adm_conv2d_wgrad_bf16_blocked(const void* x_img, int Cin, const void* dy_img, int Cout, int N, int H, int W, float* dW,
                                   int accumulate, float* workspace, int up, void* stream) {

@@ -630,17 +630,23 @@ struct Bf16BWgradParams {
 
 constexpr int WB_DSLAB = 264;                   // units per dy slab: 128 pixels x 2 + 8 (128 bytes) so that slab bases alternate halves
 constexpr int WB_DY = 8 * WB_DSLAB;             // 2112 units: 128 couts
-constexpr int WB_XSLAB = 6 * 34 * 2;            // 408 units = 6528 bytes = 128 (mod 256): no pad needed
-constexpr int WB_XA = 4 * WB_XSLAB;             // 1632 units: 64 cins
-constexpr int WB_BUF = WB_DY + WB_XA + 32;      // + 32 units of slack behind the half-used last DMA instruction
-constexpr int WB_NDMA = 32 + 26;                // DMA instructions per tile: 32 (dy) + 26 (patch; the last one half dummy)
+// patch slab of 16 cins: 6 rows x PW pixels x 2 units, padded so that slab bases alternate 128-byte halves (stride = 128 mod 256 bytes):
+// rows of 32 pixels (LW = 5): PW = 34, 408 units = 6528 bytes, no pad; LW = 4 / 3 (2 / 4 images side by side, see conv_bf16b_kernel):
+// PW = 35 / 37, 420 -> 424 / 444 -> 456 units
+constexpr int wb_pw(int LW) { return LW == 5 ? 34 : 1 + (32 >> LW) * ((1 << LW) + 1); }
+constexpr int wb_xslab(int LW) { return LW == 5 ? 408 : (LW == 4 ? 424 : 456); }
+constexpr int wb_buf(int LW) { return WB_DY + 4 * wb_xslab(LW) + 32; }     // + 32 units of slack behind the half-used last DMA instruction
+constexpr int wb_ndma(int LW) { return 32 + (4 * wb_xslab(LW) + 63) / 64; }   // DMA instructions per tile: 32 (dy) + 26 / 27 / 29 (patch)
 
 __device__ __forceinline__ int bdivb(int n, int d, unsigned magic) {   // n / d; exact via umulhi for n, d < 2^16
   return magic ? (int)(((unsigned long long)(unsigned)n * magic) >> 32) : n / d;
 }
 
-template <bool F16, bool UP = false>
+template <bool F16, bool UP = false, int LW = 5>
 __global__ void __launch_bounds__(512, 2) conv_wgradb_kernel(const Bf16BWgradParams p) {
+  constexpr int WI = 1 << LW, GI = 32 >> LW;
+  constexpr int PW = wb_pw(LW), WB_XSLAB = wb_xslab(LW), WB_XA = 4 * WB_XSLAB, WB_BUF = wb_buf(LW), WB_NDMA = wb_ndma(LW);
+  static_assert((WB_XSLAB * 16) % 256 == 128 && WB_XSLAB >= 6 * PW * 2 && WB_NDMA <= 64, "patch slab geometry");
   ADM_DYN_SMEM(u32x4, lds);
   const int tid = threadIdx.x, lane = tid & 63, wave = ADM_UNIFORM(tid >> 6);
   const int wc = wave & 3, wi = wave >> 2;          // 32-cout block, 32-cin block of this wave
@@ -665,16 +671,28 @@ __global__ void __launch_bounds__(512, 2) conv_wgradb_kernel(const Bf16BWgradPar
     if (i < 4) {
       const int slab = j >> 2, quarter = j & 3;
       const int u = quarter * 64 + lane, px = u >> 1, cgs = u & 1;
-      goff[i] = (unsigned)(((long)(slab * 2 + cgs) * planeU + (long)(px >> 5) * p.Wp + (px & 31)) * 16);
+      // LW < 5: column l of the tile = image l / W of the group, column l % W
+      const long img_off = LW < 5 ? (long)((px & 31) >> LW) * p.CgO * planeU : 0;
+      goff[i] = (unsigned)((img_off + (long)(slab * 2 + cgs) * planeU + (long)(px >> 5) * p.Wp + (LW < 5 ? (px & (WI - 1)) : (px & 31))) * 16);
       ldst[i] = slab * WB_DSLAB + quarter * 64;
     } else {
       const int k = j - 32;
       int U = 64 * k + lane;
       if (U > WB_XA - 1) U = WB_XA - 1;
-      const int slab = U / WB_XSLAB, rem = U - slab * WB_XSLAB;
-      const int pp = rem >> 1, cgs = rem & 1, prow = pp / 34, pcol = pp - prow * 34;
-      goff[i] = UP ? (unsigned)(((long)(slab * 2 + cgs) * planeX + (long)((prow + 1) >> 1) * p.WpX + ((pcol + 1) >> 1)) * 16)
-                   : (unsigned)(((long)(slab * 2 + cgs) * planeX + (long)prow * p.WpX + pcol) * 16);
+      const int slab = U / WB_XSLAB;
+      int rem = U - slab * WB_XSLAB;
+      if (rem > 6 * PW * 2 - 1) rem = 6 * PW * 2 - 1;      // the slab's pad units re-request its last unit
+      const int pp = rem >> 1, cgs = rem & 1, prow = pp / PW;
+      int pcol = pp - prow * PW;
+      long img_off = 0;
+      if (LW < 5) {       // patch column = image j, haloed column pcol - j (W + 1); neighbours share their zero halo column
+        int j = pcol / (WI + 1);
+        if (j > GI - 1) j = GI - 1;
+        pcol -= j * (WI + 1);
+        img_off = (long)j * p.CgI * planeX;
+      }
+      goff[i] = UP ? (unsigned)((img_off + (long)(slab * 2 + cgs) * planeX + (long)((prow + 1) >> 1) * p.WpX + ((pcol + 1) >> 1)) * 16)
+                   : (unsigned)((img_off + (long)(slab * 2 + cgs) * planeX + (long)prow * p.WpX + pcol) * 16);
       ldst[i] = WB_DY + 64 * k;
     }
   }
@@ -686,8 +704,9 @@ __global__ void __launch_bounds__(512, 2) conv_wgradb_kernel(const Bf16BWgradPar
     const int rem = pt - nimg * (p.tiles_x * p.tiles_y);
     const int ty = bdivb(rem, p.tiles_x, p.mTX), tx = rem - ty * p.tiles_x;
     // haloed coordinates: dy pixel (4 ty, 32 tx) = unit (4 ty + 1, 32 tx + 1); the patch starts one up / left = unit (4 ty, 32 tx)
-    const u32x4* dsrc = dy_c + ((long)nimg * p.CgO * p.Hp + (long)(ty * 4 + 1)) * p.Wp + (long)(tx * 32 + 1);
-    const u32x4* xsrc = xa_c + ((long)nimg * p.CgI * p.HpX + (long)(ty * (UP ? 2 : 4))) * p.WpX + (long)(tx * (UP ? 16 : 32));
+    const int n0 = LW < 5 ? nimg * GI : nimg;            // LW < 5: "image" of the tile index = group of GI samples
+    const u32x4* dsrc = dy_c + ((long)n0 * p.CgO * p.Hp + (long)(ty * 4 + 1)) * p.Wp + (long)(tx * 32 + 1);
+    const u32x4* xsrc = xa_c + ((long)n0 * p.CgI * p.HpX + (long)(ty * (UP ? 2 : 4))) * p.WpX + (long)(tx * (UP ? 16 : 32));
     const unsigned base = lds_a + 16u * WB_BUF * (unsigned)buf;
     ADM_UNROLL
     for (int i = 0; i < 8; ++i) {
@@ -708,7 +727,9 @@ __global__ void __launch_bounds__(512, 2) conv_wgradb_kernel(const Bf16BWgradPar
   // 8-byte piece lane & 3
   const int lgrp = (lane >> 4) & 1, lpx = 8 * (lane >> 5) + ((lane & 15) >> 2), lpc = lane & 3;
   const int abase = (2 * wc + lgrp) * (WB_DSLAB * 16) + lpx * 32 + lpc * 8;
-  const int xbase = WB_DY * 16 + (2 * wi + lgrp) * (WB_XSLAB * 16) + lpx * 32 + lpc * 8;
+  // 8-pixel rows: the two 8-pixel halves of a k-step are two images, one shared halo column apart in the patch
+  const int xbase = WB_DY * 16 + (2 * wi + lgrp) * (WB_XSLAB * 16) + (lpx + (LW == 3 ? (lane >> 5) : 0)) * 32 + lpc * 8;
+  constexpr int XC1 = LW == 5 ? 16 : (LW == 4 ? 17 : 18);      // patch column of the tile's pixel 16 (the second k-step of a row)
 
   auto read_frag = [&](const unsigned char* b, int byte_off) __attribute__((always_inline)) -> u32x4 {
     const adm_u32x2 lo = ADM_DS_READ_TR16_B64(b + byte_off), hi = ADM_DS_READ_TR16_B64(b + byte_off + 128);
@@ -729,14 +750,14 @@ __global__ void __launch_bounds__(512, 2) conv_wgradb_kernel(const Bf16BWgradPar
     u32x4 Ac, Bc[9], An, Bn[9];
     Ac = read_frag(bA, 0);
     ADM_UNROLL
-    for (int t = 0; t < 9; ++t) Bc[t] = read_frag(bX, ((t / 3) * 34 + (t % 3)) * 32);
+    for (int t = 0; t < 9; ++t) Bc[t] = read_frag(bX, ((t / 3) * PW + (t % 3)) * 32);
     ADM_UNROLL
     for (int s = 0; s < 8; ++s) {
       if (s < 7) {
         const int row = (s + 1) >> 1, col0 = ((s + 1) & 1) * 16;
         An = read_frag(bA, (row * 32 + col0) * 32);
         ADM_UNROLL
-        for (int t = 0; t < 9; ++t) Bn[t] = read_frag(bX, ((row + t / 3) * 34 + col0 + (t % 3)) * 32);
+        for (int t = 0; t < 9; ++t) Bn[t] = read_frag(bX, ((row + t / 3) * PW + ((s + 1) & 1) * XC1 + (t % 3)) * 32);
       }
       ADM_SCHED_FENCE();
       ADM_UNROLL
@@ -763,13 +784,17 @@ __global__ void __launch_bounds__(512, 2) conv_wgradb_kernel(const Bf16BWgradPar
   }
 }
 
-bool conv_wgradb_eligible(int Ct, int Cout, int H, int W) {
-  return Ct % 64 == 0 && Cout % 128 == 0 && H % 4 == 0 && W % 32 == 0;
+// N > 0 additionally admits rows of 16 / 8 pixels when the batch fills whole tiles of 2 / 4 images (as conv_bf16b_eligible)
+bool conv_wgradb_eligible(int Ct, int Cout, int H, int W, int N) {
+  if (!(Ct % 64 == 0 && Cout % 128 == 0 && H % 4 == 0)) return false;
+  if (W % 32 == 0) return true;
+  static const int narrow = [] { const char* e = getenv("ADM_BF16B_NARROW"); return e ? atoi(e) : 1; }();     // developer A/B
+  return narrow && N > 0 && (W == 16 || W == 8) && N % (32 / W) == 0;
 }
 
 // split-K factor and workspace floats ([split][Cout * Ct * 9]) of the blocked weight-gradient kernel
 long conv_wgradb_workspace(int Ct, int Cout, int N, int H, int W, int* split_out) {
-  const int n_ptiles = (W / 32) * (H / 4) * N;
+  const int n_ptiles = W % 32 == 0 ? (W / 32) * (H / 4) * N : (H / 4) * (N / (32 / W));
   const int pairs = (Cout / 128) * (Ct / 64);
   static const int target = [] { const char* e = getenv("ADM_WGRADB_WGS"); return e ? atoi(e) : 256; }();
   int split = ceil_div(target, pairs);           // one workgroup per CU (120 KiB of LDS each): 256 measured 68.3 ms per step, 384: 70.5, 512: 69.7
@@ -783,33 +808,51 @@ long conv_wgradb_workspace(int Ct, int Cout, int N, int H, int W, int* split_out
 
 int launch_conv_wgradb(const void* xa, int Ct, const void* dyb, int Cout, int N, int H, int W, float* dW, int accumulate,
                        float* workspace, hipStream_t st, int up) {
-  ADM_REQUIRE(conv_wgradb_eligible(Ct, Cout, H, W), "conv_wgradb: shape not eligible (Ct % 64, Cout % 128, H % 4, W % 32)");
+  ADM_REQUIRE(conv_wgradb_eligible(Ct, Cout, H, W, N), "conv_wgradb: shape not eligible (Ct % 64, Cout % 128, H % 4, W % 32 — or W = 16 / 8 with N % 2 / 4 == 0)");
+  const int lw = W % 32 == 0 ? 5 : (W == 16 ? 4 : 3);
+  ADM_REQUIRE(lw >= 4 || !up, "conv_wgradb: no nearest-x2 variant for 8-pixel rows");
   Bf16BWgradParams p;
   p.xa = reinterpret_cast<const u32x4*>(xa); p.CgI = Ct / 8;
   p.dyb = reinterpret_cast<const u32x4*>(dyb); p.CgO = Cout / 8;
   p.Hp = H + 2; p.Wp = W + 2; p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.Ct = Ct;   // H, W: output (= dy) dims
   p.HpX = (up ? H / 2 : H) + 2; p.WpX = (up ? W / 2 : W) + 2;
   p.part = workspace;
-  p.tiles_x = W / 32; p.tiles_y = H / 4;
-  p.n_ptiles = p.tiles_x * p.tiles_y * N;
+  p.tiles_x = lw == 5 ? W / 32 : 1; p.tiles_y = H / 4;
+  p.n_ptiles = p.tiles_x * p.tiles_y * (N >> (5 - lw));
   p.n_ct = Cout / 128; p.n_ci = Ct / 64;
   conv_wgradb_workspace(Ct, Cout, N, H, W, &p.split);
   p.tiles_per_block = ceil_div(p.n_ptiles, p.split);
   p.nblk = p.n_ct * p.n_ci * p.split;
   auto magic = [&](long d) { return (d <= 1 || p.n_ptiles >= 65536) ? 0u : (unsigned)((1ULL << 32) / (unsigned long long)d + 1ULL); };
   p.mTX = magic(p.tiles_x); p.mTXY = magic((long)p.tiles_x * p.tiles_y);
-  const size_t smem = sizeof(u32x4) * 2 * WB_BUF;
+  const size_t smem = sizeof(u32x4) * 2 * wb_buf(lw);
 #if !defined(ADM_EMU)
   static bool once = [] {
     (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<true, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<false, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgradb_kernel<true, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     return true;
   }();
   (void)once;
 #endif
-  if (up) {
+  const bool f16 = conv_op16_f16();
+  if (lw == 3) {
+    if (f16) ADM_LAUNCH((conv_wgradb_kernel<true, false, 3>), dim3(p.nblk), dim3(512), smem, st, p);
+    else ADM_LAUNCH((conv_wgradb_kernel<false, false, 3>), dim3(p.nblk), dim3(512), smem, st, p);
+  } else if (lw == 4 && up) {
+    if (f16) ADM_LAUNCH((conv_wgradb_kernel<true, true, 4>), dim3(p.nblk), dim3(512), smem, st, p);
+    else ADM_LAUNCH((conv_wgradb_kernel<false, true, 4>), dim3(p.nblk), dim3(512), smem, st, p);
+  } else if (lw == 4) {
+    if (f16) ADM_LAUNCH((conv_wgradb_kernel<true, false, 4>), dim3(p.nblk), dim3(512), smem, st, p);
+    else ADM_LAUNCH((conv_wgradb_kernel<false, false, 4>), dim3(p.nblk), dim3(512), smem, st, p);
+  } else if (up) {
     if (conv_op16_f16()) ADM_LAUNCH((conv_wgradb_kernel<true, true>), dim3(p.nblk), dim3(512), smem, st, p);
     else ADM_LAUNCH((conv_wgradb_kernel<false, true>), dim3(p.nblk), dim3(512), smem, st, p);
   } else {

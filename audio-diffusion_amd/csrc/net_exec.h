@@ -149,6 +149,7 @@ struct Net {
   struct BlkOp { void* xa = nullptr; void* dyb = nullptr; bool fwd = false, wg = false, dg = false, s2 = false; int img_for = -1; bool img_done = false; };
   std::vector<BlkOp> blk;            // indexed like ops; empty below level 3 / for inference
   float* blk_part = nullptr;         // per-workgroup channel sums of the dy image pass (bias gradients)
+  std::vector<int> reader_count;     // tensor -> number of (non-statistics) ops that read it, level-3 training plans
   std::vector<int> producer_of;      // tensor -> index of the op that writes it (-1: none), level-3 training plans
   std::vector<int> gn_fuse_of;       // per op: the GroupNorm op whose statistics this convolution's split-K finish may leave (-1: none)
   std::vector<char> gn_skip;         // per op, during a forward walk: this GroupNorm's scale / shift have been written already

@@ -622,7 +622,7 @@ int Net::plan(int B) {
         BlkOp& b = blk[i];
         b.s2 = s2;
         b.fwd = conv_bf16b_eligible(Ct, Cout, Ho, Wo, s2 ? 0 : B);      // (B: rows of 16 / 8 pixels tile 2 / 4 images side by side)
-        b.wg = conv_wgradb_eligible(Ct, Cout, Ho, Wo);
+        b.wg = conv_wgradb_eligible(Ct, Cout, Ho, Wo, s2 ? 0 : B);
         b.dg = conv_bf16b_eligible(Cout, Ct, Ho, Wo, s2 ? 0 : B);
         if (s2 && !(b.fwd && b.wg && b.dg)) { b = BlkOp(); continue; }      // all three passes or none (one zero-inserted dy image)
         if (b.fwd || b.wg) {
@@ -649,8 +649,12 @@ int Net::plan(int B) {
       // conv1 of a resnet: its output feeds one GroupNorm (+ SiLU) + convolution and nothing else, so its dy is that GroupNorm's dx —
       // the consumer's backward writes the 16-bit image (and the channel sums) straight away (launch_blk_gn_bwd_image)
       producer_of.assign(tensors.size(), -1);
-      for (size_t i = 0; i < ops.size(); ++i)
+      reader_count.assign(tensors.size(), 0);
+      for (size_t i = 0; i < ops.size(); ++i) {
         if (ops[i].out >= 0) producer_of[ops[i].out] = (int)i;
+        if (ops[i].kind == Op::GN) continue;                    // (the statistics op of a convolution is that convolution's read)
+        for (int t : {ops[i].in1, ops[i].in2, ops[i].res, ops[i].wt}) if (t >= 0) ++reader_count[t];
+      }
       if (blk_direct_dy()) {
         std::vector<int> producer(tensors.size(), -1), readers(tensors.size(), 0);
         for (size_t i = 0; i < ops.size(); ++i) {
@@ -939,7 +943,9 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
     // the shortcut convolution of this resnet (the producer of the residual) sees the SAME dy — the buffer has just been handed to
     // its output's gradient and nothing else adds to it — so its bias gradient is this convolution's channel sums: second target
     float* dbias_sc = nullptr;
-    if (res_swapped && (size_t)o.res < producer_of.size() && producer_of[o.res] >= 0) {
+    // (only when this convolution is the residual's ONLY reader — a conv_shortcut output; the output of an attention block's to_out
+    // also feeds the resnet's norm1 / conv1, and its gradient is more than this dy)
+    if (res_swapped && (size_t)o.res < producer_of.size() && producer_of[o.res] >= 0 && reader_count[o.res] == 1) {
       const int ri = producer_of[o.res];
       const Op& ro = ops[ri];
       const bool r_blocked = (size_t)ri < blk.size() && (blk[ri].wg || blk[ri].dg);
@@ -973,7 +979,7 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       ADM_REQUIRE(tmp_da_floats >= (size_t)B * Ct * Hi * Wi, "run_backward: scratch too small");
       ADM_TRY(launch_conv_small_cout_bwd(t1.ptr, Ct, B, t1.H, t1.W, gsc, gsh, o.act, ps->P(o.w->key + ".weight"), dy, Cout,
                                          tmp_da, dW, st));
-    } else if (bo && bo->wg) {
+    } else if (bo && bo->wg && conv_wgradb_eligible(Ct, Cout, bo->s2 ? t1.H : to.H, bo->s2 ? t1.W : to.W, bo->s2 ? 0 : B)) {
       ADM_TRY(launch_conv_wgradb(bo->xa, Ct, bo->dyb, Cout, B, bo->s2 ? t1.H : to.H, bo->s2 ? t1.W : to.W, dW, 0, wgrad_ws, st, o.up));
     } else {
       adm_conv_args a;
@@ -1044,7 +1050,12 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
       ADM_REQUIRE(!o.up, "run_backward: GroupNorm + upsample in one conv is not supported");
       const GnBuf& gb = gnbufs[o.gn];
       Tensor* t2 = o.in2 >= 0 ? &tensors[o.in2] : nullptr;
-      const int pi = (conv_bf16_mode() >= 3 && (size_t)i < blk.size()) ? blk[i].img_for : -1;
+      int pi = (conv_bf16_mode() >= 3 && (size_t)i < blk.size()) ? blk[i].img_for : -1;
+      if (pi >= 0) {     // a batch smaller than the planned one may not fill the narrow-row tiles: the producer then reads the fp32 dy
+        const Op& po = ops[pi];
+        const int pCt = tensors[po.in1].C + (po.in2 >= 0 ? tensors[po.in2].C : 0);
+        if (!conv_wgradb_eligible(pCt, C1, t1.H, t1.W, B) || !conv_bf16b_eligible(C1, pCt, t1.H, t1.W, B)) pi = -1;
+      }
       if (pi >= 0 && !t1.ginit) {
         const Op& po = ops[pi];
         ADM_TRY(launch_gn_backward_stats(t1.ptr, C1, nullptr, 0, tmp_da, B, (int)plane_i, groups, gb.mean_rstd, gb.g->gamma, gb.g->beta, o.act,

@@ -254,3 +254,33 @@ def test_conv_bf16_blocked_narrow_rows_tile_images_side_by_side(backend, case):
                                     chan_add=None if temb is None else temb[perm.to(x.device)],
                                     residual=None if res is None else res[perm.to(x.device)], up=bool(up))
     assert torch.equal(out_p.cpu()[perm], out.cpu())
+
+
+NARROW_WGRAD_CASES = [
+    # (N, Ct, H, W, Cout, up)
+    (2, 64, 16, 16, 128, 0),      # one pair of 16x16 images: 4 tiles
+    (4, 128, 8, 16, 128, 0),      # two pairs, two cin blocks
+    (4, 64, 8, 8, 128, 0),        # one group of four 8x8 images: 2 tiles (the k-step's two 8-pixel halves are two images)
+    (8, 64, 8, 8, 256, 0),        # two groups, two cout tiles
+    (2, 64, 16, 16, 128, 1),      # Upsample2D.conv 8x8 -> 16x16
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", NARROW_WGRAD_CASES, ids=[str(i) for i in range(len(NARROW_WGRAD_CASES))])
+def test_conv_wgrad_bf16_blocked_narrow_rows(backend, case):
+    dev = select(backend)
+    from audiodiffusion import ops
+    Nn, Ct, H, W, Cout, up = case
+    Hs, Ws = (H // 2, W // 2) if up else (H, W)
+    x = _rand((Nn, Ct, Hs, Ws), 1, dev)
+    dy = _rand((Nn, Cout, H, W), 2, dev)
+    x_img = ops.blocked_image(x)
+    dy_img = ops.blocked_image(dy)
+    dW = ops.conv2d_wgrad_bf16_blocked(x_img, dy_img, up=bool(up))
+    xa = _unblock(x_img.cpu())[:, :, 1:-1, 1:-1]
+    if up:
+        xa = F.interpolate(xa, scale_factor=2, mode="nearest")
+    dyb = _unblock(dy_img.cpu())[:, :, 1:-1, 1:-1]
+    exact = torch.nn.grad.conv2d_weight(xa, (Cout, Ct, 3, 3), dyb, padding=1)
+    assert _relerr(dW.double(), exact) < 2e-6, _relerr(dW.double(), exact)

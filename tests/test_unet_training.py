@@ -383,6 +383,41 @@ def test_mixed_precision_bf16_level3_blocked_operand_images(backend, monkeypatch
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_level3_partial_batch_leaves_the_narrow_row_tilings(backend, monkeypatch):
+    """The narrow-row tilings put 2 images of the 16x16 level side by side: a plan made for B = 4 takes them, the short last batch of an
+    epoch (B = 3, `drop_last=False`, train_unet.py:181) cannot fill the tiles and must fall back INSIDE the same plan — forward, weight
+    gradient, data gradient, and the GroupNorm backward that would otherwise write the producer's dy image directly — with up-to-date
+    weight images (optimizer step in between), to the result of a model planned at B = 3 from the start."""
+    dev = select(backend)
+    from audiodiffusion import _native as N
+    from audiodiffusion import training as T
+    from audiodiffusion.unet import UNet2DModel
+    monkeypatch.setenv("ADM_BF16_LEVEL", "3")
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn((4, 1, 32, 32), generator=g).to(dev)
+    tgt = torch.randn((4, 1, 32, 32), generator=g).to(dev)
+    ts = torch.tensor([10, 500, 900, 77])
+    try:
+        a = UNet2DModel(**BLKCFG).init_random(0)
+        fa, ga = a.enable_training(mixed_precision="bf16")
+        oa = T.AdamW(fa, lr=1e-3)
+        b = UNet2DModel(**BLKCFG).init_random(0)
+        fb, gb = b.enable_training(mixed_precision="bf16")
+        a.train_step(x, ts, tgt)
+        ws = N.lib().adm_unet_workspace_bytes(a._handle)
+        oa.step(ga, clip=T.clip_grad_norm_(ga, 1.0)); a.refresh_weights()
+        la = a.train_step(x[:3].contiguous(), ts[:3], tgt[:3].contiguous())
+        assert N.lib().adm_unet_workspace_bytes(a._handle) == ws
+        fb.copy_(fa)
+        lb = b.train_step(x[:3].contiguous(), ts[:3], tgt[:3].contiguous())
+    finally:
+        N.check(N.lib().adm_set_option(b"conv_bf16", 0))
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
+    # (bias gradients: channel sums of the dy image pass vs adm_chan_sums — another fp32 summation order)
+    assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()), float((ga - gb).abs().max()) / float(gb.abs().max())
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_mixed_precision_fp16_training_step_and_grad_scaler(backend):
     """`--mixed_precision fp16` (train_unet.py:391-395): the 16-bit-operand kernels on IEEE binary16 + GradScaler semantics.
     (1) with the loss scaled by 65536 the UN-scaled gradient is within fp16 tolerance of the fp32 autograd oracle (and closer
