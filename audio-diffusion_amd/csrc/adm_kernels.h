@@ -111,6 +111,7 @@ int launch_blk_apply(const float* x1, int C1, long x1_bs, const float* x2, int C
 int launch_blk_gn_bwd_image(const float* x, int C, const float* da, int N, int H, int W, int groups, const float* mean_rstd,
                             const float* gamma, const float* beta, int act, const float* s12, void* out, float* sum_scratch,
                             hipStream_t st);
+bool gn_bwd_streaming(int N, int C, int HW);   // k_backward.hip: elementwise passes over >= 64 MB use streaming (non-temporal) accesses
 int launch_gn_backward_stats(const float* x1, int C1, const float* x2, int C2, const float* da, int N, int HW, int groups,
                              const float* mean_rstd, const float* gamma, const float* beta, int act, float* s12_scratch,
                              float* dgamma, float* dbeta, hipStream_t st);   // k_backward.hip: pass 1 of launch_gn_backward alone

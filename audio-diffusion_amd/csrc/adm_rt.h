@@ -42,6 +42,9 @@
 // LDS hand-over between the lanes of ONE wave (hardware: a wave's LDS operations execute in order, nothing to do; the
 // emulator runs every lane as its own fiber and needs the rendezvous)
 #define ADM_WAVE_LDS_ORDER() adm_emu::wave_sync()
+// streaming (non-temporal) 16-byte accesses: plain ones here
+template <class T> static inline T adm_ld_nt(const T* p) { return *p; }
+template <class T> static inline void adm_st_nt(T* p, const T& v) { *p = v; }
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -95,6 +98,20 @@ typedef unsigned adm_u32x2 __attribute__((ext_vector_type(2)));
 #define ADM_BARRIER_LGKM() ADM_BARRIER_KEEP_VMEM(63)
 // LDS hand-over between the lanes of ONE wave: LDS executes a wave's operations in order; only the compiler must not reorder
 #define ADM_WAVE_LDS_ORDER() __builtin_amdgcn_wave_barrier()
+// Streaming (non-temporal) 16-byte global accesses for passes over tensors far larger than the L2 (4 MB per XCD): the lines are
+// not kept, which is worth +10 % (loads) / +16 % (loads and stores) on a 1.6 GB GroupNorm-backward pass (tools/microbench/
+// gnbwd_bench.hip: 5.6 -> 6.6 TB/s). T = float4 / u32x4.
+template <class T> __device__ __forceinline__ T adm_ld_nt(const T* p) {
+  typedef unsigned adm_nt4 __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(T) == 16, "adm_ld_nt: 16-byte types");
+  const adm_nt4 v = __builtin_nontemporal_load(reinterpret_cast<const adm_nt4*>(p));
+  return __builtin_bit_cast(T, v);
+}
+template <class T> __device__ __forceinline__ void adm_st_nt(T* p, const T& v) {
+  typedef unsigned adm_nt4 __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(T) == 16, "adm_st_nt: 16-byte types");
+  __builtin_nontemporal_store(__builtin_bit_cast(adm_nt4, v), reinterpret_cast<adm_nt4*>(p));
+}
 #define ADM_LAUNCH(kern, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kern, (grid), (block), (shmem), (stream), __VA_ARGS__)
 #define ADM_DYN_SMEM(type, name)                                              \

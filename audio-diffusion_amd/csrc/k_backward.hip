@@ -116,6 +116,8 @@ __global__ void __launch_bounds__(256) chan_sums_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------
 // GroupNorm(+SiLU) backward, pass 1: per (n, group) s1 = mean(g*gamma), s2 = mean(g*gamma*xhat) over the group, and the
 // affine gradients dgamma[c] += sum g*xhat, dbeta[c] += sum g (atomics over n). g = da * silu'(y) (or da).
+// NT: streaming loads (the launcher sets it for passes over >= 64 MB: nothing of them survives in the L2 anyway)
+template <bool NT>
 __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restrict__ x1, int C1,
                                                            const float* __restrict__ x2, int C2,
                                                            const float* __restrict__ da, int HW, int groups,
@@ -145,7 +147,8 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restri
         ADM_UNROLL
         for (int u = 0; u < 4; ++u) {
           const int i = i0 + 256 * u < n4 ? i0 + 256 * u : i0;          // past the end: re-read a valid element, contribution masked
-          xv[u] = xs4[i]; dv[u] = ds4[i];
+          if (NT) { xv[u] = adm_ld_nt(xs4 + i); dv[u] = adm_ld_nt(ds4 + i); }
+          else { xv[u] = xs4[i]; dv[u] = ds4[i]; }
         }
         ADM_UNROLL
         for (int u = 0; u < 4; ++u) {
@@ -186,6 +189,7 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const float* __restri
 }
 
 // pass 2: dx = rstd * (g*gamma - s1 - xhat*s2), routed to the gradient buffers of x1 / x2 (each (=|+=)).
+template <bool NT>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ x1, int C1,
                                                            const float* __restrict__ x2, int C2,
                                                            const float* __restrict__ da, int HW, int groups,
@@ -215,9 +219,10 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
       ADM_UNROLL
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * step < n4 ? i0 + u * step : i0;
-        xv[u] = xs4[i]; dv[u] = ds4[i];
+        if (NT) { xv[u] = adm_ld_nt(xs4 + i); dv[u] = adm_ld_nt(ds4 + i); }
+        else { xv[u] = xs4[i]; dv[u] = ds4[i]; }
         ov[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (acc) ov[u] = dx4[i];                                          // uniform
+        if (acc) ov[u] = NT ? adm_ld_nt(const_cast<const float4*>(dx4) + i) : dx4[i];   // uniform
       }
       ADM_UNROLL
       for (int u = 0; u < 4; ++u) {
@@ -233,7 +238,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
         }
         float4 o = ov[u];
         o.x += r[0]; o.y += r[1]; o.z += r[2]; o.w += r[3];
-        dx4[i0 + u * step] = o;
+        if (NT) adm_st_nt(dx4 + i0 + u * step, o); else dx4[i0 + u * step] = o;
       }
     }
     return;
@@ -603,24 +608,38 @@ int launch_chan_sums(const float* dy, int N, int C, int HW, float* out_nc, int n
   ADM_LAUNCH(chan_sums_kernel, dim3(C, N), dim3(256), 0, st, dy, C, HW, out_nc, nc_stride, nc_accumulate, out_c);
   return ADM_CHECK_LAUNCH();
 }
+// streaming loads / stores for the elementwise passes over a tensor of >= 64 MB (ADM_NT_STREAM=0: never; developer A/B)
+bool gn_bwd_streaming(int N, int C, int HW) {
+  static const int on = [] { const char* e = getenv("ADM_NT_STREAM"); return e ? atoi(e) : 1; }();
+  return on && (long)N * C * HW * 4 >= (64L << 20);
+}
 int launch_gn_backward(const float* x1, int C1, const float* x2, int C2, const float* da, int N, int HW, int groups,
                        const float* mean_rstd, const float* gamma, const float* beta, int act, float* s12_scratch,
                        float* dgamma, float* dbeta, float* dx1, int acc1, float* dx2, int acc2, hipStream_t st) {
   if (x2 == nullptr) C2 = 0;
-  ADM_LAUNCH(gn_bwd_stats_kernel, dim3(groups, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd, gamma,
-             beta, act, s12_scratch, dgamma, dbeta);
+  const bool nt = gn_bwd_streaming(N, C1 + C2, HW);
+  if (nt) ADM_LAUNCH(gn_bwd_stats_kernel<true>, dim3(groups, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd, gamma,
+                     beta, act, s12_scratch, dgamma, dbeta);
+  else ADM_LAUNCH(gn_bwd_stats_kernel<false>, dim3(groups, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd, gamma,
+                  beta, act, s12_scratch, dgamma, dbeta);
   int gx = (HW + 4095) / 4096;   // 256 threads x float4 x 4 iterations per workgroup
   if (gx < 1) gx = 1;
-  ADM_LAUNCH(gn_bwd_apply_kernel, dim3(gx, C1 + C2, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd,
-             gamma, beta, act, (const float*)s12_scratch, dx1, acc1, dx2, acc2);
+  if (nt) ADM_LAUNCH(gn_bwd_apply_kernel<true>, dim3(gx, C1 + C2, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd,
+                     gamma, beta, act, (const float*)s12_scratch, dx1, acc1, dx2, acc2);
+  else ADM_LAUNCH(gn_bwd_apply_kernel<false>, dim3(gx, C1 + C2, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd,
+                  gamma, beta, act, (const float*)s12_scratch, dx1, acc1, dx2, acc2);
   return ADM_CHECK_LAUNCH();
 }
 int launch_gn_backward_stats(const float* x1, int C1, const float* x2, int C2, const float* da, int N, int HW, int groups,
                              const float* mean_rstd, const float* gamma, const float* beta, int act, float* s12_scratch,
                              float* dgamma, float* dbeta, hipStream_t st) {
   if (x2 == nullptr) C2 = 0;
-  ADM_LAUNCH(gn_bwd_stats_kernel, dim3(groups, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd, gamma,
-             beta, act, s12_scratch, dgamma, dbeta);
+  if (gn_bwd_streaming(N, C1 + C2, HW))
+    ADM_LAUNCH(gn_bwd_stats_kernel<true>, dim3(groups, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd, gamma,
+               beta, act, s12_scratch, dgamma, dbeta);
+  else
+    ADM_LAUNCH(gn_bwd_stats_kernel<false>, dim3(groups, N), dim3(256), 0, st, x1, C1, x2, C2, da, HW, groups, mean_rstd, gamma,
+               beta, act, s12_scratch, dgamma, dbeta);
   return ADM_CHECK_LAUNCH();
 }
 int launch_attention_bwd(const float* qkv, const float* dout, float* dqkv, int N, int C, int T, int head_dim,

@@ -51,7 +51,8 @@ struct BlkApplyParams {
 // GNBWD: the image of dy for a convolution whose OUTPUT is read by nothing but a GroupNorm (+ SiLU) + convolution (conv1 of a resnet):
 // its dy IS the dx of that GroupNorm's backward, so pass 2 of the backward writes the 16-bit image (and the channel sums) directly —
 // the fp32 dx tensor and the image pass over it disappear.  Same arithmetic as gn_bwd_apply_kernel: rstd * (g * gamma - s1 - xhat * s2).
-template <bool F16, bool GNBWD = false>
+// NT: streaming loads of the fp32 tensors and streaming stores of the image (passes over >= 64 MB; adm_ld_nt)
+template <bool F16, bool GNBWD = false, bool NT = false>
 __global__ void __launch_bounds__(256) blk_apply_kernel(const BlkApplyParams p) {
   const int cg = blockIdx.y, n = blockIdx.z;
   const int W4 = p.W >> 2;
@@ -63,13 +64,17 @@ __global__ void __launch_bounds__(256) blk_apply_kernel(const BlkApplyParams p) 
   const float* src = c0 < p.C1 ? p.x1 + (long)n * p.x1_bs + (long)c0 * HW : p.x2 + (long)n * p.x2_bs + (long)(c0 - p.C1) * HW;
   float4 v[8];
   ADM_UNROLL
-  for (int e = 0; e < 8; ++e) v[e] = live ? *reinterpret_cast<const float4*>(src + (long)e * HW + (long)y * p.W + 4 * x4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = 0; e < 8; ++e) {
+    const float4* q4 = reinterpret_cast<const float4*>(src + (long)e * HW + (long)y * p.W + 4 * x4);
+    v[e] = !live ? make_float4(0.f, 0.f, 0.f, 0.f) : (NT ? adm_ld_nt(q4) : *q4);
+  }
   if (GNBWD) {
     const float* dsrc = p.gda + ((long)n * p.C1 + c0) * HW;
     const int cpg = p.C1 / p.g_groups;
     ADM_UNROLL
     for (int e = 0; e < 8; ++e) {
-      const float4 dv = live ? *reinterpret_cast<const float4*>(dsrc + (long)e * HW + (long)y * p.W + 4 * x4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4* q4 = reinterpret_cast<const float4*>(dsrc + (long)e * HW + (long)y * p.W + 4 * x4);
+      const float4 dv = !live ? make_float4(0.f, 0.f, 0.f, 0.f) : (NT ? adm_ld_nt(q4) : *q4);
       const int g = (c0 + e) / cpg;
       const float mean = p.g_mean_rstd[((long)n * p.g_groups + g) * 2], rstd = p.g_mean_rstd[((long)n * p.g_groups + g) * 2 + 1];
       const float s1 = p.g_s12[((long)n * p.g_groups + g) * 2], s2 = p.g_s12[((long)n * p.g_groups + g) * 2 + 1];
@@ -151,7 +156,7 @@ __global__ void __launch_bounds__(256) blk_apply_kernel(const BlkApplyParams p) 
     const int owner = 16 * j + (lane >> 2);                       // lane that produced unit 64 j + lane
     const int od = __shfl(my_dst, owner);
     const u32x4 w = stg[wave][64 * j + 4 * (lane >> 2) + ((lane & 3) ^ ((lane >> 3) & 3))];
-    if (od >= 0) plane[od + (lane & 3)] = w;
+    if (od >= 0) { if (NT) adm_st_nt(plane + od + (lane & 3), w); else plane[od + (lane & 3)] = w; }
   }
 }
 
@@ -191,8 +196,14 @@ int launch_blk_apply(const float* x1, int C1, long x1_bs, const float* x2, int C
   ADM_REQUIRE((reinterpret_cast<uintptr_t>(x1) & 15) == 0 && (x2 == nullptr || (reinterpret_cast<uintptr_t>(x2) & 15) == 0),
               "blk_apply: inputs must be 16-byte aligned");
   const dim3 grid((unsigned)ceil_div(H * (W / 4), 256), (unsigned)((C1 + p.C2) / 8), (unsigned)N);
-  if (conv_op16_f16()) ADM_LAUNCH((blk_apply_kernel<true, false>), grid, dim3(256), 0, st, p);
-  else ADM_LAUNCH((blk_apply_kernel<false, false>), grid, dim3(256), 0, st, p);
+  const bool f16 = conv_op16_f16();
+  if (gn_bwd_streaming(N, C1 + p.C2, H * W) && !zins) {
+    if (f16) ADM_LAUNCH((blk_apply_kernel<true, false, true>), grid, dim3(256), 0, st, p);
+    else ADM_LAUNCH((blk_apply_kernel<false, false, true>), grid, dim3(256), 0, st, p);
+  } else {
+    if (f16) ADM_LAUNCH((blk_apply_kernel<true, false>), grid, dim3(256), 0, st, p);
+    else ADM_LAUNCH((blk_apply_kernel<false, false>), grid, dim3(256), 0, st, p);
+  }
   return ADM_CHECK_LAUNCH();
 }
 
@@ -208,8 +219,14 @@ int launch_blk_gn_bwd_image(const float* x, int C, const float* da, int N, int H
   p.out = reinterpret_cast<u32x4*>(out); p.Hp = H + 2; p.Wp = W + 2; p.part = sum_scratch; p.zins = 0;
   p.gda = da; p.g_mean_rstd = mean_rstd; p.g_gamma = gamma; p.g_beta = beta; p.g_s12 = s12; p.g_groups = groups; p.g_act = act;
   const dim3 grid((unsigned)ceil_div(H * (W / 4), 256), (unsigned)(C / 8), (unsigned)N);
-  if (conv_op16_f16()) ADM_LAUNCH((blk_apply_kernel<true, true>), grid, dim3(256), 0, st, p);
-  else ADM_LAUNCH((blk_apply_kernel<false, true>), grid, dim3(256), 0, st, p);
+  const bool f16 = conv_op16_f16();
+  if (gn_bwd_streaming(N, C, H * W)) {
+    if (f16) ADM_LAUNCH((blk_apply_kernel<true, true, true>), grid, dim3(256), 0, st, p);
+    else ADM_LAUNCH((blk_apply_kernel<false, true, true>), grid, dim3(256), 0, st, p);
+  } else {
+    if (f16) ADM_LAUNCH((blk_apply_kernel<true, true>), grid, dim3(256), 0, st, p);
+    else ADM_LAUNCH((blk_apply_kernel<false, true>), grid, dim3(256), 0, st, p);
+  }
   return ADM_CHECK_LAUNCH();
 }
 
@@ -231,6 +248,7 @@ struct Bf16BConvParams {
   const float* residual; float* out;
   double* stats;                        // NULL or GroupNorm partial sums of the output: [n][cout][tile][2] (sum, sum of squares)
   int tiles_x, tiles_y, n_ct, nblk;
+  int nt;                               // streaming stores of the output / loads of the residual (tensors of >= 64 MB)
   int ksplit; float* part; long part_stride;   // > 1: K split over `ksplit` workgroups per tile, raw partial sums to slab kpart of `part`
   unsigned long long* prof;             // developer aid (ADM_BF16B_PROF=1): per-phase cycle counters, else NULL
 };
@@ -450,10 +468,10 @@ __global__ void __launch_bounds__(256, 2) conv_bf16b_kernel(const Bf16BConvParam
       const int o = lane_off + 8 * k * planeO + pt * p.W;
       v.x += bv[k]; v.y += bv[k]; v.z += bv[k]; v.w += bv[k];
       if (res_n) {
-        const float4 rr = *reinterpret_cast<const float4*>(res_n + o);
+        const float4 rr = p.nt ? adm_ld_nt(reinterpret_cast<const float4*>(res_n + o)) : *reinterpret_cast<const float4*>(res_n + o);
         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
       }
-      *reinterpret_cast<float4*>(out_n + o) = v;
+      if (p.nt) adm_st_nt(reinterpret_cast<float4*>(out_n + o), v); else *reinterpret_cast<float4*>(out_n + o) = v;
       if (p.stats) {        // wave-uniform: statistics of the FINAL output values for the GroupNorm that reads this tensor
         gs[k] += (v.x + v.y) + (v.z + v.w);
         gq[k] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
@@ -522,6 +540,10 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
   if (p.chan_add == nullptr) { p.chan_add = conv_zero_bias(Cout); p.chan_add_stride = 0; }
   ADM_REQUIRE(p.bias && p.chan_add, "conv_bf16b: constant buffers");
   p.residual = residual; p.out = out; p.stats = stats_out;
+  {
+    static const int nt_on = [] { const char* e = getenv("ADM_NT_CONV"); return e ? atoi(e) : 1; }();     // developer A/B
+    p.nt = nt_on && !s2 && gn_bwd_streaming(N, Cout, H * W);
+  }
   ADM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0,
               "conv_bf16b: out / residual must be 16-byte aligned");
   p.tiles_x = lw == 5 ? W / 32 : 1; p.tiles_y = H / 8; p.n_ct = Cout / 128;

@@ -1,0 +1,7 @@
+R=$GRAFT_REPO_ROOT; cd $R; O=gpurun_out/${1:-r04q2}; mkdir -p $O
+timeout 600 python -m pytest tests/test_conv_bf16_blocked.py -m gpu -x -q > $O/pytest.log 2>&1; echo "tests rc=$?"; tail -2 $O/pytest.log
+for i in 1 2; do
+  for nt in 1 0; do
+    ADM_NT_CONV=$nt PROBE_CHECK=0 PROBE_B=16 PROBE_MP=bf16 timeout 200 python tools/gpu_probe.py trainstep > $O/step_${nt}_$i.log 2>&1; echo "nt_conv=$nt run $i: $(grep 'train step' $O/step_${nt}_$i.log)"
+  done
+done
