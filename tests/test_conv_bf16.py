@@ -341,3 +341,22 @@ def test_fp16_operand_format_forward_wgrad_and_1x1(backend):
         assert _relerr(got, ref) < 2e-6, _relerr(got, ref)
     for k in range(3):
         assert 1e-5 < _relerr(out[1][k], out[0][k]) < 8e-3        # bf16 and binary16 round differently, both close to fp32
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(64, 32, 3), (128, 96, 3), (192, 64, 1), (40, 24, 3)], ids=["one-tile", "tiles", "1x1", "gather"])
+def test_bf16_filter_images_bit_for_bit(backend, case):
+    """adm_pack_bf16_weight: [tap][Cin/8][Cout] x 8 cins (forward) and [flipped tap][Cout/8][Cin] x 8 couts (data gradient), each
+    element the round-to-nearest-even bf16 of the fp32 weight — the LDS-tiled writer (Cout % 64 == 0, Cin % 32 == 0; round 4) and the
+    per-element gather (other shapes) against the layout written out in torch."""
+    dev = select(backend)
+    from audiodiffusion import ops
+    co, ci, ks = case
+    w = _rand((co, ci, ks, ks), 21, dev) if ks == 3 else _rand((co, ci), 21, dev)
+    w4 = w.cpu().reshape(co, ci, ks * ks).to(torch.bfloat16)
+    fwd = ops.pack_bf16_weight(w).cpu()
+    want = w4.permute(2, 1, 0).reshape(ks * ks, ci // 8, 8, co).permute(0, 1, 3, 2)
+    assert torch.equal(fwd.view(torch.int16), want.contiguous().view(torch.int16))
+    bwd = ops.pack_bf16_weight(w, transposed=True).cpu()
+    want_t = w4.flip(2).permute(2, 0, 1).reshape(ks * ks, co // 8, 8, ci).permute(0, 1, 3, 2)
+    assert torch.equal(bwd.view(torch.int16), want_t.contiguous().view(torch.int16))
