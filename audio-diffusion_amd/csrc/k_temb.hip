@@ -58,7 +58,38 @@ __global__ void __launch_bounds__(256) time_embedding_kernel(const float* __rest
     return acc;
   };
   const bool vec = (dim_in % 32 == 0) && (dim_emb % 32 == 0) && ((reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2)) & 15) == 0;
-  if (vec) {
+  if (vec && dim_in == 128 && dim_emb % 128 == 0) {
+    // linear_1 of the shipped models (128 -> 512; every workgroup of a sample recomputes it: 65 k MACs): the lane's 16 sinusoid words
+    // live in registers and FOUR row groups (32 rows per wave) are in flight at once — 16 independent float4 loads per lane instead
+    // of a chain of 16 dependent iterations (LDS reads of x and the LDS store of hid kept the compiler from overlapping them).
+    // Same products, same order per row as gemv8: bit-identical.
+    float4 xr[4];
+    ADM_UNROLL
+    for (int q = 0; q < 4; ++q) xr[q] = *reinterpret_cast<const float4*>(sinus + 4 * kq + 32 * q);
+    for (int j0 = 32 * wave; j0 < dim_emb; j0 += 128) {
+      float4 wv[4][4];
+      ADM_UNROLL
+      for (int g = 0; g < 4; ++g)
+        ADM_UNROLL
+        for (int q = 0; q < 4; ++q) wv[g][q] = *reinterpret_cast<const float4*>(w1 + (long)(j0 + 8 * g + rl) * 128 + 4 * kq + 32 * q);
+      ADM_UNROLL
+      for (int g = 0; g < 4; ++g) {
+        float acc = 0.f;
+        ADM_UNROLL
+        for (int q = 0; q < 4; ++q) {
+          acc = fmaf(wv[g][q].x, xr[q].x, acc); acc = fmaf(wv[g][q].y, xr[q].y, acc);
+          acc = fmaf(wv[g][q].z, xr[q].z, acc); acc = fmaf(wv[g][q].w, xr[q].w, acc);
+        }
+        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+        const int j = j0 + 8 * g + rl;
+        if (kq == 0) {
+          acc += b1[j];
+          hid[j] = silu_t(acc);
+          if (save_z && part == 0) save_z[(long)b * dim_emb + j] = acc;  // pre-activation of linear_1 (training)
+        }
+      }
+    }
+  } else if (vec) {
     for (int j0 = 8 * wave; j0 < dim_emb; j0 += 32) {          // linear_1 (every workgroup of a sample recomputes it: 65 k MACs)
       const int j = j0 + rl;
       float acc = 0.f;
@@ -86,6 +117,29 @@ __global__ void __launch_bounds__(256) time_embedding_kernel(const float* __rest
   __syncthreads();
   const int rows = (dim_emb + TE_SPLIT - 1) / TE_SPLIT;
   const int j_end = (part + 1) * rows < dim_emb ? (part + 1) * rows : dim_emb;
+  if (vec && dim_emb == 512 && rows % 8 == 0) {
+    // linear_2 of the shipped models (512 -> 512): a row group's 16 float4 loads per lane issued together (the generic loop below
+    // leaves it to the compiler, which keeps them behind the LDS reads of hid); same products in the same order: bit-identical
+    for (int j0 = part * rows + 8 * wave; j0 < j_end; j0 += 32) {
+      const int j = j0 + rl;
+      float4 wv[16];
+      ADM_UNROLL
+      for (int q = 0; q < 16; ++q) wv[q] = *reinterpret_cast<const float4*>(w2 + (long)(j < j_end ? j : j0) * 512 + 4 * kq + 32 * q);
+      float acc = 0.f;
+      ADM_UNROLL
+      for (int q = 0; q < 16; ++q) {
+        const float4 xv = *reinterpret_cast<const float4*>(hid + 4 * kq + 32 * q);
+        acc = fmaf(wv[q].x, xv.x, acc); acc = fmaf(wv[q].y, xv.y, acc); acc = fmaf(wv[q].z, xv.z, acc); acc = fmaf(wv[q].w, xv.w, acc);
+      }
+      acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+      if (kq == 0 && j < j_end) {
+        acc += b2[j];
+        emb[(long)b * dim_emb + j] = acc;
+        if (emb_act) emb_act[(long)b * dim_emb + j] = silu_t(acc);
+      }
+    }
+    return;
+  }
   if (vec && rows % 8 == 0) {
     for (int j0 = part * rows + 8 * wave; j0 < j_end; j0 += 32) {   // linear_2: this workgroup's slice of the rows
       const int j = j0 + rl;
@@ -162,6 +216,36 @@ __global__ void __launch_bounds__(256) temb_proj_kernel(const float* __restrict_
     se[i] = e;
   }
   __syncthreads();
+  if (K == 512) {
+    // the shipped models: the wave's four rows' 32 weight words per lane requested together (the loop below takes the rows one
+    // after the other: four L2 round trips in a row); same products in the same order, bit-identical
+    float wv[4][8];
+    ADM_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      const int r = blockIdx.x * 16 + wave * 4 + j;
+      ADM_UNROLL
+      for (int q = 0; q < 8; ++q) wv[j][q] = w[(long)(r < R ? r : R - 1) * 512 + lane + 64 * q];
+    }
+    ADM_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      const int r = blockIdx.x * 16 + wave * 4 + j;
+      float acc[8];
+      ADM_UNROLL
+      for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+      ADM_UNROLL
+      for (int q = 0; q < 8; ++q)
+        ADM_UNROLL
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(wv[j][q], se[i * 512 + lane + 64 * q], acc[i]);
+      ADM_UNROLL
+      for (int i = 0; i < 8; ++i) {
+        float v = acc[i];
+        ADM_UNROLL
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0 && b0 + i < B && r < R) out[(long)(b0 + i) * R + r] = v + bias[r];
+      }
+    }
+    return;
+  }
   for (int j = 0; j < 4; ++j) {
     const int r = blockIdx.x * 16 + wave * 4 + j;
     if (r >= R) break;

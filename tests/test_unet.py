@@ -29,8 +29,12 @@ def _pair(cfg, seed=0):
     return ref, mine
 
 
+WIDE = dict(sample_size=8, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(128, 128),
+            down_block_types=("DownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "UpBlock2D"))   # the shipped models' 128 -> 512 -> 512 time embedding
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("cfg,B", [(TINY, 2), (TINY3, 3)], ids=["tiny2", "tiny3"])
+@pytest.mark.parametrize("cfg,B", [(TINY, 2), (TINY3, 3), (WIDE, 2), (WIDE, 9)], ids=["tiny2", "tiny3", "wide", "wide9"])
 def test_unet_forward_matches_oracle(backend, cfg, B):
     dev = select(backend)
     ref, mine = _pair(cfg)
@@ -45,7 +49,7 @@ def test_unet_forward_matches_oracle(backend, cfg, B):
         assert o.shape == r.shape
         assert float((o - r).abs().max()) < 1e-3 * max(1.0, float(r.abs().max())), float((o - r).abs().max())
     # per-sample timesteps (training form, train_unet.py:241-257)
-    ts = torch.tensor([5, 500, 999][:B])
+    ts = torch.tensor(([5, 500, 999] * 3)[:B])
     with torch.no_grad():
         r = ref(x, ts)["sample"]
     o = mine(x.to(dev), ts)["sample"].cpu()
