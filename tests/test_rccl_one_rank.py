@@ -75,7 +75,7 @@ def test_bench_py_itself_with_a_one_rank_nccl_group():
     timing, and the training leg's overlapped bucket all-reduce all run over RCCL."""
     env = dict(os.environ, ADM_BENCH_FORCE_PG="1", MASTER_PORT=str(29600 + os.getpid() % 300))
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch-per-gpu", "2",
-                        "--ddim-steps", "3", "--no-cpu-baseline", "--train-steps", "2", "--train-batch-per-gpu", "2"],
+                        "--ddim-steps", "3", "--no-cpu-baseline", "--no-configs-leg", "--train-steps", "2", "--train-batch-per-gpu", "2"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
