@@ -348,9 +348,12 @@ int adm_conv2d_wgrad(const adm_conv_args* a, const float* dy, float* dW, int acc
  *     (adm_blocked_sums_scratch floats: one partial per workgroup, added in a fixed order).
  *   adm_conv2d_bf16_blocked: out (N,Cout,H,W) fp32 = conv3x3(img, stride 1, pad 1) + bias[co] + chan_add[n][co] + residual
  *     (each NULL ok), filters `wb` from adm_pack_bf16_weight (transposed = 1 and img = image of dy: the data gradient).
- *     Cin % 16 == 0, Cin >= 32, Cout % 128 == 0, H % 8 == 0, W % 32 == 0 (adm_conv2d_bf16_blocked_eligible).
+ *     Cin % 16 == 0, Cin >= 32, Cout % 128 == 0, H % 8 == 0, W % 32 == 0 (adm_conv2d_bf16_blocked_eligible) — or W == 16 / W == 8 with
+ *     Cin >= 64 and N % 2 / N % 4 == 0: two / four images side by side in one 32-column tile, K split over workgroups and finished in
+ *     slab order through the library's per-(device, stream) scratch (no stats_out, no stride-2 variant; up = 1 at W == 16 only).
  *   adm_conv2d_wgrad_bf16_blocked: dW (Cout,Cin,3,3) (+)= sum over pixels of dy x activated input, both as blocked images;
- *     Cin % 64 == 0, Cout % 128 == 0, H % 4 == 0, W % 32 == 0; workspace: adm_conv_wgrad_blocked_workspace floats.
+ *     Cin % 64 == 0, Cout % 128 == 0, H % 4 == 0, W % 32 == 0 (or W == 16 / 8 with N % 2 / N % 4 == 0, as above); workspace:
+ *     adm_conv_wgrad_blocked_workspace floats (0 = shape not eligible for this N).
  *     stats_out: NULL or (N, Cout, (H/8)*(W/32), 2) fp64 — per 8x32-pixel tile the (sum, sum of squares) of the final output
  *     values, the input adm_groupnorm_finalize needs (as adm_conv_args.stats_out).
  *   up = 1 (both): the convolution of Upsample2D — H, W are the OUTPUT dims and the input image is the half-resolution tensor
