@@ -105,7 +105,11 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], const Conv
 // s of the scratch buffer; ksplit_finish_kernel adds the slabs in order with bias / per-sample term / residual (deterministic).
 // Waves whose 32-pixel column blocks lie entirely beyond the batch skip their MFMAs (a 1x1-pixel level at B = 16 fills 16 of a
 // tile's 128 columns).
-template <int KS, int STRIDE, int WM, int TM, bool KSP = false>
+// KPF (split K, stride 1): the register pipeline of the stride-2 instantiation for the split kernel's two-to-eight
+// chunks — chunk c + 1's patch values and weight slab are requested before chunk c's MFMAs (4.4 us per chunk and wave) instead of
+// after them: a 2-chunk workgroup spent two full load round trips per chunk around 8.8 us of MFMA (28 us per launch). Same
+// MFMA order: bit-identical.
+template <int KS, int STRIDE, int WM, int TM, bool KSP = false, bool KPF = false>
 __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(const ConvParams p) {
   constexpr int WN = 4 / WM;
   constexpr int TN = 4 / WN;
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
   // STRIDE == 2 (Downsample2D: patches of 33 x 17 pixels, 3 elements per thread and channel plane — the single-element plan
   // of conv_mfma_pf_kernel does not fit): the same loop, software-pipelined through registers — the raw patch values and the
   // weight slab of chunk c + 1 are requested before the MFMAs of chunk c and written to LDS after them.
-  constexpr bool PF = STRIDE == 2;
+  constexpr bool PF = STRIDE == 2 || KPF;
   constexpr int ROW4 = BM / 4;
   constexpr int TOT4 = CK * KS2 * ROW4;
   constexpr int NW4 = (TOT4 + 255) / 256;
@@ -221,7 +225,8 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
       wraw[PF ? i : 0] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < TOT4) {
         const int row = idx / ROW4, c4 = idx - row * ROW4;
-        if (m0 + c4 * 4 < p.Cout) wraw[PF ? i : 0] = *reinterpret_cast<const float4*>(wsrc + (long)row * p.Cout + c4 * 4);
+        const bool live_tap = !(KSP && KS2 > 1) || ((tmask >> (row % KS2)) & 1);      // a tap no pixel of this plane can use: never read
+        if (m0 + c4 * 4 < p.Cout && live_tap) wraw[PF ? i : 0] = *reinterpret_cast<const float4*>(wsrc + (long)row * p.Cout + c4 * 4);
       }
     }
   };
@@ -884,7 +889,11 @@ static int launch_ksplit_generic(const ConvParams& p, hipStream_t st) {
         if (((rows >> ty) & 1) && ((cols >> tx) & 1)) q.tap_mask |= 1 << (ty * 3 + tx);
   }
   const size_t smem = sizeof(float) * ((size_t)CK * p.CS + (size_t)CK * KS * KS * bm);
-  if (bm == 128) {
+  static const int kpf = [] { const char* e = getenv("ADM_KSP_PIPE"); return e ? atoi(e) : 1; }();     // developer A/B
+  if (bm == 128 && STRIDE == 1 && kpf) {       // (patch elements beyond three per thread are loaded at stash time, as in the stride-2 kernel)
+    allow_big_lds(conv_mfma_kernel<KS, STRIDE, 2, 2, true, STRIDE == 1>, smem);
+    ADM_LAUNCH((conv_mfma_kernel<KS, STRIDE, 2, 2, true, STRIDE == 1>), dim3(q.nblk), dim3(256), smem, st, q);
+  } else if (bm == 128) {
     allow_big_lds(conv_mfma_kernel<KS, STRIDE, 2, 2, true>, smem);
     ADM_LAUNCH((conv_mfma_kernel<KS, STRIDE, 2, 2, true>), dim3(q.nblk), dim3(256), smem, st, q);
   } else if (bm == 64) {
