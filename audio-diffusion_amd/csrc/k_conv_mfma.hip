@@ -823,7 +823,8 @@ static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
     // 512+ input channels (the 8x8 level of the 256x256 model), measured at B = 32 (the bench batch): 14 layers 1.54 ms with 4
     // parts, 1.90 ms with 8 (twice the slab traffic). Up to 384 channels (the 8x8 levels of the 64x64 and latent 32x32 models, whose
     // batches are 1..16 images: 16..128 workgroups with 4 parts): 8 parts, -85 us per config-4 step, -70 us per config-1 step.
-    int S = nch <= 48 ? 8 : 4;
+    static const int s8_cout = [] { const char* e = getenv("ADM_KSP_PF_S8_COUT"); return e ? atoi(e) : 256; }();     // developer A/B
+    int S = (nch <= 48 || p.Cout <= s8_cout) ? 8 : 4;     // (<= 256 couts: the up-path 8x8 layers of those models, 768 -> 256)
     while (S > 1 && nch / S < 4) --S;
     if (S > 1) {
       const int rc = launch_ksplit<KS>(p, bm2, S, st);
@@ -1009,7 +1010,11 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
     g_last_variant += 2000;
     return dispatch_pf<3>(p, bm, st);
   }
-  if (use_pf() && a.ks == 1 && p.CS == 128 && Ct % 32 == 0 && a.C1 % 32 == 0 && TW % 4 == 0 && p.Wo % 4 == 0 && a.W % 4 == 0) {
+  // (1x1 on planes of <= 4x4 pixels with >= 64 input channels: the split generic kernel — the pipelined one has no split for 1x1, and a
+  // 768 -> 256 shortcut at 4x4 pixels, B = 16, was 16 workgroups walking 24 chunks: 33 us for 0.1 GFLOP; a function of the layer only)
+  static const int small1x1 = [] { const char* e = getenv("ADM_KSP_1X1_SMALL"); return e ? atoi(e) : 1; }();     // developer A/B
+  const bool split_1x1 = small1x1 && a.ks == 1 && p.Ho * p.Wo <= 16 && Ct / CK >= 8 && a.w_bstride == 0;
+  if (!split_1x1 && use_pf() && a.ks == 1 && p.CS == 128 && Ct % 32 == 0 && a.C1 % 32 == 0 && TW % 4 == 0 && p.Wo % 4 == 0 && a.W % 4 == 0) {
     g_last_variant += 2000;
     return dispatch_pf<1>(p, bm, st);
   }
