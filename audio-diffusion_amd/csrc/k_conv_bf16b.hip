@@ -614,8 +614,12 @@ int launch_conv_bf16b(const void* img, int Cin, int N, int H, int W, const void*
       else ADM_LAUNCH((conv_bf16b_kernel<false, false, false, 0, 4>), dim3(p.nblk), dim3(256), smem, st, p);
     }
     if (ADM_CHECK_LAUNCH() != 0) return -1;
-    if (p.ksplit > 1)
+    if (p.ksplit > 1) {
+      if (const GnFuse* f = conv_gn_fuse_pending(Cout))      // the executor announced the GroupNorm that reads `out` next (k_groupnorm.hip)
+        return launch_ksplit_finish_gn(p.part, p.ksplit, p.part_stride, bias ? bias : conv_zero_bias(Cout), chan_add, chan_add_stride, residual,
+                                       out, N, Cout, H * W, *f, st);
       return launch_ksplit_finish(p.part, p.ksplit, p.part_stride, bias, chan_add, chan_add_stride, residual, out, Cout, H * W, st);
+    }
     return 0;
   }
   if (mode == 2) {

@@ -781,10 +781,9 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
       if (bo)    // level 3: the activated input once as a blocked 16-bit image (kept for the weight gradient)
         ADM_TRY(launch_blk_apply(a.x1, a.C1, a.x1_bstride, a.x2, a.C2, a.x2_bstride, B, a.H, a.W, a.gn_scale, a.gn_shift, a.act, bo->xa,
                                  nullptr, st));
-      if (bo && bo->fwd && conv_bf16b_eligible(a.C1 + a.C2, a.Cout, o.up ? 2 * a.H : a.H, o.up ? 2 * a.W : a.W, bo->s2 ? 0 : B))
-        ADM_TRY(launch_conv_bf16b(bo->xa, a.C1 + a.C2, B, o.up ? 2 * a.H : a.H, o.up ? 2 * a.W : a.W, o.w->wb, a.Cout, a.bias, a.chan_add,
-                                  a.chan_add_stride, a.residual, a.out, st, bo->s2 ? (o.pad_lo ? 3 : 2) : o.up, bo->s2 ? nullptr : tensors[o.out].stats));
-      else {
+      {
+        // the first single-input GroupNorm that reads this output, announced to the launch: a split-K finish pass that can leave its
+        // scale / shift takes the request (k_groupnorm.hip), and the statistics op below is then skipped
         GnFuse gf;
         const int gk = oi < gn_fuse_of.size() ? gn_fuse_of[oi] : -1;
         const bool ask = gk >= 0 && tensors[o.out].stats == nullptr;
@@ -795,7 +794,12 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
           gf.scale = gb.scale; gf.shift = gb.shift; gf.mean_rstd = gb.mean_rstd;
           conv_gn_fuse_request(&gf);
         }
-        const int rc = launch_conv2d(a, st);
+        int rc;
+        if (bo && bo->fwd && conv_bf16b_eligible(a.C1 + a.C2, a.Cout, o.up ? 2 * a.H : a.H, o.up ? 2 * a.W : a.W, bo->s2 ? 0 : B))
+          rc = launch_conv_bf16b(bo->xa, a.C1 + a.C2, B, o.up ? 2 * a.H : a.H, o.up ? 2 * a.W : a.W, o.w->wb, a.Cout, a.bias, a.chan_add,
+                                 a.chan_add_stride, a.residual, a.out, st, bo->s2 ? (o.pad_lo ? 3 : 2) : o.up, bo->s2 ? nullptr : tensors[o.out].stats);
+        else
+          rc = launch_conv2d(a, st);
         if (ask) {
           if (rc == 0 && conv_gn_fuse_taken()) gn_skip[gk] = 1;
           conv_gn_fuse_request(nullptr);
