@@ -710,6 +710,37 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
     for (int i = 0; i < 4; ++i)
       ADM_UNROLL
       for (int j = 0; j < 4; ++j) d[i * 4 + j] = UP ? P[((i + 1) >> 1) * 10 + ((j + 1) >> 1)] : P[i * WPW + j];
+#if !defined(ADM_EMU)
+    if constexpr (V4) {
+      // The 32 additions as 16 packed ones (v_pk_add_f32, full rate on gfx950): the rows first, two columns per instruction; then
+      // per row (v0, v1) = (t0 - t2, t1 + t2) and (v2, v3) = (t2 - t1, t1 - t3) through the operand-select / negate modifiers.
+      // Same additions on the same values (a - b issued as a + (-b)): bit-identical. Every producer instruction costs the
+      // co-resident MFMA stream ~7 cycles of issue (profiles/r02_wino_v4.md), so 16 fewer per chunk is ~4 % of a chunk.
+      typedef float wf2 __attribute__((ext_vector_type(2)));
+      wf2 D[4][2], T[4][2];
+      ADM_UNROLL
+      for (int i = 0; i < 4; ++i) { D[i][0] = wf2{d[i * 4 + 0], d[i * 4 + 1]}; D[i][1] = wf2{d[i * 4 + 2], d[i * 4 + 3]}; }
+      ADM_UNROLL
+      for (int h2 = 0; h2 < 2; ++h2) {
+        T[0][h2] = D[0][h2] - D[2][h2];
+        T[1][h2] = D[1][h2] + D[2][h2];
+        T[2][h2] = D[2][h2] - D[1][h2];
+        T[3][h2] = D[1][h2] - D[3][h2];
+      }
+      float* vdst = ldsV + (g & RING) * W3VSLAB + vofs;
+      ADM_UNROLL
+      for (int i = 0; i < 4; ++i) {
+        wf2 lo, hi;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(lo) : "v"(T[i][0]), "v"(T[i][1]));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(hi) : "v"(T[i][0]), "v"(T[i][1]));
+        vdst[(i * 4 + 0) * (WCK * 32)] = lo.x;     // t0 - t2
+        vdst[(i * 4 + 1) * (WCK * 32)] = lo.y;     // t1 + t2
+        vdst[(i * 4 + 2) * (WCK * 32)] = hi.x;     // t2 - t1
+        vdst[(i * 4 + 3) * (WCK * 32)] = hi.y;     // t1 - t3
+      }
+      return;
+    }
+#endif
     float t[4][4];
     ADM_UNROLL
     for (int j = 0; j < 4; ++j) {

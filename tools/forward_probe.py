@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "audio-diffusion_amd"))
 from audiodiffusion import UNet2DModel, _native as N  # noqa: E402
 from bench import CFG256  # noqa: E402
 
-N.load()
+N.load(os.environ.get("ADM_LIB") or None)      # ADM_LIB=<path to another build of libadm_hip.so>: A/B of two builds on one box
 dev = torch.device("cuda:0")
 B = int(os.environ.get("PROBE_B", "32"))
 unet = UNet2DModel(**CFG256).init_random(0)
