@@ -85,8 +85,13 @@ SMALL_PLANES = dict(sample_size=8, in_channels=1, out_channels=1, layers_per_blo
                     down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"))
 
 
+ONE_PIXEL = dict(sample_size=4, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(64, 128, 128),
+                 down_block_types=("DownBlock2D", "AttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "AttnUpBlock2D", "UpBlock2D"))
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_groupnorm_from_the_split_k_finish_pass(backend):
+@pytest.mark.parametrize("cfg", [SMALL_PLANES, ONE_PIXEL], ids=["8x8-4x4", "4x4-2x2-1x1"])
+def test_groupnorm_from_the_split_k_finish_pass(backend, cfg):
     """Option gn_fuse_finish (default 1): on planes of <= 8x8 pixels a split-K convolution's finish pass leaves the scale / shift
     of the GroupNorm that reads its output (one launch instead of two). The statistics ops it replaces show up as (kind 0,
     variant 2) zero-cost records in the op profile; the forward stays inside the oracle tolerance and agrees with the two-launch path
@@ -94,10 +99,11 @@ def test_groupnorm_from_the_split_k_finish_pass(backend):
     import ctypes as C
     from audiodiffusion import _native as N
     dev = select(backend)
-    ref, mine = _pair(SMALL_PLANES, seed=3)
+    ref, mine = _pair(cfg, seed=3)
     mine = mine.to(dev)
     B = 3
-    x = torch.randn(B, 1, 8, 8, generator=torch.Generator().manual_seed(2))
+    ss = cfg["sample_size"]
+    x = torch.randn(B, 1, ss, ss, generator=torch.Generator().manual_seed(2))     # (1- and 2-pixel planes: the scalar slab loop)
     with torch.no_grad():
         r = ref(x, 37)["sample"]
     outs, fused = {}, {}
