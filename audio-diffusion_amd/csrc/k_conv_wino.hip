@@ -508,7 +508,11 @@ __global__ void __launch_bounds__(512, 2) conv_wino2_kernel(const WinoParams p) 
 constexpr int W3BM = 64;
 constexpr int W3USLAB = WCK * 16 * W3BM;    // 8192 floats
 constexpr int W3VSLAB = 16 * WCK * 32;      // 4096 floats
-constexpr int W3PSLAB = WCK * WPH * WPW + 264;   // 1440 floats (x2-upsample variant: 480) + one dummy word per producer lane
+// LDS pitch of a patch row in the wave-specialised kernels: 24 words instead of the 18 the patch is wide. Stage C reads the 4x4 windows of
+// a channel's 32 tiles with ds_read2_b64 at word offsets 2 tyy P + 2 txx: with P = 18 the four tile rows start at banks 0 / 36 / 8 / 44
+// and overlap pairwise (the 0.23 LDS conflict ratio of rounds 2-3); with P = 24 they start at 0 / 48 / 32 / 16 — conflict-free.
+constexpr int WPP = 24;
+constexpr int W3PSLAB = WCK * WPH * WPP + 264;   // 1920 floats (x2-upsample variant: 480) + one dummy word per producer lane
 constexpr int W3LDS = 2 * W3VSLAB + 2 * W3USLAB + 2 * W3PSLAB;
 
 struct Wino3Tile { int n, ty, tx, m0; };
@@ -586,7 +590,7 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
   // patch 8 x 6 x 10): two scalars e = tid and 256 + tid. Items beyond the patch go to a private dummy word.
   constexpr bool wide1 = !UP && WIDE1;
   int it_ch[2], it_row[2], it_col[2], it_pofs[2];
-  const int dummy = WCK * WPH * WPW + tid;
+  const int dummy = WCK * WPH * WPP + tid;
   if (UP) {
     ADM_UNROLL
     for (int k = 0; k < 2; ++k) {
@@ -599,25 +603,25 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
   } else {
     const int row0 = tid >> 2, q0 = tid & 3;
     it_ch[0] = row0 / WPH; it_row[0] = row0 % WPH; it_col[0] = 4 * q0;       // image x = tx*16 + col
-    it_pofs[0] = row0 * WPW + 1 + 4 * q0;
+    it_pofs[0] = row0 * WPP + 1 + 4 * q0;
     if (wide1) {
       const int f = 256 + tid;
       const int row = f >> 2, q = f & 3;
       it_ch[1] = row / WPH; it_row[1] = row % WPH; it_col[1] = 4 * q;
-      it_pofs[1] = row * WPW + 1 + 4 * q;
+      it_pofs[1] = row * WPP + 1 + 4 * q;
     } else {
       const int hI = tid - 64;
       const bool en = hI < 160;
       const int hc = en ? hI : 0;
       const int hrow = hc >> 1, side = hc & 1;
       it_ch[1] = hrow / WPH; it_row[1] = hrow % WPH; it_col[1] = side ? 16 : -1;
-      it_pofs[1] = en ? hrow * WPW + (side ? 17 : 0) : dummy;
+      it_pofs[1] = en ? hrow * WPP + (side ? 17 : 0) : dummy;
     }
   }
   // stage C: window origin of this thread's (channel, tile) inside the patch
   const int pc = tid >> 5, ptile = tid & 31;
   const int tyy = ptile >> 3, txx = ptile & 7;
-  const int wbase = UP ? pc * 60 + tyy * 10 + txx : pc * WCS + 2 * tyy * WPW + 2 * txx;
+  const int wbase = UP ? pc * 60 + tyy * 10 + txx : pc * (WPH * WPP) + 2 * tyy * WPP + 2 * txx;
   const int vofs = V4 ? pc * 32 + ptile : pc * 32 + ((ptile + 16 * (pc & 1)) & 31);   // + xi * 256
 
   // ---- stage A cursor: (tile, chunk) of the next global load ----------------------------------------------------------------
@@ -709,7 +713,7 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
     ADM_UNROLL
     for (int i = 0; i < 4; ++i)
       ADM_UNROLL
-      for (int j = 0; j < 4; ++j) d[i * 4 + j] = UP ? P[((i + 1) >> 1) * 10 + ((j + 1) >> 1)] : P[i * WPW + j];
+      for (int j = 0; j < 4; ++j) d[i * 4 + j] = UP ? P[((i + 1) >> 1) * 10 + ((j + 1) >> 1)] : P[i * WPP + j];
 #if !defined(ADM_EMU)
     if constexpr (V4) {
       // The 32 additions as 16 packed ones (v_pk_add_f32, full rate on gfx950): the rows first, two columns per instruction; then
