@@ -1081,14 +1081,19 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   ADM_BARRIER_KEEP_VMEM(63);               // barrier "-1": V(0) complete
 
   f32x4 acc[16][2];
-  float2 rb[4][2];                         // rolling B window: 4 Winograd points ahead, running across tile boundaries
+  // rolling B window, running across tile boundaries: RB Winograd points ahead. 4 points = 16 MFMAs = 512 cycles of cover for an LDS
+  // read that the producers' traffic delays; the role accounting (tools/wino_prof_probe.py) has the consumer on the critical path with
+  // ~900 non-MFMA cycles per chunk, so the window is 8 points (16 more registers; the chunk hand-over barrier moves from point 12 to 8,
+  // where the first read of the next chunk is issued — the producers have 16 % of barrier slack)
+  constexpr int RB = ABL == 0 ? 8 : 4;
+  float2 rb[RB][2];
   auto read_group = [&](int slot, int gg, int xi) {
     const float* V = ldsV + (gg & RING) * W3VSLAB + vlane;
     rb[slot][0] = *reinterpret_cast<const float2*>(V + (xi * WCK) * 32);
     rb[slot][1] = *reinterpret_cast<const float2*>(V + (xi * WCK + 4) * 32);
   };
   ADM_UNROLL
-  for (int xi = 0; xi < 4; ++xi) read_group(xi, 0, xi);
+  for (int xi = 0; xi < RB; ++xi) read_group(xi, 0, xi);
   int g = 0;                               // running chunk index
   const long planeO = (long)p.Ho * p.Wo;
   for (int v = b0; v < p.nblk; v += bs) {
@@ -1133,7 +1138,7 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
       }
       ADM_UNROLL
       for (int xi = 0; xi < 16; ++xi) {
-        const int s = xi & 3, q = xi >> 2, e = xi & 3;
+        const int s = xi & (RB - 1), q = xi >> 2, e = xi & 3;
         ADM_UNROLL
         for (int ks = 0; ks < 2; ++ks) {
           if (ABL == 2) {
@@ -1152,10 +1157,10 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
         }
         // barrier g: every read of V(g) has landed, V(g + 1) is complete. PAIR: only behind the second chunk of a pair (its
         // first chunk runs on into V(g + 1), which the previous pair's barrier certified)
-        if (xi == 12 && ABL != 11 && (!PAIR || (g & 1))) W3_BARRIER(63, pr, 1, 2);
+        if (xi == 16 - RB && ABL != 11 && (!PAIR || (g & 1))) W3_BARRIER(63, pr, 1, 2);
         if (ABL != 10) {
-          if (xi < 12) read_group(s, g, xi + 4);
-          else read_group(s, g + 1, xi - 12);   // next chunk — of this tile or the next one (past the end: stale words, unused)
+          if (xi < 16 - RB) read_group(s, g, xi + RB);
+          else read_group(s, g + 1, xi - (16 - RB));   // next chunk — of this tile or the next one (past the end: stale words, unused)
         }
         ADM_SCHED_FENCE();
       }

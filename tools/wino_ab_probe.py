@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "audio-diffusion_amd"))
 from audiodiffusion import _native, ops  # noqa: E402
 from audiodiffusion.unet import UNet2DModel  # noqa: E402
 
-_native.load()
+_native.load(os.environ.get("ADM_LIB") or None)      # ADM_LIB: another build (e.g. libadm_hip_exp.so for ADM_WINO_PROF)
 dev = torch.device("cuda:0")
 B = int(os.environ.get("PROBE_B", "32"))
 modes = [int(m) for m in sys.argv[1:]] or [3, 4]
