@@ -1085,7 +1085,7 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   // read that the producers' traffic delays; the role accounting (tools/wino_prof_probe.py) has the consumer on the critical path with
   // ~900 non-MFMA cycles per chunk, so the window is 8 points (16 more registers; the chunk hand-over barrier moves from point 12 to 8,
   // where the first read of the next chunk is issued — the producers have 16 % of barrier slack)
-  constexpr int RB = ABL == 0 ? 8 : 4;
+  constexpr int RB = (ABL == 0 || ABL == 12) ? 8 : 4;
   float2 rb[RB][2];
   auto read_group = [&](int slot, int gg, int xi) {
     const float* V = ldsV + (gg & RING) * W3VSLAB + vlane;
@@ -1149,7 +1149,7 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
             acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].y, acc[xi][1], 0, 0, 0);
           }
         }
-        if (e == 3 && ABL != 9) {          // group q consumed: its registers take the NEXT chunk's words
+        if (e == 3 && ABL != 9 && ABL != 12) {   // group q consumed: its registers take the NEXT chunk's words (12: never, beside WORKING producers)
           if (q == 0) W4_LOAD_A(0);
           if (q == 1) W4_LOAD_A(1);
           if (q == 2) W4_LOAD_A(2);
@@ -1525,6 +1525,7 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
         case 7: ADM_LAUNCH((conv_wino4_kernel<false, false, 7>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         case 8: ADM_LAUNCH((conv_wino4_kernel<false, false, 8>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         case 9: ADM_LAUNCH((conv_wino4_kernel<false, false, 9>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        case 12: ADM_LAUNCH((conv_wino4_kernel<false, false, 12>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         case 10: ADM_LAUNCH((conv_wino4_kernel<false, false, 10>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         default: ADM_LAUNCH((conv_wino4_kernel<false, false, 11>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
       }

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "audio-diffusion_amd"))
 from audiodiffusion import _native, ops  # noqa: E402
 
-_native.load()
+_native.load(os.environ.get("ADM_LIB") or None)      # the -DADM_EXPERIMENTS build has the ablation instantiations
 _native.check(_native.lib().adm_set_option(b"conv_wino", int(os.environ.get("WINO_MODE", "4"))))
 dev = torch.device("cuda:0")
 for (C, H, Co) in ((128, 256, 128), (256, 64, 256)):
