@@ -696,9 +696,34 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
       P[it_pofs[1]] = act1(r.b.x, r.sc1, r.sh1, r.ok & 2u);
     } else {
       float* P0 = P + it_pofs[0];
+      float* P1 = P + it_pofs[1];
+#if !defined(ADM_EMU)
+      if constexpr (V4) {
+        // two values per instruction wherever the operation has a packed form (affine, the exponent's scaling, 1 + e, the final product):
+        // 8 VALU instructions per pair instead of 12; v_exp_f32 / v_rcp_f32 stay scalar. The operations and their order are act1's
+        // (__expf(-v) = v_exp_f32(v * -log2(e)), ADM_RCP = v_rcp_f32): bit-identical.
+        typedef float wf2 __attribute__((ext_vector_type(2)));
+        auto act2 = [&](float x0, float x1, float sc, float sh, float* dst) __attribute__((always_inline)) {
+          wf2 v = wf2{x0, x1} * sc + sh;
+          if (act_on) {
+            const wf2 t = v * -1.44269504088896340736f;
+            wf2 e;
+            e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+            const wf2 d = e + 1.0f;
+            wf2 q;
+            q.x = __builtin_amdgcn_rcpf(d.x); q.y = __builtin_amdgcn_rcpf(d.y);
+            v = v * q;
+          }
+          dst[0] = v.x; dst[1] = v.y;
+        };
+        act2(r.a.x, r.a.y, r.sc0, r.sh0, P0); act2(r.a.z, r.a.w, r.sc0, r.sh0, P0 + 2);
+        if (wide1) { act2(r.b.x, r.b.y, r.sc1, r.sh1, P1); act2(r.b.z, r.b.w, r.sc1, r.sh1, P1 + 2); }
+        else P1[0] = act1(r.h, r.sc1, r.sh1, r.ok & 2u);
+        return;
+      }
+#endif
       P0[0] = act1(r.a.x, r.sc0, r.sh0, r.ok & 1u); P0[1] = act1(r.a.y, r.sc0, r.sh0, r.ok & 1u);
       P0[2] = act1(r.a.z, r.sc0, r.sh0, r.ok & 1u); P0[3] = act1(r.a.w, r.sc0, r.sh0, r.ok & 1u);
-      float* P1 = P + it_pofs[1];
       if (wide1) {
         P1[0] = act1(r.b.x, r.sc1, r.sh1, r.ok & 2u); P1[1] = act1(r.b.y, r.sc1, r.sh1, r.ok & 2u);
         P1[2] = act1(r.b.z, r.sc1, r.sh1, r.ok & 2u); P1[3] = act1(r.b.w, r.sc1, r.sh1, r.ok & 2u);
