@@ -629,6 +629,14 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
   int a_off0 = 0, a_off1 = 0;         // element offset of the items inside the sample: channel plane + row + column
   unsigned a_ok = 0;
   const float *a_x1 = nullptr, *a_x2 = nullptr, *a_gs = nullptr, *a_gh = nullptr;   // per-tile wave-uniform bases
+#if !defined(ADM_EMU)
+  // v4: the same bases as buffer resources (SGPR quads). A buffer load takes the per-lane byte offset as a 32-bit VGPR and the chunk's
+  // offset as an SGPR, so the per-load 64-bit address arithmetic (sign extension + v_lshl_add_u64: ~10 VALU per chunk) leaves the
+  // producers' instruction stream — which is what the co-resident MFMA wave pays for (profiles/r04_wino.md).
+  __amdgpu_buffer_rsrc_t a_rx1, a_rx2, a_rgs, a_rgh;
+  int a_vo0 = 0, a_vo1 = 0;
+  const int ch_vo0 = it_ch[0] * 4, ch_vo1 = it_ch[1] * 4;
+#endif
   auto a_geometry = [&]() {
     const Wino3Tile t = wino3_tile(p, a_v);
     a_x1 = p.x1 + (long)t.n * p.x1_bs;
@@ -646,10 +654,47 @@ __device__ __forceinline__ void wino3_producer(const WinoParams& p, float* ldsV,
       a_ok |= ok ? 1u << k : 0u;
     }
     a_off0 = off[0]; a_off1 = off[1];
+#if !defined(ADM_EMU)
+    if constexpr (V4) {
+      a_rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_x1), (short)0, 0x7fffffff, 0x00027000);
+      a_rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_x2), (short)0, 0x7fffffff, 0x00027000);
+      a_rgs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_gs), (short)0, 0x7fffffff, 0x00027000);
+      a_rgh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_gh), (short)0, 0x7fffffff, 0x00027000);
+      a_vo0 = a_off0 * 4; a_vo1 = a_off1 * 4;
+    }
+#endif
   };
   a_geometry();
   auto stage_a = [&](Wino3Raw& r) {           // issue the global loads of chunk (a_v, a_ci); then advance the cursor
     const int c0 = a_ci * WCK;
+#if !defined(ADM_EMU)
+    if constexpr (V4) {
+      const __amdgpu_buffer_rsrc_t rx = c0 < p.C1 ? a_rx1 : a_rx2;
+      const int so = c0 * planeS * 4, sg = c0 * 4;            // wave-uniform byte offsets of the chunk (< 2^31: one sample's channels)
+      if (UP) {
+        r.a.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, a_vo0, so, 0));
+        r.b.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, a_vo1, so, 0));
+      } else {
+        r.a = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_vo0, so, 0));
+        if (wide1) r.b = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_vo1, so, 0));
+        else r.h = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, a_vo1, so, 0));
+      }
+      r.sc0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgs, ch_vo0, sg, 0));
+      r.sh0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgh, ch_vo0, sg, 0));
+      r.sc1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgs, ch_vo1, sg, 0));
+      r.sh1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgh, ch_vo1, sg, 0));
+      r.ok = a_ok;
+      if (a_left > 1) {
+        --a_left;
+        if (++a_ci == nch) {
+          ADM_SCHED_FENCE();
+          a_ci = 0; a_v += bs;
+          a_geometry();
+        }
+      }
+      return;
+    }
+#endif
     const float* base = (c0 < p.C1 ? a_x1 : a_x2) + (long)c0 * planeS;
     if (UP) {
       r.a.x = base[a_off0];
