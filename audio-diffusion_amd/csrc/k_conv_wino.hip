@@ -1129,19 +1129,50 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   const long chunk_stride = (long)n_cblk * W4ABLK;
   const float* d_src = p.wu + ((long)(wino3_tile(p, d_v).m0 >> 4) + wave) * W4ABLK + lane * 4;   // chunk 0 of the tile
   f32x4 a[4][2];                            // [point group][k step]: component e = Winograd point 4 q + e
+  // ABL 13 (experiments build; CORRECT results, not an ablation): the filter stream as raw buffer loads — resource = this wave's
+  // 16-cout block of the tile's filter image with an EXPLICITLY uniform base (readfirstlane: derived from the wave index, the compiler
+  // does not prove it uniform and waterfalls every load — measured +20 % that way), lane offset = lane * 16 bytes, chunk offset = an
+  // SGPR. The producers' loads gained 4.9 % from the same change; this one was written after the round's last GPU minute: UNMEASURED.
+  constexpr bool ABUF = ABL == 13;
+#if !defined(ADM_EMU)
+  auto tile_rsrc = [&](int v) {
+    const float* b = p.wu + ((long)(wino3_tile(p, v).m0 >> 4) + ADM_UNIFORM(wave)) * W4ABLK;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(adm_uniform_ptr(b)), (short)0, 0x7fffffff, 0x00027000);
+  };
+  __amdgpu_buffer_rsrc_t d_rs = tile_rsrc(d_v);
+  const int d_vo = lane * 16, chunk_stride_b = (int)(chunk_stride * 4);
+  int d_so = 0;
+#define W4_LOAD_A(q)                                                                                                          \
+  do {                                                                                                                        \
+    if (ABUF) {                                                                                                               \
+      a[q][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, d_vo, d_so + (q) * 2048, 0));           \
+      a[q][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, d_vo, d_so + (q) * 2048 + 1024, 0));    \
+    } else {                                                                                                                  \
+      a[q][0] = *reinterpret_cast<const f32x4*>(d_src + (q) * 512);                                                           \
+      a[q][1] = *reinterpret_cast<const f32x4*>(d_src + (q) * 512 + 256);                                                     \
+    }                                                                                                                         \
+  } while (0)
+#else
 #define W4_LOAD_A(q)                                                                   \
   do {                                                                                 \
     a[q][0] = *reinterpret_cast<const f32x4*>(d_src + (q) * 512);                      \
     a[q][1] = *reinterpret_cast<const f32x4*>(d_src + (q) * 512 + 256);                \
   } while (0)
+#endif
   auto advance_a = [&]() {
     if (d_left > 1) {
       --d_left;
       d_src += chunk_stride;
+#if !defined(ADM_EMU)
+      if (ABUF) d_so += chunk_stride_b;
+#endif
       if (++d_ci == nch) {
         ADM_SCHED_FENCE();
         d_ci = 0; d_v += bs;
         d_src = p.wu + ((long)(wino3_tile(p, d_v).m0 >> 4) + wave) * W4ABLK + lane * 4;
+#if !defined(ADM_EMU)
+        if (ABUF) { d_so = 0; d_rs = tile_rsrc(d_v); }
+#endif
       }
     }
   };
@@ -1155,7 +1186,7 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   // read that the producers' traffic delays; the role accounting (tools/wino_prof_probe.py) has the consumer on the critical path with
   // ~900 non-MFMA cycles per chunk, so the window is 8 points (16 more registers; the chunk hand-over barrier moves from point 12 to 8,
   // where the first read of the next chunk is issued — the producers have 16 % of barrier slack)
-  constexpr int RB = (ABL == 0 || ABL == 12) ? 8 : 4;
+  constexpr int RB = (ABL == 0 || ABL == 12 || ABL == 13) ? 8 : 4;
   float2 rb[RB][2];
   auto read_group = [&](int slot, int gg, int xi) {
     const float* V = ldsV + (gg & RING) * W3VSLAB + vlane;
@@ -1596,6 +1627,7 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
         case 8: ADM_LAUNCH((conv_wino4_kernel<false, false, 8>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         case 9: ADM_LAUNCH((conv_wino4_kernel<false, false, 9>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         case 12: ADM_LAUNCH((conv_wino4_kernel<false, false, 12>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
+        case 13: ADM_LAUNCH((conv_wino4_kernel<false, false, 13>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         case 10: ADM_LAUNCH((conv_wino4_kernel<false, false, 10>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
         default: ADM_LAUNCH((conv_wino4_kernel<false, false, 11>), dim3(grid), dim3(512), sizeof(float) * W4LDS, st, p); break;
       }
