@@ -284,3 +284,38 @@ def test_conv_wgrad_bf16_blocked_narrow_rows(backend, case):
     dyb = _unblock(dy_img.cpu())[:, :, 1:-1, 1:-1]
     exact = torch.nn.grad.conv2d_weight(xa, (Cout, Ct, 3, 3), dyb, padding=1)
     assert _relerr(dW.double(), exact) < 2e-6, _relerr(dW.double(), exact)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("shape", [(1, 64, 8, 32), (2, 64, 16, 16), (4, 64, 8, 8)], ids=["rows32", "rows16", "rows8"])
+def test_blocked_kernels_on_binary16_operands(backend, shape):
+    """`--mixed_precision fp16` (train_unet.py:391-395): option conv_op16_f16 = 1 makes the operand format of the image writer, the
+    forward / data-gradient kernel and the weight-gradient kernel IEEE binary16 (template flag; same staging, `v_mfma_f32_32x32x16_f16`).
+    Tight bars against float64 convolutions of the kernels' OWN operand images read as binary16, on the 32-pixel-row tiling and on
+    both narrow-row tilings."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn, C, H, W = shape
+    Cout = 128
+    x = _rand((Nn, C, H, W), 1, dev)
+    dy = _rand((Nn, Cout, H, W), 2, dev)
+    w = _rand((Cout, C, 3, 3), 3, dev, scale=(C * 9) ** -0.5)
+    lib = _native.lib()
+
+    def as_f16(img):            # the blocked image tensor is typed bfloat16; under the option its bits are binary16
+        n, cg, hp, wp, _ = img.shape
+        return img.cpu().view(torch.float16).permute(0, 1, 4, 2, 3).reshape(n, cg * 8, hp, wp).to(torch.float64)[:, :, 1:-1, 1:-1]
+
+    _native.check(lib.adm_set_option(b"conv_op16_f16", 1))
+    try:
+        x_img, dy_img = ops.blocked_image(x), ops.blocked_image(dy)
+        wb = ops.pack_bf16_weight(w)
+        out = ops.conv2d_bf16_blocked(x_img, wb, Cout)
+        dW = ops.conv2d_wgrad_bf16_blocked(x_img, dy_img)
+    finally:
+        _native.check(lib.adm_set_option(b"conv_op16_f16", 0))
+    xa, dya = as_f16(x_img), as_f16(dy_img)
+    assert float((xa - x.cpu().half().double()).abs().max()) == 0.0          # round-to-nearest-even binary16 of the input
+    w16 = w.cpu().half().double()
+    assert _relerr(out.double(), F.conv2d(xa, w16, None, padding=1)) < 2e-6
+    assert _relerr(dW.double(), torch.nn.grad.conv2d_weight(xa, (Cout, C, 3, 3), dya, padding=1)) < 2e-6
