@@ -1132,7 +1132,8 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   // ABL 13 (experiments build; CORRECT results, not an ablation): the filter stream as raw buffer loads — resource = this wave's
   // 16-cout block of the tile's filter image with an EXPLICITLY uniform base (readfirstlane: derived from the wave index, the compiler
   // does not prove it uniform and waterfalls every load — measured +20 % that way), lane offset = lane * 16 bytes, chunk offset = an
-  // SGPR. The producers' loads gained 4.9 % from the same change; this one was written after the round's last GPU minute: UNMEASURED.
+  // SGPR. The producers' loads gained 4.9 % from the same change; this one measured 1.5-4 % SLOWER (2.963 vs 2.919 ms, 0.687 vs 0.661):
+  // the eight loads of a chunk already share one address register pair. Kept as a record, experiments build only.
   constexpr bool ABUF = ABL == 13;
 #if !defined(ADM_EMU)
   auto tile_rsrc = [&](int v) {
