@@ -1,7 +1,7 @@
 """Timing of conv_wino4_kernel on 128->128 @256x256, B = 32 (and 256->256 @64x64) under the ADM_WINO_ABL role ablations (barrier per chunk:
 compare with ADM_WINO_PAIR=0 ADM_WINO_ABL=0). ABL 12 = consumer without its filter loads beside working producers; ABL 13 is NOT an ablation
-(correct results): the filter stream as raw buffer loads with an explicitly uniform resource — a candidate written after round 4's last GPU
-minute, unmeasured:  for a in 0 13; do ADM_WINO_PAIR=0 ADM_WINO_ABL=$a ADM_LIB=.../libadm_hip_exp.so python tools/wino_abl_probe.py; done"""
+(correct results): the filter stream as raw buffer loads with an explicitly uniform resource — measured 1.5-4 % slower than the plain
+loads (round 4):  for a in 0 13; do ADM_WINO_PAIR=0 ADM_WINO_ABL=$a ADM_LIB=.../libadm_hip_exp.so python tools/wino_abl_probe.py; done"""
 import os
 import sys
 
