@@ -76,6 +76,7 @@ void set_wgrad_max_split(int v);  // k_conv_wgrad.hip
 void bump_dispatch_epoch();        // net_exec.hip: a process-wide option changed -> training nets re-learn which packings they read
 unsigned dispatch_epoch();
 void set_blk_direct_dy(int v);     // net_exec.hip: option "blk_direct_dy" (read when a training plan is made)
+void set_winograd_v5(int v);    // conv_wino5_kernel (128-cout tiles) where eligible: 1 (default) / 0 = conv_wino4_kernel everywhere (bit-identical)
 void set_winograd_pair(int v);  // conv_wino4_kernel: 1 (default) = one workgroup barrier per two chunks, 0 = one per chunk (bit-identical)
 void set_winograd_mode(int m);  // 0 off, 1 v1, 2 wave-specialised v2, 3 persistent v3 (default), -1 = default
 bool winograd_eligible(const adm_conv_args& a);

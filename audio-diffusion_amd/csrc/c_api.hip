@@ -20,12 +20,15 @@ const char* adm_last_error(void) { return adm::last_error(); }
 int adm_set_option(const char* name, int value) {
   ADM_REQUIRE(name, "set_option: null name");
   const std::string nm(name);
-  static const char* known[] = {"conv_wino", "wino_pair", "wgrad_max_split", "conv_bf16", "conv_op16_f16", "blk_direct_dy", "gn_fuse_finish"};
+  static const char* known[] = {"conv_wino", "wino_pair", "wino5", "wgrad_max_split", "conv_bf16", "conv_op16_f16", "blk_direct_dy", "gn_fuse_finish"};
   bool ok = false;
   for (const char* k : known) ok |= nm == k;
   if (!ok) ADM_FAIL(std::string("set_option: unknown option ") + name);
   // the dispatch epoch (training nets re-learn which weight images they read: a full re-pack) moves only when a value really
   // changes — a model that sets the options it already runs under (every enable_training does) leaves other nets alone
+  if (nm == "conv_wino")   // validate BEFORE the value is recorded: a rejected value must neither move the epoch nor be remembered
+    ADM_REQUIRE(adm::winograd_mode_available(value), "set_option: conv_wino modes 1-3 are earlier kernel generations, built only with "
+                "-DADM_EXPERIMENTS (audio-diffusion_amd/csrc/build.sh hip exp); this library has 0 (direct MFMA kernel) and 4");
   static std::mutex mu;
   static std::map<std::string, int> last;
   {
@@ -35,12 +38,8 @@ int adm_set_option(const char* name, int value) {
     last[nm] = value;
     if (!same) adm::bump_dispatch_epoch();
   }
-  if (nm == "conv_wino") {
-    ADM_REQUIRE(adm::winograd_mode_available(value), "set_option: conv_wino modes 1-3 are earlier kernel generations, built only with "
-                "-DADM_EXPERIMENTS (audio-diffusion_amd/csrc/build.sh hip exp); this library has 0 (direct MFMA kernel) and 4");
-    adm::set_winograd_mode(value);
-    return 0;
-  }
+  if (nm == "conv_wino") { adm::set_winograd_mode(value); return 0; }
+  if (nm == "wino5") { adm::set_winograd_v5(value); return 0; }
   if (nm == "wino_pair") { adm::set_winograd_pair(value); return 0; }
   if (nm == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
   if (nm == "conv_bf16") { adm::set_conv_bf16(value); return 0; }

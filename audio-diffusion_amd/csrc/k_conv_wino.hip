@@ -35,6 +35,7 @@ struct WinoParams {
   int gn_nstride;             // per-sample stride of gn_scale / gn_shift (0: shared identity rows, conv without GroupNorm)
   unsigned long long* prof;   // optional cycle counters of the wave-specialised kernel (ADM_WINO_PROF=1), else NULL
   double* stats;              // optional (v4): GroupNorm partial sums of the output, [n][cout][tile][2] (adm_conv_args.stats_out)
+  int tune;                   // conv_wino5_kernel: developer switches (ADM_WINO5_TUNE; bit 0 = s_setprio 1 for waves 4-7)
 };
 
 __device__ __forceinline__ float silu_w(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
@@ -1344,6 +1345,392 @@ __global__ void __launch_bounds__(512) conv_wino4_kernel(const WinoParams p) {
   else wino4_consumer<PROF, ABL, PAIR>(p, ldsV, tid, wave, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// =====================================================================================================================
+// v5 (round 5) — every input patch is transformed ONCE per 128 output channels: the workgroup tile is 128 couts x 8x16 pixels
+// and there are no dedicated producer waves any more. What v4's measurements asked for (profiles/r04_wino.md): a v4
+// workgroup transforms its patch for 64 couts, so every patch is fetched, activated and transformed Cout / 64 times, and 0.95 of the
+// 1.16 ms a 128 -> 128 launch spends above the matrix pipe's own pace is what the co-resident producer wave issues. A 128-cout tile
+// needs 128 x 32 x 16 accumulators = half of the CU's register file, i.e. ALL EIGHT waves must hold 128 of them:
+//   * all 8 waves are MFMA waves (wave w owns couts 16 w .. 16 w + 15 of the tile x all 32 Winograd tiles x all 16 points: v4's
+//     consumer body, filter image and lane-local inverse transform unchanged), and every wave also does 1/8 of the staging work
+//     (v4's stages A / B / C re-mapped to 512 threads: per PAIR of chunks one (channel, tile) transform, two patch items, six loads);
+//   * the two waves of a SIMD run in antiphase ("ping-pong", MI355X_MICROARCH.md "Two waves per SIMD"): waves 0-3 run
+//     [128 MFMAs of a chunk pair][staging], waves 4-7 [staging][128 MFMAs], one workgroup barrier per pair — while one wave of a
+//     SIMD stages, its partner owns the matrix pipe; while both are in their MFMA blocks the pipe is saturated by construction
+//     (2 x 4096 cycles of MFMA per 8192-cycle interval against ~5500 cycles of serial instruction stream per wave);
+//   * per MFMA the staging instructions are HALF of v4's at Cout = 128 (a quarter at 256: two cout tiles instead of four), the
+//     filter traffic per MFMA is unchanged (each filter word once per workgroup tile, L2 -> registers), HBM / L2 input traffic per
+//     launch halves.
+// Ring protocol (rings of four V slabs / patch buffers, as v4 PAIR). Interval I = chunks 2I, 2I + 1 of the workgroup's chunk stream:
+//   M(I) reads V(2I), V(2I+1);   P(I) = { C: patches 2I+2, 2I+3 -> V(2I+2), V(2I+3);  B: raw -> patches 2I+4, 2I+5;  A: global loads of
+//   chunks 2I+6, 2I+7 into the registers B just emptied }.   Barrier I ends interval I for all eight waves; inside an interval the order of
+//   M and P is free (they touch disjoint ring slots), which is what lets the two halves run them in opposite order.
+// Arithmetic and summation order are v4's: outputs are bit-identical to conv_wino4_kernel (tests/test_conv_winograd.py).
+constexpr int W5BM = 128;
+struct Wino5Raw { f32x4 a; float sc, sh; unsigned ok; };      // one item of one chunk (HALO / UP: a[0] only)
+
+__device__ __forceinline__ Wino3Tile wino5_tile(const WinoParams& p, int v) {
+  const int q = p.nblk >> 3, r = p.nblk & 7, xcd = v & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+  const int ct = lid % p.n_ct, pt = lid / p.n_ct;
+  Wino3Tile t;
+  t.tx = pt % p.tiles_x; t.ty = (pt / p.tiles_x) % p.tiles_y; t.n = pt / (p.tiles_x * p.tiles_y);
+  t.m0 = ct * W5BM;
+  return t;
+}
+
+// HALO: this wave's staging item is a halo element (waves 5-7 of the non-UP kernel), else a float4 row piece (UP: one scalar of the
+// source-resolution patch). TUNE bit 0: static s_setprio 1 for the second half (waves 4-7); bit 1: B window of 4 points instead of 8.
+template <bool UP, bool HALO, int ACT>
+__device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, float* ldsP, const int tid, const int wave,
+                                           const int b0, const int bs) {
+  const bool yrole = wave >= 4;               // second half: staging first, MFMA block second
+  const int lane = tid & 63;
+  const int li = lane & 15, k4 = lane >> 4;
+  const int Ct = p.C1 + p.C2;
+  const int planeS = p.Hs * p.Ws;
+  const int nch = Ct / WCK;
+  const int n_cblk = p.Cout >> 4;
+  const int ntile = (p.nblk - b0 + bs - 1) / bs;
+  const int total = ntile * nch;              // chunks of this workgroup's stream (a multiple of 4)
+  const int npairs = total >> 1;
+  // ---- staging item of this thread (one per chunk) ----------------------------------------------------------------------------
+  int it_ch, it_row, it_col, it_pofs;
+  const int dummy = WCK * WPH * WPP + (tid & 255);
+  if (UP) {                                   // source-resolution patch 8 x 6 x 10 = 480 scalars
+    const bool en = tid < 480;
+    const int ec = en ? tid : 0;
+    it_ch = ec / 60; it_row = (ec % 60) / 10; it_col = ec % 10;
+    it_pofs = en ? ec : dummy;
+  } else if (!HALO) {                         // waves 0-4: float4 piece f = tid of the 320
+    const int row0 = tid >> 2, q0 = tid & 3;
+    it_ch = row0 / WPH; it_row = row0 % WPH; it_col = 4 * q0;
+    it_pofs = row0 * WPP + 1 + 4 * q0;
+  } else {                                    // waves 5-7: the 160 halo elements (threads 480-511 write a private dummy word)
+    const int hI = tid - 320;
+    const bool en = hI < 160;
+    const int hc = en ? hI : 0;
+    const int hrow = hc >> 1, side = hc & 1;
+    it_ch = hrow / WPH; it_row = hrow % WPH; it_col = side ? 16 : -1;
+    it_pofs = en ? hrow * WPP + (side ? 17 : 0) : dummy;
+  }
+  // stage C: this thread's (chunk of the pair, channel, Winograd tile)
+  const int cpar = tid >> 8;
+  const int pc = (tid >> 5) & 7, ptile = tid & 31;
+  const int tyy = ptile >> 3, txx = ptile & 7;
+  const int wbase = UP ? pc * 60 + tyy * 10 + txx : pc * (WPH * WPP) + 2 * tyy * WPP + 2 * txx;
+  const int vofs = pc * 32 + ptile;
+  // ---- stage A cursor ---------------------------------------------------------------------------------------------------------
+  int a_v = b0, a_ci = 0, a_left = total;
+  int a_off = 0;
+  unsigned a_ok = 0;
+  const float *a_x1 = nullptr, *a_x2 = nullptr, *a_gs = nullptr, *a_gh = nullptr;
+#if !defined(ADM_EMU)
+  __amdgpu_buffer_rsrc_t a_rx1, a_rx2, a_rgs, a_rgh;
+  int a_vo = 0;
+  const int ch_vo = it_ch * 4;
+#endif
+  auto a_geometry = [&]() {
+    const Wino3Tile t = wino5_tile(p, a_v);
+    a_x1 = p.x1 + (long)t.n * p.x1_bs;
+    a_x2 = p.x2 + (long)t.n * p.x2_bs - (long)p.C1 * planeS;
+    a_gs = p.gn_scale + (long)t.n * p.gn_nstride;
+    a_gh = p.gn_shift + (long)t.n * p.gn_nstride;
+    const int sy = UP ? t.ty * 4 - 1 + it_row : t.ty * 8 - 1 + it_row;
+    const int sx = UP ? t.tx * 8 - 1 + it_col : t.tx * 16 + it_col;
+    const bool ok = sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws;
+    a_off = it_ch * planeS + (ok ? sy * p.Ws + sx : 0);
+    a_ok = ok ? 1u : 0u;
+#if !defined(ADM_EMU)
+    a_rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_x1), (short)0, 0x7fffffff, 0x00027000);
+    a_rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_x2), (short)0, 0x7fffffff, 0x00027000);
+    a_rgs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_gs), (short)0, 0x7fffffff, 0x00027000);
+    a_rgh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_gh), (short)0, 0x7fffffff, 0x00027000);
+    a_vo = a_off * 4;
+#endif
+  };
+  a_geometry();
+  auto stage_a = [&](Wino5Raw& r) {           // global loads of the next chunk of the stream; then advance (saturating)
+    const int c0 = a_ci * WCK;
+#if !defined(ADM_EMU)
+    const __amdgpu_buffer_rsrc_t rx = c0 < p.C1 ? a_rx1 : a_rx2;
+    const int so = c0 * planeS * 4, sg = c0 * 4;
+    if (UP || HALO) r.a[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, a_vo, so, 0));
+    else r.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_vo, so, 0));
+    r.sc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgs, ch_vo, sg, 0));
+    r.sh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgh, ch_vo, sg, 0));
+#else
+    const float* base = (c0 < p.C1 ? a_x1 : a_x2) + (long)c0 * planeS;
+    if (UP || HALO) r.a[0] = base[a_off];
+    else r.a = *reinterpret_cast<const f32x4*>(base + a_off);
+    r.sc = a_gs[c0 + it_ch]; r.sh = a_gh[c0 + it_ch];
+#endif
+    r.ok = a_ok;
+    if (a_left > 1) {
+      --a_left;
+      if (++a_ci == nch) {
+        ADM_SCHED_FENCE();
+        a_ci = 0; a_v += bs;
+        a_geometry();
+      }
+    }
+  };
+  constexpr bool act_on = ACT != 0;
+  auto stage_b = [&](const Wino5Raw& r_, int g) {     // raw -> GroupNorm affine (+ SiLU) -> patch buffer g & 3; zero padding = zeroed affine
+    float* P0 = ldsP + (g & 3) * W3PSLAB + it_pofs;
+    const float sc = r_.ok ? r_.sc : 0.f, sh = r_.ok ? r_.sh : 0.f;
+    if (UP || HALO) {
+      const float v0 = r_.a[0] * sc + sh;
+      P0[0] = act_on ? silu_w(v0) : v0;
+      return;
+    }
+#if !defined(ADM_EMU)
+    typedef float wf2 __attribute__((ext_vector_type(2)));
+    auto act2 = [&](float x0, float x1, float* dst) __attribute__((always_inline)) {   // v4's packed activation: bit-identical to silu_w
+      wf2 v = wf2{x0, x1} * sc + sh;
+      if (act_on) {
+        const wf2 t = v * -1.44269504088896340736f;
+        wf2 e;
+        e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+        const wf2 d = e + 1.0f;
+        wf2 q;
+        q.x = __builtin_amdgcn_rcpf(d.x); q.y = __builtin_amdgcn_rcpf(d.y);
+        v = v * q;
+      }
+      dst[0] = v.x; dst[1] = v.y;
+    };
+    act2(r_.a[0], r_.a[1], P0); act2(r_.a[2], r_.a[3], P0 + 2);
+#else
+    ADM_UNROLL
+    for (int k = 0; k < 4; ++k) { const float v0 = r_.a[k] * sc + sh; P0[k] = act_on ? silu_w(v0) : v0; }
+#endif
+  };
+  auto stage_c = [&](int g) {                 // patch g & 3 -> 4x4 window -> V = B^T d B -> V slab g & 3
+    const float* P = ldsP + (g & 3) * W3PSLAB + wbase;
+    float d[16];
+    ADM_UNROLL
+    for (int i = 0; i < 4; ++i)
+      ADM_UNROLL
+      for (int j = 0; j < 4; ++j) d[i * 4 + j] = UP ? P[((i + 1) >> 1) * 10 + ((j + 1) >> 1)] : P[i * WPP + j];
+    float* vdst = ldsV + (g & 3) * W3VSLAB + vofs;
+#if !defined(ADM_EMU)
+    typedef float wf2 __attribute__((ext_vector_type(2)));
+    wf2 D[4][2], T[4][2];
+    ADM_UNROLL
+    for (int i = 0; i < 4; ++i) { D[i][0] = wf2{d[i * 4 + 0], d[i * 4 + 1]}; D[i][1] = wf2{d[i * 4 + 2], d[i * 4 + 3]}; }
+    ADM_UNROLL
+    for (int h2 = 0; h2 < 2; ++h2) {
+      T[0][h2] = D[0][h2] - D[2][h2];
+      T[1][h2] = D[1][h2] + D[2][h2];
+      T[2][h2] = D[2][h2] - D[1][h2];
+      T[3][h2] = D[1][h2] - D[3][h2];
+    }
+    ADM_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      wf2 lo, hi;
+      asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(lo) : "v"(T[i][0]), "v"(T[i][1]));
+      asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(hi) : "v"(T[i][0]), "v"(T[i][1]));
+      vdst[(i * 4 + 0) * (WCK * 32)] = lo.x;     // t0 - t2
+      vdst[(i * 4 + 1) * (WCK * 32)] = lo.y;     // t1 + t2
+      vdst[(i * 4 + 2) * (WCK * 32)] = hi.x;     // t2 - t1
+      vdst[(i * 4 + 3) * (WCK * 32)] = hi.y;     // t1 - t3
+    }
+#else
+    float t[4][4];
+    ADM_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = d[0 * 4 + j] - d[2 * 4 + j];
+      t[1][j] = d[1 * 4 + j] + d[2 * 4 + j];
+      t[2][j] = d[2 * 4 + j] - d[1 * 4 + j];
+      t[3][j] = d[1 * 4 + j] - d[3 * 4 + j];
+    }
+    ADM_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      vdst[(i * 4 + 0) * (WCK * 32)] = t[i][0] - t[i][2];
+      vdst[(i * 4 + 1) * (WCK * 32)] = t[i][1] + t[i][2];
+      vdst[(i * 4 + 2) * (WCK * 32)] = t[i][2] - t[i][1];
+      vdst[(i * 4 + 3) * (WCK * 32)] = t[i][1] - t[i][3];
+    }
+#endif
+  };
+  // ---- filter stream cursor (v4's: [chunk][cout block][q][ks][lane][4 points], this wave's block = m0 / 16 + wave) -------------
+  int d_v = b0, d_ci = 0, d_left = total;
+  const long chunk_stride = (long)n_cblk * W4ABLK;
+  const float* d_src = p.wu + ((long)(wino5_tile(p, d_v).m0 >> 4) + wave) * W4ABLK + lane * 4;
+  f32x4 a[4][2];
+#define W5_LOAD_A(q)                                                                 \
+  do {                                                                               \
+    a[q][0] = *reinterpret_cast<const f32x4*>(d_src + (q) * 512);                    \
+    a[q][1] = *reinterpret_cast<const f32x4*>(d_src + (q) * 512 + 256);              \
+  } while (0)
+  auto advance_a = [&]() {
+    if (d_left > 1) {
+      --d_left;
+      d_src += chunk_stride;
+      if (++d_ci == nch) {
+        ADM_SCHED_FENCE();
+        d_ci = 0; d_v += bs;
+        d_src = p.wu + ((long)(wino5_tile(p, d_v).m0 >> 4) + wave) * W4ABLK + lane * 4;
+      }
+    }
+  };
+  // ---- prologue ------------------------------------------------------------------------------------------------------------------
+  Wino5Raw r0, r1;
+  r0.a = f32x4{0.f, 0.f, 0.f, 0.f}; r1.a = r0.a;
+  int pg = 0;                                 // first chunk of the pair the next staging block transforms (stage C)
+  auto produce = [&]() {                      // P: C(pg, pg + 1), B(pg + 2, pg + 3), A(next two chunks of the stream)
+    stage_c(pg + cpar);
+    stage_b(r0, pg + 2); stage_b(r1, pg + 3);
+    stage_a(r0); stage_a(r1);
+    pg += 2;
+  };
+  stage_a(r0); stage_a(r1);                   // chunks 0, 1
+  stage_b(r0, 0); stage_b(r1, 1);
+  stage_a(r0); stage_a(r1);                   // chunks 2, 3
+  W5_LOAD_A(0); W5_LOAD_A(1); W5_LOAD_A(2); W5_LOAD_A(3);      // filters of chunk 0
+  advance_a();
+  ADM_BARRIER_KEEP_VMEM(63);                  // patches 0, 1 complete
+  produce();                                  // V(0), V(1); patches 2, 3; loads of chunks 4, 5
+  ADM_BARRIER_KEEP_VMEM(63);                  // V(0), V(1) and patches 2, 3 complete: interval 0 may start
+  if (yrole) produce();                       // P(0) of the second half
+
+  const int vlane = k4 * 32 + 2 * li;
+  constexpr int RB = 8;
+  float2 rb[RB][2];
+  auto read_group = [&](int slot, int gg, int xi) {
+    const float* V = ldsV + (gg & 3) * W3VSLAB + vlane;
+    rb[slot][0] = *reinterpret_cast<const float2*>(V + (xi * WCK) * 32);
+    rb[slot][1] = *reinterpret_cast<const float2*>(V + (xi * WCK + 4) * 32);
+  };
+  f32x4 acc[16][2];
+  int g = 0;                                  // running chunk index of the MFMA stream
+  int ival = 0;                               // interval index
+  const long planeO = (long)p.Ho * p.Wo;
+  for (int v = b0; v < p.nblk; v += bs) {
+    const Wino3Tile t = wino5_tile(p, v);
+    ADM_UNROLL
+    for (int xi = 0; xi < 16; ++xi)
+      ADM_UNROLL
+      for (int c = 0; c < 2; ++c)
+        ADM_UNROLL
+        for (int r = 0; r < 4; ++r) acc[xi][c][r] = 0.f;
+    const int oy = t.ty * 8 + 2 * (li >> 2), ox = t.tx * 16 + 4 * (li & 3);
+    const long obase = ((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4) * planeO + (long)oy * p.Wo + ox;
+    f32x4 fr0 = {0.f, 0.f, 0.f, 0.f}, fr1 = fr0;
+    float fb0 = 0.f, fb1 = 0.f;
+    for (int ci = 0; ci < nch; ci += 2, g += 2, ++ival) {
+      // ---- M: the 128 MFMAs of chunks g, g + 1 -----------------------------------------------------------------------------------
+      ADM_UNROLL
+      for (int xi = 0; xi < RB; ++xi) read_group(xi, g, xi);
+      ADM_UNROLL
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const int cc = ci + c2;
+        if (cc < 4) {                          // wave-uniform: this chunk carries cout row r = cc of the bias / residual fold (v4)
+          const int co = t.m0 + 16 * wave + 4 * k4 + cc;
+          fb0 = p.bias[co];
+          fb1 = p.chan_add[(long)t.n * p.chan_add_stride + co];
+          if (p.residual != nullptr) {
+            fr0 = *reinterpret_cast<const f32x4*>(p.residual + obase + cc * planeO);
+            fr1 = *reinterpret_cast<const f32x4*>(p.residual + obase + cc * planeO + p.Wo);
+          }
+        }
+        ADM_UNROLL
+        for (int xi = 0; xi < 16; ++xi) {
+          const int s = xi & (RB - 1), q = xi >> 2, e = xi & 3;
+          ADM_UNROLL
+          for (int ks = 0; ks < 2; ++ks) {
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].x, acc[xi][0], 0, 0, 0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].y, acc[xi][1], 0, 0, 0);
+          }
+          if (e == 3) {                        // group q consumed: its registers take the NEXT chunk's words
+            if (q == 0) W5_LOAD_A(0);
+            if (q == 1) W5_LOAD_A(1);
+            if (q == 2) W5_LOAD_A(2);
+            if (q == 3) { W5_LOAD_A(3); advance_a(); }
+          }
+          if (xi < 16 - RB) read_group(s, g + c2, xi + RB);
+          else if (c2 == 0) read_group(s, g + 1, xi - (16 - RB));
+          ADM_SCHED_FENCE();
+        }
+        if (cc < 4) {
+          const float bsum = fb0 + fb1;
+#define W5_FOLD(R)                                                                                         \
+  do {                                                                                                     \
+    acc[0][0][R] += bsum + fr0[0];  acc[0][1][R] += bsum + fr0[2];                                          \
+    acc[3][0][R] -= bsum + fr0[1];  acc[3][1][R] -= bsum + fr0[3];                                          \
+    acc[12][0][R] -= bsum + fr1[0]; acc[12][1][R] -= bsum + fr1[2];                                         \
+    acc[15][0][R] += bsum + fr1[1]; acc[15][1][R] += bsum + fr1[3];                                         \
+  } while (0)
+          if (cc == 0) W5_FOLD(0);
+          else if (cc == 1) W5_FOLD(1);
+          else if (cc == 2) W5_FOLD(2);
+          else W5_FOLD(3);
+#undef W5_FOLD
+        }
+      }
+      const bool last = ci + 2 == nch;
+      auto epilogue = [&]() {                  // lane-local inverse transform Y = A^T M A + stores (+ GroupNorm partial sums): v4's
+        ADM_UNROLL
+        for (int r = 0; r < 4; ++r) {
+          f32x4 y0, y1;
+          ADM_UNROLL
+          for (int c = 0; c < 2; ++c) {
+            float t0[4], t1[4];
+            ADM_UNROLL
+            for (int j = 0; j < 4; ++j) {
+              t0[j] = acc[0 * 4 + j][c][r] + acc[1 * 4 + j][c][r] + acc[2 * 4 + j][c][r];
+              t1[j] = acc[1 * 4 + j][c][r] - acc[2 * 4 + j][c][r] - acc[3 * 4 + j][c][r];
+            }
+            y0[2 * c] = t0[0] + t0[1] + t0[2];
+            y0[2 * c + 1] = t0[1] - t0[2] - t0[3];
+            y1[2 * c] = t1[0] + t1[1] + t1[2];
+            y1[2 * c + 1] = t1[1] - t1[2] - t1[3];
+          }
+          *reinterpret_cast<f32x4*>(p.out + obase + r * planeO) = y0;
+          *reinterpret_cast<f32x4*>(p.out + obase + r * planeO + p.Wo) = y1;
+          if (p.stats != nullptr) {
+            float f1 = (y0[0] + y0[1]) + (y0[2] + y0[3]) + ((y1[0] + y1[1]) + (y1[2] + y1[3]));
+            float f2 = (y0[0] * y0[0] + y0[1] * y0[1]) + (y0[2] * y0[2] + y0[3] * y0[3]) +
+                       ((y1[0] * y1[0] + y1[1] * y1[1]) + (y1[2] * y1[2] + y1[3] * y1[3]));
+            double s1 = (double)f1, s2 = (double)f2;
+            ADM_UNROLL
+            for (int m = 8; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+            if (li == 0) {
+              const int tiles = p.tiles_x * p.tiles_y;
+              double* dst = p.stats + (((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4 + r) * tiles + t.ty * p.tiles_x + t.tx) * 2;
+              dst[0] = s1; dst[1] = s2;
+            }
+          }
+        }
+      };
+      if (!yrole) {
+        if (last) epilogue();
+        produce();                             // P(ival)
+        ADM_BARRIER_KEEP_VMEM(63);
+      } else {
+        ADM_BARRIER_KEEP_VMEM(63);
+        if (last) epilogue();
+        if (ival + 1 < npairs) produce();      // P(ival + 1), ahead of the first half by design
+      }
+    }
+  }
+#undef W5_LOAD_A
+}
+
+template <bool UP, int ACT>
+__global__ void __launch_bounds__(512) conv_wino5_kernel(const WinoParams p) {
+  ADM_DYN_SMEM(float, smem);
+  float* ldsV = smem;
+  float* ldsP = smem + 4 * W3VSLAB;
+  const int tid = threadIdx.x;
+  const int wave = ADM_UNIFORM(tid >> 6);     // an SGPR: role tests and the barrier placement become scalar branches
+#if !defined(ADM_EMU)
+  if (wave >= 4 && (p.tune & 1)) __builtin_amdgcn_s_setprio(1);
+#endif
+  if (!UP && wave >= 5) wino5_wave<UP, true, ACT>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+  else wino5_wave<UP, false, ACT>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // Filter image of conv_wino4_kernel: U = G g G^T as [Cin/8][Cout/16][point group q][k step ks][lane = 16 k4 + li][e]
 // holding U[xi = 4 q + e][cout = 16 cblk + li][cin = 8 chunk + 4 ks + k4]. transposed: the data-gradient filters (roles of
 // Cout / Cin swapped, taps flipped), as pack_winograd_weight_kernel.
@@ -1472,6 +1859,14 @@ static int wino_pair() {
   if (g_wino_pair < 0) { const char* e = getenv("ADM_WINO_PAIR"); g_wino_pair = e ? atoi(e) : 1; }
   return g_wino_pair;
 }
+// conv_wino5_kernel (128-cout workgroup tiles, all eight waves MFMA + staging): 1 (default) = used wherever the layer has 128 | Cout
+// and its 128-cout tiles fill the chip; 0 = conv_wino4_kernel everywhere. Bit-identical results either way (same filter image).
+static int g_wino5 = -1;       // -1: take ADM_WINO5 from the environment (default 1) on first use
+void set_winograd_v5(int v) { g_wino5 = v; }
+static int wino5_on() {
+  if (g_wino5 < 0) { const char* e = getenv("ADM_WINO5"); g_wino5 = e ? atoi(e) : 1; }
+  return g_wino5;
+}
 static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 4) on first use
 bool winograd_mode_available(int m) {
 #if defined(ADM_EXPERIMENTS)
@@ -1528,6 +1923,7 @@ int winograd_stats_tiles(const adm_conv_args& a) {
 int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
   WinoParams p;
   p.stats = nullptr;
+  p.tune = 0;
   const int C2 = a.x2 ? a.C2 : 0;
   p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2;
   p.N = a.N; p.Hs = a.H; p.Ws = a.W;
@@ -1561,7 +1957,7 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     // Per device (a function-local `static once` ran for the device that happened to be current on first use only):
     // the CU count, and the permission for the PAIR kernels' 91 KiB of dynamic LDS — checked; where the runtime refuses it the
     // bit-identical one-barrier-per-chunk instantiation (43 KiB, no attribute needed) runs instead.
-    struct DevInfo { int n_cu = 0; bool pair_ok = false; };
+    struct DevInfo { int n_cu = 0; bool pair_ok = false; bool v5_ok = false; };
     static DevInfo info[16];
     static std::mutex info_mu;
     const int dslot = conv_dev_slot() & 15;
@@ -1579,6 +1975,13 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
         ok &= hipFuncSetAttribute((const void*)conv_wino4_kernel<false, false, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
         if (!ok) (void)hipGetLastError();
         info[dslot].pair_ok = ok;
+        bool ok5 = true;
+        ok5 &= hipFuncSetAttribute((const void*)conv_wino5_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        ok5 &= hipFuncSetAttribute((const void*)conv_wino5_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        ok5 &= hipFuncSetAttribute((const void*)conv_wino5_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        ok5 &= hipFuncSetAttribute((const void*)conv_wino5_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        if (!ok5) (void)hipGetLastError();
+        info[dslot].v5_ok = ok5;
 #if defined(ADM_EXPERIMENTS)
         (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * W4LDS));
         (void)hipFuncSetAttribute((const void*)conv_wino4_kernel<false, true, 0, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, by);
@@ -1590,10 +1993,37 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     }
     const int n_cu = info[dslot].n_cu;
     const bool pair_ok = info[dslot].pair_ok;
+    const bool v5_ok = info[dslot].v5_ok;
 #else
     const int n_cu = 3;                                          // exercise persistence (several tiles per block) on the emulator
-    const bool pair_ok = true;
+    const bool pair_ok = true, v5_ok = true;
 #endif
+    // v5: 128-cout workgroup tiles (every patch transformed once per 128 couts), taken when those tiles still fill the chip — with
+    // fewer, v4's 64-cout tiles are twice as many workgroups. The two kernels are bit-identical (same filter image, same summation
+    // order), so this batch-dependent choice cannot move a sample's bits.
+    if (v4 && v5_ok && wino5_on() && a.Cout % W5BM == 0) {
+      const int nblk5 = p.tiles_x * p.tiles_y * a.N * (a.Cout / W5BM);
+      if (nblk5 >= n_cu) {
+        p.n_ct = a.Cout / W5BM;
+        p.nblk = nblk5;
+        p.prof = nullptr;
+        p.stats = a.stats_out;
+#if !defined(ADM_EMU)
+        static const int tune = [] { const char* e = getenv("ADM_WINO5_TUNE"); return e ? atoi(e) : 1; }();
+        p.tune = tune;
+#endif
+        set_last_conv_variant(4000 + 315);
+        const size_t need5 = sizeof(float) * W4LDS_PAIR;
+        if (a.up) {
+          if (a.act) ADM_LAUNCH((conv_wino5_kernel<true, 1>), dim3(n_cu), dim3(512), need5, st, p);
+          else ADM_LAUNCH((conv_wino5_kernel<true, 0>), dim3(n_cu), dim3(512), need5, st, p);
+        } else {
+          if (a.act) ADM_LAUNCH((conv_wino5_kernel<false, 1>), dim3(n_cu), dim3(512), need5, st, p);
+          else ADM_LAUNCH((conv_wino5_kernel<false, 0>), dim3(n_cu), dim3(512), need5, st, p);
+        }
+        return ADM_CHECK_LAUNCH();
+      }
+    }
     const int grid = p.nblk < n_cu ? p.nblk : n_cu;
     set_last_conv_variant(4000 + (v4 ? 314 : 313));
     p.prof = nullptr;

@@ -34,10 +34,12 @@ def test_conv_winograd(backend, case, mode):
     if mode == 4 and (case[1] + case[2]) % 32 != 0:
         pytest.skip("v4 tiles 32 input channels (four chunks in flight)")
     _native.check(_native.lib().adm_set_option(b"conv_wino", mode))
+    _native.check(_native.lib().adm_set_option(b"wino5", 0))            # this test pins conv_wino4_kernel (v5 has its own below)
     try:
         _run_case(dev, case, 4310 + mode)
     finally:
         _native.check(_native.lib().adm_set_option(b"conv_wino", -1))   # back to the default
+        _native.check(_native.lib().adm_set_option(b"wino5", -1))
 
 
 def _run_case(dev, case, want_variant):
@@ -148,6 +150,7 @@ def test_conv_wino4_barrier_cadence_does_not_change_a_bit(backend, shape):
     wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
     outs = []
     try:
+        _native.check(lib.adm_set_option(b"wino5", 0))
         for pair in (0, 1):
             _native.check(lib.adm_set_option(b"wino_pair", pair))
             o, st = ops.conv2d(x1, wp, b, 3, x2=x2, up=bool(up), gn=gn, act=True, chan_add=temb, residual=res, wino=wu, stats=True)
@@ -156,5 +159,58 @@ def test_conv_wino4_barrier_cadence_does_not_change_a_bit(backend, shape):
     finally:
         _native.check(lib.adm_set_option(b"wino_pair", -1))
         _native.check(lib.adm_set_option(b"conv_wino", -1))
+        _native.check(lib.adm_set_option(b"wino5", -1))
     assert torch.equal(outs[0][0], outs[1][0])
     assert (outs[0][1] is None) == (outs[1][1] is None) and (outs[0][1] is None or torch.equal(outs[0][1], outs[1][1]))
+
+
+# ---- round 5: conv_wino5_kernel (128-cout workgroup tiles; every wave MFMA + staging, the two halves in antiphase) -------------------
+V5_CASES = [
+    # (N, C1, C2, H, W, Cout, up, gn, act, temb, res)
+    (3, 64, 0, 8, 16, 128, 0, 1, 1, 1, 1),     # one tile per sample, all epilogue terms
+    (2, 32, 32, 24, 48, 128, 0, 1, 1, 1, 1),   # virtual concat, interior + border tiles, residual; 18 tiles on 3 persistent blocks
+    (2, 32, 0, 8, 8, 128, 1, 1, 1, 1, 0),      # nearest-x2 folded, GroupNorm + SiLU
+    (1, 64, 0, 8, 16, 256, 1, 0, 0, 1, 0),     # nearest-x2 folded, no GroupNorm, two cout tiles
+    (3, 96, 0, 16, 32, 256, 0, 1, 0, 0, 1),    # 12 chunks, two cout tiles, no activation
+    (5, 128, 0, 8, 16, 128, 0, 1, 1, 0, 0),    # several tiles per block, 16 chunks
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", V5_CASES, ids=[str(i) for i in range(len(V5_CASES))])
+def test_conv_wino5_against_torch_and_bit_for_bit_against_v4(backend, case):
+    """conv_wino5_kernel vs the torch fp32 convolution (1e-4) AND bit for bit against conv_wino4_kernel on the same filter image: v5
+    changes who transforms what and when (one transform per 128 couts, staging spread over all eight waves, the two halves of the
+    workgroup in antiphase), not one addition of the arithmetic — outputs and the GroupNorm partial sums of the epilogue must be identical.
+    The launcher relies on this: it picks v4 or v5 by how many tiles a launch has, i.e. by the batch."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    lib = _native.lib()
+    Nn, C1, C2, H, W, Cout, up, use_gn, act, use_temb, use_res = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    w = _rand((Cout, Ct, 3, 3), 3, dev, scale=(Ct * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
+    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
+    wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
+    outs = {}
+    _native.check(lib.adm_set_option(b"conv_wino", 4))
+    try:
+        for v5 in (1, 0):
+            _native.check(lib.adm_set_option(b"wino5", v5))
+            o, st = ops.conv2d(x1, wp, b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb, residual=res, wino=wu, stats=True)
+            assert lib.adm_last_conv_variant() == (4315 if v5 else 4314)
+            outs[v5] = (o.clone(), st.clone())
+    finally:
+        _native.check(lib.adm_set_option(b"wino5", -1))
+        _native.check(lib.adm_set_option(b"conv_wino", -1))
+    c = lambda t: None if t is None else t.cpu()  # noqa: E731
+    ref = _conv_ref(c(x1), c(x2), c(w), c(b), 3, 1, up, (c(gamma), c(beta)) if use_gn else None, act, c(temb), c(res))
+    assert _relerr(outs[1][0], ref) < 1e-4, _relerr(outs[1][0], ref)
+    assert torch.equal(outs[1][0], outs[0][0]), (outs[1][0] - outs[0][0]).abs().max()
+    assert torch.equal(outs[1][1], outs[0][1])
