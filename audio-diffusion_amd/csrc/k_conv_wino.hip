@@ -1367,6 +1367,7 @@ __global__ void __launch_bounds__(512) conv_wino4_kernel(const WinoParams p) {
 //   M and P is free (they touch disjoint ring slots), which is what lets the two halves run them in opposite order.
 // Arithmetic and summation order are v4's: outputs are bit-identical to conv_wino4_kernel (tests/test_conv_winograd.py).
 constexpr int W5BM = 128;
+constexpr int W5RB = 8;          // B window of the MFMA block, in Winograd points
 struct Wino5Raw { f32x4 a; float sc, sh; unsigned ok; };      // one item of one chunk (HALO / UP: a[0] only)
 
 __device__ __forceinline__ Wino3Tile wino5_tile(const WinoParams& p, int v) {
@@ -1450,25 +1451,40 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
 #endif
   };
   a_geometry();
-  auto stage_a = [&](Wino5Raw& r) {           // global loads of the next chunk of the stream; then advance (saturating)
+  // global loads of the next PAIR of chunks of the stream (a pair never straddles tiles: chunk counts are multiples of 4); then advance,
+  // saturating on the last pair (the loads stay unconditional, their data is never used)
+  auto stage_a2 = [&](Wino5Raw& ra, Wino5Raw& rb_) {
     const int c0 = a_ci * WCK;
 #if !defined(ADM_EMU)
     const __amdgpu_buffer_rsrc_t rx = c0 < p.C1 ? a_rx1 : a_rx2;
     const int so = c0 * planeS * 4, sg = c0 * 4;
-    if (UP || HALO) r.a[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, a_vo, so, 0));
-    else r.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_vo, so, 0));
-    r.sc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgs, ch_vo, sg, 0));
-    r.sh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgh, ch_vo, sg, 0));
+    const int so1 = so + WCK * planeS * 4, sg1 = sg + WCK * 4;
+    if (UP || HALO) {
+      ra.a[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, a_vo, so, 0));
+      rb_.a[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, a_vo, so1, 0));
+    } else {
+      ra.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_vo, so, 0));
+      rb_.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_vo, so1, 0));
+    }
+    ra.sc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgs, ch_vo, sg, 0));
+    ra.sh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgh, ch_vo, sg, 0));
+    rb_.sc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgs, ch_vo, sg1, 0));
+    rb_.sh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rgh, ch_vo, sg1, 0));
 #else
     const float* base = (c0 < p.C1 ? a_x1 : a_x2) + (long)c0 * planeS;
-    if (UP || HALO) r.a[0] = base[a_off];
-    else r.a = *reinterpret_cast<const f32x4*>(base + a_off);
-    r.sc = a_gs[c0 + it_ch]; r.sh = a_gh[c0 + it_ch];
+    if (UP || HALO) { ra.a[0] = base[a_off]; rb_.a[0] = base[a_off + (long)WCK * planeS]; }
+    else {
+      ra.a = *reinterpret_cast<const f32x4*>(base + a_off);
+      rb_.a = *reinterpret_cast<const f32x4*>(base + a_off + (long)WCK * planeS);
+    }
+    ra.sc = a_gs[c0 + it_ch]; ra.sh = a_gh[c0 + it_ch];
+    rb_.sc = a_gs[c0 + WCK + it_ch]; rb_.sh = a_gh[c0 + WCK + it_ch];
 #endif
-    r.ok = a_ok;
-    if (a_left > 1) {
-      --a_left;
-      if (++a_ci == nch) {
+    ra.ok = a_ok; rb_.ok = a_ok;
+    if (a_left > 2) {
+      a_left -= 2;
+      a_ci += 2;
+      if (a_ci == nch) {
         ADM_SCHED_FENCE();
         a_ci = 0; a_v += bs;
         a_geometry();
@@ -1578,24 +1594,15 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
   Wino5Raw r0, r1;
   r0.a = f32x4{0.f, 0.f, 0.f, 0.f}; r1.a = r0.a;
   int pg = 0;                                 // first chunk of the pair the next staging block transforms (stage C)
-  auto produce = [&]() {                      // P: C(pg, pg + 1), B(pg + 2, pg + 3), A(next two chunks of the stream)
-    stage_c(pg + cpar);
-    stage_b(r0, pg + 2); stage_b(r1, pg + 3);
-    stage_a(r0); stage_a(r1);
-    pg += 2;
-  };
-  stage_a(r0); stage_a(r1);                   // chunks 0, 1
+  stage_a2(r0, r1);                           // chunks 0, 1
   stage_b(r0, 0); stage_b(r1, 1);
-  stage_a(r0); stage_a(r1);                   // chunks 2, 3
+  stage_a2(r0, r1);                           // chunks 2, 3
   W5_LOAD_A(0); W5_LOAD_A(1); W5_LOAD_A(2); W5_LOAD_A(3);      // filters of chunk 0
   advance_a();
   ADM_BARRIER_KEEP_VMEM(63);                  // patches 0, 1 complete
-  produce();                                  // V(0), V(1); patches 2, 3; loads of chunks 4, 5
-  ADM_BARRIER_KEEP_VMEM(63);                  // V(0), V(1) and patches 2, 3 complete: interval 0 may start
-  if (yrole) produce();                       // P(0) of the second half
 
   const int vlane = k4 * 32 + 2 * li;
-  constexpr int RB = 8;
+  constexpr int RB = W5RB;
   float2 rb[RB][2];
   auto read_group = [&](int slot, int gg, int xi) {
     const float* V = ldsV + (gg & 3) * W3VSLAB + vlane;
@@ -1603,36 +1610,52 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
     rb[slot][1] = *reinterpret_cast<const float2*>(V + (xi * WCK + 4) * 32);
   };
   f32x4 acc[16][2];
-  int g = 0;                                  // running chunk index of the MFMA stream
-  int ival = 0;                               // interval index
   const long planeO = (long)p.Ho * p.Wo;
-  for (int v = b0; v < p.nblk; v += bs) {
-    const Wino3Tile t = wino5_tile(p, v);
-    ADM_UNROLL
-    for (int xi = 0; xi < 16; ++xi)
-      ADM_UNROLL
-      for (int c = 0; c < 2; ++c)
+  // ONE loop body serves the prologue as well: iterations -2 and -1 have no MFMA block. Barrier / staging schedule per iteration `it`:
+  //   first half  (waves 0-3): [M(it)] [epilogue] P            barrier      — P from it = -1 on (P#0 = V(0), V(1), patches 2, 3, loads 4, 5)
+  //   second half (waves 4-7): [M(it)] barrier    [epilogue] P              — P from it = -2 on, i.e. one staging block AHEAD of the first half
+  // Both halves execute the same barriers (from it = -1 on); between two of them M and P of either half touch disjoint ring slots.
+  int v = b0 - bs, ci = 0;                    // tile / chunk cursor of the MFMA stream (ci == nch: step to the next tile)
+  ci = nch;
+  Wino3Tile t = wino5_tile(p, b0);
+  long obase = 0;
+  f32x4 fr0 = {0.f, 0.f, 0.f, 0.f}, fr1 = fr0;
+  float fb0 = 0.f, fb1 = 0.f;
+  for (int it = -2; it < npairs; ++it) {
+    bool last = false;
+    if (it >= 0) {
+      if (ci == nch) {                        // next tile
+        ADM_SCHED_FENCE();
+        ci = 0; v += bs;
+        t = wino5_tile(p, v);
         ADM_UNROLL
-        for (int r = 0; r < 4; ++r) acc[xi][c][r] = 0.f;
-    const int oy = t.ty * 8 + 2 * (li >> 2), ox = t.tx * 16 + 4 * (li & 3);
-    const long obase = ((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4) * planeO + (long)oy * p.Wo + ox;
-    f32x4 fr0 = {0.f, 0.f, 0.f, 0.f}, fr1 = fr0;
-    float fb0 = 0.f, fb1 = 0.f;
-    for (int ci = 0; ci < nch; ci += 2, g += 2, ++ival) {
+        for (int xi = 0; xi < 16; ++xi)
+          ADM_UNROLL
+          for (int c = 0; c < 2; ++c)
+            ADM_UNROLL
+            for (int r = 0; r < 4; ++r) acc[xi][c][r] = 0.f;
+        const int oy = t.ty * 8 + 2 * (li >> 2), ox = t.tx * 16 + 4 * (li & 3);
+        obase = ((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4) * planeO + (long)oy * p.Wo + ox;
+      }
+      const int g = 2 * it;
       // ---- M: the 128 MFMAs of chunks g, g + 1 -----------------------------------------------------------------------------------
       ADM_UNROLL
       for (int xi = 0; xi < RB; ++xi) read_group(xi, g, xi);
-      ADM_UNROLL
+      // (a real two-trip loop, NOT unrolled: the loop-carried values pin the accumulators and the filter registers in place — unrolled,
+      // hipcc renamed them across the two copies: 156 accumulator and 48 filter registers instead of 128 + 32, and spilled)
+      _Pragma("clang loop unroll(disable)")
       for (int c2 = 0; c2 < 2; ++c2) {
         const int cc = ci + c2;
         if (cc < 4) {                          // wave-uniform: this chunk carries cout row r = cc of the bias / residual fold (v4)
           const int co = t.m0 + 16 * wave + 4 * k4 + cc;
           fb0 = p.bias[co];
           fb1 = p.chan_add[(long)t.n * p.chan_add_stride + co];
+#ifndef W5X_NORES
           if (p.residual != nullptr) {
             fr0 = *reinterpret_cast<const f32x4*>(p.residual + obase + cc * planeO);
             fr1 = *reinterpret_cast<const f32x4*>(p.residual + obase + cc * planeO + p.Wo);
           }
+#endif
         }
         ADM_UNROLL
         for (int xi = 0; xi < 16; ++xi) {
@@ -1648,71 +1671,87 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
             if (q == 2) W5_LOAD_A(2);
             if (q == 3) { W5_LOAD_A(3); advance_a(); }
           }
+          // the window runs on into the next chunk; behind the pair's second chunk those are words of a slab that is being written
+          // (never used: the next block primes its window afresh behind the barrier) — unconditional, so the body has no branch
           if (xi < 16 - RB) read_group(s, g + c2, xi + RB);
-          else if (c2 == 0) read_group(s, g + 1, xi - (16 - RB));
+          else read_group(s, g + c2 + 1, xi - (16 - RB));
           ADM_SCHED_FENCE();
         }
         if (cc < 4) {
+          // v4's fold (cout row r = cc gets bias + per-sample term + residual through the four corner points), written without a branch
+          // per row: a four-way branch on cc made hipcc copy the eight accumulators through 32 spare registers (phi copies) and spill.
+          // Row r's lanes add their value, the other rows add +0.0f (x + 0 = x bit for bit, except -0 -> +0).
           const float bsum = fb0 + fb1;
-#define W5_FOLD(R)                                                                                         \
-  do {                                                                                                     \
-    acc[0][0][R] += bsum + fr0[0];  acc[0][1][R] += bsum + fr0[2];                                          \
-    acc[3][0][R] -= bsum + fr0[1];  acc[3][1][R] -= bsum + fr0[3];                                          \
-    acc[12][0][R] -= bsum + fr1[0]; acc[12][1][R] -= bsum + fr1[2];                                         \
-    acc[15][0][R] += bsum + fr1[1]; acc[15][1][R] += bsum + fr1[3];                                         \
-  } while (0)
-          if (cc == 0) W5_FOLD(0);
-          else if (cc == 1) W5_FOLD(1);
-          else if (cc == 2) W5_FOLD(2);
-          else W5_FOLD(3);
-#undef W5_FOLD
+          const float v00 = bsum + fr0[0], v01 = bsum + fr0[2], v30 = bsum + fr0[1], v31 = bsum + fr0[3];
+          const float vc0 = bsum + fr1[0], vc1 = bsum + fr1[2], vf0 = bsum + fr1[1], vf1 = bsum + fr1[3];
+          ADM_UNROLL
+          for (int R = 0; R < 4; ++R) {
+            const bool on = cc == R;
+            acc[0][0][R] += on ? v00 : 0.f;  acc[0][1][R] += on ? v01 : 0.f;
+            acc[3][0][R] -= on ? v30 : 0.f;  acc[3][1][R] -= on ? v31 : 0.f;
+            acc[12][0][R] -= on ? vc0 : 0.f; acc[12][1][R] -= on ? vc1 : 0.f;
+            acc[15][0][R] += on ? vf0 : 0.f; acc[15][1][R] += on ? vf1 : 0.f;
+          }
         }
       }
-      const bool last = ci + 2 == nch;
-      auto epilogue = [&]() {                  // lane-local inverse transform Y = A^T M A + stores (+ GroupNorm partial sums): v4's
+      ci += 2;
+      last = ci == nch;
+    }
+    if (yrole && it >= -1) ADM_BARRIER_KEEP_VMEM(63);
+    if (last) {                                // lane-local inverse transform Y = A^T M A + stores (+ GroupNorm partial sums): v4's
+      ADM_UNROLL
+      for (int r = 0; r < 4; ++r) {
+        f32x4 y0, y1;
         ADM_UNROLL
-        for (int r = 0; r < 4; ++r) {
-          f32x4 y0, y1;
+        for (int c = 0; c < 2; ++c) {
+          float t0[4], t1[4];
           ADM_UNROLL
-          for (int c = 0; c < 2; ++c) {
-            float t0[4], t1[4];
-            ADM_UNROLL
-            for (int j = 0; j < 4; ++j) {
-              t0[j] = acc[0 * 4 + j][c][r] + acc[1 * 4 + j][c][r] + acc[2 * 4 + j][c][r];
-              t1[j] = acc[1 * 4 + j][c][r] - acc[2 * 4 + j][c][r] - acc[3 * 4 + j][c][r];
-            }
-            y0[2 * c] = t0[0] + t0[1] + t0[2];
-            y0[2 * c + 1] = t0[1] - t0[2] - t0[3];
-            y1[2 * c] = t1[0] + t1[1] + t1[2];
-            y1[2 * c + 1] = t1[1] - t1[2] - t1[3];
+          for (int j = 0; j < 4; ++j) {
+            t0[j] = acc[0 * 4 + j][c][r] + acc[1 * 4 + j][c][r] + acc[2 * 4 + j][c][r];
+            t1[j] = acc[1 * 4 + j][c][r] - acc[2 * 4 + j][c][r] - acc[3 * 4 + j][c][r];
           }
-          *reinterpret_cast<f32x4*>(p.out + obase + r * planeO) = y0;
-          *reinterpret_cast<f32x4*>(p.out + obase + r * planeO + p.Wo) = y1;
-          if (p.stats != nullptr) {
-            float f1 = (y0[0] + y0[1]) + (y0[2] + y0[3]) + ((y1[0] + y1[1]) + (y1[2] + y1[3]));
-            float f2 = (y0[0] * y0[0] + y0[1] * y0[1]) + (y0[2] * y0[2] + y0[3] * y0[3]) +
-                       ((y1[0] * y1[0] + y1[1] * y1[1]) + (y1[2] * y1[2] + y1[3] * y1[3]));
-            double s1 = (double)f1, s2 = (double)f2;
-            ADM_UNROLL
-            for (int m = 8; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
-            if (li == 0) {
-              const int tiles = p.tiles_x * p.tiles_y;
-              double* dst = p.stats + (((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4 + r) * tiles + t.ty * p.tiles_x + t.tx) * 2;
-              dst[0] = s1; dst[1] = s2;
-            }
+          y0[2 * c] = t0[0] + t0[1] + t0[2];
+          y0[2 * c + 1] = t0[1] - t0[2] - t0[3];
+          y1[2 * c] = t1[0] + t1[1] + t1[2];
+          y1[2 * c + 1] = t1[1] - t1[2] - t1[3];
+        }
+        *reinterpret_cast<f32x4*>(p.out + obase + r * planeO) = y0;
+        *reinterpret_cast<f32x4*>(p.out + obase + r * planeO + p.Wo) = y1;
+#ifndef W5X_NOSTATS
+        if (p.stats != nullptr) {
+          float f1 = (y0[0] + y0[1]) + (y0[2] + y0[3]) + ((y1[0] + y1[1]) + (y1[2] + y1[3]));
+          float f2 = (y0[0] * y0[0] + y0[1] * y0[1]) + (y0[2] * y0[2] + y0[3] * y0[3]) +
+                     ((y1[0] * y1[0] + y1[1] * y1[1]) + (y1[2] * y1[2] + y1[3] * y1[3]));
+          double s1 = (double)f1, s2 = (double)f2;
+          ADM_UNROLL
+          for (int m = 8; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+          if (li == 0) {
+            const int tiles = p.tiles_x * p.tiles_y;
+            double* dst = p.stats + (((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4 + r) * tiles + t.ty * p.tiles_x + t.tx) * 2;
+            dst[0] = s1; dst[1] = s2;
           }
         }
-      };
-      if (!yrole) {
-        if (last) epilogue();
-        produce();                             // P(ival)
-        ADM_BARRIER_KEEP_VMEM(63);
-      } else {
-        ADM_BARRIER_KEEP_VMEM(63);
-        if (last) epilogue();
-        if (ival + 1 < npairs) produce();      // P(ival + 1), ahead of the first half by design
+#endif
+        ADM_SCHED_FENCE();
       }
     }
+    if (yrole ? it + 1 < npairs : it >= -1) {  // P: C(pg, pg + 1), B(pg + 2, pg + 3), A(the next pair of the stream)
+#ifndef W5X_NOC
+      stage_c(pg + cpar);
+      ADM_SCHED_FENCE();
+#endif
+#ifndef W5X_NOB
+      stage_b(r0, pg + 2);
+      ADM_SCHED_FENCE();
+      stage_b(r1, pg + 3);
+      ADM_SCHED_FENCE();
+#endif
+#ifndef W5X_NOA
+      stage_a2(r0, r1);
+#endif
+      pg += 2;
+    }
+    if (!yrole && it >= -1) ADM_BARRIER_KEEP_VMEM(63);
   }
 #undef W5_LOAD_A
 }

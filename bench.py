@@ -417,6 +417,10 @@ def roofline(unet, x, B):
         4314: "adm::conv_wino4_kernel (Winograd F(2x2,3x3) 3x3 stride-1 conv, v_mfma_f32_16x16x4_f32, persistent wave-specialised: "
               "4 producer waves (patch -> GroupNorm/SiLU -> B^T d B into LDS) + 4 consumer waves (16 couts x 32 tiles each, filters "
               "L2 -> registers, lane-local A^T M A), 64-cout x 8x16-pixel tile)",
+        4315: "adm::conv_wino5_kernel (Winograd F(2x2,3x3) 3x3 stride-1 conv, v_mfma_f32_16x16x4_f32, persistent: 128-cout x 8x16-pixel "
+              "workgroup tile, every input patch transformed once per 128 couts; all 8 waves are MFMA waves (16 couts x 32 tiles x 16 "
+              "points each, filters L2 -> registers, lane-local A^T M A) and share the staging (patch -> GroupNorm/SiLU -> B^T d B into "
+              "LDS); the two waves of a SIMD run MFMA block and staging in antiphase)",
         2314: "adm::conv_mfma_pf_kernel<3,2,2> (v_mfma_f32_32x32x2_f32 implicit GEMM, 3x3 stride 1, 128-cout tile)",
     }
     per_var = {}

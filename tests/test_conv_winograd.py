@@ -65,8 +65,8 @@ def _run_case(dev, case, want_variant):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("mode,Cin,Cout,variant", [(3, 64, 32, 4313), (4, 64, 32, 4314), (4, 128, 64, 4314)],
-                         ids=["v3", "v4", "v4-two-cout-tiles"])
+@pytest.mark.parametrize("mode,Cin,Cout,variant", [(3, 64, 32, 4313), (4, 64, 32, 4314), (4, 128, 64, 4315)],
+                         ids=["v3", "v4", "v5-128-couts"])
 def test_conv_winograd_data_gradient(backend, mode, Cin, Cout, variant):
     """3x3 stride-1 backward-data pass as a Winograd convolution with transposed/flipped filters vs torch autograd
     (the data-gradient convolution maps Cout -> Cin channels, so ITS output-channel count is the forward's Cin)."""
