@@ -20,6 +20,7 @@
 // (256^2 ... 1x1). Algorithmic bytes per launch: 4*(N*Cin*Hs*Ws + N*Cout*Ho*Wo [+ residual]) + 4*Cout*Cin*ks^2.
 #include <cstdlib>
 
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -707,13 +708,15 @@ __global__ void __launch_bounds__(256) ksplit_finish1_kernel(const float* __rest
 // scratch for the split-K partial slabs, one buffer per (device, stream): launches on one stream are ordered, two streams must
 // not share it. Grown only outside stream capture (the executors run one uncaptured forward before they capture), geometrically,
 // and the superseded buffer is freed once the stream has drained (it used to be leaked on every growth).
-// When more than 8 streams have used one device the least recently used slot is taken over (after a device sync).
-// nullptr = it cannot be provided (capture in progress and the buffer too small / no slot, out of memory):
+// The table is keyed dynamically (round 5): a slot is NEVER taken away from the stream it belongs to — a captured
+// hipGraph of that stream holds the buffer's address — so a process may use up to 256 streams per device (>= 32 MiB each) and the
+// 257th fails loudly instead of stealing a live stream's scratch.
+// nullptr = it cannot be provided (capture in progress and the buffer too small, table full, out of memory):
 // the callers FAIL the launch — the unsplit kernel sums in another fp32 order, and a row's bits must not depend on such things.
 static float* ksplit_scratch(size_t floats, hipStream_t st) {
-  struct Slot { hipStream_t st; float* buf; size_t cap; bool used; unsigned long long tick; };
-  static Slot slots[16][8] = {};
-  static unsigned long long clock_ = 0;
+  struct Slot { float* buf = nullptr; size_t cap = 0; };
+  static std::map<std::pair<int, hipStream_t>, Slot> slots;
+  static int per_dev[16] = {};
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
   const int d = conv_dev_slot();
@@ -724,22 +727,17 @@ static float* ksplit_scratch(size_t floats, hipStream_t st) {
     capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
   }
 #endif
-  Slot* sl = nullptr;
-  for (Slot& s : slots[d]) if (s.used && s.st == st) { sl = &s; break; }
-  if (sl == nullptr)
-    for (Slot& s : slots[d]) if (!s.used) { sl = &s; sl->used = true; sl->st = st; sl->buf = nullptr; sl->cap = 0; break; }
-  if (sl == nullptr) {
-    // every slot belongs to some other stream (a long-lived process that has used many streams: their handles may be long gone):
-    // take over the least recently used one. Its buffer may still be read by launches queued on its stream -> drain the device first.
-    if (capturing) { set_error("split-K scratch: no free slot for this stream during stream capture (run one uncaptured pass first)"); return nullptr; }
-    for (Slot& s : slots[d]) if (sl == nullptr || s.tick < sl->tick) sl = &s;
-#if !defined(ADM_EMU)
-    (void)hipDeviceSynchronize();
-#endif
-    if (sl->buf) dfree(sl->buf);
-    sl->st = st; sl->buf = nullptr; sl->cap = 0;
+  auto it = slots.find(std::make_pair(d, st));
+  if (it == slots.end()) {
+    if (per_dev[d & 15] >= 256) {
+      set_error("split-K scratch: more than 256 streams have run split-K convolutions on this device; a stream's scratch is never "
+                "taken over (captured graphs hold its address) — reuse streams");
+      return nullptr;
+    }
+    ++per_dev[d & 15];
+    it = slots.emplace(std::make_pair(d, st), Slot()).first;
   }
-  sl->tick = ++clock_;
+  Slot* sl = &it->second;
   if (floats <= sl->cap) return sl->buf;
   if (capturing) {
     set_error("split-K scratch must grow during stream capture: run one uncaptured pass at this batch size first");

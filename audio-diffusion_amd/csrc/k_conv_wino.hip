@@ -1382,10 +1382,18 @@ __device__ __forceinline__ Wino3Tile wino5_tile(const WinoParams& p, int v) {
 
 // HALO: this wave's staging item is a halo element (waves 5-7 of the non-UP kernel), else a float4 row piece (UP: one scalar of the
 // source-resolution patch). TUNE bit 0: static s_setprio 1 for the second half (waves 4-7); bit 1: B window of 4 points instead of 8.
-template <bool UP, bool HALO, int ACT>
+// ABL (experiments build, TIMING ONLY — results are wrong): bit 0 / 1 / 2 = stage C / B / A skipped, 3 = no MFMAs (operands still fetched),
+// 4 = no filter loads, 5 = no LDS operand reads, 6 = no workgroup barriers, 7 = no bias / residual fold. PROF: per-half cycle accounting
+// (s_memtime) into p.prof: [0] total, [1] MFMA blocks, [2] staging, [3] barrier waits, [4] epilogues; second half at +8.
+template <bool UP, bool HALO, int ACT, int ABL = 0, bool PROF = false>
 __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, float* ldsP, const int tid, const int wave,
                                            const int b0, const int bs) {
   const bool yrole = wave >= 4;               // second half: staging first, MFMA block second
+  unsigned long long pr[5] = {0, 0, 0, 0, 0};
+  const unsigned long long t_start = W3_CLK();
+  unsigned long long tq = t_start, tn;
+#define W5_LAP(slot) do { if (PROF) { tn = W3_CLK(); pr[slot] += tn - tq; tq = tn; } } while (0)
+#define W5_BARRIER() do { if (!(ABL & 64)) ADM_BARRIER_KEEP_VMEM(63); } while (0)
   const int lane = tid & 63;
   const int li = lane & 15, k4 = lane >> 4;
   const int Ct = p.C1 + p.C2;
@@ -1574,11 +1582,12 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
   const long chunk_stride = (long)n_cblk * W4ABLK;
   const float* d_src = p.wu + ((long)(wino5_tile(p, d_v).m0 >> 4) + wave) * W4ABLK + lane * 4;
   f32x4 a[4][2];
-#define W5_LOAD_A(q)                                                                 \
+#define W5_LOAD_A_(q)                                                                \
   do {                                                                               \
     a[q][0] = *reinterpret_cast<const f32x4*>(d_src + (q) * 512);                    \
     a[q][1] = *reinterpret_cast<const f32x4*>(d_src + (q) * 512 + 256);              \
   } while (0)
+#define W5_LOAD_A(q) do { if (!(ABL & 16)) W5_LOAD_A_(q); } while (0)
   auto advance_a = [&]() {
     if (d_left > 1) {
       --d_left;
@@ -1597,9 +1606,9 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
   stage_a2(r0, r1);                           // chunks 0, 1
   stage_b(r0, 0); stage_b(r1, 1);
   stage_a2(r0, r1);                           // chunks 2, 3
-  W5_LOAD_A(0); W5_LOAD_A(1); W5_LOAD_A(2); W5_LOAD_A(3);      // filters of chunk 0
+  W5_LOAD_A_(0); W5_LOAD_A_(1); W5_LOAD_A_(2); W5_LOAD_A_(3);  // filters of chunk 0
   advance_a();
-  ADM_BARRIER_KEEP_VMEM(63);                  // patches 0, 1 complete
+  W5_BARRIER();                               // patches 0, 1 complete
 
   const int vlane = k4 * 32 + 2 * li;
   constexpr int RB = W5RB;
@@ -1639,6 +1648,7 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
       }
       const int g = 2 * it;
       // ---- M: the 128 MFMAs of chunks g, g + 1 -----------------------------------------------------------------------------------
+      if (PROF) tq = W3_CLK();
       ADM_UNROLL
       for (int xi = 0; xi < RB; ++xi) read_group(xi, g, xi);
       // (a real two-trip loop, NOT unrolled: the loop-carried values pin the accumulators and the filter registers in place — unrolled,
@@ -1646,24 +1656,27 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
       _Pragma("clang loop unroll(disable)")
       for (int c2 = 0; c2 < 2; ++c2) {
         const int cc = ci + c2;
-        if (cc < 4) {                          // wave-uniform: this chunk carries cout row r = cc of the bias / residual fold (v4)
+        if (cc < 4 && !(ABL & 128)) {          // wave-uniform: this chunk carries cout row r = cc of the bias / residual fold (v4)
           const int co = t.m0 + 16 * wave + 4 * k4 + cc;
           fb0 = p.bias[co];
           fb1 = p.chan_add[(long)t.n * p.chan_add_stride + co];
-#ifndef W5X_NORES
           if (p.residual != nullptr) {
             fr0 = *reinterpret_cast<const f32x4*>(p.residual + obase + cc * planeO);
             fr1 = *reinterpret_cast<const f32x4*>(p.residual + obase + cc * planeO + p.Wo);
           }
-#endif
         }
         ADM_UNROLL
         for (int xi = 0; xi < 16; ++xi) {
           const int s = xi & (RB - 1), q = xi >> 2, e = xi & 3;
           ADM_UNROLL
           for (int ks = 0; ks < 2; ++ks) {
-            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].x, acc[xi][0], 0, 0, 0);
-            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].y, acc[xi][1], 0, 0, 0);
+            if (ABL & 8) {
+              acc[xi][0][0] += a[q][ks][e] * rb[s][ks].x;
+              acc[xi][1][0] += a[q][ks][e] * rb[s][ks].y;
+            } else {
+              acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].x, acc[xi][0], 0, 0, 0);
+              acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].y, acc[xi][1], 0, 0, 0);
+            }
           }
           if (e == 3) {                        // group q consumed: its registers take the NEXT chunk's words
             if (q == 0) W5_LOAD_A(0);
@@ -1673,11 +1686,13 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
           }
           // the window runs on into the next chunk; behind the pair's second chunk those are words of a slab that is being written
           // (never used: the next block primes its window afresh behind the barrier) — unconditional, so the body has no branch
-          if (xi < 16 - RB) read_group(s, g + c2, xi + RB);
-          else read_group(s, g + c2 + 1, xi - (16 - RB));
+          if (!(ABL & 32)) {
+            if (xi < 16 - RB) read_group(s, g + c2, xi + RB);
+            else read_group(s, g + c2 + 1, xi - (16 - RB));
+          }
           ADM_SCHED_FENCE();
         }
-        if (cc < 4) {
+        if (cc < 4 && !(ABL & 128)) {
           // v4's fold (cout row r = cc gets bias + per-sample term + residual through the four corner points), written without a branch
           // per row: a four-way branch on cc made hipcc copy the eight accumulators through 32 spare registers (phi copies) and spill.
           // Row r's lanes add their value, the other rows add +0.0f (x + 0 = x bit for bit, except -0 -> +0).
@@ -1696,8 +1711,9 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
       }
       ci += 2;
       last = ci == nch;
+      W5_LAP(1);
     }
-    if (yrole && it >= -1) ADM_BARRIER_KEEP_VMEM(63);
+    if (yrole && it >= -1) { if (PROF) tq = W3_CLK(); W5_BARRIER(); W5_LAP(3); }
     if (last) {                                // lane-local inverse transform Y = A^T M A + stores (+ GroupNorm partial sums): v4's
       ADM_UNROLL
       for (int r = 0; r < 4; ++r) {
@@ -1717,7 +1733,6 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
         }
         *reinterpret_cast<f32x4*>(p.out + obase + r * planeO) = y0;
         *reinterpret_cast<f32x4*>(p.out + obase + r * planeO + p.Wo) = y1;
-#ifndef W5X_NOSTATS
         if (p.stats != nullptr) {
           float f1 = (y0[0] + y0[1]) + (y0[2] + y0[3]) + ((y1[0] + y1[1]) + (y1[2] + y1[3]));
           float f2 = (y0[0] * y0[0] + y0[1] * y0[1]) + (y0[2] * y0[2] + y0[3] * y0[3]) +
@@ -1731,32 +1746,39 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
             dst[0] = s1; dst[1] = s2;
           }
         }
-#endif
         ADM_SCHED_FENCE();
       }
+      W5_LAP(4);
     }
     if (yrole ? it + 1 < npairs : it >= -1) {  // P: C(pg, pg + 1), B(pg + 2, pg + 3), A(the next pair of the stream)
-#ifndef W5X_NOC
-      stage_c(pg + cpar);
-      ADM_SCHED_FENCE();
-#endif
-#ifndef W5X_NOB
-      stage_b(r0, pg + 2);
-      ADM_SCHED_FENCE();
-      stage_b(r1, pg + 3);
-      ADM_SCHED_FENCE();
-#endif
-#ifndef W5X_NOA
-      stage_a2(r0, r1);
-#endif
+      if (PROF) tq = W3_CLK();
+      if (!(ABL & 1)) {
+        stage_c(pg + cpar);
+        ADM_SCHED_FENCE();
+      }
+      if (!(ABL & 2)) {
+        stage_b(r0, pg + 2);
+        ADM_SCHED_FENCE();
+        stage_b(r1, pg + 3);
+        ADM_SCHED_FENCE();
+      }
+      if (!(ABL & 4)) stage_a2(r0, r1);
       pg += 2;
+      W5_LAP(2);
     }
-    if (!yrole && it >= -1) ADM_BARRIER_KEEP_VMEM(63);
+    if (!yrole && it >= -1) { if (PROF) tq = W3_CLK(); W5_BARRIER(); W5_LAP(3); }
   }
+  if (PROF && (tid & 255) == 0) {
+    pr[0] = W3_CLK() - t_start;
+    for (int i = 0; i < 5; ++i) atomicAdd(p.prof + (yrole ? 8 : 0) + i, pr[i]);
+  }
+#undef W5_LAP
+#undef W5_BARRIER
+#undef W5_LOAD_A_
 #undef W5_LOAD_A
 }
 
-template <bool UP, int ACT>
+template <bool UP, int ACT, int ABL = 0, bool PROF = false>
 __global__ void __launch_bounds__(512) conv_wino5_kernel(const WinoParams p) {
   ADM_DYN_SMEM(float, smem);
   float* ldsV = smem;
@@ -1766,8 +1788,8 @@ __global__ void __launch_bounds__(512) conv_wino5_kernel(const WinoParams p) {
 #if !defined(ADM_EMU)
   if (wave >= 4 && (p.tune & 1)) __builtin_amdgcn_s_setprio(1);
 #endif
-  if (!UP && wave >= 5) wino5_wave<UP, true, ACT>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
-  else wino5_wave<UP, false, ACT>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+  if (!UP && wave >= 5) wino5_wave<UP, true, ACT, ABL, PROF>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+  else wino5_wave<UP, false, ACT, ABL, PROF>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Filter image of conv_wino4_kernel: U = G g G^T as [Cin/8][Cout/16][point group q][k step ks][lane = 16 k4 + li][e]
@@ -2042,7 +2064,7 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     // order), so this batch-dependent choice cannot move a sample's bits.
     if (v4 && v5_ok && wino5_on() && a.Cout % W5BM == 0) {
       const int nblk5 = p.tiles_x * p.tiles_y * a.N * (a.Cout / W5BM);
-      if (nblk5 >= n_cu) {
+      if (nblk5 >= n_cu || wino5_on() >= 2) {          // ("wino5" = 2: wherever the shape allows — tests on small tensors)
         p.n_ct = a.Cout / W5BM;
         p.nblk = nblk5;
         p.prof = nullptr;
@@ -2053,12 +2075,54 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
 #endif
         set_last_conv_variant(4000 + 315);
         const size_t need5 = sizeof(float) * W4LDS_PAIR;
+        const int grid5 = nblk5 < n_cu ? nblk5 : n_cu;
+#if !defined(ADM_EMU) && defined(ADM_EXPERIMENTS)
+        static const int abl5 = [] { const char* e = getenv("ADM_WINO5_ABL"); return e ? atoi(e) : 0; }();
+        static const bool prof5 = getenv("ADM_WINO5_PROF") != nullptr;
+        if (!a.up && a.act && (abl5 || prof5)) {   // developer aids (see wino5_wave): role / stage ablations (TIMING ONLY) and cycle accounting
+#define W5_EXP(A, P)                                                                                                                \
+  do {                                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)conv_wino5_kernel<false, 1, A, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need5); \
+    ADM_LAUNCH((conv_wino5_kernel<false, 1, A, P>), dim3(grid5), dim3(512), need5, st, p);                                           \
+  } while (0)
+          if (prof5) {
+            static unsigned long long* dprof = [] { void* q = nullptr; (void)hipMalloc(&q, 16 * sizeof(unsigned long long)); return (unsigned long long*)q; }();
+            (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
+            p.prof = dprof;
+            W5_EXP(0, true);
+            unsigned long long h[16];
+            (void)hipMemcpyAsync(h, dprof, sizeof(h), hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            const double nb = 2.0 * grid5;      // two sampled waves (tid 0 / 256 of each half... one per half: waves 0 and 4) — see wino5_wave
+            fprintf(stderr, "[wino5 prof] per-wave cycles, first half: total %.0f M %.0f P %.0f barrier %.0f epilogue %.0f | second half: total %.0f M %.0f P %.0f barrier %.0f epilogue %.0f\n",
+                    h[0] / nb * 2, h[1] / nb * 2, h[2] / nb * 2, h[3] / nb * 2, h[4] / nb * 2, h[8] / nb * 2, h[9] / nb * 2, h[10] / nb * 2, h[11] / nb * 2, h[12] / nb * 2);
+            return ADM_CHECK_LAUNCH();
+          }
+          switch (abl5) {
+            case 7: W5_EXP(7, false); break;        // no staging: MFMA blocks + barriers
+            case 56: W5_EXP(56, false); break;      // no MFMA block at all (no MFMAs, no operand fetch): staging + barriers
+            case 32: W5_EXP(32, false); break;      // no LDS operand reads
+            case 16: W5_EXP(16, false); break;      // no filter loads
+            case 48: W5_EXP(48, false); break;      // bare MFMAs beside working staging
+            case 55: W5_EXP(55, false); break;      // bare MFMAs, no staging: the pipe's own pace under this schedule
+            case 64: W5_EXP(64, false); break;      // no barriers
+            case 1: W5_EXP(1, false); break;
+            case 2: W5_EXP(2, false); break;
+            case 4: W5_EXP(4, false); break;
+            case 128: W5_EXP(128, false); break;    // no bias / residual fold
+            case 8: W5_EXP(8, false); break;        // MFMAs replaced by two FMAs (operands still fetched)
+            default: W5_EXP(119, false); break;     // 119 = 55 | 64: bare MFMAs, nothing else
+          }
+#undef W5_EXP
+          return ADM_CHECK_LAUNCH();
+        }
+#endif
         if (a.up) {
-          if (a.act) ADM_LAUNCH((conv_wino5_kernel<true, 1>), dim3(n_cu), dim3(512), need5, st, p);
-          else ADM_LAUNCH((conv_wino5_kernel<true, 0>), dim3(n_cu), dim3(512), need5, st, p);
+          if (a.act) ADM_LAUNCH((conv_wino5_kernel<true, 1>), dim3(grid5), dim3(512), need5, st, p);
+          else ADM_LAUNCH((conv_wino5_kernel<true, 0>), dim3(grid5), dim3(512), need5, st, p);
         } else {
-          if (a.act) ADM_LAUNCH((conv_wino5_kernel<false, 1>), dim3(n_cu), dim3(512), need5, st, p);
-          else ADM_LAUNCH((conv_wino5_kernel<false, 0>), dim3(n_cu), dim3(512), need5, st, p);
+          if (a.act) ADM_LAUNCH((conv_wino5_kernel<false, 1>), dim3(grid5), dim3(512), need5, st, p);
+          else ADM_LAUNCH((conv_wino5_kernel<false, 0>), dim3(grid5), dim3(512), need5, st, p);
         }
         return ADM_CHECK_LAUNCH();
       }

@@ -619,6 +619,9 @@ int Net::plan(int B) {
         const int Ho = o.up ? 2 * H : H, Wo = o.up ? 2 * W : W;
         if (!blk_apply_eligible(C1, C2, H, W) || !blk_apply_eligible(Cout, 0, s2 ? H / 2 : Ho, s2 ? W / 2 : Wo)) continue;
         if (o.act && o.gn < 0) continue;
+        // Upsample2D.conv onto an 8x8 plane: the blocked kernels have no nearest-x2 variant for 8-pixel rows (such a layer
+        // was planned and then failed in train_step) — it stays on launch_conv2d / launch_conv_wgrad
+        if (o.up && Wo == 8) continue;
         BlkOp& b = blk[i];
         b.s2 = s2;
         b.fwd = conv_bf16b_eligible(Ct, Cout, Ho, Wo, s2 ? 0 : B);      // (B: rows of 16 / 8 pixels tile 2 / 4 images side by side)
@@ -631,7 +634,9 @@ int Net::plan(int B) {
           ADM_TRY(dmemset(b.xa, 0, bytes, nullptr));          // the halo stays zero for the life of the plan
         }
         if (b.wg || b.dg) {
-          void*& img = dy_imgs[std::make_tuple(s2 ? -Cout : Cout, Ho, Wo)];   // (a zero-inserted image keeps its own zeros)
+          // (a zero-inserted image keeps its own zeros — the pad-0 variant dirties the odd pixels, the pad-1 variant the even ones, so
+          // the two never share an image: key -Cout / -Cout - 2^20)
+          void*& img = dy_imgs[std::make_tuple(s2 ? -Cout - (o.pad_lo == 0 ? (1 << 20) : 0) : Cout, Ho, Wo)];
           if (img == nullptr) {
             const size_t bytes = blk_image_bytes(B, Cout, Ho, Wo);
             ADM_TRY(arena_alloc(&img, bytes));
@@ -672,6 +677,12 @@ int Net::plan(int B) {
           const BlkOp& pb = blk[pi];
           if (po.kind != Op::CONV || !pb.wg || !pb.dg || pb.s2 || po.up || po.res >= 0 || po.w == nullptr || !po.w->qkv_prefix.empty()) continue;
           if (tensors[t].C % groups != 0 || tensors[t].C <= 4) continue;
+          // the consumer's GroupNorm backward writes the producer's dy image when op i runs in the reverse walk; the producer reads it
+          // when op pi runs. No blocked convolution in between may use the same image (one buffer per (Cout, H, W)): true for the resnet
+          // order conv1, GN, shortcut, conv2 — checked, not assumed
+          bool clash = false;
+          for (int j = pi + 1; j < (int)i; ++j) clash |= blk[j].dyb != nullptr && blk[j].dyb == pb.dyb;
+          if (clash) continue;
           blk[i].img_for = pi;
         }
       }
@@ -1027,7 +1038,8 @@ int Net::run_backward(int B, float* dtemb_all, int temb_stride, hipStream_t st) 
         ADM_REQUIRE(tmp_da_floats >= (size_t)B * Ct * Hi * Wi, "run_backward: scratch too small");
         a.out = tmp_da;
       }
-      if (o.ks == 1 && o.in2 >= 0 && o.gn < 0 && !o.up && conv_bf16_mode() >= 2 && C1 % 32 == 0 && a.bf16_packed != nullptr) {
+      if (o.ks == 1 && o.in2 >= 0 && o.gn < 0 && !o.act && o.in1_C == 0 && !o.up && conv_bf16_mode() >= 2 && C1 % 32 == 0 &&
+          a.bf16_packed != nullptr) {
         // 1x1 convolution over a virtual concat (the shortcuts of the up blocks): its data gradient goes straight into the two source
         // tensors' gradient buffers (each written or accumulated in the epilogue) instead of a scratch tensor + two fan-in passes
         adm_conv_args a2 = a;

@@ -81,6 +81,8 @@ def test_conv_winograd_data_gradient(backend, mode, Cin, Cout, variant):
     _native.check(_native.lib().adm_set_option(b"conv_wino", mode))
     try:
         dx = ops.conv2d(dy, ops.pack_conv_weight_T(w), None, 3, residual=acc, wino=ops.pack_winograd_weight_T(w))
+        if variant == 4315 and backend == "hip":   # 8 tiles of 128 couts do not fill 256 CUs: the launcher keeps v4's 64-cout tiles (bit-identical)
+            variant = 4314
         assert _native.lib().adm_last_conv_variant() == variant, "the Winograd kernel was not selected"
     finally:
         _native.check(_native.lib().adm_set_option(b"conv_wino", -1))
@@ -201,7 +203,7 @@ def test_conv_wino5_against_torch_and_bit_for_bit_against_v4(backend, case):
     outs = {}
     _native.check(lib.adm_set_option(b"conv_wino", 4))
     try:
-        for v5 in (1, 0):
+        for v5 in (2, 0):      # 2 = v5 wherever the shape allows (1, the default, also asks that the 128-cout tiles fill the chip)
             _native.check(lib.adm_set_option(b"wino5", v5))
             o, st = ops.conv2d(x1, wp, b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb, residual=res, wino=wu, stats=True)
             assert lib.adm_last_conv_variant() == (4315 if v5 else 4314)
@@ -211,6 +213,6 @@ def test_conv_wino5_against_torch_and_bit_for_bit_against_v4(backend, case):
         _native.check(lib.adm_set_option(b"conv_wino", -1))
     c = lambda t: None if t is None else t.cpu()  # noqa: E731
     ref = _conv_ref(c(x1), c(x2), c(w), c(b), 3, 1, up, (c(gamma), c(beta)) if use_gn else None, act, c(temb), c(res))
-    assert _relerr(outs[1][0], ref) < 1e-4, _relerr(outs[1][0], ref)
-    assert torch.equal(outs[1][0], outs[0][0]), (outs[1][0] - outs[0][0]).abs().max()
-    assert torch.equal(outs[1][1], outs[0][1])
+    assert _relerr(outs[2][0], ref) < 1e-4, _relerr(outs[2][0], ref)
+    assert torch.equal(outs[2][0], outs[0][0]), (outs[2][0] - outs[0][0]).abs().max()
+    assert torch.equal(outs[2][1], outs[0][1])

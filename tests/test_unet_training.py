@@ -382,6 +382,40 @@ def test_mixed_precision_bf16_level3_blocked_operand_images(backend, monkeypatch
     assert l3t == l3 and torch.equal(g3, g3t)
 
 
+UP8CFG = dict(sample_size=32, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(128, 128, 128, 128),
+              down_block_types=("DownBlock2D",) * 4, up_block_types=("UpBlock2D",) * 4)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_level3_upsample_onto_an_8x8_plane_stays_off_the_blocked_kernels(backend, monkeypatch):
+    """at level 3 an Upsample2D conv whose OUTPUT plane is 8x8 (4x4 -> 8x8) passed the blocked kernels' shape test when
+    B % 4 == 0, but they have no nearest-x2 variant for 8-pixel rows: `train_step` failed with 'conv_bf16b: no nearest-x2 variant for
+    8-pixel rows' (sample_size 32, four levels of 128 channels, B = 4 — and the stock 256-model config at 64x64 / 32x32). The plan now
+    leaves such a layer on the fp32 kernels; the step must run and meet the toy model's gradient bar."""
+    dev = select(backend)
+    from audiodiffusion import _native
+    from audiodiffusion.unet import UNet2DModel
+    monkeypatch.setenv("ADM_BF16_LEVEL", "3")
+    torch.manual_seed(0)
+    ref = OracleUNet(**UP8CFG)
+    g = torch.Generator().manual_seed(3)
+    x, tgt = torch.randn((4, 1, 32, 32), generator=g), torch.randn((4, 1, 32, 32), generator=g)
+    ts = torch.tensor([5, 700, 33, 999])
+    loss_ref = F.mse_loss(ref(x, ts)["sample"], tgt)
+    loss_ref.backward()
+    g32 = torch.cat([p.grad.flatten() for _, p in ref.named_parameters()])
+    try:
+        m = UNet2DModel(**UP8CFG).load_state_dict(ref.state_dict())
+        _, grads = m.enable_training(mixed_precision="bf16")
+        loss = float(m.train_step(x.to(dev), ts, tgt.to(dev)))
+        flat = torch.cat([grads[m.flat.offsets[n][0]:m.flat.offsets[n][0] + p.numel()].cpu() for n, p in ref.named_parameters()])
+    finally:
+        _native.check(_native.lib().adm_set_option(b"conv_bf16", 0))
+    assert abs(loss - float(loss_ref.detach())) <= 5e-3 * float(loss_ref.detach())
+    e = float((flat - g32).double().norm() / g32.double().norm())
+    assert 1e-4 < e < 1.5e-2, e
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_level3_partial_batch_leaves_the_narrow_row_tilings(backend, monkeypatch):
     """The narrow-row tilings put 2 images of the 16x16 level side by side: a plan made for B = 4 takes them, the short last batch of an
