@@ -1367,7 +1367,7 @@ __global__ void __launch_bounds__(512) conv_wino4_kernel(const WinoParams p) {
 //   M and P is free (they touch disjoint ring slots), which is what lets the two halves run them in opposite order.
 // Arithmetic and summation order are v4's: outputs are bit-identical to conv_wino4_kernel (tests/test_conv_winograd.py).
 constexpr int W5BM = 128;
-constexpr int W5RB = 8;          // B window of the MFMA block, in Winograd points
+constexpr int W5RB = 4;          // B window of the MFMA block, in Winograd points
 struct Wino5Raw { f32x4 a; float sc, sh; unsigned ok; };      // one item of one chunk (HALO / UP: a[0] only)
 
 __device__ __forceinline__ Wino3Tile wino5_tile(const WinoParams& p, int v) {
@@ -1389,8 +1389,8 @@ template <bool UP, bool HALO, int ACT, int ABL = 0, bool PROF = false>
 __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, float* ldsP, const int tid, const int wave,
                                            const int b0, const int bs) {
   const bool yrole = wave >= 4;               // second half: staging first, MFMA block second
-  unsigned long long pr[5] = {0, 0, 0, 0, 0};
-  const unsigned long long t_start = W3_CLK();
+  unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_start = PROF ? W3_CLK() : 0ull;
   unsigned long long tq = t_start, tn;
 #define W5_LAP(slot) do { if (PROF) { tn = W3_CLK(); pr[slot] += tn - tq; tq = tn; } } while (0)
 #define W5_BARRIER() do { if (!(ABL & 64)) ADM_BARRIER_KEEP_VMEM(63); } while (0)
@@ -1529,13 +1529,15 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
     for (int k = 0; k < 4; ++k) { const float v0 = r_.a[k] * sc + sh; P0[k] = act_on ? silu_w(v0) : v0; }
 #endif
   };
-  auto stage_c = [&](int g) {                 // patch g & 3 -> 4x4 window -> V = B^T d B -> V slab g & 3
+  // stage C in two parts, so that the window's LDS round trip runs under stage B's arithmetic
+  auto stage_c_read = [&](int g, float (&d)[16]) {     // patch g & 3 -> this thread's 4x4 window
     const float* P = ldsP + (g & 3) * W3PSLAB + wbase;
-    float d[16];
     ADM_UNROLL
     for (int i = 0; i < 4; ++i)
       ADM_UNROLL
       for (int j = 0; j < 4; ++j) d[i * 4 + j] = UP ? P[((i + 1) >> 1) * 10 + ((j + 1) >> 1)] : P[i * WPP + j];
+  };
+  auto stage_c_math = [&](int g, const float (&d)[16]) {   // V = B^T d B -> V slab g & 3
     float* vdst = ldsV + (g & 3) * W3VSLAB + vofs;
 #if !defined(ADM_EMU)
     typedef float wf2 __attribute__((ext_vector_type(2)));
@@ -1619,102 +1621,26 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
     rb[slot][1] = *reinterpret_cast<const float2*>(V + (xi * WCK + 4) * 32);
   };
   f32x4 acc[16][2];
-  const long planeO = (long)p.Ho * p.Wo;
   // ONE loop body serves the prologue as well: iterations -2 and -1 have no MFMA block. Barrier / staging schedule per iteration `it`:
   //   first half  (waves 0-3): [M(it)] [epilogue] P            barrier      — P from it = -1 on (P#0 = V(0), V(1), patches 2, 3, loads 4, 5)
   //   second half (waves 4-7): [M(it)] barrier    [epilogue] P              — P from it = -2 on, i.e. one staging block AHEAD of the first half
   // Both halves execute the same barriers (from it = -1 on); between two of them M and P of either half touch disjoint ring slots.
+  const long planeO = (long)p.Ho * p.Wo;
   int v = b0 - bs, ci = 0;                    // tile / chunk cursor of the MFMA stream (ci == nch: step to the next tile)
   ci = nch;
   Wino3Tile t = wino5_tile(p, b0);
   long obase = 0;
+#if !defined(ADM_EMU)
+  // Output stores and residual loads as raw buffer operations: resource = this wave's 16 cout rows of the tile's sample (SGPRs, made once
+  // per tile), lane term = one 32-bit byte offset, cout row / pixel row = SGPR offsets. The 64-bit per-row VGPR addresses (eight pairs
+  // that hipcc kept alive through the whole tile) are gone.
+  __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(p.out, (short)0, 0x7fffffff, 0x00027000), r_rs = o_rs;
+  int o_vo = 0;
+  const int plane_b = (int)planeO * 4, row_b = p.Wo * 4;
+#endif
   f32x4 fr0 = {0.f, 0.f, 0.f, 0.f}, fr1 = fr0;
   float fb0 = 0.f, fb1 = 0.f;
-  for (int it = -2; it < npairs; ++it) {
-    bool last = false;
-    if (it >= 0) {
-      if (ci == nch) {                        // next tile
-        ADM_SCHED_FENCE();
-        ci = 0; v += bs;
-        t = wino5_tile(p, v);
-        ADM_UNROLL
-        for (int xi = 0; xi < 16; ++xi)
-          ADM_UNROLL
-          for (int c = 0; c < 2; ++c)
-            ADM_UNROLL
-            for (int r = 0; r < 4; ++r) acc[xi][c][r] = 0.f;
-        const int oy = t.ty * 8 + 2 * (li >> 2), ox = t.tx * 16 + 4 * (li & 3);
-        obase = ((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4) * planeO + (long)oy * p.Wo + ox;
-      }
-      const int g = 2 * it;
-      // ---- M: the 128 MFMAs of chunks g, g + 1 -----------------------------------------------------------------------------------
-      if (PROF) tq = W3_CLK();
-      ADM_UNROLL
-      for (int xi = 0; xi < RB; ++xi) read_group(xi, g, xi);
-      // (a real two-trip loop, NOT unrolled: the loop-carried values pin the accumulators and the filter registers in place — unrolled,
-      // hipcc renamed them across the two copies: 156 accumulator and 48 filter registers instead of 128 + 32, and spilled)
-      _Pragma("clang loop unroll(disable)")
-      for (int c2 = 0; c2 < 2; ++c2) {
-        const int cc = ci + c2;
-        if (cc < 4 && !(ABL & 128)) {          // wave-uniform: this chunk carries cout row r = cc of the bias / residual fold (v4)
-          const int co = t.m0 + 16 * wave + 4 * k4 + cc;
-          fb0 = p.bias[co];
-          fb1 = p.chan_add[(long)t.n * p.chan_add_stride + co];
-          if (p.residual != nullptr) {
-            fr0 = *reinterpret_cast<const f32x4*>(p.residual + obase + cc * planeO);
-            fr1 = *reinterpret_cast<const f32x4*>(p.residual + obase + cc * planeO + p.Wo);
-          }
-        }
-        ADM_UNROLL
-        for (int xi = 0; xi < 16; ++xi) {
-          const int s = xi & (RB - 1), q = xi >> 2, e = xi & 3;
-          ADM_UNROLL
-          for (int ks = 0; ks < 2; ++ks) {
-            if (ABL & 8) {
-              acc[xi][0][0] += a[q][ks][e] * rb[s][ks].x;
-              acc[xi][1][0] += a[q][ks][e] * rb[s][ks].y;
-            } else {
-              acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].x, acc[xi][0], 0, 0, 0);
-              acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].y, acc[xi][1], 0, 0, 0);
-            }
-          }
-          if (e == 3) {                        // group q consumed: its registers take the NEXT chunk's words
-            if (q == 0) W5_LOAD_A(0);
-            if (q == 1) W5_LOAD_A(1);
-            if (q == 2) W5_LOAD_A(2);
-            if (q == 3) { W5_LOAD_A(3); advance_a(); }
-          }
-          // the window runs on into the next chunk; behind the pair's second chunk those are words of a slab that is being written
-          // (never used: the next block primes its window afresh behind the barrier) — unconditional, so the body has no branch
-          if (!(ABL & 32)) {
-            if (xi < 16 - RB) read_group(s, g + c2, xi + RB);
-            else read_group(s, g + c2 + 1, xi - (16 - RB));
-          }
-          ADM_SCHED_FENCE();
-        }
-        if (cc < 4 && !(ABL & 128)) {
-          // v4's fold (cout row r = cc gets bias + per-sample term + residual through the four corner points), written without a branch
-          // per row: a four-way branch on cc made hipcc copy the eight accumulators through 32 spare registers (phi copies) and spill.
-          // Row r's lanes add their value, the other rows add +0.0f (x + 0 = x bit for bit, except -0 -> +0).
-          const float bsum = fb0 + fb1;
-          const float v00 = bsum + fr0[0], v01 = bsum + fr0[2], v30 = bsum + fr0[1], v31 = bsum + fr0[3];
-          const float vc0 = bsum + fr1[0], vc1 = bsum + fr1[2], vf0 = bsum + fr1[1], vf1 = bsum + fr1[3];
-          ADM_UNROLL
-          for (int R = 0; R < 4; ++R) {
-            const bool on = cc == R;
-            acc[0][0][R] += on ? v00 : 0.f;  acc[0][1][R] += on ? v01 : 0.f;
-            acc[3][0][R] -= on ? v30 : 0.f;  acc[3][1][R] -= on ? v31 : 0.f;
-            acc[12][0][R] -= on ? vc0 : 0.f; acc[12][1][R] -= on ? vc1 : 0.f;
-            acc[15][0][R] += on ? vf0 : 0.f; acc[15][1][R] += on ? vf1 : 0.f;
-          }
-        }
-      }
-      ci += 2;
-      last = ci == nch;
-      W5_LAP(1);
-    }
-    if (yrole && it >= -1) { if (PROF) tq = W3_CLK(); W5_BARRIER(); W5_LAP(3); }
-    if (last) {                                // lane-local inverse transform Y = A^T M A + stores (+ GroupNorm partial sums): v4's
+  auto epilogue = [&]() {
       ADM_UNROLL
       for (int r = 0; r < 4; ++r) {
         f32x4 y0, y1;
@@ -1731,8 +1657,13 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
           y1[2 * c] = t1[0] + t1[1] + t1[2];
           y1[2 * c + 1] = t1[1] - t1[2] - t1[3];
         }
+#if !defined(ADM_EMU)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y0), o_rs, o_vo, r * plane_b, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y1), o_rs, o_vo, r * plane_b + row_b, 0);
+#else
         *reinterpret_cast<f32x4*>(p.out + obase + r * planeO) = y0;
         *reinterpret_cast<f32x4*>(p.out + obase + r * planeO + p.Wo) = y1;
+#endif
         if (p.stats != nullptr) {
           float f1 = (y0[0] + y0[1]) + (y0[2] + y0[3]) + ((y1[0] + y1[1]) + (y1[2] + y1[3]));
           float f2 = (y0[0] * y0[0] + y0[1] * y0[1]) + (y0[2] * y0[2] + y0[3] * y0[3]) +
@@ -1749,12 +1680,123 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
         ADM_SCHED_FENCE();
       }
       W5_LAP(4);
-    }
-    if (yrole ? it + 1 < npairs : it >= -1) {  // P: C(pg, pg + 1), B(pg + 2, pg + 3), A(the next pair of the stream)
-      if (PROF) tq = W3_CLK();
-      if (!(ABL & 1)) {
-        stage_c(pg + cpar);
+  };
+  bool pend = false;                          // a finished tile waits for its inverse transform + stores
+  for (int it = -2; it <= npairs; ++it) {     // (iteration npairs: nothing but the last tile's epilogue)
+    // Both halves store a finished tile at the top of the NEXT iteration — behind the barrier that ended its last interval: in front of
+    // it, the first half's ~4000 cycles of inverse transform and stores kept the second half waiting once per tile.
+    if (pend) { if (PROF) tq = W3_CLK(); epilogue(); pend = false; }
+    if (it >= 0 && it < npairs) {
+      if (ci == nch) {                        // next tile
         ADM_SCHED_FENCE();
+        ci = 0; v += bs;
+        t = wino5_tile(p, v);
+        ADM_UNROLL
+        for (int xi = 0; xi < 16; ++xi)
+          ADM_UNROLL
+          for (int c = 0; c < 2; ++c)
+            ADM_UNROLL
+            for (int r = 0; r < 4; ++r) acc[xi][c][r] = 0.f;
+        const int oy = t.ty * 8 + 2 * (li >> 2), ox = t.tx * 16 + 4 * (li & 3);
+#if !defined(ADM_EMU)
+        const long tbase = ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO;       // wave-uniform
+        o_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + tbase, (short)0, 0x7fffffff, 0x00027000);
+        if (p.residual != nullptr) r_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual) + tbase, (short)0, 0x7fffffff, 0x00027000);
+        o_vo = (4 * k4 * (int)planeO + oy * p.Wo + ox) * 4;
+#else
+        obase = ((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4) * planeO + (long)oy * p.Wo + ox;
+#endif
+      }
+      const int g = 2 * it;
+      // ---- M: the 128 MFMAs of chunks g, g + 1 -----------------------------------------------------------------------------------
+      if (PROF) tq = W3_CLK();
+      ADM_UNROLL
+      for (int xi = 0; xi < RB; ++xi) read_group(xi, g, xi);
+      // (a real two-trip loop, NOT unrolled: the loop-carried values pin the accumulators and the filter registers in place — unrolled,
+      // hipcc renamed them across the two copies: 156 accumulator and 48 filter registers instead of 128 + 32, and spilled)
+      _Pragma("clang loop unroll(disable)")
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const int cc = ci + c2;
+        if (cc < 4 && !(ABL & 128)) {          // wave-uniform: this chunk carries cout row r = cc of the bias / residual fold (v4)
+          const int co = t.m0 + 16 * wave + 4 * k4 + cc;
+          fb0 = p.bias[co];
+          fb1 = p.chan_add[(long)t.n * p.chan_add_stride + co];
+          if (p.residual != nullptr) {
+#if !defined(ADM_EMU)
+            fr0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, o_vo, cc * plane_b, 0));
+            fr1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, o_vo, cc * plane_b + row_b, 0));
+#else
+            fr0 = *reinterpret_cast<const f32x4*>(p.residual + obase + cc * planeO);
+            fr1 = *reinterpret_cast<const f32x4*>(p.residual + obase + cc * planeO + p.Wo);
+#endif
+          }
+        }
+        ADM_UNROLL
+        for (int xi = 0; xi < 16; ++xi) {
+          const int s = xi & (RB - 1), q = xi >> 2, e = xi & 3;
+          ADM_UNROLL
+          for (int ks = 0; ks < 2; ++ks) {
+            if (ABL & 8) {
+              acc[xi][0][0] += a[q][ks][e] * rb[s][ks].x;
+              acc[xi][1][0] += a[q][ks][e] * rb[s][ks].y;
+            } else {
+              acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].x, acc[xi][0], 0, 0, 0);
+              acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][ks][e], rb[s][ks].y, acc[xi][1], 0, 0, 0);
+            }
+          }
+          if (e == 3) {                        // group q consumed: its registers take the NEXT chunk's words
+            // (measured and dropped: the pair's second refill issued from the staging block behind stage B, so that stage B's wait for its
+            // raw activations no longer waits for these loads too — the block's counted waits then ran into the raw HBM loads queued behind
+            // the refill: 2.92 -> 3.04 ms on 128 -> 128 @256^2)
+            if (q == 0) W5_LOAD_A(0);
+            if (q == 1) W5_LOAD_A(1);
+            if (q == 2) W5_LOAD_A(2);
+            if (q == 3) { W5_LOAD_A(3); advance_a(); }
+          }
+          // the window runs on into the next chunk; behind the pair's second chunk those are words of a slab that is being written
+          // (never used: the next block primes its window afresh behind the barrier) — unconditional, so the body has no branch
+          if (!(ABL & 32)) {
+            if (xi < 16 - RB) read_group(s, g + c2, xi + RB);
+            else read_group(s, g + c2 + 1, xi - (16 - RB));
+          }
+          ADM_SCHED_FENCE();
+        }
+        if (cc < 4 && !(ABL & 128)) {
+          // v4's fold (cout row r = cc gets bias + per-sample term + residual through the four corner points), written without a branch
+          // per row: a four-way branch on cc made hipcc copy the eight accumulators through 32 spare registers (phi copies) and spill.
+          // Row r adds its value, the other rows add 0 * value (x + 0 = x bit for bit, except -0 -> +0; a non-finite residual value
+          // would reach the lane's other three rows as NaN — such a tensor is lost either way).
+          const float bsum = fb0 + fb1;
+          const float v00 = bsum + fr0[0], v01 = bsum + fr0[2], v30 = -(bsum + fr0[1]), v31 = -(bsum + fr0[3]);
+          const float vc0 = -(bsum + fr1[0]), vc1 = -(bsum + fr1[2]), vf0 = bsum + fr1[1], vf1 = bsum + fr1[3];
+          ADM_UNROLL
+          for (int R = 0; R < 4; ++R) {
+            // one fma per (accumulator, row) with a wave-uniform 1.0 / 0.0 factor: fma(1, v, acc) = acc + v exactly; fma(0, v, acc) = acc
+            // (for finite v; acc - x = acc + (-x) exactly, so v4's subtractions are additions of the negated value)
+            const float on = cc == R ? 1.f : 0.f;
+            acc[0][0][R] = __builtin_fmaf(on, v00, acc[0][0][R]);   acc[0][1][R] = __builtin_fmaf(on, v01, acc[0][1][R]);
+            acc[3][0][R] = __builtin_fmaf(on, v30, acc[3][0][R]);   acc[3][1][R] = __builtin_fmaf(on, v31, acc[3][1][R]);
+            acc[12][0][R] = __builtin_fmaf(on, vc0, acc[12][0][R]); acc[12][1][R] = __builtin_fmaf(on, vc1, acc[12][1][R]);
+            acc[15][0][R] = __builtin_fmaf(on, vf0, acc[15][0][R]); acc[15][1][R] = __builtin_fmaf(on, vf1, acc[15][1][R]);
+          }
+        }
+      }
+      ci += 2;
+      pend = ci == nch;
+      W5_LAP(1);
+    }
+    if (yrole && it >= -1 && it < npairs) { if (PROF) tq = W3_CLK(); W5_BARRIER(); W5_LAP(3); }
+    if (yrole ? it + 1 < npairs : (it >= -1 && it < npairs)) {  // P: C(pg, pg + 1), B(pg + 2, pg + 3), A(the next pair of the stream)
+      if (PROF) tq = W3_CLK();
+      // Stage C's window read first (its LDS round trip runs under what follows). The second half stages right behind its MFMA block, whose
+      // last filter refills are still in flight and sit in front of stage B's raw activations in the in-order counter: it finishes stage C
+      // before stage B, the first half (a whole MFMA block between its loads and this point is not the issue there) the other way round.
+      float cd[16];
+      if (!(ABL & 1)) stage_c_read(pg + cpar, cd);
+      if (yrole && !(ABL & 1)) {
+        stage_c_math(pg + cpar, cd);
+        ADM_SCHED_FENCE();
+        W5_LAP(2);
       }
       if (!(ABL & 2)) {
         stage_b(r0, pg + 2);
@@ -1762,15 +1804,21 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
         stage_b(r1, pg + 3);
         ADM_SCHED_FENCE();
       }
+      W5_LAP(5);
+      if (!yrole && !(ABL & 1)) {
+        stage_c_math(pg + cpar, cd);
+        ADM_SCHED_FENCE();
+        W5_LAP(2);
+      }
       if (!(ABL & 4)) stage_a2(r0, r1);
       pg += 2;
-      W5_LAP(2);
+      W5_LAP(6);
     }
-    if (!yrole && it >= -1) { if (PROF) tq = W3_CLK(); W5_BARRIER(); W5_LAP(3); }
+    if (!yrole && it >= -1 && it < npairs) { if (PROF) tq = W3_CLK(); W5_BARRIER(); W5_LAP(3); }
   }
   if (PROF && (tid & 255) == 0) {
     pr[0] = W3_CLK() - t_start;
-    for (int i = 0; i < 5; ++i) atomicAdd(p.prof + (yrole ? 8 : 0) + i, pr[i]);
+    for (int i = 0; i < 8; ++i) atomicAdd(p.prof + (yrole ? 8 : 0) + i, pr[i]);
   }
 #undef W5_LAP
 #undef W5_BARRIER
@@ -2094,8 +2142,8 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
             (void)hipMemcpyAsync(h, dprof, sizeof(h), hipMemcpyDeviceToHost, st);
             (void)hipStreamSynchronize(st);
             const double nb = 2.0 * grid5;      // two sampled waves (tid 0 / 256 of each half... one per half: waves 0 and 4) — see wino5_wave
-            fprintf(stderr, "[wino5 prof] per-wave cycles, first half: total %.0f M %.0f P %.0f barrier %.0f epilogue %.0f | second half: total %.0f M %.0f P %.0f barrier %.0f epilogue %.0f\n",
-                    h[0] / nb * 2, h[1] / nb * 2, h[2] / nb * 2, h[3] / nb * 2, h[4] / nb * 2, h[8] / nb * 2, h[9] / nb * 2, h[10] / nb * 2, h[11] / nb * 2, h[12] / nb * 2);
+            fprintf(stderr, "[wino5 prof] per-wave cycles, first half: total %.0f M %.0f C %.0f B %.0f A %.0f barrier %.0f epilogue %.0f | second half: total %.0f M %.0f C %.0f B %.0f A %.0f barrier %.0f epilogue %.0f\n",
+                    h[0] / nb * 2, h[1] / nb * 2, h[2] / nb * 2, h[5] / nb * 2, h[6] / nb * 2, h[3] / nb * 2, h[4] / nb * 2, h[8] / nb * 2, h[9] / nb * 2, h[10] / nb * 2, h[13] / nb * 2, h[14] / nb * 2, h[11] / nb * 2, h[12] / nb * 2);
             return ADM_CHECK_LAUNCH();
           }
           switch (abl5) {
