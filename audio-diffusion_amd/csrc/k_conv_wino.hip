@@ -1368,6 +1368,8 @@ __global__ void __launch_bounds__(512) conv_wino4_kernel(const WinoParams p) {
 // Arithmetic and summation order are v4's: outputs are bit-identical to conv_wino4_kernel (tests/test_conv_winograd.py).
 constexpr int W5BM = 128;
 constexpr int W5RB = 4;          // B window of the MFMA block, in Winograd points
+// INTER: behind which MFMA group (0..31 = chunk * 16 + Winograd point) of an interval each staging piece is placed
+constexpr int W5S_CR = 0, W5S_CM = 3, W5S_B0 = 7, W5S_B1 = 10, W5S_A = 14, W5S_SHIFT = 16;
 struct Wino5Raw { f32x4 a; float sc, sh; unsigned ok; };      // one item of one chunk (HALO / UP: a[0] only)
 
 __device__ __forceinline__ Wino3Tile wino5_tile(const WinoParams& p, int v) {
@@ -1385,12 +1387,14 @@ __device__ __forceinline__ Wino3Tile wino5_tile(const WinoParams& p, int v) {
 // ABL (experiments build, TIMING ONLY — results are wrong): bit 0 / 1 / 2 = stage C / B / A skipped, 3 = no MFMAs (operands still fetched),
 // 4 = no filter loads, 5 = no LDS operand reads, 6 = no workgroup barriers, 7 = no bias / residual fold. PROF: per-half cycle accounting
 // (s_memtime) into p.prof: [0] total, [1] MFMA blocks, [2] staging, [3] barrier waits, [4] epilogues; second half at +8.
-template <bool UP, bool HALO, int ACT, int ABL = 0, bool PROF = false>
+// INTER: no halves — every wave runs [MFMA block with the staging pieces placed between its MFMA groups] barrier: both waves of a SIMD
+// always have MFMAs to issue, and whatever one of them waits for (an LDS round trip, a vector-memory issue) the other's MFMAs cover.
+template <bool UP, bool HALO, int ACT, int ABL = 0, bool PROF = false, bool INTER = false, bool H2 = false>
 __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, float* ldsP, const int tid, const int wave,
                                            const int b0, const int bs) {
-  const bool yrole = wave >= 4;               // second half: staging first, MFMA block second
+  const bool yrole = !INTER && wave >= 4;     // second half: staging first, MFMA block second
   unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long t_start = PROF ? W3_CLK() : 0ull;
+  const unsigned long long t_start = (PROF || p.prof != nullptr) ? W3_CLK() : 0ull;   // (p.prof alone: total cycles only, two reads per wave)
   unsigned long long tq = t_start, tn;
 #define W5_LAP(slot) do { if (PROF) { tn = W3_CLK(); pr[slot] += tn - tq; tq = tn; } } while (0)
 #define W5_BARRIER() do { if (!(ABL & 64)) ADM_BARRIER_KEEP_VMEM(63); } while (0)
@@ -1673,8 +1677,17 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
           for (int m = 8; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
           if (li == 0) {
             const int tiles = p.tiles_x * p.tiles_y;
+#if !defined(ADM_EMU)
+            // (a buffer store: SGPR base + 32-bit lane term — the 64-bit lane part of the address was a loop invariant hipcc spilled)
+            typedef double wd2 __attribute__((ext_vector_type(2)));
+            const int so = (((t.n * p.Cout + t.m0 + 16 * wave) * tiles + t.ty * p.tiles_x + t.tx)) * 16;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, wd2{s1, s2}),
+                                                   __builtin_amdgcn_make_buffer_rsrc(p.stats, (short)0, 0x7fffffff, 0x00027000),
+                                                   (4 * k4 + r) * tiles * 16, so, 0);
+#else
             double* dst = p.stats + (((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4 + r) * tiles + t.ty * p.tiles_x + t.tx) * 2;
             dst[0] = s1; dst[1] = s2;
+#endif
           }
         }
         ADM_SCHED_FENCE();
@@ -1714,8 +1727,8 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
       for (int xi = 0; xi < RB; ++xi) read_group(xi, g, xi);
       // (a real two-trip loop, NOT unrolled: the loop-carried values pin the accumulators and the filter registers in place — unrolled,
       // hipcc renamed them across the two copies: 156 accumulator and 48 filter registers instead of 128 + 32, and spilled)
-      _Pragma("clang loop unroll(disable)")
-      for (int c2 = 0; c2 < 2; ++c2) {
+      float cd[16];                            // (INTER) stage C's window, between its read and its transform
+      auto chunk = [&](const int c2) __attribute__((always_inline)) {
         const int cc = ci + c2;
         if (cc < 4 && !(ABL & 128)) {          // wave-uniform: this chunk carries cout row r = cc of the bias / residual fold (v4)
           const int co = t.m0 + 16 * wave + 4 * k4 + cc;
@@ -1760,6 +1773,20 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
             else read_group(s, g + c2 + 1, xi - (16 - RB));
           }
           ADM_SCHED_FENCE();
+          if (INTER) {                         // staging pieces of P(it) between the MFMA groups (s is a compile-time constant here)
+            // The two waves of a SIMD (w and w + 4) run the same stream and restart together behind every barrier; with the SAME
+            // placement their staging pieces — and the stalls that come with them — would coincide. The second half places its pieces
+            // W5S_SHIFT groups later (same order, so the register hand-overs between the pieces hold).
+            const int sl = c2 * 16 + xi;
+#define W5_AT(S) (sl == (S) + (H2 ? W5S_SHIFT : 0))
+            if (W5_AT(W5S_CR) && !(ABL & 1)) stage_c_read(pg + cpar, cd);
+            if (W5_AT(W5S_CM) && !(ABL & 1)) stage_c_math(pg + cpar, cd);
+            if (W5_AT(W5S_B0) && !(ABL & 2)) stage_b(r0, pg + 2);
+            if (W5_AT(W5S_B1) && !(ABL & 2)) stage_b(r1, pg + 3);
+            if (W5_AT(W5S_A)) { if (!(ABL & 4)) stage_a2(r0, r1); pg += 2; }
+#undef W5_AT
+            ADM_SCHED_FENCE();
+          }
         }
         if (cc < 4 && !(ABL & 128)) {
           // v4's fold (cout row r = cc gets bias + per-sample term + residual through the four corner points), written without a branch
@@ -1780,13 +1807,20 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
             acc[15][0][R] = __builtin_fmaf(on, vf0, acc[15][0][R]); acc[15][1][R] = __builtin_fmaf(on, vf1, acc[15][1][R]);
           }
         }
+      
+      };
+      if constexpr (INTER) { chunk(0); chunk(1); }          // straight-line: the slot numbers below are compile-time constants
+      else {
+        // (a real two-trip loop, NOT unrolled: see above)
+        _Pragma("clang loop unroll(disable)")
+        for (int c2 = 0; c2 < 2; ++c2) chunk(c2);
       }
       ci += 2;
       pend = ci == nch;
       W5_LAP(1);
     }
     if (yrole && it >= -1 && it < npairs) { if (PROF) tq = W3_CLK(); W5_BARRIER(); W5_LAP(3); }
-    if (yrole ? it + 1 < npairs : (it >= -1 && it < npairs)) {  // P: C(pg, pg + 1), B(pg + 2, pg + 3), A(the next pair of the stream)
+    if (INTER ? it == -1 : (yrole ? it + 1 < npairs : (it >= -1 && it < npairs))) {  // P: C(pg, pg + 1), B(pg + 2, pg + 3), A(the next pair of the stream)
       if (PROF) tq = W3_CLK();
       // Stage C's window read first (its LDS round trip runs under what follows). The second half stages right behind its MFMA block, whose
       // last filter refills are still in flight and sit in front of stage B's raw activations in the in-order counter: it finishes stage C
@@ -1816,9 +1850,9 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
     }
     if (!yrole && it >= -1 && it < npairs) { if (PROF) tq = W3_CLK(); W5_BARRIER(); W5_LAP(3); }
   }
-  if (PROF && (tid & 255) == 0) {
+  if ((PROF || p.prof != nullptr) && (tid & 255) == 0) {
     pr[0] = W3_CLK() - t_start;
-    for (int i = 0; i < 8; ++i) atomicAdd(p.prof + (yrole ? 8 : 0) + i, pr[i]);
+    for (int i = 0; i < (PROF ? 8 : 1); ++i) atomicAdd(p.prof + (tid >= 256 ? 8 : 0) + i, pr[i]);
   }
 #undef W5_LAP
 #undef W5_BARRIER
@@ -1826,7 +1860,7 @@ __device__ __forceinline__ void wino5_wave(const WinoParams& p, float* ldsV, flo
 #undef W5_LOAD_A
 }
 
-template <bool UP, int ACT, int ABL = 0, bool PROF = false>
+template <bool UP, int ACT, int ABL = 0, bool PROF = false, bool INTER = false>
 __global__ void __launch_bounds__(512) conv_wino5_kernel(const WinoParams p) {
   ADM_DYN_SMEM(float, smem);
   float* ldsV = smem;
@@ -1834,10 +1868,15 @@ __global__ void __launch_bounds__(512) conv_wino5_kernel(const WinoParams p) {
   const int tid = threadIdx.x;
   const int wave = ADM_UNIFORM(tid >> 6);     // an SGPR: role tests and the barrier placement become scalar branches
 #if !defined(ADM_EMU)
-  if (wave >= 4 && (p.tune & 1)) __builtin_amdgcn_s_setprio(1);
+  if (!INTER && wave >= 4 && (p.tune & 1)) __builtin_amdgcn_s_setprio(1);
 #endif
-  if (!UP && wave >= 5) wino5_wave<UP, true, ACT, ABL, PROF>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
-  else wino5_wave<UP, false, ACT, ABL, PROF>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+  if (INTER && wave >= 4) {                   // (INTER: the second half is its own instantiation — its staging pieces sit at other places)
+    if (!UP && wave >= 5) wino5_wave<UP, true, ACT, ABL, PROF, INTER, INTER>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+    else wino5_wave<UP, false, ACT, ABL, PROF, INTER, INTER>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+    return;
+  }
+  if (!UP && wave >= 5) wino5_wave<UP, true, ACT, ABL, PROF, INTER>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+  else wino5_wave<UP, false, ACT, ABL, PROF, INTER>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Filter image of conv_wino4_kernel: U = G g G^T as [Cin/8][Cout/16][point group q][k step ks][lane = 16 k4 + li][e]
@@ -1969,7 +2008,8 @@ static int wino_pair() {
   return g_wino_pair;
 }
 // conv_wino5_kernel (128-cout workgroup tiles, all eight waves MFMA + staging): 1 (default) = used wherever the layer has 128 | Cout
-// and its 128-cout tiles fill the chip; 0 = conv_wino4_kernel everywhere. Bit-identical results either way (same filter image).
+// and its 128-cout tiles fill the chip; 0 = conv_wino4_kernel everywhere; bit 1 (2) = also when the tiles do not fill the chip (tests);
+// bit 3 (8) = the two-halves-in-antiphase schedule instead of the interleaved one. Bit-identical results in every case (same filter image).
 static int g_wino5 = -1;       // -1: take ADM_WINO5 from the environment (default 1) on first use
 void set_winograd_v5(int v) { g_wino5 = v; }
 static int wino5_on() {
@@ -2089,6 +2129,10 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
         ok5 &= hipFuncSetAttribute((const void*)conv_wino5_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
         ok5 &= hipFuncSetAttribute((const void*)conv_wino5_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
         ok5 &= hipFuncSetAttribute((const void*)conv_wino5_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        ok5 &= hipFuncSetAttribute((const void*)conv_wino5_kernel<true, 1, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        ok5 &= hipFuncSetAttribute((const void*)conv_wino5_kernel<true, 0, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        ok5 &= hipFuncSetAttribute((const void*)conv_wino5_kernel<false, 1, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
+        ok5 &= hipFuncSetAttribute((const void*)conv_wino5_kernel<false, 0, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, by) == hipSuccess;
         if (!ok5) (void)hipGetLastError();
         info[dslot].v5_ok = ok5;
 #if defined(ADM_EXPERIMENTS)
@@ -2112,7 +2156,7 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     // order), so this batch-dependent choice cannot move a sample's bits.
     if (v4 && v5_ok && wino5_on() && a.Cout % W5BM == 0) {
       const int nblk5 = p.tiles_x * p.tiles_y * a.N * (a.Cout / W5BM);
-      if (nblk5 >= n_cu || wino5_on() >= 2) {          // ("wino5" = 2: wherever the shape allows — tests on small tensors)
+      if (nblk5 >= n_cu || (wino5_on() & 2)) {         // ("wino5" bit 1: wherever the shape allows — tests on small tensors)
         p.n_ct = a.Cout / W5BM;
         p.nblk = nblk5;
         p.prof = nullptr;
@@ -2146,7 +2190,15 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
                     h[0] / nb * 2, h[1] / nb * 2, h[2] / nb * 2, h[5] / nb * 2, h[6] / nb * 2, h[3] / nb * 2, h[4] / nb * 2, h[8] / nb * 2, h[9] / nb * 2, h[10] / nb * 2, h[13] / nb * 2, h[14] / nb * 2, h[11] / nb * 2, h[12] / nb * 2);
             return ADM_CHECK_LAUNCH();
           }
+          static unsigned long long* dcyc = [] { void* q = nullptr; (void)hipMalloc(&q, 16 * sizeof(unsigned long long)); return (unsigned long long*)q; }();
+          (void)hipMemsetAsync(dcyc, 0, 16 * sizeof(unsigned long long), st);
+          p.prof = dcyc;
           switch (abl5) {
+            case 1000: (void)hipFuncSetAttribute((const void*)conv_wino5_kernel<false, 1, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need5);
+                       ADM_LAUNCH((conv_wino5_kernel<false, 1, 0, false, true>), dim3(grid5), dim3(512), need5, st, p); break;   // the interleaved schedule
+            case 1007: (void)hipFuncSetAttribute((const void*)conv_wino5_kernel<false, 1, 7, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need5);
+                       ADM_LAUNCH((conv_wino5_kernel<false, 1, 7, false, true>), dim3(grid5), dim3(512), need5, st, p); break;
+            case 999: W5_EXP(0, false); break;      // the product kernel, with the cycle count
             case 7: W5_EXP(7, false); break;        // no staging: MFMA blocks + barriers
             case 56: W5_EXP(56, false); break;      // no MFMA block at all (no MFMAs, no operand fetch): staging + barriers
             case 32: W5_EXP(32, false); break;      // no LDS operand reads
@@ -2162,9 +2214,25 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
             default: W5_EXP(119, false); break;     // 119 = 55 | 64: bare MFMAs, nothing else
           }
 #undef W5_EXP
+          {
+            unsigned long long h[16];
+            (void)hipMemcpyAsync(h, dcyc, sizeof(h), hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            fprintf(stderr, "[wino5 cycles] ABL %d: %.0f cycles per wave (waves 0 / 4 of every workgroup)\n", abl5, (double)(h[0] + h[8]) / (2.0 * grid5));
+          }
           return ADM_CHECK_LAUNCH();
         }
 #endif
+        if (!(wino5_on() & 8)) {                      // the interleaved schedule (INTER: the default); "wino5" bit 3 = the two halves in antiphase
+          if (a.up) {
+            if (a.act) ADM_LAUNCH((conv_wino5_kernel<true, 1, 0, false, true>), dim3(grid5), dim3(512), need5, st, p);
+            else ADM_LAUNCH((conv_wino5_kernel<true, 0, 0, false, true>), dim3(grid5), dim3(512), need5, st, p);
+          } else {
+            if (a.act) ADM_LAUNCH((conv_wino5_kernel<false, 1, 0, false, true>), dim3(grid5), dim3(512), need5, st, p);
+            else ADM_LAUNCH((conv_wino5_kernel<false, 0, 0, false, true>), dim3(grid5), dim3(512), need5, st, p);
+          }
+          return ADM_CHECK_LAUNCH();
+        }
         if (a.up) {
           if (a.act) ADM_LAUNCH((conv_wino5_kernel<true, 1>), dim3(grid5), dim3(512), need5, st, p);
           else ADM_LAUNCH((conv_wino5_kernel<true, 0>), dim3(grid5), dim3(512), need5, st, p);

@@ -32,8 +32,10 @@ int adm_has_experiments(void);
  *   so set the mode BEFORE weights are packed) | -1 (back to the default / ADM_CONV_WINO environment variable) | 1 / 2 / 3 (earlier
  *   Winograd kernel generations: only in a library built with -DADM_EXPERIMENTS, see adm_has_experiments; an error otherwise);
  * "wino5" = 1 (default, round 5) layers with 128 | Cout whose 128-cout workgroup tiles fill the chip run on conv_wino5_kernel (every input patch
- *   transformed once per 128 output channels; all eight waves MFMA + staging in antiphase) | 0 conv_wino4_kernel everywhere (same filter
- *   image, bit-identical results) | 2 conv_wino5_kernel for every layer with 128 | Cout, however few tiles (tests) | -1 (ADM_WINO5);
+ *   transformed once per 128 output channels; all eight waves are MFMA waves and share the staging work, placed between their MFMA groups) |
+ *   0 conv_wino4_kernel everywhere (same filter image, bit-identical results) | bit 1 (2): conv_wino5_kernel for every layer with 128 | Cout,
+ *   however few tiles (tests) | bit 3 (8): the two halves of the workgroup run MFMA block and staging block in antiphase instead (the first
+ *   schedule built; same results, same speed) | -1 (ADM_WINO5);
  * "wino_pair" = 1 (default) one workgroup barrier per two chunks in conv_wino4_kernel | 0 one per chunk (bit-identical) | -1 (ADM_WINO_PAIR);
  * "wgrad_max_split" = n caps the split-K factor of adm_conv2d_wgrad (0 = heuristic; tests use it to put several pixel tiles on
  *   one workgroup);

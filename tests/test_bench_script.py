@@ -72,3 +72,33 @@ def test_bench_py_reports_a_hung_training_leg_beside_the_measured_headline():
     assert d["value"] > 0 and d["n_gpus"] == 2
     assert "timeout" in d["train"]["error"]
 
+
+
+def test_bench_py_eight_ranks_weak_with_the_training_leg_and_strong_against_one_rank():
+    """The world size BASELINE configs 3 and 5 are written for: 8 ranks (gloo, toy network on the emulator). Weak mode with the training
+    leg — every gradient bucket all-reduced from inside the reverse pass on EVERY rank (MIN over the job) — and config 3 as written
+    (`--scaling strong`: one global batch of 8 split by rows) against the same 8 rows on one rank: identical gathered images."""
+    d = _run(8, ["--batch-per-gpu", "1", "--no-mel-leg"])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    tr = d["train"]
+    assert "error" not in tr, tr
+    assert tr["global_batch"] == 8 * tr["batch_per_gpu"] and tr["allreduce_buckets_overlapped"] == tr["allreduce_buckets"] >= 1
+    assert tr["allreduce_overlapped_on_every_rank"] is True
+    eight = _run(8, ["--no-train-leg", "--no-mel-leg", "--scaling", "strong", "--global-batch", "8"])
+    os.environ["ADM_BENCH_FORCE_PG"] = "1"
+    try:
+        one = _run(1, ["--batch-per-gpu", "8", "--no-train-leg", "--no-mel-leg"])
+    finally:
+        del os.environ["ADM_BENCH_FORCE_PG"]
+    assert eight["scaling"] == "strong" and eight["config"]["global_batch"] == 8
+    assert eight["gathered_checksum"] == one["gathered_checksum"] > 0
+
+
+def test_bench_py_one_rank_training_leg_runs_the_overlapped_all_reduce_in_its_own_group():
+    """The driver's N = 1 line: no launcher, no process group — the training leg builds a one-rank group of its own so that the
+    bucket-hook -> asynchronous all-reduce path executes under a real backward pass (every bucket, overlapped)."""
+    d = _run(1, ["--no-mel-leg"])
+    tr = d["train"]
+    assert "error" not in tr, tr
+    assert tr["one_rank_group"] is True and tr["allreduce_buckets_overlapped"] == tr["allreduce_buckets"] >= 1
+    assert tr["allreduce_overlapped_on_every_rank"] is True

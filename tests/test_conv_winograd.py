@@ -203,7 +203,9 @@ def test_conv_wino5_against_torch_and_bit_for_bit_against_v4(backend, case):
     outs = {}
     _native.check(lib.adm_set_option(b"conv_wino", 4))
     try:
-        for v5 in (2, 0):      # 2 = v5 wherever the shape allows (1, the default, also asks that the 128-cout tiles fill the chip)
+        # bit 1 (2) = v5 wherever the shape allows (1, the default, also asks that the 128-cout tiles fill the chip); bit 3 (8) = the two
+        # halves of the workgroup in antiphase instead of the default interleaved schedule (staging pieces between every wave's MFMA groups)
+        for v5 in (2, 10, 0):
             _native.check(lib.adm_set_option(b"wino5", v5))
             o, st = ops.conv2d(x1, wp, b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb, residual=res, wino=wu, stats=True)
             assert lib.adm_last_conv_variant() == (4315 if v5 else 4314)
@@ -214,5 +216,6 @@ def test_conv_wino5_against_torch_and_bit_for_bit_against_v4(backend, case):
     c = lambda t: None if t is None else t.cpu()  # noqa: E731
     ref = _conv_ref(c(x1), c(x2), c(w), c(b), 3, 1, up, (c(gamma), c(beta)) if use_gn else None, act, c(temb), c(res))
     assert _relerr(outs[2][0], ref) < 1e-4, _relerr(outs[2][0], ref)
-    assert torch.equal(outs[2][0], outs[0][0]), (outs[2][0] - outs[0][0]).abs().max()
-    assert torch.equal(outs[2][1], outs[0][1])
+    for v5 in (2, 10):
+        assert torch.equal(outs[v5][0], outs[0][0]), (v5, (outs[v5][0] - outs[0][0]).abs().max())
+        assert torch.equal(outs[v5][1], outs[0][1]), v5
