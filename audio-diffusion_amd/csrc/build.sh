@@ -38,7 +38,10 @@ else
   for s in "${srcs[@]}"; do
     o="$here/obj$suf/${s%.hip}.o"
     if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ adm_rt.h -nt "$o" ] || [ adm_kernels.h -nt "$o" ] || [ net_exec.h -nt "$o" ] || [ "$root/include/adm.h" -nt "$o" ]; then
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $exp -c "$s" -o "$o" &
+      # k_conv_wino.hip: no SLP vectorisation — hipcc packs the scalar adds of the inverse transform into v_pk_add_f32 fed by ~2 v_mov each
+      # (1813 -> 1333 VALU instructions in the kernel), and on gfx950 the fp32 MFMAs run on the same FMA lanes as the VALU: nothing is hidden
+      extra=""; [ "$s" = "k_conv_wino.hip" ] && extra="-fno-slp-vectorize"
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $exp $extra -c "$s" -o "$o" &
     fi
     objs+=("$o")
   done
