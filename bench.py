@@ -49,6 +49,9 @@ CFG_TOY = dict(sample_size=16, in_channels=1, out_channels=1, layers_per_block=1
                down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"))
 F1_TFLOP = 0.496          # algorithmic TFLOP per UNet forward per sample @256^2
 A1_GB, W_GB = 1.871, 0.4547  # fused-minimum activation bytes per forward per sample; weight bytes per forward per GPU
+CFG_COND = dict(sample_size=(64, 64), in_channels=1, out_channels=1, layers_per_block=2, block_out_channels=(128, 256, 512, 512),
+                down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",),
+                up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3, cross_attention_dim=100, attention_head_dim=8)
 PEAK_F32_TF = 157.3       # MI355X dense fp32 MFMA == vector peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_BF16_TF = 2500.0     # dense bf16 MFMA
 PEAK_HBM_TBS = 8.0
@@ -388,6 +391,27 @@ def side_cpu_baselines(nt):
                        "spectrograms_per_s_extrapolated": round(1.0 / (t / 20 * 1000 + td), 5),
                        "sample": "20 latent 32x32 DDPM steps + ONE AutoencoderKL decode to 256x256 at B = 1, x50 extrapolation of the loop"}
     del m32, vae
+    try:
+        from oracle.schedulers import DDIMScheduler as ODDIM
+        from oracle.unet_condition import UNet2DConditionModel as OCond
+        mc = OCond(**CFG_COND).eval()
+        sc = ODDIM()
+        sc.set_timesteps(50)
+        g = torch.Generator().manual_seed(8)
+        x = torch.randn(1, 1, 64, 64, generator=g)
+        enc = torch.randn(1, 1, 100, generator=g)
+        with torch.no_grad():
+            mc(x, sc.timesteps[0], enc)
+            t0 = time.perf_counter()
+            for t_ in sc.timesteps[:10]:
+                x = sc.step(mc(x, t_, enc)["sample"], t_, x)["prev_sample"]
+        tcnd = time.perf_counter() - t0
+        out["conditional"] = {"ms_per_step": round(tcnd / 10 * 1e3, 1), "spectrograms_per_s_extrapolated": round(1.0 / (tcnd * 5), 5),
+                              "cores": nt, "kind": "port",
+                              "sample": "10 of the 50 DDIM steps of the conditional 64x64 latent UNet at B = 1 (oracle), x5 extrapolation"}
+        del mc
+    except Exception as e:  # noqa: BLE001
+        out["conditional"] = {"error": f"{type(e).__name__}: {e}"}
     m = UNet2DModel(**CFG256)
     opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8)
     g = torch.Generator().manual_seed(7)
@@ -576,6 +600,34 @@ def configs_leg(job):
                                    f"separately; x{1000 // n} extrapolation of the loop + the decode = the full sampling",
                        "ms_per_step": round(t / n * 1e3, 3), "steps_timed": n, "ms_vae_decode": round(td * 1e3, 2),
                        "spectrograms_per_s_extrapolated": round(B / (t / n * 1000 + td), 4)}
+    # (f2) conditional generation at size: UNet2DConditionModel as scripts/train_unet.py:139-159 builds it for a 512-resolution latent model
+    # (64x64 latents, (128, 256, 512, 512), three cross-attention blocks each way, encoding = one 100-wide row per sample as
+    # audiodiffusion/audio_encoder.py produces it), DDIM steps with the encoding held constant over the loop (pipeline...py:160-161)
+    try:
+        from audiodiffusion import DDIMScheduler, UNet2DConditionModel
+        cu = UNet2DConditionModel(**CFG_COND).init_random(0)
+        pc = AudioDiffusionPipeline(None, cu, Mel(x_res=64, y_res=64), DDIMScheduler()).to(dev)
+        pc.set_progress_bar_config(disable=True)
+        pc.scheduler.set_timesteps(50)
+        g = torch.Generator().manual_seed(8)
+        xc = torch.randn(B, 1, 64, 64, generator=g).to(dev)
+        enc = torch.randn(B, 1, 100, generator=g).to(dev)
+
+        def loopc():
+            return pc._denoise(xc, 0, 0.0, None, None, 0, 0, encoding=enc)[0]
+        loopc()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        loopc()
+        torch.cuda.synchronize(dev)
+        tc = time.perf_counter() - t0
+        out["conditional"] = {"workload": "UNet2DConditionModel (scripts/train_unet.py:139-159: (128, 256, 512, 512), CrossAttn blocks, "
+                                          f"cross_attention_dim 100, 135.6 M parameters), 64x64 latents (512-resolution model), batch {B}, "
+                                          "complete DDIM-50 sampling with a constant encoding through the native loop",
+                              "ms_per_step": round(tc / 50 * 1e3, 3), "steps_timed": 50, "spectrograms_per_s": round(B / tc, 3)}
+        del pc, cu
+    except Exception as e:  # noqa: BLE001
+        out["conditional"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -665,7 +717,7 @@ def main():
                 if "error" in side_cpu:
                     res["side_cpu_baselines"] = side_cpu
                 if isinstance(res.get("configs"), dict):
-                    for k in ("config_1", "config_4"):
+                    for k in ("config_1", "config_4", "conditional"):
                         if k in side_cpu and k in res["configs"]:
                             res["configs"][k]["cpu_baseline"] = side_cpu[k]
                 res["_side_cpu"] = side_cpu

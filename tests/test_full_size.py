@@ -218,6 +218,23 @@ def test_config3_complete_ddim50_sampling_matches_the_oracle_on_a_briefly_traine
     assert err <= 1e-3, err
     assert np.abs(a - b).max() <= 1 and (a == b).mean() >= 0.995, (np.abs(a - b).max(), (a == b).mean())
     assert float(rf.std()) > 0.02, "degenerate sample: the comparison would be vacuous"
+    # A SECOND checkpoint (40 more optimizer steps of the same run) and a SECOND start noise (the headline's only
+    # end-to-end oracle comparison was one seed on one checkpoint): the same three bars.
+    trainee = UNet2DModel(**CFG256).load_state_dict(sd)
+    losses2 = train_product(trainee, (256, 256), 40, dev, batch=16, lr=1e-4, seed=3)
+    assert np.isfinite(losses2).all()
+    sd2 = trainee.state_dict()
+    del trainee
+    assert max(float((sd2[k].float() - sd[k].float()).abs().max()) for k in sd if sd[k].dtype.is_floating_point) > 0     # it did move
+    noise2 = torch.randn(1, 1, 256, 256, generator=torch.Generator().manual_seed(777))
+    mi2, mf2 = sample(UNet2DModel(**CFG256).load_state_dict(sd2), noise2)
+    ref_unet.load_state_dict(sd2)
+    ri2, rf2 = ref(batch_size=1, noise=noise2.clone(), audio=False, return_float=True)
+    err2 = float((mf2.cpu() - rf2).abs().max())
+    a2, b2 = np.asarray(mi2[0]).astype(int), np.asarray(ri2[0]).astype(int)
+    assert err2 <= 1e-3, err2
+    assert np.abs(a2 - b2).max() <= 1 and (a2 == b2).mean() >= 0.995, (np.abs(a2 - b2).max(), (a2 == b2).mean())
+    assert float(rf2.std()) > 0.02 and float((rf2 - rf).abs().max()) > 0.05, "the second sample must be another picture"
 
 
 def test_config2_ddpm_1000_schedule_crosses_a_noise_staging_chunk_boundary_at_size(dev):
