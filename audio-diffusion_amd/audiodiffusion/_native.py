@@ -83,6 +83,7 @@ _SIGS = {
     "adm_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_void_p]),
     "adm_cross_attention": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]),
     "adm_attention_blocked": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "adm_attention_mfma_eligible": (C.c_int, [C.c_int] * 3),
     "adm_layernorm_nct_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_long, C.c_float, C.c_void_p]),
     "adm_geglu_backward": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_long, C.c_void_p]),
     "adm_cross_attention_backward": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.c_void_p]),

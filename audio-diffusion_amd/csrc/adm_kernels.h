@@ -166,6 +166,8 @@ int launch_cross_attention_bwd(const float* q, const float* ctx, const float* Wk
 int launch_attention_bwd_blocked(const float* qkv, const float* dout, float* dqkv, float* stats, int N, int C, int T,
                                  int head_dim, int block, hipStream_t st);
 int launch_attention_blocked(const float* qkv, float* out, int N, int C, int T, int head_dim, int key_block, hipStream_t st);
+bool attention_mfma_eligible(int C, int T, int head_dim);                // k_transformer.hip: flash self-attention on the f32 MFMAs (head_dim 16 / 32 / 64)
+int launch_attention_mfma(const float* qkv, float* out, int N, int C, int T, int head_dim, hipStream_t st);
 
 // k_audio_encoder.hip (AudioEncoder: audiodiffusion/audio_encoder.py:62-84)
 int launch_sepconv_block(const float* x, const float* dw, const float* pw, const float* pb, const float* bn_scale,

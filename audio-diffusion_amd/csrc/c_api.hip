@@ -163,6 +163,7 @@ int adm_cross_attention(const float* q, const float* ctx, const float* Wk, const
   ADM_REQUIRE(q && ctx && Wk && Wv && out, "cross_attention: null argument");
   return launch_cross_attention(q, ctx, Wk, Wv, out, N, C, T, S, Dc, head_dim, (hipStream_t)stream);
 }
+int adm_attention_mfma_eligible(int C, int T, int head_dim) { return attention_mfma_eligible(C, T, head_dim) ? 1 : 0; }
 int adm_attention_blocked(const float* qkv, float* out, int N, int C, int T, int head_dim, int key_block, void* stream) {
   ADM_REQUIRE(qkv && out, "attention_blocked: null argument");
   return launch_attention_blocked(qkv, out, N, C, T, head_dim, key_block, (hipStream_t)stream);

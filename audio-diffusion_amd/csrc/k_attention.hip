@@ -9,6 +9,7 @@
 // With d = 8 the QK^T / PV products are K=8 / N=8 GEMMs — below any MFMA tile's useful shape (a 16x16x4 f32
 // MFMA version costs the same issue cycles) — so this stays on the vector ALUs.
 // Algorithmic bytes: 4*(3*N*C*T + N*C*T); total work 4*N*heads*T*T*d FLOP (0.8 GFLOP/sample/forward).
+#include <cstdint>
 #include "adm_kernels.h"
 
 namespace adm {
@@ -66,6 +67,9 @@ int launch_attention(const float* qkv, float* out, int N, int C, int T, int head
   const int bs = T >= 256 ? 256 : ((T + 63) / 64) * 64;
   dim3 grid(ceil_div(T, bs), heads, N), block(bs);
   const size_t smem = sizeof(float) * 2 * (size_t)T * head_dim;
+  // head dimensions 16 / 32 / 64 (the Transformer2DModel blocks of the conditional UNet): flash attention on the f32 MFMAs — chosen by the
+  // layer's shape alone (a sample's bits must not depend on the batch it is in)
+  if (attention_mfma_eligible(C, T, head_dim) && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0) return launch_attention_mfma(qkv, out, N, C, T, head_dim, st);
   if (smem > 64 * 1024)   // K/V of a head no longer fit the default LDS window: key-blocked online-softmax kernel
     return launch_attention_blocked(qkv, out, N, C, T, head_dim, 0, st);
   const float scale = 1.0f / sqrtf((float)head_dim);

@@ -5,6 +5,7 @@
 // Activations stay in the UNet's (N, C, T = H*W) layout, so every Linear of the block is a 1x1 convolution on the MFMA
 // kernel (k_conv_mfma.hip) with its bias / residual epilogue; only the four operations here are new. All HBM-bound
 // elementwise / small-GEMM work: lanes run along T (coalesced), no MFMA.
+#include <cstdint>
 #include "adm_kernels.h"
 
 namespace adm {
@@ -28,8 +29,41 @@ __global__ void __launch_bounds__(256) layernorm_nct_kernel(const float* __restr
   for (int c = 0; c < C; ++c) yp[(long)c * T] = (xp[(long)c * T] - mean) * rstd * gamma[c] + beta[c];
 }
 
+// The same LayerNorm for token counts that are multiples of 64 (round 5): one workgroup per 64 tokens, the four waves split the channels
+// (wave w takes c = w, w + 4, ...), lanes stay along T (256-byte coalesced rows), eight independent loads in flight per lane, the three
+// reductions meet in LDS. One lane per token walked C dependent-looking strided loads on a quarter of the waves: 150-236 us per launch at
+// 64x64 latents (7.2 of the 52 ms of a conditional forward, profiles/r05_conditional.md). Mean, then centred variance, then the write pass —
+// the tile (64 tokens x C x 4 B <= 128 KiB) is read once from HBM and twice from the caches.
+__global__ void __launch_bounds__(256) layernorm_nct_tile_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ y, int C,
+                                                                 long T, float eps) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long t = (long)blockIdx.x * 64 + lane;
+  const float* xp = x + (long)blockIdx.y * C * T + t;
+  float* yp = y + (long)blockIdx.y * C * T + t;
+  float s = 0.f;
+  _Pragma("unroll 8")
+  for (int c = w; c < C; c += 4) s += xp[(long)c * T];
+  red[0][w][lane] = s;
+  __syncthreads();
+  const float mean = ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])) / (float)C;
+  float v = 0.f;
+  _Pragma("unroll 8")
+  for (int c = w; c < C; c += 4) { const float d = xp[(long)c * T] - mean; v = fmaf(d, d, v); }
+  red[1][w][lane] = v;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])) / (float)C + eps);
+  _Pragma("unroll 8")
+  for (int c = w; c < C; c += 4) yp[(long)c * T] = (xp[(long)c * T] - mean) * rstd * gamma[c] + beta[c];
+}
+
 int launch_layernorm_nct(const float* x, const float* gamma, const float* beta, float* y, int N, int C, long T, float eps,
                          hipStream_t st) {
+  if (T % 64 == 0 && C >= 4) {
+    ADM_LAUNCH(layernorm_nct_tile_kernel, dim3((unsigned)(T / 64), N), dim3(256), 0, st, x, gamma, beta, y, C, T, eps);
+    return ADM_CHECK_LAUNCH();
+  }
   ADM_LAUNCH(layernorm_nct_kernel, dim3((unsigned)((T + 255) / 256), N), dim3(256), 0, st, x, gamma, beta, y, C, T, eps);
   return ADM_CHECK_LAUNCH();
 }
@@ -198,6 +232,135 @@ int launch_attention_blocked(const float* qkv, float* out, int N, int C, int T, 
   ADM_ATTB_CASE(4) ADM_ATTB_CASE(8) ADM_ATTB_CASE(16) ADM_ATTB_CASE(32) ADM_ATTB_CASE(64)
 #undef ADM_ATTB_CASE
   ADM_FAIL("attention: unsupported head_dim (4/8/16/32/64)");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Self-attention of the Transformer2DModel blocks on the matrix pipe (round 5): flash form on v_mfma_f32_16x16x4_f32 for head
+// dimensions 16 / 32 / 64 (the conditional UNet's 8 heads at 128 / 256 / 512 channels) and token counts that are multiples of 128.
+// The VALU kernel above spent 5.2 ms per launch at 4096 tokens (B = 16: 26 of the 52 ms of a conditional forward,
+// profiles/r05_conditional.md); here K and V of a key block are staged once per 128 queries and every operand of the two products
+// is an MFMA fragment:
+//   workgroup = 8 waves, wave w owns 16 queries; per 64 keys
+//     S^T[key][query] = sum_d K[d][key] Q[d][query]      A = K (LDS, lanes along keys), B = Q (registers, loaded once)   D MFMAs
+//     online softmax per query: the lane's 16 scores + two cross-lane maxima; p = exp(s * scale - m); O *= exp(m_old - m_new)
+//     O^T[d][query] += sum_key V[d][key] p[key][query]    A = V (one ds_read_b128 = four k-steps), B = p                  D MFMAs
+//   The accumulator layout of the first product (lane group g, register r <-> key 4 g + r, lane & 15 <-> query) IS the B-operand
+//   layout of the second one when its k-step s takes key 4 k4 + s from lane group k4 — so the probabilities never move between lanes.
+// LDS: K rows at a pitch = 16 (mod 32) words (the four d-rows of an A fragment fall into disjoint banks), V rows at a pitch = 4 (mod 64).
+template <int D>
+__global__ void __launch_bounds__(512) attention_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int T,
+                                                             float scale) {
+  constexpr int KB = D <= 32 ? 256 : 128;          // keys per LDS block
+  constexpr int PK = KB + 16, PV = KB + 4;
+  ADM_DYN_SMEM(float, smem);
+  float* Ks = smem;                                // [D][PK]
+  float* Vs = smem + D * PK;                       // [D][PV]
+  const int head = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, k4 = lane >> 4;
+  const float* qb = qkv + ((long)n * 3 * C + head * D) * T;
+  const float* kb = qb + (long)C * T;
+  const float* vb = kb + (long)C * T;
+  const int i0 = blockIdx.x * 128 + 16 * wave;     // this wave's 16 queries
+  float qreg[D / 4];
+  ADM_UNROLL
+  for (int ks = 0; ks < D / 4; ++ks) qreg[ks] = qb[(long)(4 * ks + k4) * T + i0 + l15];
+  f32x4 o[D / 16];
+  ADM_UNROLL
+  for (int dt = 0; dt < D / 16; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -3.0e38f, l = 0.f;                     // l: this lane's share of the denominator (its 16 of every 64 keys)
+  for (int j0 = 0; j0 < T; j0 += KB) {
+    __syncthreads();                               // previous block fully consumed
+    ADM_UNROLL
+    for (int e0 = 0; e0 < D * (KB / 4); e0 += 512) {
+      const int e = e0 + tid;
+      const int d = e / (KB / 4), c4 = e % (KB / 4);
+      *reinterpret_cast<float4*>(Ks + d * PK + 4 * c4) = *reinterpret_cast<const float4*>(kb + (long)d * T + j0 + 4 * c4);
+      *reinterpret_cast<float4*>(Vs + d * PV + 4 * c4) = *reinterpret_cast<const float4*>(vb + (long)d * T + j0 + 4 * c4);
+    }
+    __syncthreads();
+    for (int jj = 0; jj < KB; jj += 64) {
+      f32x4 st[4];
+      ADM_UNROLL
+      for (int kt = 0; kt < 4; ++kt) {
+        st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ADM_UNROLL
+        for (int ks = 0; ks < D / 4; ++ks)
+          st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(4 * ks + k4) * PK + jj + 16 * kt + l15], qreg[ks], st[kt], 0, 0, 0);
+      }
+      float mx = st[0][0];
+      ADM_UNROLL
+      for (int kt = 0; kt < 4; ++kt)
+        ADM_UNROLL
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx * scale);
+      const float corr = __expf(m - mn);
+      m = mn;
+      l *= corr;
+      ADM_UNROLL
+      for (int dt = 0; dt < D / 16; ++dt)
+        ADM_UNROLL
+        for (int r = 0; r < 4; ++r) o[dt][r] *= corr;
+      ADM_UNROLL
+      for (int kt = 0; kt < 4; ++kt)
+        ADM_UNROLL
+        for (int r = 0; r < 4; ++r) {
+          const float pj = __expf(st[kt][r] * scale - m);
+          st[kt][r] = pj;
+          l += pj;
+        }
+      ADM_UNROLL
+      for (int kt = 0; kt < 4; ++kt)
+        ADM_UNROLL
+        for (int dt = 0; dt < D / 16; ++dt) {
+          const float4 v4 = *reinterpret_cast<const float4*>(Vs + (16 * dt + l15) * PV + jj + 16 * kt + 4 * k4);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.x, st[kt][0], o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.y, st[kt][1], o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.z, st[kt][2], o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.w, st[kt][3], o[dt], 0, 0, 0);
+        }
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  float* ob = out + ((long)n * C + head * D) * T + i0 + l15;
+  ADM_UNROLL
+  for (int dt = 0; dt < D / 16; ++dt)
+    ADM_UNROLL
+    for (int r = 0; r < 4; ++r) ob[(long)(16 * dt + 4 * k4 + r) * T] = o[dt][r] * inv;
+}
+
+bool attention_mfma_eligible(int C, int T, int head_dim) {
+  if (head_dim != 16 && head_dim != 32 && head_dim != 64) return false;
+  const int KB = head_dim <= 32 ? 256 : 128;
+  return C % head_dim == 0 && T % 128 == 0 && T % KB == 0;
+}
+
+int launch_attention_mfma(const float* qkv, float* out, int N, int C, int T, int head_dim, hipStream_t st) {
+  ADM_REQUIRE(attention_mfma_eligible(C, T, head_dim), "attention_mfma: head_dim 16 / 32 / 64 and T % 128 == 0 (T % 256 for head_dim <= 32)");
+  ADM_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "attention_mfma: qkv must be 16-byte aligned");
+  const int heads = C / head_dim;
+  const int KB = head_dim <= 32 ? 256 : 128;
+  dim3 grid(T / 128, heads, N), block(512);
+  const size_t smem = sizeof(float) * (size_t)head_dim * (KB + 16 + KB + 4);
+  const float scale = 1.0f / sqrtf((float)head_dim);
+#define ADM_ATTM_CASE(DD)                                                                                        \
+  if (head_dim == DD) {                                                                                          \
+    ADM_ATTM_ATTR(DD);                                                                                           \
+    ADM_LAUNCH((attention_mfma_kernel<DD>), grid, block, smem, st, qkv, out, C, T, scale);                       \
+    return ADM_CHECK_LAUNCH();                                                                                   \
+  }
+#if !defined(ADM_EMU)
+#define ADM_ATTM_ATTR(DD) (void)hipFuncSetAttribute((const void*)attention_mfma_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+#else
+#define ADM_ATTM_ATTR(DD) ((void)0)
+#endif
+  ADM_ATTM_CASE(16) ADM_ATTM_CASE(32) ADM_ATTM_CASE(64)
+#undef ADM_ATTM_CASE
+#undef ADM_ATTM_ATTR
+  ADM_FAIL("attention_mfma: unsupported head_dim");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -168,13 +168,18 @@ int adm_attention(const float* qkv, float* out, int N, int C, int T, int head_di
  *   adm_geglu: (N, 2*C4, T) = [h | gate] -> (N, C4, T) = h * gelu(gate) (exact erf GELU).
  *   adm_cross_attention: tokens attend to the encoding ctx (N, S, Dc) through to_k / to_v weights (C, Dc), q given.
  *   adm_attention_blocked: adm_attention with the keys in blocks of `key_block` (0 = 64 KiB of K+V) and an online
- *   softmax; adm_attention switches to it by itself when a head's K/V exceed 64 KiB. */
+ *   softmax; adm_attention switches to it by itself when a head's K/V exceed 64 KiB.
+ *   Round 5: for head_dim 16 / 32 / 64 and T % 128 == 0 (T % 256 for head_dim <= 32) — the Transformer2DModel blocks of the conditional UNet —
+ *   adm_attention runs the flash form on the f32 matrix pipe (attention_mfma_kernel: both products on v_mfma_f32_16x16x4_f32, online softmax;
+ *   the choice depends on the layer's shape only). */
 int adm_layernorm_nct(const float* x, const float* gamma, const float* beta, float* y, int N, int C, long T, float eps,
                       void* stream);
 int adm_geglu(const float* in, float* out, int N, int C4, long T, void* stream);
 int adm_cross_attention(const float* q, const float* ctx, const float* Wk, const float* Wv, float* out, int N, int C, int T,
                         int S, int Dc, int head_dim, void* stream);
 int adm_attention_blocked(const float* qkv, float* out, int N, int C, int T, int head_dim, int key_block, void* stream);
+/* 1 if adm_attention runs this shape on the f32 matrix pipe (attention_mfma_kernel), 0 if on the VALU kernels. */
+int adm_attention_mfma_eligible(int C, int T, int head_dim);
 /* Backward passes of the three (training of the conditional UNet, scripts/train_unet.py:254-259 with --encodings):
  *   adm_layernorm_nct_backward: dx (accumulate != 0: +=), dgamma += , dbeta += ; stats: 2*N*T floats of scratch.
  *   adm_geglu_backward: d(in) (N, 2*C4, T) from dy (N, C4, T).

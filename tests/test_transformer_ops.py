@@ -8,7 +8,7 @@ from test_kernels import _rand, _relerr
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("shape", [(2, 32, 4, 8), (1, 96, 16, 16), (3, 64, 1, 5)])
+@pytest.mark.parametrize("shape", [(2, 32, 4, 8), (1, 96, 16, 16), (3, 64, 1, 5), (2, 128, 8, 16), (1, 320, 16, 16)])
 def test_layernorm_over_channels(backend, shape):
     dev = select(backend)
     from audiodiffusion import ops
@@ -73,6 +73,28 @@ def test_self_attention_key_blocks_match_one_pass(backend, C, heads, HW, key_blo
     ref = _mha(q, k, v, heads).reshape(Nn, C, *HW)
     assert _relerr(out, ref) < 5e-6
     assert _relerr(out, ops.attention(qkv, C // heads)) < 5e-6
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("C,heads,HW", [(128, 8, (16, 16)), (256, 8, (16, 16)), (512, 8, (8, 16)), (128, 8, (16, 32)), (64, 4, (16, 16))],
+                         ids=["d16-T256", "d32-T256", "d64-T128", "d16-T512", "d16-4heads"])
+def test_self_attention_on_the_matrix_pipe(backend, C, heads, HW):
+    """Round 5: for head dimensions 16 / 32 / 64 `adm_attention` runs the flash form on v_mfma_f32_16x16x4_f32 (the conditional UNet's
+    Transformer2DModel blocks: 8 heads at 128 / 256 / 512 channels; 4096 tokens at the 512-resolution latent size). Against torch's
+    softmax attention and against the VALU online-softmax kernel (another program, another summation order) on the same tensor."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    Nn = 2
+    T = HW[0] * HW[1]
+    assert _native.lib().adm_attention_mfma_eligible(C, T, C // heads) == 1
+    qkv = _rand((Nn, 3 * C) + HW, 3, dev) * 1.5
+    out = ops.attention(qkv, C // heads)
+    q, k, v = qkv.cpu().reshape(Nn, 3, C, T).unbind(1)
+    ref = _mha(q, k, v, heads).reshape(Nn, C, *HW)
+    assert _relerr(out, ref) < 5e-6, _relerr(out, ref)
+    assert _relerr(out, ops.attention_blocked(qkv, C // heads, 64)) < 5e-6
+    # the shapes the kernel does not tile stay on the VALU kernels
+    assert _native.lib().adm_attention_mfma_eligible(64, 256, 8) == 0 and _native.lib().adm_attention_mfma_eligible(128, 192, 16) == 0
 
 
 # ---------------------------------------------------------------- backward passes vs torch autograd
