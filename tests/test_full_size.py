@@ -417,6 +417,31 @@ def test_vae_256_matches_the_oracle_and_rows_are_independent(dev):
     assert float((both[:1] - v.encode(x[:1].to(dev)).latent_dist.mode()).abs().max()) <= 1e-5
 
 
+def test_conditional_unet_at_the_512_resolution_latent_size(dev):
+    """SURVEY 8(f2) at size: `UNet2DConditionModel` as scripts/train_unet.py:139-159 builds it (135.6 M parameters), 64x64
+    latents = the 512-resolution model — 4096 tokens per Transformer2DModel block at the first level, where self-attention runs as the flash
+    kernel on the f32 MFMAs (round 5) — against the oracle at B = 1, and rows of a batch against single-sample runs, bit for bit."""
+    from audiodiffusion import UNet2DConditionModel
+    from oracle.unet_condition import UNet2DConditionModel as Oracle
+    cfg = dict(sample_size=(64, 64), in_channels=1, out_channels=1, layers_per_block=2, block_out_channels=(128, 256, 512, 512),
+               down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",),
+               up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3, cross_attention_dim=100, attention_head_dim=8)
+    m = UNet2DConditionModel(**cfg).init_random(0)
+    ref = Oracle(**cfg).eval()
+    ref.load_state_dict(m.state_dict())
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 1, 64, 64, generator=g)
+    enc = torch.randn(3, 1, 100, generator=g)
+    t = torch.tensor(321)
+    with torch.no_grad():
+        want = ref(x[:1], t, enc[:1])["sample"]
+    got = m(x.to(dev), t, enc.to(dev))["sample"]
+    assert float((got[:1].cpu() - want).abs().max()) <= 1e-4 * float(want.abs().max()), float((got[:1].cpu() - want).abs().max())
+    for r in (0, 2):
+        alone = m(x[r:r + 1].contiguous().to(dev), t, enc[r:r + 1].contiguous().to(dev))["sample"]
+        assert torch.equal(alone[0], got[r])
+
+
 def test_mel_default_config_forward_and_inverse_vs_oracle(dev):
     from audiodiffusion import Mel
     from oracle import mel as omel
