@@ -107,7 +107,8 @@ def pack_winograd_weight(w):
     """(Cout,Cin,3,3) -> Winograd-domain U = G g G^T as [Cin][16][Cout]."""
     _f32(w)
     co, ci = w.shape[:2]
-    wu = torch.empty((ci, 16, co), dtype=torch.float32, device=w.device)
+    # the buffer holds the F(2x2,3x3) image and, where conv_wino6_kernel may run, the F(4x4,3x3) image behind it (adm.h)
+    wu = torch.empty((int(N.lib().adm_winograd_packed_floats(co, ci, 0)),), dtype=torch.float32, device=w.device)
     N.check(N.lib().adm_pack_winograd_weight(N.ptr(w), N.ptr(wu), co, ci, N.stream_for(w)))
     return wu
 
@@ -116,7 +117,7 @@ def pack_winograd_weight_T(w):
     """(Cout,Cin,3,3) -> Winograd-domain filters of the data-gradient convolution as [Cout][16][Cin]."""
     _f32(w)
     co, ci = w.shape[:2]
-    wu = torch.empty((co, 16, ci), dtype=torch.float32, device=w.device)
+    wu = torch.empty((int(N.lib().adm_winograd_packed_floats(co, ci, 1)),), dtype=torch.float32, device=w.device)
     N.check(N.lib().adm_pack_winograd_weight_T(N.ptr(w), N.ptr(wu), co, ci, N.stream_for(w)))
     return wu
 

@@ -15,12 +15,13 @@ using namespace adm;
 
 extern "C" {
 
-int adm_version(void) { return 101; }   // 101 (round 4): adm_slerp_grid takes double weights (round 3), blocked-image entry points
+int adm_version(void) { return 102; }   // 102 (round 5): Winograd buffers hold two images (adm_winograd_packed_floats)
+//   // 101 (round 4): adm_slerp_grid takes double weights (round 3), blocked-image entry points
 const char* adm_last_error(void) { return adm::last_error(); }
 int adm_set_option(const char* name, int value) {
   ADM_REQUIRE(name, "set_option: null name");
   const std::string nm(name);
-  static const char* known[] = {"conv_wino", "wino_pair", "wino5", "wgrad_max_split", "conv_bf16", "conv_op16_f16", "blk_direct_dy", "gn_fuse_finish"};
+  static const char* known[] = {"conv_wino", "wino_pair", "wino5", "wino6", "wgrad_max_split", "conv_bf16", "conv_op16_f16", "blk_direct_dy", "gn_fuse_finish"};
   bool ok = false;
   for (const char* k : known) ok |= nm == k;
   if (!ok) ADM_FAIL(std::string("set_option: unknown option ") + name);
@@ -40,6 +41,7 @@ int adm_set_option(const char* name, int value) {
   }
   if (nm == "conv_wino") { adm::set_winograd_mode(value); return 0; }
   if (nm == "wino5") { adm::set_winograd_v5(value); return 0; }
+  if (nm == "wino6") { adm::set_winograd_v6(value); return 0; }
   if (nm == "wino_pair") { adm::set_winograd_pair(value); return 0; }
   if (nm == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
   if (nm == "conv_bf16") { adm::set_conv_bf16(value); return 0; }
@@ -120,6 +122,7 @@ int adm_pack_conv_weight_T(const float* w, float* wpT, int Cout, int Cin, int ks
   return launch_pack_conv_weight_T(w, wpT, Cout, Cin, ks, (hipStream_t)stream);
 }
 
+long adm_winograd_packed_floats(int Cout, int Cin, int transposed) { return winograd_packed_floats(Cout, Cin, transposed); }
 int adm_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, void* stream) {
   ADM_REQUIRE(w && wu, "pack_winograd_weight: null argument");
   return launch_pack_winograd_weight(w, wu, Cout, Cin, (hipStream_t)stream);

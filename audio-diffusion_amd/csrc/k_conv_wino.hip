@@ -1879,6 +1879,445 @@ __global__ void __launch_bounds__(512) conv_wino5_kernel(const WinoParams p) {
   else wino5_wave<UP, false, ACT, ABL, PROF, INTER>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// =====================================================================================================================
+// v6 (round 5) — Winograd F(4x4,3x3) on v5's skeleton. Round 5's accounting of v4 / v5 (profiles/r05_wino.md): 70 % of the kernel's cycles are
+// MFMA cycles, vector instructions add to them one for one, and three different schedules of the same arithmetic land within 2 % of each
+// other — what is left to cut is the MFMA count itself. F(4x4,3x3) multiplies 36 Winograd points per 16 outputs instead of 16 per 4:
+// 1.78x fewer MFMAs than F(2x2,3x3), 4x fewer than the direct convolution; its fp32 error is 5-9e-6 of max|out| on this network's layer
+// shapes (F(2x2): 4-5e-7; the per-layer bar is 1e-4; tools/... measured before the kernel was written).
+//   Y = A^T [ (G g G^T) . (B^T d B) ] A,  d = 6x6 input window, Y = 4x4 outputs, the standard matrices of Lavin & Gray.
+// Workgroup tile = 128 couts x 16x16 pixels = 16 Winograd tiles; 8 waves, wave w owns couts 16 w .. 16 w + 15 x all 16 tiles x all 36 points
+// (144 accumulators on v_mfma_f32_16x16x4_f32; the inverse transform is lane-local). Per 8-channel chunk and wave: 72 MFMAs (v5: 64 for HALF
+// the pixels). Filters: their own image [chunk][cout block][k step 2][point group 9][lane 64][4 points], streamed L2 -> registers through a
+// ring of six point groups; B operands: V slab [point 36][channel 8][tile 16] in LDS, one ds_read2_b32 per pair of points. Staging per PAIR of
+// chunks, shared by all 512 threads: 1152 float4 row pieces + 576 halo elements (raw buffer loads one interval ahead -> GroupNorm affine +
+// SiLU -> 18x18 patch per channel), 256 (channel, tile) windows transformed by two threads each (V rows 0-2 / 3-5: 72 VALU per thread).
+// Rings of four V slabs / patch buffers, one workgroup barrier per pair of chunks — v5's protocol.
+constexpr int W6PP = 20;                           // patch row pitch (18 columns: left halo, 16 pixels, right halo)
+constexpr int W6CS = 18 * W6PP;                    // 360 floats per channel
+constexpr int W6PSLAB = WCK * W6CS + 512;          // + one dummy word per thread
+constexpr int W6VSLAB = 36 * WCK * 16;             // 4608 floats
+constexpr int W6LDS = 4 * (W6VSLAB + W6PSLAB);     // 32000 floats = 125 KiB
+constexpr int W6ABLK = 2 * 9 * 64 * 4;             // floats of one (chunk, 16-cout block) filter image: 18 KiB
+constexpr int W6AR = 6;                            // filter ring: point groups in flight (18 per chunk = 3 turns of the ring)
+
+// 1D input transform B^T (6 x 6) on (d0 .. d5) -> (v0 .. v5): 12 operations
+#define W6_BT(d0, d1, d2, d3, d4, d5, v0, v1, v2, v3, v4, v5)                  \
+  do {                                                                          \
+    const float a_ = fmaf(-4.f, d2, d4), b_ = fmaf(-4.f, d1, d3);               \
+    const float c_ = d4 - d2, e_ = d3 - d1;                                     \
+    v0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));                                     \
+    v1 = a_ + b_; v2 = a_ - b_;                                                 \
+    v3 = fmaf(2.f, e_, c_); v4 = fmaf(-2.f, e_, c_);                            \
+    v5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));                                     \
+  } while (0)
+// 1D inverse transform A^T (4 x 6) on (m0 .. m5) -> (y0 .. y3): 10 operations
+#define W6_AT(m0, m1, m2, m3, m4, m5, y0, y1, y2, y3)                           \
+  do {                                                                          \
+    const float s1_ = m1 + m2, d1_ = m1 - m2, s2_ = m3 + m4, d2_ = m3 - m4;     \
+    y0 = (m0 + s1_) + s2_;                                                      \
+    y1 = fmaf(2.f, d2_, d1_);                                                   \
+    y2 = fmaf(4.f, s2_, s1_);                                                   \
+    y3 = fmaf(8.f, d2_, d1_) + m5;                                              \
+  } while (0)
+
+// KIND (staging slots of this wave; four slots per thread and pair of chunks): non-UP 0 = waves 0-1 (float4, float4, float4, halo),
+// 1 = wave 2 (float4, float4, halo, halo), 2 = waves 3-7 (float4, float4, halo, -); UP (source-resolution 10x10 patches, scalars only)
+// 0 = wave 0 (four scalars), 2 = the others (three).
+template <bool UP, int KIND, int ACT>
+__device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, float* ldsP, const int tid, const int wave,
+                                           const int b0, const int bs) {
+  constexpr int NS = (KIND == 2) ? 3 : 4;                       // active slots
+  constexpr int NF = UP ? 0 : (KIND == 0 ? 3 : 2);              // of which float4 pieces (the first NF)
+  const int lane = tid & 63;
+  const int l15 = lane & 15, k4 = lane >> 4;
+  const int Ct = p.C1 + p.C2;
+  const int planeS = p.Hs * p.Ws;
+  const int nch = Ct / WCK;
+  const int n_cblk = p.Cout >> 4;
+  const int ntile = (p.nblk - b0 + bs - 1) / bs;
+  const int total = ntile * nch;
+  const int npairs = total >> 1;
+  // ---- staging items of this thread (NS per pair of chunks) ---------------------------------------------------------------------
+  int it_chrel[4], it_prow[4], it_col[4], it_pofs[4];          // channel within the pair (0..15), patch row, column, LDS offset
+  ADM_UNROLL
+  for (int s = 0; s < 4; ++s) {
+    int c2 = 0, ch = 0, prow = 0, col = 0, pofs = WCK * W6CS + tid;      // (default: the thread's dummy word of slab 0)
+    if (UP) {
+      const int e = 512 * s + tid;
+      if (e < 1600) {
+        c2 = e / 800; const int rem = e % 800;
+        ch = rem / 100; prow = (rem % 100) / 10; col = rem % 10;
+        pofs = c2 * W6PSLAB + rem;
+      }
+    } else if (s < NF) {
+      const int f = 512 * s + tid;                               // float4 piece 0..1151
+      const int row = f >> 2, q = f & 3;
+      c2 = row / 144; const int rr = row % 144;
+      ch = rr / 18; prow = rr % 18; col = 4 * q;
+      pofs = c2 * W6PSLAB + ch * W6CS + prow * W6PP + 1 + 4 * q;
+    } else if (s < NS) {
+      const int h = (s == 2) ? tid - 128 : 384 + tid;            // halo element 0..575
+      const int row = h >> 1, side = h & 1;
+      c2 = row / 144; const int rr = row % 144;
+      ch = rr / 18; prow = rr % 18; col = side ? 16 : -1;
+      pofs = c2 * W6PSLAB + ch * W6CS + prow * W6PP + (side ? 17 : 0);
+    }
+    it_chrel[s] = 8 * c2 + ch; it_prow[s] = prow; it_col[s] = col; it_pofs[s] = pofs;
+  }
+  // stage C: half of a (chunk of the pair, channel, tile) window transform
+  // (the half is wave-uniform — waves 2k and 2k + 1 share 64 items — so that the two code paths below are scalar branches)
+  const int c_item = (tid & 63) | ((wave >> 1) << 6), c_half = wave & 1;
+  const int c_c2 = c_item >> 7, c_ch = (c_item >> 4) & 7, c_tile = c_item & 15;
+  const int c_tyy = c_tile >> 2, c_txx = c_tile & 3;
+  const int c_wbase = UP ? c_ch * 100 + (2 * c_tyy) * 10 + 2 * c_txx : c_ch * W6CS + (4 * c_tyy) * W6PP + 4 * c_txx;
+  const int c_vofs = c_ch * 16 + c_tile;
+  // ---- stage A cursor (one PAIR of chunks per step) -----------------------------------------------------------------------------------
+  int a_v = b0, a_ci = 0, a_left = total;
+  const float *a_x1 = nullptr, *a_x2 = nullptr;
+  int a_vo[4];
+  unsigned a_ok = 0;
+  int a_sg = 0;                                // element offset of the pair's first channel in the GroupNorm rows (sample included)
+#if !defined(ADM_EMU)
+  __amdgpu_buffer_rsrc_t a_rx1, a_rx2;
+  const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gn_scale), (short)0, 0x7fffffff, 0x00027000);
+  const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gn_shift), (short)0, 0x7fffffff, 0x00027000);
+#endif
+  int a_n = 0;
+  auto a_geometry = [&]() {
+    const Wino3Tile t = wino5_tile(p, a_v);
+    a_n = t.n;
+    a_x1 = p.x1 + (long)t.n * p.x1_bs;
+    a_x2 = p.x2 + (long)t.n * p.x2_bs - (long)p.C1 * planeS;
+    a_ok = 0;
+    ADM_UNROLL
+    for (int s = 0; s < NS; ++s) {
+      const int sy = UP ? t.ty * 8 - 1 + it_prow[s] : t.ty * 16 - 1 + it_prow[s];
+      const int sx = UP ? t.tx * 8 - 1 + it_col[s] : t.tx * 16 + it_col[s];
+      const bool ok = sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws;
+      a_vo[s] = (it_chrel[s] * planeS + (ok ? sy * p.Ws + sx : 0)) * 4;
+      a_ok |= ok ? 1u << s : 0u;
+    }
+#if !defined(ADM_EMU)
+    a_rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_x1), (short)0, 0x7fffffff, 0x00027000);
+    a_rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_x2), (short)0, 0x7fffffff, 0x00027000);
+#endif
+  };
+  a_geometry();
+  struct Raw { f32x4 v[3]; float h0, h1; unsigned ok; int sg; };      // v[s]: float4 slots; h0 / h1: the scalar slots behind them
+  // (UP: slots 0-2 use v[s][0], slot 3 uses h1)
+  auto stage_a = [&](Raw& r) {                 // global loads of the next pair of chunks; then advance (saturating)
+    const int c0 = a_ci * WCK;
+#if !defined(ADM_EMU)
+    const __amdgpu_buffer_rsrc_t rx = c0 < p.C1 ? a_rx1 : a_rx2;
+    const int so = c0 * planeS * 4;
+    ADM_UNROLL
+    for (int s = 0; s < NS; ++s) {
+      if (s < NF) r.v[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_vo[s], so, 0));
+      else {
+        const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, a_vo[s], so, 0));
+        if (UP && s < 3) r.v[s][0] = x;
+        else if (s == 3) r.h1 = x;
+        else r.h0 = x;
+      }
+    }
+#else
+    const float* base = (c0 < p.C1 ? a_x1 : a_x2) + (long)c0 * planeS;
+    ADM_UNROLL
+    for (int s = 0; s < NS; ++s) {
+      if (s < NF) r.v[s] = *reinterpret_cast<const f32x4*>(base + a_vo[s] / 4);
+      else {
+        const float x = base[a_vo[s] / 4];
+        if (UP && s < 3) r.v[s][0] = x;
+        else if (s == 3) r.h1 = x;
+        else r.h0 = x;
+      }
+    }
+#endif
+    r.ok = a_ok;
+    r.sg = a_n * p.gn_nstride + c0;
+    if (a_left > 2) {
+      a_left -= 2;
+      a_ci += 2;
+      if (a_ci == nch) {
+        ADM_SCHED_FENCE();
+        a_ci = 0; a_v += bs;
+        a_geometry();
+      }
+    }
+  };
+  constexpr bool act_on = ACT != 0;
+  auto act1 = [&](float x, float sc, float sh) { const float v0 = x * sc + sh; return act_on ? silu_w(v0) : v0; };
+  auto stage_b = [&](const Raw& r, int g) {    // raw -> GroupNorm affine (+ SiLU) -> patch buffers of chunks g, g + 1 (zero padding = zeroed affine)
+    float* P = ldsP + (g & 3) * W6PSLAB;       // (a pair never wraps the ring: g is even, so slab g + 1 follows slab g)
+    float sc[4], sh[4];
+    ADM_UNROLL
+    for (int s = 0; s < NS; ++s) {
+#if !defined(ADM_EMU)
+      sc[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rs, it_chrel[s] * 4, r.sg * 4, 0));
+      sh[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(h_rs, it_chrel[s] * 4, r.sg * 4, 0));
+#else
+      sc[s] = p.gn_scale[r.sg + it_chrel[s]]; sh[s] = p.gn_shift[r.sg + it_chrel[s]];
+#endif
+    }
+    ADM_UNROLL
+    for (int s = 0; s < NS; ++s) {
+      const bool ok = (r.ok >> s) & 1u;
+      const float c = ok ? sc[s] : 0.f, h = ok ? sh[s] : 0.f;
+      float* dst = P + it_pofs[s];
+      if (s < NF) {
+        dst[0] = act1(r.v[s][0], c, h); dst[1] = act1(r.v[s][1], c, h); dst[2] = act1(r.v[s][2], c, h); dst[3] = act1(r.v[s][3], c, h);
+      } else {
+        const float x = (UP && s < 3) ? r.v[s][0] : (s == 3 ? r.h1 : r.h0);
+        dst[0] = act1(x, c, h);
+      }
+    }
+  };
+  auto stage_c = [&](int g) {                  // patches of chunks g, g + 1 -> this thread's half window -> V = B^T d B (three rows of it)
+    const float* P = ldsP + ((g + c_c2) & 3) * W6PSLAB + c_wbase;
+    float* V = ldsV + ((g + c_c2) & 3) * W6VSLAB + c_vofs + (c_half ? 18 * 128 : 0);
+    // rows of d this half needs: half 0 -> d rows 0..4 (V rows 0, 1, 2), half 1 -> d rows 1..5 (V rows 3, 4, 5)
+    float t[3][6];
+    ADM_UNROLL
+    for (int l = 0; l < 6; ++l) {
+      float r[5];                              // r[k] = d[c_half + k][l]
+      ADM_UNROLL
+      for (int k = 0; k < 5; ++k) {
+        if (UP) r[k] = c_half ? P[((k + 2) >> 1) * 10 + ((l + 1) >> 1)] : P[((k + 1) >> 1) * 10 + ((l + 1) >> 1)];
+        else r[k] = P[(c_half + k) * W6PP + l];
+      }
+      if (c_half) {                            // V rows 3, 4, 5 from d rows 1..5
+        const float c_ = r[3] - r[1], e_ = r[2] - r[0];
+        t[0][l] = fmaf(2.f, e_, c_); t[1][l] = fmaf(-2.f, e_, c_);
+        t[2][l] = fmaf(4.f, r[0], fmaf(-5.f, r[2], r[4]));
+      } else {                                 // V rows 0, 1, 2 from d rows 0..4
+        const float a_ = fmaf(-4.f, r[2], r[4]), b_ = fmaf(-4.f, r[1], r[3]);
+        t[0][l] = fmaf(4.f, r[0], fmaf(-5.f, r[2], r[4]));
+        t[1][l] = a_ + b_; t[2][l] = a_ - b_;
+      }
+    }
+    ADM_UNROLL
+    for (int i = 0; i < 3; ++i) {
+      float v0, v1, v2, v3, v4, v5;
+      W6_BT(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v0, v1, v2, v3, v4, v5);
+      float* dst = V + (6 * i) * 128;
+      dst[0] = v0; dst[128] = v1; dst[256] = v2; dst[384] = v3; dst[512] = v4; dst[640] = v5;
+    }
+  };
+  // ---- filter stream: ring of W6AR point groups, in memory order [chunk][ks][pg] ---------------------------------------------------------
+  int d_v = b0, d_ci = 0, d_left = total;
+  const long chunk_stride = (long)n_cblk * W6ABLK;
+  const float* d_cur = p.wu + ((long)(wino5_tile(p, d_v).m0 >> 4) + wave) * W6ABLK + lane * 4;      // chunk being consumed
+  const float* d_nxt = d_cur;                                                                        // chunk after it (saturating)
+  auto advance_next = [&]() {                  // d_nxt <- address of the chunk after d_nxt's
+    if (d_left > 1) {
+      --d_left;
+      d_nxt += chunk_stride;
+      if (++d_ci == nch) {
+        ADM_SCHED_FENCE();
+        d_ci = 0; d_v += bs;
+        d_nxt = p.wu + ((long)(wino5_tile(p, d_v).m0 >> 4) + wave) * W6ABLK + lane * 4;
+      }
+    }
+  };
+  advance_next();                              // d_nxt = chunk 1
+  f32x4 aR[W6AR];
+  ADM_UNROLL
+  for (int q = 0; q < W6AR; ++q) aR[q] = *reinterpret_cast<const f32x4*>(d_cur + q * 256);
+  // ---- prologue ------------------------------------------------------------------------------------------------------------------
+  Raw r0;
+  ADM_UNROLL
+  for (int s = 0; s < 3; ++s) r0.v[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  r0.h0 = 0.f; r0.h1 = 0.f;
+  int pg = 0;
+  stage_a(r0);                                 // chunks 0, 1
+  stage_b(r0, 0);
+  stage_a(r0);                                 // chunks 2, 3
+  ADM_BARRIER_KEEP_VMEM(63);                   // patches 0, 1 complete
+  stage_c(0);                                  // V(0), V(1)
+  stage_b(r0, 2);
+  stage_a(r0);                                 // chunks 4, 5
+  pg = 2;
+  ADM_BARRIER_KEEP_VMEM(63);                   // V(0), V(1) and patches 2, 3 complete
+  const int vlane = k4 * 16 + l15;
+  f32x4 acc[36];
+  const long planeO = (long)p.Ho * p.Wo;
+  int v = b0 - bs, ci = nch;
+  Wino3Tile t = wino5_tile(p, b0);
+  const int tyy = l15 >> 2, txx = l15 & 3;
+#if !defined(ADM_EMU)
+  __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(p.out, (short)0, 0x7fffffff, 0x00027000), r_rs = o_rs;
+  const int plane_b = (int)planeO * 4, row_b = p.Wo * 4;
+#endif
+  int o_vo = 0;                                // element (emulator) / byte offset of this lane's tile inside the wave's 16 cout planes
+  auto epilogue = [&]() {                      // lane-local inverse transform Y = A^T M A (6x6 -> 4x4), bias / per-sample term / residual, stores
+    ADM_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      const int co = t.m0 + 16 * wave + 4 * k4 + r;
+      const float bsum = p.bias[co] + p.chan_add[(long)t.n * p.chan_add_stride + co];
+      f32x4 res[4];
+      if (p.residual != nullptr) {
+        ADM_UNROLL
+        for (int a = 0; a < 4; ++a) {
+#if !defined(ADM_EMU)
+          res[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, o_vo, r * plane_b + a * row_b, 0));
+#else
+          res[a] = *reinterpret_cast<const f32x4*>(p.residual + ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO + o_vo + r * planeO + a * p.Wo);
+#endif
+        }
+      }
+      float tt[4][6];
+      ADM_UNROLL
+      for (int j = 0; j < 6; ++j)
+        W6_AT(acc[0 * 6 + j][r], acc[1 * 6 + j][r], acc[2 * 6 + j][r], acc[3 * 6 + j][r], acc[4 * 6 + j][r], acc[5 * 6 + j][r],
+              tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
+      float f1 = 0.f, f2 = 0.f;
+      ADM_UNROLL
+      for (int a = 0; a < 4; ++a) {
+        f32x4 y;
+        W6_AT(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], tt[a][5], y[0], y[1], y[2], y[3]);
+        ADM_UNROLL
+        for (int b = 0; b < 4; ++b) y[b] += bsum;
+        if (p.residual != nullptr) {
+          ADM_UNROLL
+          for (int b = 0; b < 4; ++b) y[b] += res[a][b];
+        }
+#if !defined(ADM_EMU)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), o_rs, o_vo, r * plane_b + a * row_b, 0);
+#else
+        *reinterpret_cast<f32x4*>(p.out + ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO + o_vo + r * planeO + a * p.Wo) = y;
+#endif
+        f1 += (y[0] + y[1]) + (y[2] + y[3]);
+        f2 += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+      }
+      if (p.stats != nullptr) {                // (sum, sum of squares) of this cout row over the 16x16 tile: 16 values per lane in fp32, lanes in fp64
+        double s1 = (double)f1, s2 = (double)f2;
+        ADM_UNROLL
+        for (int m = 8; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+        if (l15 == 0) {
+          const int tiles = p.tiles_x * p.tiles_y;
+          double* dst = p.stats + (((long)t.n * p.Cout + co) * tiles + t.ty * p.tiles_x + t.tx) * 2;
+          dst[0] = s1; dst[1] = s2;
+        }
+      }
+      ADM_SCHED_FENCE();
+    }
+  };
+  bool pend = false;
+  for (int it = 0; it <= npairs; ++it) {       // (iteration npairs: nothing but the last tile's epilogue)
+    if (pend) { epilogue(); pend = false; }
+    if (it == npairs) break;
+    if (ci == nch) {                           // next tile
+      ADM_SCHED_FENCE();
+      ci = 0; v += bs;
+      t = wino5_tile(p, v);
+      ADM_UNROLL
+      for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int oy = t.ty * 16 + 4 * tyy, ox = t.tx * 16 + 4 * txx;
+#if !defined(ADM_EMU)
+      const long tbase = ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO;
+      o_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + tbase, (short)0, 0x7fffffff, 0x00027000);
+      if (p.residual != nullptr) r_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual) + tbase, (short)0, 0x7fffffff, 0x00027000);
+      o_vo = (4 * k4 * (int)planeO + oy * p.Wo + ox) * 4;
+#else
+      o_vo = 4 * k4 * (int)planeO + oy * p.Wo + ox;
+#endif
+    }
+    // ---- staging block P(it): C(pg, pg + 1), B(pg + 2, pg + 3), A(next pair) ------------------------------------------------------------
+    stage_c(pg);
+    ADM_SCHED_FENCE();
+    stage_b(r0, pg + 2);
+    ADM_SCHED_FENCE();
+    stage_a(r0);
+    pg += 2;
+    ADM_SCHED_FENCE();
+    // ---- M: the 144 MFMAs of chunks g, g + 1 -------------------------------------------------------------------------------------------
+    const int g = 2 * it;
+    float rbw[3][4];                           // B operands: a window of three point groups (read two groups ahead of their MFMAs)
+    auto read_b = [&](int slot, int gg, int gi) {
+      const float* Vb = ldsV + (gg & 3) * W6VSLAB + vlane + (4 * (gi % 9)) * 128 + (4 * (gi / 9)) * 16;
+      ADM_UNROLL
+      for (int e = 0; e < 4; ++e) rbw[slot][e] = Vb[e * 128];
+    };
+    read_b(0, g, 0); read_b(1, g, 1); read_b(2, g, 2);
+    ADM_UNROLL
+    for (int c2 = 0; c2 < 2; ++c2) {
+      ADM_UNROLL
+      for (int gi = 0; gi < 18; ++gi) {        // point group gi = 9 ks + pgi of this chunk
+        const int pgi = gi % 9;
+        ADM_UNROLL
+        for (int e = 0; e < 4; ++e)
+          acc[4 * pgi + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(aR[gi % W6AR][e], rbw[gi % 3][e], acc[4 * pgi + e], 0, 0, 0);
+        if (gi + 3 < 18) read_b(gi % 3, g + c2, gi + 3);
+        else if (c2 == 0) read_b(gi % 3, g + 1, gi + 3 - 18);        // (behind the pair's second chunk: nothing — the next slab is not certified yet)
+        // the ring slot takes the group W6AR places further down the stream (this chunk's, or the next chunk's first ones)
+        if (gi + W6AR < 18) aR[gi % W6AR] = *reinterpret_cast<const f32x4*>(d_cur + (gi + W6AR) * 256);
+        else aR[gi % W6AR] = *reinterpret_cast<const f32x4*>(d_nxt + (gi + W6AR - 18) * 256);
+        ADM_SCHED_FENCE();
+      }
+      d_cur = d_nxt;
+      advance_next();
+    }
+    ci += 2;
+    pend = ci == nch;
+    ADM_BARRIER_KEEP_VMEM(63);
+  }
+}
+
+template <bool UP, int ACT>
+__global__ void __launch_bounds__(512) conv_wino6_kernel(const WinoParams p) {
+  ADM_DYN_SMEM(float, smem);
+  float* ldsV = smem;
+  float* ldsP = smem + 4 * W6VSLAB;
+  const int tid = threadIdx.x;
+  const int wave = ADM_UNIFORM(tid >> 6);
+  if (UP) {
+    if (wave == 0) wino6_wave<UP, 0, ACT>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+    else wino6_wave<UP, 2, ACT>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+  } else {
+    if (wave <= 1) wino6_wave<UP, 0, ACT>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+    else if (wave == 2) wino6_wave<UP, 1, ACT>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+    else wino6_wave<UP, 2, ACT>(p, ldsV, ldsP, tid, wave, (int)blockIdx.x, (int)gridDim.x);
+  }
+}
+
+// Filter image of conv_wino6_kernel: U = G g G^T (6x6) as [Cin/8][Cout/16][k step 2][point group 9][lane = 16 k4 + l15][4 points] holding
+// U[point = 4 pg + e][cout = 16 cblk + l15][cin = 8 chunk + 4 ks + k4]; transposed: the data-gradient filters (as pack_winograd4_body).
+__device__ __forceinline__ void pack_winograd6_body(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin,
+                                                    int transposed, long first, long step) {
+  const int PCo = transposed ? Cin : Cout, PCi = transposed ? Cout : Cin;
+  const long total = (long)PCo * PCi;
+  const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                         {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+  for (long i = first; i < total; i += step) {
+    const int l15 = (int)(i & 15);
+    long r = i >> 4;
+    const int k4 = (int)(r & 3); r >>= 2;
+    const int ks = (int)(r & 1); r >>= 1;
+    const int cblk = (int)(r % (PCo >> 4));
+    const int chunk = (int)(r / (PCo >> 4));
+    const int po = cblk * 16 + l15, pi = chunk * 8 + 4 * ks + k4;
+    const int co = transposed ? pi : po, c = transposed ? po : pi;
+    const float* g = w + ((long)co * Cin + c) * 9;
+    float gg[3][3];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) gg[a][b] = transposed ? g[(2 - a) * 3 + (2 - b)] : g[a * 3 + b];
+    float t[6][3];
+    for (int a = 0; a < 6; ++a)
+      for (int b = 0; b < 3; ++b) t[a][b] = G[a][0] * gg[0][b] + G[a][1] * gg[1][b] + G[a][2] * gg[2][b];
+    float* blk = wu + ((long)chunk * (PCo >> 4) + cblk) * W6ABLK + (long)ks * 9 * 256 + (k4 * 16 + l15) * 4;
+    for (int a = 0; a < 6; ++a)
+      for (int b = 0; b < 6; ++b) {
+        const int pt = a * 6 + b;
+        blk[(pt >> 2) * 256 + (pt & 3)] = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+      }
+  }
+}
+
+__global__ void pack_winograd6_weight_kernel(const float* __restrict__ w, float* __restrict__ wu, int Cout, int Cin, int transposed) {
+  pack_winograd6_body(w, wu, Cout, Cin, transposed, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
 // Filter image of conv_wino4_kernel: U = G g G^T as [Cin/8][Cout/16][point group q][k step ks][lane = 16 k4 + li][e]
 // holding U[xi = 4 q + e][cout = 16 cblk + li][cin = 8 chunk + 4 ks + k4]. transposed: the data-gradient filters (roles of
 // Cout / Cin swapped, taps flipped), as pack_winograd_weight_kernel.
@@ -1961,6 +2400,7 @@ __global__ void __launch_bounds__(256) pack_winograd_batch_kernel(const PackItem
   const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, step = (long)gridDim.x * blockDim.x;
   if (it.flag & 2) pack_winograd4_body(it.src, (float*)it.dst, it.Cout, it.Cin, it.flag & 1, first, step);
   else pack_winograd3_body(it.src, (float*)it.dst, it.Cout, it.Cin, it.flag & 1, first, step);
+  if (it.flag & 4) pack_winograd6_body(it.src, (float*)it.dst + (long)it.Cout * it.Cin * 16, it.Cout, it.Cin, it.flag & 1, first, step);
 }
 
 static int wino_mode();
@@ -1971,9 +2411,18 @@ static int wino_pair();
 // direct kernel — never on v1-v3, which could not read it). The option must be set before the weights are packed.
 static bool wino4_layout(int couts, int cins) { return wino_mode() == 4 && couts % W3BM == 0 && cins % (4 * WCK) == 0; }
 
+// The F(4x4,3x3) image of conv_wino6_kernel FOLLOWS the F(2x2,3x3) image in the same buffer (16 + 36 transformed values per filter) whenever
+// the packed channel counts allow the kernel (128 | couts on top of the v4 rule) — whatever the "wino6" option says at packing time, so that
+// the option may change between packing and launch.
+static bool wino6_layout(int couts, int cins) { return wino4_layout(couts, cins) && couts % W5BM == 0; }
+long winograd_packed_floats(int Cout, int Cin, int transposed) {
+  return (long)Cout * Cin * (wino6_layout(transposed ? Cin : Cout, transposed ? Cout : Cin) ? 52 : 16);
+}
 static int pack_winograd(const float* w, float* wu, int Cout, int Cin, int transposed, hipStream_t st) {
   long g = ((long)Cout * Cin + 255) / 256;
   if (g > 4096) g = 4096;
+  if (wino6_layout(transposed ? Cin : Cout, transposed ? Cout : Cin))
+    ADM_LAUNCH(pack_winograd6_weight_kernel, dim3((unsigned)g), dim3(256), 0, st, w, wu + (long)Cout * Cin * 16, Cout, Cin, transposed);
   if (wino4_layout(transposed ? Cin : Cout, transposed ? Cout : Cin))
     ADM_LAUNCH(pack_winograd4_weight_kernel, dim3((unsigned)g), dim3(256), 0, st, w, wu, Cout, Cin, transposed);
   else
@@ -1986,7 +2435,8 @@ int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hi
 // PackItem::flag of a Winograd image: bit 0 = transposed, bit 1 = the conv_wino4_kernel layout — decided exactly as pack_winograd
 // decides it, so that the batched re-pack writes the image the kernels read
 int winograd_pack_flag(int Cout, int Cin, int transposed) {
-  return (transposed ? 1 : 0) | (wino4_layout(transposed ? Cin : Cout, transposed ? Cout : Cin) ? 2 : 0);
+  return (transposed ? 1 : 0) | (wino4_layout(transposed ? Cin : Cout, transposed ? Cout : Cin) ? 2 : 0) |
+         (wino6_layout(transposed ? Cin : Cout, transposed ? Cout : Cin) ? 4 : 0);
 }
 int launch_pack_winograd_batch(const PackItem* items_dev, int n, hipStream_t st) {
   if (n <= 0) return 0;
@@ -2015,6 +2465,23 @@ void set_winograd_v5(int v) { g_wino5 = v; }
 static int wino5_on() {
   if (g_wino5 < 0) { const char* e = getenv("ADM_WINO5"); g_wino5 = e ? atoi(e) : 1; }
   return g_wino5;
+}
+// conv_wino6_kernel (F(4x4,3x3)): 1 (default) = every layer the kernel tiles (128 | Cout, 32 | Cin, 16 | H, 16 | W) whose plane is at
+// least W6_MIN_PLANE pixels a side — a function of the LAYER only: F(4x4) is not bit-identical to F(2x2), so the choice must not depend on
+// the batch (a sample's bits must not depend on the batch it is sampled in); 0 = F(2x2,3x3) kernels everywhere; 2 = no plane-size floor (tests).
+static int g_wino6 = -1;
+void set_winograd_v6(int v) { g_wino6 = v; }
+static int wino6_on() {
+  if (g_wino6 < 0) { const char* e = getenv("ADM_WINO6"); g_wino6 = e ? atoi(e) : 1; }
+  return g_wino6;
+}
+constexpr int W6_MIN_PLANE = 64;
+static bool wino6_eligible(const adm_conv_args& a) {
+  if (!wino6_on()) return false;
+  const int C2 = a.x2 ? a.C2 : 0;
+  const int Ho = a.up ? 2 * a.H : a.H, Wo = a.up ? 2 * a.W : a.W;
+  if (!wino6_layout(a.Cout, a.C1 + C2) || a.C1 % 16 != 0 || Ho % 16 != 0 || Wo % 16 != 0) return false;
+  return wino6_on() >= 2 || (Ho >= W6_MIN_PLANE && Wo >= W6_MIN_PLANE);
 }
 static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 4) on first use
 bool winograd_mode_available(int m) {
@@ -2066,6 +2533,7 @@ int winograd_stats_tiles(const adm_conv_args& a) {
   const int C2 = a.x2 ? a.C2 : 0;
   if (!wino4_layout(a.Cout, a.C1 + C2)) return 0;
   const int Ho = a.up ? 2 * a.H : a.H, Wo = a.up ? 2 * a.W : a.W;
+  if (wino6_eligible(a)) return (Wo / 16) * (Ho / 16);          // conv_wino6_kernel: one (sum, sum of squares) per 16x16-pixel tile
   return (Wo / 16) * (Ho / 8);
 }
 
@@ -2151,6 +2619,38 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     const int n_cu = 3;                                          // exercise persistence (several tiles per block) on the emulator
     const bool pair_ok = true, v5_ok = true;
 #endif
+    if (v4 && wino6_eligible(a)) {                               // F(4x4,3x3): chosen by the layer alone (see wino6_on)
+#if !defined(ADM_EMU)
+      static bool attr6[16] = {};
+      if (!attr6[dslot]) {
+        const int by6 = (int)(sizeof(float) * W6LDS);
+        bool ok6 = true;
+        ok6 &= hipFuncSetAttribute((const void*)conv_wino6_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, by6) == hipSuccess;
+        ok6 &= hipFuncSetAttribute((const void*)conv_wino6_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, by6) == hipSuccess;
+        ok6 &= hipFuncSetAttribute((const void*)conv_wino6_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, by6) == hipSuccess;
+        ok6 &= hipFuncSetAttribute((const void*)conv_wino6_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, by6) == hipSuccess;
+        ADM_REQUIRE(ok6, "conv_winograd: the runtime refused 125 KiB of dynamic LDS for conv_wino6_kernel");
+        attr6[dslot] = true;
+      }
+#endif
+      p.tiles_x = p.Wo / 16; p.tiles_y = p.Ho / 16;
+      p.n_ct = a.Cout / W5BM;
+      p.nblk = p.tiles_x * p.tiles_y * a.N * p.n_ct;
+      p.wu = a.wino_packed + (long)a.Cout * (a.C1 + C2) * 16;    // the F(4x4) image follows the F(2x2) image
+      p.prof = nullptr;
+      p.stats = a.stats_out;
+      set_last_conv_variant(4000 + 316);
+      const size_t need6 = sizeof(float) * W6LDS;
+      const int grid6 = p.nblk < n_cu ? p.nblk : n_cu;
+      if (a.up) {
+        if (a.act) ADM_LAUNCH((conv_wino6_kernel<true, 1>), dim3(grid6), dim3(512), need6, st, p);
+        else ADM_LAUNCH((conv_wino6_kernel<true, 0>), dim3(grid6), dim3(512), need6, st, p);
+      } else {
+        if (a.act) ADM_LAUNCH((conv_wino6_kernel<false, 1>), dim3(grid6), dim3(512), need6, st, p);
+        else ADM_LAUNCH((conv_wino6_kernel<false, 0>), dim3(grid6), dim3(512), need6, st, p);
+      }
+      return ADM_CHECK_LAUNCH();
+    }
     // v5: 128-cout workgroup tiles (every patch transformed once per 128 couts), taken when those tiles still fill the chip — with
     // fewer, v4's 64-cout tiles are twice as many workgroups. The two kernels are bit-identical (same filter image, same summation
     // order), so this batch-dependent choice cannot move a sample's bits.

@@ -156,14 +156,14 @@ static int pack_one(Net* net, ConvW& w, hipStream_t st) {
   const unsigned need = (net->training && net->use_known) ? w.used : ~0u;
   if (need & PK_WP) ADM_TRY(launch_pack_conv_weight(src, w.wp, w.Cout, w.Cin, w.ks, st));
   if (w.ks == 3 && w.qkv_prefix.empty() && winograd_enabled() && w.Cout % 32 == 0 && w.Cin % 8 == 0) {
-    if (!w.wu) ADM_TRY(net->dalloc((void**)&w.wu, sizeof(float) * (size_t)w.Cout * w.Cin * 16));
+    if (!w.wu) ADM_TRY(net->dalloc((void**)&w.wu, sizeof(float) * (size_t)winograd_packed_floats(w.Cout, w.Cin, 0)));
     if (need & PK_WU) ADM_TRY(launch_pack_winograd_weight(src, w.wu, w.Cout, w.Cin, st));
   }
   if (net->training) {
     if (!w.wpT) ADM_TRY(net->dalloc((void**)&w.wpT, sizeof(float) * (size_t)w.Cout * w.Cin * w.ks * w.ks));
     if (need & PK_WPT) ADM_TRY(launch_pack_conv_weight_T(src, w.wpT, w.Cout, w.Cin, w.ks, st));
     if (w.ks == 3 && w.qkv_prefix.empty() && winograd_enabled() && w.Cin % 32 == 0 && w.Cout % 8 == 0) {
-      if (!w.wuT) ADM_TRY(net->dalloc((void**)&w.wuT, sizeof(float) * (size_t)w.Cout * w.Cin * 16));
+      if (!w.wuT) ADM_TRY(net->dalloc((void**)&w.wuT, sizeof(float) * (size_t)winograd_packed_floats(w.Cout, w.Cin, 1)));
       if (need & PK_WUT) ADM_TRY(launch_pack_winograd_weight_T(src, w.wuT, w.Cout, w.Cin, st));
     }
     // mixed precision (`--mixed_precision bf16`): the filters as bf16 MFMA operands, re-rounded from the fp32 masters after

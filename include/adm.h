@@ -36,6 +36,10 @@ int adm_has_experiments(void);
  *   0 conv_wino4_kernel everywhere (same filter image, bit-identical results) | bit 1 (2): conv_wino5_kernel for every layer with 128 | Cout,
  *   however few tiles (tests) | bit 3 (8): the two halves of the workgroup run MFMA block and staging block in antiphase instead (the first
  *   schedule built; same results, same speed) | -1 (ADM_WINO5);
+ * "wino6" = 1 (default, round 5) 3x3 stride-1 convolutions with 128 | Cout, 32 | Cin on planes of at least 64x64 pixels (16 | H, 16 | W) run on
+ *   conv_wino6_kernel: Winograd F(4x4,3x3), 1.78x fewer MFMAs than F(2x2,3x3) at 5-9e-6 of max|out| (F(2x2): 5e-7; the per-layer bar is 1e-4).
+ *   The choice depends on the layer only (the two transforms are not bit-identical) | 0 F(2x2,3x3) kernels everywhere | 2 no plane-size floor
+ *   (tests) | -1 (ADM_WINO6);
  * "wino_pair" = 1 (default) one workgroup barrier per two chunks in conv_wino4_kernel | 0 one per chunk (bit-identical) | -1 (ADM_WINO_PAIR);
  * "wgrad_max_split" = n caps the split-K factor of adm_conv2d_wgrad (0 = heuristic; tests use it to put several pixel tiles on
  *   one workgroup);
@@ -51,7 +55,7 @@ int adm_has_experiments(void);
  *   that GroupNorm's scale / shift from its finish pass (one launch instead of finish + statistics; the tensor is bit-identical) |
  *   0 separate launches | -1 ADM_GN_FUSE_FINISH.
  * The dispatch epoch moves only when a value really changes; set options BEFORE adm_unet_refresh_weights / the next train step.
- * adm_version() = 101 since round 4 (adm_slerp_grid takes DOUBLE weights since round 3; blocked-image entry points). */
+ * adm_version() = 102 since round 5 (Winograd filter buffers hold two images: adm_winograd_packed_floats); 101 since round 4 (adm_slerp_grid takes DOUBLE weights since round 3; blocked-image entry points). */
 int adm_set_option(const char* name, int value);
 /* Kernel variant the last adm_conv2d on this thread dispatched to (see adm_op_profile.variant; 4311 = Winograd). */
 int adm_last_conv_variant(void);
@@ -144,7 +148,12 @@ int adm_pack_conv_weight(const float* w, float* wpacked, int Cout, int Cin, int 
  * adm_conv2d with x1 = dy (Cout channels) yields d(input): stride-1 convs directly; stride-2 convs with up = 2
  * (zero-insertion); nearest-upsampled convs give the gradient at the upsampled resolution (then adm_sumpool2x2). */
 int adm_pack_conv_weight_T(const float* w, float* wpT, int Cout, int Cin, int ks, void* stream);
-/* (Cout,Cin,3,3) -> Winograd-domain weights U = G g G^T, layout [Cin][16][Cout]; both device pointers. */
+/* Number of floats a Winograd filter buffer (wu: transposed = 0, wuT: transposed = 1) must hold: the F(2x2,3x3) image (16 per filter) and,
+ * where the channel counts allow conv_wino6_kernel (128 | output channels, 32 | input channels of the packed convolution), the F(4x4,3x3)
+ * image (36 per filter) behind it. adm_version() >= 102. */
+long adm_winograd_packed_floats(int Cout, int Cin, int transposed);
+/* (Cout,Cin,3,3) -> Winograd-domain weights U = G g G^T into a buffer of adm_winograd_packed_floats(Cout, Cin, 0) floats (kernel-specific
+ * layouts: [Cin][16][Cout], or the MFMA-fragment images of conv_wino4/5/6_kernel); both device pointers. */
 int adm_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, void* stream);
 /* ... of the data-gradient convolution (input channels = Cout, output channels = Cin, taps flipped): [Cout][16][Cin].
  * Pass it as `wino_packed` together with adm_pack_conv_weight_T's packing to run the backward-data pass of a 3x3
