@@ -1939,10 +1939,11 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
   const int total = ntile * nch;
   const int npairs = total >> 1;
   // ---- staging items of this thread (NS per pair of chunks) ---------------------------------------------------------------------
-  int it_chrel[4], it_prow[4], it_col[4], it_pofs[4];          // channel within the pair (0..15), patch row, column, LDS offset
-  ADM_UNROLL
-  for (int s = 0; s < 4; ++s) {
-    int c2 = 0, ch = 0, prow = 0, col = 0, pofs = WCK * W6CS + tid;      // (default: the thread's dummy word of slab 0)
+  // per slot ONE register: channel within the pair (4 bits) | LDS offset << 4 (the patch row / column are recomputed per tile in a_geometry:
+  // sixteen per-lane constants beside 144 accumulators were sixteen spilled registers)
+  auto slot_item = [&](int s, int& chrel, int& prow, int& col, int& pofs) {
+    int c2 = 0, ch = 0;
+    prow = 0; col = 0; pofs = WCK * W6CS + tid;                  // (default: the thread's dummy word of slab 0)
     if (UP) {
       const int e = 512 * s + tid;
       if (e < 1600) {
@@ -1963,7 +1964,14 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
       ch = rr / 18; prow = rr % 18; col = side ? 16 : -1;
       pofs = c2 * W6PSLAB + ch * W6CS + prow * W6PP + (side ? 17 : 0);
     }
-    it_chrel[s] = 8 * c2 + ch; it_prow[s] = prow; it_col[s] = col; it_pofs[s] = pofs;
+    chrel = 8 * c2 + ch;
+  };
+  int it_pk[4];
+  ADM_UNROLL
+  for (int s = 0; s < 4; ++s) {
+    int chrel, prow, col, pofs;
+    slot_item(s, chrel, prow, col, pofs);
+    it_pk[s] = chrel | (pofs << 4);
   }
   // stage C: half of a (chunk of the pair, channel, tile) window transform
   // (the half is wave-uniform — waves 2k and 2k + 1 share 64 items — so that the two code paths below are scalar branches)
@@ -1992,10 +2000,12 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     a_ok = 0;
     ADM_UNROLL
     for (int s = 0; s < NS; ++s) {
-      const int sy = UP ? t.ty * 8 - 1 + it_prow[s] : t.ty * 16 - 1 + it_prow[s];
-      const int sx = UP ? t.tx * 8 - 1 + it_col[s] : t.tx * 16 + it_col[s];
+      int chrel, prow, col, pofs;
+      slot_item(s, chrel, prow, col, pofs);
+      const int sy = UP ? t.ty * 8 - 1 + prow : t.ty * 16 - 1 + prow;
+      const int sx = UP ? t.tx * 8 - 1 + col : t.tx * 16 + col;
       const bool ok = sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws;
-      a_vo[s] = (it_chrel[s] * planeS + (ok ? sy * p.Ws + sx : 0)) * 4;
+      a_vo[s] = (chrel * planeS + (ok ? sy * p.Ws + sx : 0)) * 4;
       a_ok |= ok ? 1u << s : 0u;
     }
 #if !defined(ADM_EMU)
@@ -2050,27 +2060,29 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
   auto act1 = [&](float x, float sc, float sh) { const float v0 = x * sc + sh; return act_on ? silu_w(v0) : v0; };
   auto stage_b = [&](const Raw& r, int g) {    // raw -> GroupNorm affine (+ SiLU) -> patch buffers of chunks g, g + 1 (zero padding = zeroed affine)
     float* P = ldsP + (g & 3) * W6PSLAB;       // (a pair never wraps the ring: g is even, so slab g + 1 follows slab g)
-    float sc[4], sh[4];
+    // one slot at a time, its scale / shift fetched just in time (L2 / L1 hits), a scheduling fence behind every two values: anything
+    // more at once and the activations' temporaries spill beside 144 accumulators
     ADM_UNROLL
     for (int s = 0; s < NS; ++s) {
+      float sc, sh;
 #if !defined(ADM_EMU)
-      sc[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rs, it_chrel[s] * 4, r.sg * 4, 0));
-      sh[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(h_rs, it_chrel[s] * 4, r.sg * 4, 0));
+      sc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rs, (it_pk[s] & 15) * 4, r.sg * 4, 0));
+      sh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(h_rs, (it_pk[s] & 15) * 4, r.sg * 4, 0));
 #else
-      sc[s] = p.gn_scale[r.sg + it_chrel[s]]; sh[s] = p.gn_shift[r.sg + it_chrel[s]];
+      sc = p.gn_scale[r.sg + (it_pk[s] & 15)]; sh = p.gn_shift[r.sg + (it_pk[s] & 15)];
 #endif
-    }
-    ADM_UNROLL
-    for (int s = 0; s < NS; ++s) {
       const bool ok = (r.ok >> s) & 1u;
-      const float c = ok ? sc[s] : 0.f, h = ok ? sh[s] : 0.f;
-      float* dst = P + it_pofs[s];
+      const float c = ok ? sc : 0.f, h = ok ? sh : 0.f;
+      float* dst = P + (it_pk[s] >> 4);
       if (s < NF) {
-        dst[0] = act1(r.v[s][0], c, h); dst[1] = act1(r.v[s][1], c, h); dst[2] = act1(r.v[s][2], c, h); dst[3] = act1(r.v[s][3], c, h);
+        dst[0] = act1(r.v[s][0], c, h); dst[1] = act1(r.v[s][1], c, h);
+        ADM_SCHED_FENCE();
+        dst[2] = act1(r.v[s][2], c, h); dst[3] = act1(r.v[s][3], c, h);
       } else {
         const float x = (UP && s < 3) ? r.v[s][0] : (s == 3 ? r.h1 : r.h0);
         dst[0] = act1(x, c, h);
       }
+      ADM_SCHED_FENCE();
     }
   };
   auto stage_c = [&](int g) {                  // patches of chunks g, g + 1 -> this thread's half window -> V = B^T d B (three rows of it)
@@ -2105,25 +2117,34 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     }
   };
   // ---- filter stream: ring of W6AR point groups, in memory order [chunk][ks][pg] ---------------------------------------------------------
+  // (raw buffer loads: resource = the whole image, lane term = lane * 16 bytes in ONE register, everything else — this wave's cout block, the
+  // chunk, the group — a scalar offset: global loads 1 KiB apart needed a 64-bit VGPR pair per 4 KiB of immediate range)
   int d_v = b0, d_ci = 0, d_left = total;
-  const long chunk_stride = (long)n_cblk * W6ABLK;
-  const float* d_cur = p.wu + ((long)(wino5_tile(p, d_v).m0 >> 4) + wave) * W6ABLK + lane * 4;      // chunk being consumed
-  const float* d_nxt = d_cur;                                                                        // chunk after it (saturating)
-  auto advance_next = [&]() {                  // d_nxt <- address of the chunk after d_nxt's
+  const int chunk_stride = n_cblk * W6ABLK;                      // floats; the image of a 512 -> 512 layer is 38 MB: 32-bit offsets
+  int d_cur = ((wino5_tile(p, d_v).m0 >> 4) + wave) * W6ABLK;    // float offset of the chunk being consumed (this wave's cout block)
+  int d_nxt = d_cur;                                             // ... of the chunk after it (saturating)
+  auto advance_next = [&]() {
     if (d_left > 1) {
       --d_left;
       d_nxt += chunk_stride;
       if (++d_ci == nch) {
         ADM_SCHED_FENCE();
         d_ci = 0; d_v += bs;
-        d_nxt = p.wu + ((long)(wino5_tile(p, d_v).m0 >> 4) + wave) * W6ABLK + lane * 4;
+        d_nxt = ((wino5_tile(p, d_v).m0 >> 4) + wave) * W6ABLK;
       }
     }
   };
   advance_next();                              // d_nxt = chunk 1
+#if !defined(ADM_EMU)
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wu), (short)0, 0x7fffffff, 0x00027000);
+  const int w_vo = lane * 16;
+#define W6_LOAD_A(off_floats) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_vo, (off_floats) * 4, 0))
+#else
+#define W6_LOAD_A(off_floats) (*reinterpret_cast<const f32x4*>(p.wu + (off_floats) + lane * 4))
+#endif
   f32x4 aR[W6AR];
   ADM_UNROLL
-  for (int q = 0; q < W6AR; ++q) aR[q] = *reinterpret_cast<const f32x4*>(d_cur + q * 256);
+  for (int q = 0; q < W6AR; ++q) aR[q] = W6_LOAD_A(d_cur + q * 256);
   // ---- prologue ------------------------------------------------------------------------------------------------------------------
   Raw r0;
   ADM_UNROLL
@@ -2155,17 +2176,17 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     for (int r = 0; r < 4; ++r) {
       const int co = t.m0 + 16 * wave + 4 * k4 + r;
       const float bsum = p.bias[co] + p.chan_add[(long)t.n * p.chan_add_stride + co];
-      f32x4 res[4];
-      if (p.residual != nullptr) {
-        ADM_UNROLL
-        for (int a = 0; a < 4; ++a) {
+      auto load_res = [&](int a) {             // residual row a of cout row r (issued one row ahead of its use: two rows in registers)
 #if !defined(ADM_EMU)
-          res[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, o_vo, r * plane_b + a * row_b, 0));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, o_vo, r * plane_b + a * row_b, 0));
 #else
-          res[a] = *reinterpret_cast<const f32x4*>(p.residual + ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO + o_vo + r * planeO + a * p.Wo);
+        return *reinterpret_cast<const f32x4*>(p.residual + ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO + o_vo + r * planeO + a * p.Wo);
 #endif
-        }
-      }
+      };
+      f32x4 res_cur = {0.f, 0.f, 0.f, 0.f}, res_nxt = res_cur;
+#ifndef W6X_NORES
+      if (p.residual != nullptr) res_cur = load_res(0);
+#endif
       float tt[4][6];
       ADM_UNROLL
       for (int j = 0; j < 6; ++j)
@@ -2174,14 +2195,20 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
       float f1 = 0.f, f2 = 0.f;
       ADM_UNROLL
       for (int a = 0; a < 4; ++a) {
+#ifndef W6X_NORES
+        if (p.residual != nullptr && a < 3) res_nxt = load_res(a + 1);
+#endif
         f32x4 y;
         W6_AT(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], tt[a][5], y[0], y[1], y[2], y[3]);
         ADM_UNROLL
         for (int b = 0; b < 4; ++b) y[b] += bsum;
+#ifndef W6X_NORES
         if (p.residual != nullptr) {
           ADM_UNROLL
-          for (int b = 0; b < 4; ++b) y[b] += res[a][b];
+          for (int b = 0; b < 4; ++b) y[b] += res_cur[b];
+          res_cur = res_nxt;
         }
+#endif
 #if !defined(ADM_EMU)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), o_rs, o_vo, r * plane_b + a * row_b, 0);
 #else
@@ -2189,7 +2216,9 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
 #endif
         f1 += (y[0] + y[1]) + (y[2] + y[3]);
         f2 += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+        ADM_SCHED_FENCE();
       }
+#ifndef W6X_NOSTATS
       if (p.stats != nullptr) {                // (sum, sum of squares) of this cout row over the 16x16 tile: 16 values per lane in fp32, lanes in fp64
         double s1 = (double)f1, s2 = (double)f2;
         ADM_UNROLL
@@ -2200,12 +2229,18 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
           dst[0] = s1; dst[1] = s2;
         }
       }
+#endif
       ADM_SCHED_FENCE();
     }
   };
   bool pend = false;
   for (int it = 0; it <= npairs; ++it) {       // (iteration npairs: nothing but the last tile's epilogue)
-    if (pend) { epilogue(); pend = false; }
+    if (pend) {
+      epilogue(); pend = false;
+      if (it == npairs) break;
+      ADM_UNROLL
+      for (int q = 0; q < W6AR; ++q) aR[q] = W6_LOAD_A(d_cur + q * 256);     // the next tile's first chunk (see the MFMA block)
+    }
     if (it == npairs) break;
     if (ci == nch) {                           // next tile
       ADM_SCHED_FENCE();
@@ -2224,23 +2259,31 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
 #endif
     }
     // ---- staging block P(it): C(pg, pg + 1), B(pg + 2, pg + 3), A(next pair) ------------------------------------------------------------
+#ifndef W6X_NOC
     stage_c(pg);
     ADM_SCHED_FENCE();
+#endif
+#ifndef W6X_NOB
     stage_b(r0, pg + 2);
     ADM_SCHED_FENCE();
+#endif
+#ifndef W6X_NOA
     stage_a(r0);
+#endif
     pg += 2;
     ADM_SCHED_FENCE();
     // ---- M: the 144 MFMAs of chunks g, g + 1 -------------------------------------------------------------------------------------------
     const int g = 2 * it;
-    float rbw[3][4];                           // B operands: a window of three point groups (read two groups ahead of their MFMAs)
+    float rbw[3][4];                           // B operands: a window of three point groups (read three groups ahead of their MFMAs)
     auto read_b = [&](int slot, int gg, int gi) {
       const float* Vb = ldsV + (gg & 3) * W6VSLAB + vlane + (4 * (gi % 9)) * 128 + (4 * (gi / 9)) * 16;
       ADM_UNROLL
       for (int e = 0; e < 4; ++e) rbw[slot][e] = Vb[e * 128];
     };
     read_b(0, g, 0); read_b(1, g, 1); read_b(2, g, 2);
-    ADM_UNROLL
+    // (a real two-trip loop, NOT unrolled — 18 groups = 3 turns of the filter ring and 6 of the B window, so both chunks run the same code:
+    // the loop-carried values pin the 144 accumulators and the rings in place; unrolled, hipcc renamed them across the copies and spilled)
+    _Pragma("clang loop unroll(disable)")
     for (int c2 = 0; c2 < 2; ++c2) {
       ADM_UNROLL
       for (int gi = 0; gi < 18; ++gi) {        // point group gi = 9 ks + pgi of this chunk
@@ -2248,11 +2291,14 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
         ADM_UNROLL
         for (int e = 0; e < 4; ++e)
           acc[4 * pgi + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(aR[gi % W6AR][e], rbw[gi % 3][e], acc[4 * pgi + e], 0, 0, 0);
+        // (behind the pair's second chunk these are words of a slab that is not certified yet — never used: the next block primes afresh)
         if (gi + 3 < 18) read_b(gi % 3, g + c2, gi + 3);
-        else if (c2 == 0) read_b(gi % 3, g + 1, gi + 3 - 18);        // (behind the pair's second chunk: nothing — the next slab is not certified yet)
+        else read_b(gi % 3, g + c2 + 1, gi + 3 - 18);
         // the ring slot takes the group W6AR places further down the stream (this chunk's, or the next chunk's first ones)
-        if (gi + W6AR < 18) aR[gi % W6AR] = *reinterpret_cast<const f32x4*>(d_cur + (gi + W6AR) * 256);
-        else aR[gi % W6AR] = *reinterpret_cast<const f32x4*>(d_nxt + (gi + W6AR - 18) * 256);
+        // (behind a tile's LAST chunk the ring is not refilled: the epilogue that follows needs those 24 registers, and the next tile's
+        // first six groups are loaded right behind it — one exposed L2 round trip per tile)
+        if (gi + W6AR < 18) aR[gi % W6AR] = W6_LOAD_A(d_cur + (gi + W6AR) * 256);
+        else if (!(c2 == 1 && ci + 2 == nch)) aR[gi % W6AR] = W6_LOAD_A(d_nxt + (gi + W6AR - 18) * 256);
         ADM_SCHED_FENCE();
       }
       d_cur = d_nxt;
@@ -2262,6 +2308,7 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     pend = ci == nch;
     ADM_BARRIER_KEEP_VMEM(63);
   }
+#undef W6_LOAD_A
 }
 
 template <bool UP, int ACT>

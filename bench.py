@@ -479,6 +479,9 @@ def roofline(unet, x, B):
               "workgroup tile, every input patch transformed once per 128 couts; all 8 waves are MFMA waves (16 couts x 32 tiles x 16 "
               "points each, filters L2 -> registers, lane-local A^T M A) and share the staging (patch -> GroupNorm/SiLU -> B^T d B into "
               "LDS); the two waves of a SIMD run MFMA block and staging in antiphase)",
+        4316: "adm::conv_wino6_kernel (Winograd F(4x4,3x3) 3x3 stride-1 conv, v_mfma_f32_16x16x4_f32, persistent: 128-cout x 16x16-pixel "
+              "workgroup tile = 16 Winograd tiles x 36 points; all 8 waves are MFMA waves (144 accumulators each, filters L2 -> registers "
+              "through a ring, lane-local A^T M A) and share the staging (18x18 patch -> GroupNorm/SiLU -> B^T d B into LDS))",
         2314: "adm::conv_mfma_pf_kernel<3,2,2> (v_mfma_f32_32x32x2_f32 implicit GEMM, 3x3 stride 1, 128-cout tile)",
     }
     per_var = {}
@@ -500,12 +503,13 @@ def roofline(unet, x, B):
                                     for v, e in sorted(per_var.items())}
     alg = fl / (ms * 1e-3) / 1e12                       # algorithmic (direct-convolution) TFLOP/s of the dominant kernel
     wino = var // 100 == 43
-    executed = alg / 2.25 if wino else alg              # F(2x2,3x3): 16 MFMA products per 4 outputs instead of 36
+    # F(2x2,3x3): 16 MFMA products per 4 outputs instead of 36 (/ 2.25); F(4x4,3x3): 36 per 16 outputs instead of 144 (/ 4)
+    executed = alg / 4.0 if var == 4316 else (alg / 2.25 if wino else alg)
     total_ms = sum(r[2] for r in rows)
     out = {"bound": "mfma", "kernel": KERNELS.get(var, f"conv variant {var}"),
            "achieved": round(executed, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(executed / PEAK_F32_TF, 4),
-           "achieved_definition": "EXECUTED fp32 MFMA FLOPs per launch (algorithmic direct-convolution FLOPs / 2.25 for the "
-                                  "Winograd kernel) / average launch duration, HIP events on the launch stream",
+           "achieved_definition": "EXECUTED fp32 MFMA FLOPs per launch (algorithmic direct-convolution FLOPs / 4 for the F(4x4,3x3) "
+                                  "Winograd kernel, / 2.25 for the F(2x2,3x3) ones) / average launch duration, HIP events on the launch stream",
            "algorithmic_TFLOPs": round(alg, 2), "algorithmic_frac_of_peak": round(alg / PEAK_F32_TF, 4),
            "traffic": None, "launches_per_forward": cnt, "avg_launch_us": round(ms / cnt * 1e3, 2),
            "avg_algorithmic_flops_per_launch": fl / cnt, "share_of_forward_time": round(ms / total_ms, 3),

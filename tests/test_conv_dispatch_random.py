@@ -70,10 +70,12 @@ def test_conv2d_random_dispatch(backend, case):
     # the persistent Winograd kernel must be the one that ran whenever the shape allows it
     eligible = (ks == 3 and stride == 1 and Wi % 16 == 0 and Hi % 8 == 0 and Ct % 16 == 0 and C1 % 8 == 0 and Cout % 64 == 0
                 and (use_gn or not act))
-    assert (variant in (4313, 4314, 4315)) == eligible, (variant, eligible)
-    if eligible:      # filters L2 -> registers (v4 / v5) whenever 32 | input channels, else the LDS-DMA kernel (v3)
+    assert (variant in (4313, 4314, 4315, 4316)) == eligible, (variant, eligible)
+    if eligible:      # filters L2 -> registers (v4 / v5 / v6) whenever 32 | input channels, else the LDS-DMA kernel (v3)
         if Ct % 32 != 0:
             assert variant == 4313, (variant, Ct)
+        elif Cout % 128 == 0 and C1 % 16 == 0 and Hi % 16 == 0 and Wi % 16 == 0 and min(Hi, Wi) >= 64:
+            assert variant == 4316, (variant, Hi, Wi)          # F(4x4,3x3): by the layer alone
         elif Cout % 128 != 0:
             assert variant == 4314, (variant, Cout)
         else:         # v5 when its 128-cout tiles fill the chip (the emulator's 3 "CUs"), else v4: bit-identical either way

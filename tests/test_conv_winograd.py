@@ -219,3 +219,78 @@ def test_conv_wino5_against_torch_and_bit_for_bit_against_v4(backend, case):
     for v5 in (2, 10):
         assert torch.equal(outs[v5][0], outs[0][0]), (v5, (outs[v5][0] - outs[0][0]).abs().max())
         assert torch.equal(outs[v5][1], outs[0][1]), v5
+
+
+# ---- round 5: conv_wino6_kernel — Winograd F(4x4,3x3) -----------------------------------------------------------------------------------
+V6_CASES = [
+    # (N, C1, C2, H, W, Cout, up, gn, act, temb, res)
+    (1, 32, 0, 16, 16, 128, 0, 0, 0, 0, 0),     # one tile, nothing fused
+    (2, 32, 0, 16, 32, 128, 0, 1, 1, 1, 1),     # two tiles per sample, all epilogue terms
+    (3, 32, 32, 32, 16, 128, 0, 1, 1, 1, 1),    # virtual concat; 6 tiles on 3 persistent blocks (the rings roll over tile boundaries)
+    (2, 64, 0, 8, 8, 128, 1, 1, 1, 1, 0),       # nearest-x2 folded (8x8 -> 16x16), GroupNorm + SiLU
+    (1, 64, 0, 8, 16, 256, 1, 0, 0, 1, 0),      # nearest-x2 folded, two cout tiles, no GroupNorm
+    (2, 96, 0, 32, 32, 256, 0, 1, 0, 0, 1),     # 12 chunks, interior + border tiles, two cout tiles
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", V6_CASES, ids=[str(i) for i in range(len(V6_CASES))])
+def test_conv_wino6_f4x4_against_torch(backend, case):
+    """conv_wino6_kernel (Winograd F(4x4,3x3): 36 points per 16 outputs, 1.78x fewer MFMAs than F(2x2,3x3)) against the torch fp32
+    convolution at the per-layer bar (1e-4 of max|ref|; measured ~2-5e-6: the F(4x4) transforms cost a decimal digit against F(2x2)'s
+    5e-7), and the GroupNorm partial sums of its epilogue (one (sum, sum of squares) per 16x16-pixel tile) against the stored output."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    lib = _native.lib()
+    Nn, C1, C2, H, W, Cout, up, use_gn, act, use_temb, use_res = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    w = _rand((Cout, Ct, 3, 3), 3, dev, scale=(Ct * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2) if use_gn else None
+    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
+    wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
+    assert wu.numel() == Cout * Ct * 52                      # the F(2x2) image and the F(4x4) image behind it
+    _native.check(lib.adm_set_option(b"wino6", 2))           # 2: no plane-size floor (the default asks for planes of >= 64x64 pixels)
+    try:
+        out, st = ops.conv2d(x1, wp, b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb, residual=res, wino=wu, stats=True)
+        assert lib.adm_last_conv_variant() == 4316
+        _native.check(lib.adm_set_option(b"wino6", 0))
+        out2, _ = ops.conv2d(x1, wp, b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb, residual=res, wino=wu, stats=True)
+        assert lib.adm_last_conv_variant() in (4314, 4315)   # the F(2x2) kernels read the first image of the same buffer
+    finally:
+        _native.check(lib.adm_set_option(b"wino6", -1))
+    c = lambda t: None if t is None else t.cpu()  # noqa: E731
+    ref = _conv_ref(c(x1), c(x2), c(w), c(b), 3, 1, up, (c(gamma), c(beta)) if use_gn else None, act, c(temb), c(res))
+    assert _relerr(out, ref) < 1e-4, _relerr(out, ref)
+    assert _relerr(out2, ref) < 1e-4 and _relerr(out, out2) < 1e-4
+    assert tuple(st.shape) == (Nn, Cout, (Ho // 16) * (Wo // 16), 2) and not torch.isnan(st).any()
+    y = out.double().reshape(Nn, Cout, Ho // 16, 16, Wo // 16, 16)
+    want = torch.stack([y.sum((3, 5)).reshape(Nn, Cout, -1), (y ** 2).sum((3, 5)).reshape(Nn, Cout, -1)], -1)
+    assert torch.allclose(st.cpu(), want.cpu(), rtol=2e-6, atol=2e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv_wino6_is_chosen_by_the_layer_alone_and_rows_do_not_depend_on_the_batch(backend):
+    """F(4x4) and F(2x2) are different arithmetic, so which of them a layer runs on must not depend on the batch (a random-weight sampler
+    amplifies one bit to another picture): the default rule is the plane size (>= 64x64) and the channel counts. Row r of a batch is
+    bit-identical to the sample convolved alone; a 32x32 plane of the same layer stays on the F(2x2) kernels at every batch size."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    lib = _native.lib()
+    w = _rand((128, 32, 3, 3), 3, dev, scale=(32 * 9) ** -0.5)
+    b = _rand((128,), 4, dev)
+    wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
+    x = _rand((3, 32, 64, 64), 1, dev)
+    out = ops.conv2d(x, wp, b, 3, wino=wu)
+    assert lib.adm_last_conv_variant() == 4316
+    for r in (0, 2):
+        alone = ops.conv2d(x[r:r + 1].contiguous(), wp, b, 3, wino=wu)
+        assert lib.adm_last_conv_variant() == 4316 and torch.equal(alone[0], out[r])
+    for n in (1, 3):
+        ops.conv2d(_rand((n, 32, 32, 32), 2, dev), wp, b, 3, wino=wu)
+        assert lib.adm_last_conv_variant() in (4314, 4315)
