@@ -1927,6 +1927,7 @@ constexpr int W6AR = 6;                            // filter ring: point groups 
 template <bool UP, int KIND, int ACT>
 __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, float* ldsP, const int tid, const int wave,
                                            const int b0, const int bs) {
+  const bool yrole = wave >= 4;
   constexpr int NS = (KIND == 2) ? 3 : 4;                       // active slots
   constexpr int NF = UP ? 0 : (KIND == 0 ? 3 : 2);              // of which float4 pieces (the first NF)
   const int lane = tid & 63;
@@ -1941,7 +1942,7 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
   // ---- staging items of this thread (NS per pair of chunks) ---------------------------------------------------------------------
   // per slot ONE register: channel within the pair (4 bits) | LDS offset << 4 (the patch row / column are recomputed per tile in a_geometry:
   // sixteen per-lane constants beside 144 accumulators were sixteen spilled registers)
-  auto slot_item = [&](int s, int& chrel, int& prow, int& col, int& pofs) {
+  auto slot_item = [&](const int tid, int s, int& chrel, int& prow, int& col, int& pofs) {
     int c2 = 0, ch = 0;
     prow = 0; col = 0; pofs = WCK * W6CS + tid;                  // (default: the thread's dummy word of slab 0)
     if (UP) {
@@ -1970,7 +1971,7 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
   ADM_UNROLL
   for (int s = 0; s < 4; ++s) {
     int chrel, prow, col, pofs;
-    slot_item(s, chrel, prow, col, pofs);
+    slot_item(tid, s, chrel, prow, col, pofs);
     it_pk[s] = chrel | (pofs << 4);
   }
   // stage C: half of a (chunk of the pair, channel, tile) window transform
@@ -1981,7 +1982,7 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
   const int c_wbase = UP ? c_ch * 100 + (2 * c_tyy) * 10 + 2 * c_txx : c_ch * W6CS + (4 * c_tyy) * W6PP + 4 * c_txx;
   const int c_vofs = c_ch * 16 + c_tile;
   // ---- stage A cursor (one PAIR of chunks per step) -----------------------------------------------------------------------------------
-  int a_v = b0, a_ci = 0, a_left = total;
+  int a_v = b0, a_ci = -2, a_left = total + 2;   // (stage A advances BEFORE it loads: the first call lands on chunks 0, 1)
   const float *a_x1 = nullptr, *a_x2 = nullptr;
   int a_vo[4];
   unsigned a_ok = 0;
@@ -1998,10 +1999,12 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     a_x1 = p.x1 + (long)t.n * p.x1_bs;
     a_x2 = p.x2 + (long)t.n * p.x2_bs - (long)p.C1 * planeS;
     a_ok = 0;
+    int tid_o = tid;                           // opaque: the items' rows / columns are RE-computed here — hoisted out of the main loop as
+    ADM_OPAQUE_V(tid_o);                       // invariants they are twelve more registers carried through every block
     ADM_UNROLL
     for (int s = 0; s < NS; ++s) {
       int chrel, prow, col, pofs;
-      slot_item(s, chrel, prow, col, pofs);
+      slot_item(tid_o, s, chrel, prow, col, pofs);
       const int sy = UP ? t.ty * 8 - 1 + prow : t.ty * 16 - 1 + prow;
       const int sx = UP ? t.tx * 8 - 1 + col : t.tx * 16 + col;
       const bool ok = sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws;
@@ -2016,7 +2019,19 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
   a_geometry();
   struct Raw { f32x4 v[3]; float h0, h1; unsigned ok; int sg; };      // v[s]: float4 slots; h0 / h1: the scalar slots behind them
   // (UP: slots 0-2 use v[s][0], slot 3 uses h1)
-  auto stage_a = [&](Raw& r) {                 // global loads of the next pair of chunks; then advance (saturating)
+  float b_sc[4], b_sh[4];                      // GroupNorm scale / shift of the four slots' channels: fetched with the activations they belong to
+  auto stage_a = [&](Raw& r) {                 // advance to the next pair of chunks (saturating), then its global loads
+    // (the advance comes first: a new tile's geometry needs ~30 temporaries, and here the previous pair's activations are already consumed)
+    if (a_left > 2) {
+      a_left -= 2;
+      a_ci += 2;
+      if (a_ci == nch) {
+        ADM_SCHED_FENCE();
+        a_ci = 0; a_v += bs;
+        a_geometry();
+      }
+    }
+    ADM_SCHED_FENCE();
     const int c0 = a_ci * WCK;
 #if !defined(ADM_EMU)
     const __amdgpu_buffer_rsrc_t rx = c0 < p.C1 ? a_rx1 : a_rx2;
@@ -2046,33 +2061,25 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
 #endif
     r.ok = a_ok;
     r.sg = a_n * p.gn_nstride + c0;
-    if (a_left > 2) {
-      a_left -= 2;
-      a_ci += 2;
-      if (a_ci == nch) {
-        ADM_SCHED_FENCE();
-        a_ci = 0; a_v += bs;
-        a_geometry();
-      }
+    ADM_UNROLL
+    for (int s = 0; s < NS; ++s) {             // (L2 / L1 hits; a whole MFMA block passes before stage B reads them)
+#if !defined(ADM_EMU)
+      b_sc[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rs, (it_pk[s] & 15) * 4, r.sg * 4, 0));
+      b_sh[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(h_rs, (it_pk[s] & 15) * 4, r.sg * 4, 0));
+#else
+      b_sc[s] = p.gn_scale[r.sg + (it_pk[s] & 15)]; b_sh[s] = p.gn_shift[r.sg + (it_pk[s] & 15)];
+#endif
     }
   };
   constexpr bool act_on = ACT != 0;
   auto act1 = [&](float x, float sc, float sh) { const float v0 = x * sc + sh; return act_on ? silu_w(v0) : v0; };
   auto stage_b = [&](const Raw& r, int g) {    // raw -> GroupNorm affine (+ SiLU) -> patch buffers of chunks g, g + 1 (zero padding = zeroed affine)
     float* P = ldsP + (g & 3) * W6PSLAB;       // (a pair never wraps the ring: g is even, so slab g + 1 follows slab g)
-    // one slot at a time, its scale / shift fetched just in time (L2 / L1 hits), a scheduling fence behind every two values: anything
-    // more at once and the activations' temporaries spill beside 144 accumulators
+    // one slot at a time, a scheduling fence behind every two values: anything more at once and the activations' temporaries spill
     ADM_UNROLL
     for (int s = 0; s < NS; ++s) {
-      float sc, sh;
-#if !defined(ADM_EMU)
-      sc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rs, (it_pk[s] & 15) * 4, r.sg * 4, 0));
-      sh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(h_rs, (it_pk[s] & 15) * 4, r.sg * 4, 0));
-#else
-      sc = p.gn_scale[r.sg + (it_pk[s] & 15)]; sh = p.gn_shift[r.sg + (it_pk[s] & 15)];
-#endif
       const bool ok = (r.ok >> s) & 1u;
-      const float c = ok ? sc : 0.f, h = ok ? sh : 0.f;
+      const float c = ok ? b_sc[s] : 0.f, h = ok ? b_sh[s] : 0.f;
       float* dst = P + (it_pk[s] >> 4);
       if (s < NF) {
         dst[0] = act1(r.v[s][0], c, h); dst[1] = act1(r.v[s][1], c, h);
@@ -2172,41 +2179,53 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
 #endif
   int o_vo = 0;                                // element (emulator) / byte offset of this lane's tile inside the wave's 16 cout planes
   auto epilogue = [&]() {                      // lane-local inverse transform Y = A^T M A (6x6 -> 4x4), bias / per-sample term / residual, stores
+    // Residual: the four rows of TWO cout rows are in flight at any time (2 x 16 registers: the filter ring and the B window are dead here);
+    // fetched row by row just in time, the sixteen HBM round trips of a tile ran one behind the other — 18 of a tile's 54 us.
+    auto load_res = [&](int r, int a) {
+#if !defined(ADM_EMU)
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, o_vo, r * plane_b + a * row_b, 0));
+#else
+      return *reinterpret_cast<const f32x4*>(p.residual + ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO + o_vo + r * planeO + a * p.Wo);
+#endif
+    };
+    f32x4 res[2][4];
+    ADM_UNROLL
+    for (int q = 0; q < 2; ++q)
+      ADM_UNROLL
+      for (int a = 0; a < 4; ++a) res[q][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef W6X_NORES
+    if (p.residual != nullptr) {
+      ADM_UNROLL
+      for (int q = 0; q < 2; ++q)
+        ADM_UNROLL
+        for (int a = 0; a < 4; ++a) res[q][a] = load_res(q, a);
+    }
+#endif
     ADM_UNROLL
     for (int r = 0; r < 4; ++r) {
       const int co = t.m0 + 16 * wave + 4 * k4 + r;
       const float bsum = p.bias[co] + p.chan_add[(long)t.n * p.chan_add_stride + co];
-      auto load_res = [&](int a) {             // residual row a of cout row r (issued one row ahead of its use: two rows in registers)
-#if !defined(ADM_EMU)
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, o_vo, r * plane_b + a * row_b, 0));
-#else
-        return *reinterpret_cast<const f32x4*>(p.residual + ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO + o_vo + r * planeO + a * p.Wo);
-#endif
-      };
-      f32x4 res_cur = {0.f, 0.f, 0.f, 0.f}, res_nxt = res_cur;
-#ifndef W6X_NORES
-      if (p.residual != nullptr) res_cur = load_res(0);
-#endif
-      float tt[4][6];
-      ADM_UNROLL
-      for (int j = 0; j < 6; ++j)
-        W6_AT(acc[0 * 6 + j][r], acc[1 * 6 + j][r], acc[2 * 6 + j][r], acc[3 * 6 + j][r], acc[4 * 6 + j][r], acc[5 * 6 + j][r],
-              tt[0][j], tt[1][j], tt[2][j], tt[3][j]);
       float f1 = 0.f, f2 = 0.f;
       ADM_UNROLL
       for (int a = 0; a < 4; ++a) {
-#ifndef W6X_NORES
-        if (p.residual != nullptr && a < 3) res_nxt = load_res(a + 1);
-#endif
+        // row a of A^T M for the six columns, then that row times A — the column transforms are recomputed per output row (14 instead of 10
+        // operations per column) so that six, not twenty-four, intermediate values are alive beside the 32 residual registers
+        float tr[6];
+        ADM_UNROLL
+        for (int j = 0; j < 6; ++j) {
+          const float m0 = acc[0 * 6 + j][r], m1 = acc[1 * 6 + j][r], m2 = acc[2 * 6 + j][r], m3 = acc[3 * 6 + j][r], m4 = acc[4 * 6 + j][r],
+                      m5 = acc[5 * 6 + j][r];
+          tr[j] = a == 0 ? (m0 + (m1 + m2)) + (m3 + m4) : a == 1 ? fmaf(2.f, m3 - m4, m1 - m2) : a == 2 ? fmaf(4.f, m3 + m4, m1 + m2)
+                                                                                                  : fmaf(8.f, m3 - m4, m1 - m2) + m5;
+        }
         f32x4 y;
-        W6_AT(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], tt[a][5], y[0], y[1], y[2], y[3]);
+        W6_AT(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5], y[0], y[1], y[2], y[3]);
         ADM_UNROLL
         for (int b = 0; b < 4; ++b) y[b] += bsum;
 #ifndef W6X_NORES
         if (p.residual != nullptr) {
           ADM_UNROLL
-          for (int b = 0; b < 4; ++b) y[b] += res_cur[b];
-          res_cur = res_nxt;
+          for (int b = 0; b < 4; ++b) y[b] += res[r & 1][a][b];
         }
 #endif
 #if !defined(ADM_EMU)
@@ -2231,47 +2250,74 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
       }
 #endif
       ADM_SCHED_FENCE();
+#ifndef W6X_NORES
+      // the row after next is fetched here, not piece by piece above: the statistics' shuffles find these 16 registers free
+      if (p.residual != nullptr && r + 2 < 4) {
+        ADM_UNROLL
+        for (int a = 0; a < 4; ++a) res[r & 1][a] = load_res(r + 2, a);
+      }
+#endif
     }
   };
-  bool pend = false;
-  for (int it = 0; it <= npairs; ++it) {       // (iteration npairs: nothing but the last tile's epilogue)
-    if (pend) {
-      epilogue(); pend = false;
-      if (it == npairs) break;
-      ADM_UNROLL
-      for (int q = 0; q < W6AR; ++q) aR[q] = W6_LOAD_A(d_cur + q * 256);     // the next tile's first chunk (see the MFMA block)
-    }
-    if (it == npairs) break;
-    if (ci == nch) {                           // next tile
-      ADM_SCHED_FENCE();
-      ci = 0; v += bs;
-      t = wino5_tile(p, v);
-      ADM_UNROLL
-      for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int oy = t.ty * 16 + 4 * tyy, ox = t.tx * 16 + 4 * txx;
+  bool pend = false;                           // a finished tile waits for its inverse transform + stores
+  auto tile_switch = [&]() {
+    ADM_SCHED_FENCE();
+    ci = 0; v += bs;
+    t = wino5_tile(p, v);
+    ADM_UNROLL
+    for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int oy = t.ty * 16 + 4 * tyy, ox = t.tx * 16 + 4 * txx;
 #if !defined(ADM_EMU)
-      const long tbase = ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO;
-      o_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + tbase, (short)0, 0x7fffffff, 0x00027000);
-      if (p.residual != nullptr) r_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual) + tbase, (short)0, 0x7fffffff, 0x00027000);
-      o_vo = (4 * k4 * (int)planeO + oy * p.Wo + ox) * 4;
+    const long tbase = ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO;
+    o_rs = __builtin_amdgcn_make_buffer_rsrc(p.out + tbase, (short)0, 0x7fffffff, 0x00027000);
+    if (p.residual != nullptr) r_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual) + tbase, (short)0, 0x7fffffff, 0x00027000);
+    o_vo = (4 * k4 * (int)planeO + oy * p.Wo + ox) * 4;
 #else
-      o_vo = 4 * k4 * (int)planeO + oy * p.Wo + ox;
+    o_vo = 4 * k4 * (int)planeO + oy * p.Wo + ox;
+#endif
+  };
+  // ---- staging block P: B(pg + 2, pg + 3), C(pg, pg + 1), [the finished tile's epilogue], A(next pair) ----------------------------------
+  // (B first: the prefetched activations — up to 13 registers + 8 of scale / shift — die before C's 35 temporaries are born.)
+  // The epilogue sits in front of stage A: there the prefetched activations have been consumed and the filter ring
+  // (24: not refilled behind a tile's last chunk) is dead, which is what its 32 residual registers need.
+  auto staging = [&](bool more) {            // (more: false = nothing but the last tile's epilogue)
+    if (more) {
+#ifndef W6X_NOB
+      stage_b(r0, pg + 2);
+      ADM_SCHED_FENCE();
+#endif
+#ifndef W6X_NOC
+      stage_c(pg);
+      ADM_SCHED_FENCE();
 #endif
     }
-    // ---- staging block P(it): C(pg, pg + 1), B(pg + 2, pg + 3), A(next pair) ------------------------------------------------------------
-#ifndef W6X_NOC
-    stage_c(pg);
-    ADM_SCHED_FENCE();
+    if (pend) {
+#ifndef W6X_NOEPI
+      epilogue();
 #endif
-#ifndef W6X_NOB
-    stage_b(r0, pg + 2);
-    ADM_SCHED_FENCE();
-#endif
+      pend = false;
+      // the next tile's first chunk (see the MFMA block). Unconditional — behind the very last tile the (saturated) cursor re-reads the last
+      // chunk — so that the compiler sees the ring dead across the epilogue.
+      ADM_UNROLL
+      for (int q = 0; q < W6AR; ++q) aR[q] = W6_LOAD_A(d_cur + q * 256);
+    }
+    // (unconditional — behind the last pair the saturated cursor re-reads it — so that the activations and their scale / shift are dead
+    // across the epilogue in the compiler's eyes too)
 #ifndef W6X_NOA
     stage_a(r0);
 #endif
     pg += 2;
     ADM_SCHED_FENCE();
+  };
+  // The two halves of the workgroup run an interval in opposite order (inside an interval the staging block and the MFMA block touch disjoint
+  // ring slots): waves 4-7 run P(it), M(it), barrier; waves 0-3 run M(it), P(it), barrier — written as ONE loop body [P; M] in which the
+  // first half's P is the previous interval's and its barrier sits between the two blocks (s_barrier counts arrivals, not program counters):
+  // while one wave of a SIMD stages, its partner owns the matrix pipe.
+  for (int it = 0; it <= npairs; ++it) {
+    if (yrole || it > 0) staging(yrole ? it < npairs : true);
+    if (!yrole && it > 0) ADM_BARRIER_KEEP_VMEM(63);
+    if (it == npairs) break;
+    if (ci == nch) tile_switch();
     // ---- M: the 144 MFMAs of chunks g, g + 1 -------------------------------------------------------------------------------------------
     const int g = 2 * it;
     float rbw[3][4];                           // B operands: a window of three point groups (read three groups ahead of their MFMAs)
@@ -2292,13 +2338,17 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
         for (int e = 0; e < 4; ++e)
           acc[4 * pgi + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(aR[gi % W6AR][e], rbw[gi % 3][e], acc[4 * pgi + e], 0, 0, 0);
         // (behind the pair's second chunk these are words of a slab that is not certified yet — never used: the next block primes afresh)
+#ifndef W6X_NOLDS
         if (gi + 3 < 18) read_b(gi % 3, g + c2, gi + 3);
         else read_b(gi % 3, g + c2 + 1, gi + 3 - 18);
+#endif
         // the ring slot takes the group W6AR places further down the stream (this chunk's, or the next chunk's first ones)
         // (behind a tile's LAST chunk the ring is not refilled: the epilogue that follows needs those 24 registers, and the next tile's
         // first six groups are loaded right behind it — one exposed L2 round trip per tile)
+#ifndef W6X_NOFILT
         if (gi + W6AR < 18) aR[gi % W6AR] = W6_LOAD_A(d_cur + (gi + W6AR) * 256);
         else if (!(c2 == 1 && ci + 2 == nch)) aR[gi % W6AR] = W6_LOAD_A(d_nxt + (gi + W6AR - 18) * 256);
+#endif
         ADM_SCHED_FENCE();
       }
       d_cur = d_nxt;
@@ -2306,7 +2356,7 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     }
     ci += 2;
     pend = ci == nch;
-    ADM_BARRIER_KEEP_VMEM(63);
+    if (yrole) ADM_BARRIER_KEEP_VMEM(63);
   }
 #undef W6_LOAD_A
 }
