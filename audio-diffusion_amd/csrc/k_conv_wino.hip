@@ -2092,20 +2092,21 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
       ADM_SCHED_FENCE();
     }
   };
-  auto stage_c = [&](int g) {                  // patches of chunks g, g + 1 -> this thread's half window -> V = B^T d B (three rows of it)
+  auto stage_c_half = [&](int g, auto half_c) {  // one copy per half: each a single basic block, its 30 window reads free to run ahead of the math
+    constexpr int HALF = decltype(half_c)::value;
     const float* P = ldsP + ((g + c_c2) & 3) * W6PSLAB + c_wbase;
-    float* V = ldsV + ((g + c_c2) & 3) * W6VSLAB + c_vofs + (c_half ? 18 * 128 : 0);
+    float* V = ldsV + ((g + c_c2) & 3) * W6VSLAB + c_vofs + (HALF ? 18 * 128 : 0);
     // rows of d this half needs: half 0 -> d rows 0..4 (V rows 0, 1, 2), half 1 -> d rows 1..5 (V rows 3, 4, 5)
     float t[3][6];
     ADM_UNROLL
     for (int l = 0; l < 6; ++l) {
-      float r[5];                              // r[k] = d[c_half + k][l]
+      float r[5];                              // r[k] = d[HALF + k][l]
       ADM_UNROLL
       for (int k = 0; k < 5; ++k) {
-        if (UP) r[k] = c_half ? P[((k + 2) >> 1) * 10 + ((l + 1) >> 1)] : P[((k + 1) >> 1) * 10 + ((l + 1) >> 1)];
-        else r[k] = P[(c_half + k) * W6PP + l];
+        if (UP) r[k] = HALF ? P[((k + 2) >> 1) * 10 + ((l + 1) >> 1)] : P[((k + 1) >> 1) * 10 + ((l + 1) >> 1)];
+        else r[k] = P[(HALF + k) * W6PP + l];
       }
-      if (c_half) {                            // V rows 3, 4, 5 from d rows 1..5
+      if (HALF) {                              // V rows 3, 4, 5 from d rows 1..5
         const float c_ = r[3] - r[1], e_ = r[2] - r[0];
         t[0][l] = fmaf(2.f, e_, c_); t[1][l] = fmaf(-2.f, e_, c_);
         t[2][l] = fmaf(4.f, r[0], fmaf(-5.f, r[2], r[4]));
@@ -2122,6 +2123,10 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
       float* dst = V + (6 * i) * 128;
       dst[0] = v0; dst[128] = v1; dst[256] = v2; dst[384] = v3; dst[512] = v4; dst[640] = v5;
     }
+  };
+  auto stage_c = [&](int g) {                  // patches of chunks g, g + 1 -> this thread's half window -> V = B^T d B (three rows of it)
+    if (c_half) stage_c_half(g, std::integral_constant<int, 1>{});
+    else stage_c_half(g, std::integral_constant<int, 0>{});
   };
   // ---- filter stream: ring of W6AR point groups, in memory order [chunk][ks][pg] ---------------------------------------------------------
   // (raw buffer loads: resource = the whole image, lane term = lane * 16 bytes in ONE register, everything else — this wave's cout block, the
@@ -2178,33 +2183,42 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
   const int plane_b = (int)planeO * 4, row_b = p.Wo * 4;
 #endif
   int o_vo = 0;                                // element (emulator) / byte offset of this lane's tile inside the wave's 16 cout planes
-  auto epilogue = [&]() {                      // lane-local inverse transform Y = A^T M A (6x6 -> 4x4), bias / per-sample term / residual, stores
-    // Residual: the four rows of TWO cout rows are in flight at any time (2 x 16 registers: the filter ring and the B window are dead here);
-    // fetched row by row just in time, the sixteen HBM round trips of a tile ran one behind the other — 18 of a tile's 54 us.
-    auto load_res = [&](int r, int a) {
+  // Epilogue operands, fetched one stage B ahead of the epilogue (the filter ring is dead there): the residual rows of TWO cout rows (2 x 16
+  // registers; fetched row by row just in time, the sixteen HBM round trips of a tile ran one behind the other — 18 of a tile's 54 us) and the
+  // four cout rows' bias and per-sample term (the time embedding projection).
+  struct EpiOps { f32x4 res[2][4]; float bias[4], add[4]; };
+  auto load_res = [&](int r, int a) {
 #if !defined(ADM_EMU)
-      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, o_vo, r * plane_b + a * row_b, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, o_vo, r * plane_b + a * row_b, 0));
 #else
-      return *reinterpret_cast<const f32x4*>(p.residual + ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO + o_vo + r * planeO + a * p.Wo);
+    return *reinterpret_cast<const f32x4*>(p.residual + ((long)t.n * p.Cout + t.m0 + 16 * wave) * planeO + o_vo + r * planeO + a * p.Wo);
 #endif
-    };
-    f32x4 res[2][4];
+  };
+  auto epilogue_fetch = [&](EpiOps& e) {
+    ADM_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      const int co = t.m0 + 16 * wave + 4 * k4 + r;
+      e.bias[r] = p.bias[co];
+      e.add[r] = p.chan_add[(long)t.n * p.chan_add_stride + co];
+    }
     ADM_UNROLL
     for (int q = 0; q < 2; ++q)
       ADM_UNROLL
-      for (int a = 0; a < 4; ++a) res[q][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int a = 0; a < 4; ++a) e.res[q][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifndef W6X_NORES
     if (p.residual != nullptr) {
       ADM_UNROLL
       for (int q = 0; q < 2; ++q)
         ADM_UNROLL
-        for (int a = 0; a < 4; ++a) res[q][a] = load_res(q, a);
+        for (int a = 0; a < 4; ++a) e.res[q][a] = load_res(q, a);
     }
 #endif
+  };
+  auto epilogue = [&](EpiOps& e) {             // lane-local inverse transform Y = A^T M A (6x6 -> 4x4), bias / per-sample term / residual, stores
     ADM_UNROLL
     for (int r = 0; r < 4; ++r) {
       const int co = t.m0 + 16 * wave + 4 * k4 + r;
-      const float bsum = p.bias[co] + p.chan_add[(long)t.n * p.chan_add_stride + co];
+      const float bsum = e.bias[r] + e.add[r];
       float f1 = 0.f, f2 = 0.f;
       ADM_UNROLL
       for (int a = 0; a < 4; ++a) {
@@ -2225,7 +2239,7 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
 #ifndef W6X_NORES
         if (p.residual != nullptr) {
           ADM_UNROLL
-          for (int b = 0; b < 4; ++b) y[b] += res[r & 1][a][b];
+          for (int b = 0; b < 4; ++b) y[b] += e.res[r & 1][a][b];
         }
 #endif
 #if !defined(ADM_EMU)
@@ -2240,8 +2254,23 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
 #ifndef W6X_NOSTATS
       if (p.stats != nullptr) {                // (sum, sum of squares) of this cout row over the 16x16 tile: 16 values per lane in fp32, lanes in fp64
         double s1 = (double)f1, s2 = (double)f2;
+#if !defined(ADM_EMU)
+        // rotations inside the 16-lane row as DPP moves (row_ror 8, 4, 2, 1): the same pairs as the xor butterfly — so the same bits — without
+        // sixteen ds_bpermute round trips per cout row
+        auto ror = [](double x, auto ctrl) {
+          const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+          const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, decltype(ctrl)::value, 0xf, 0xf, false);
+          const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), decltype(ctrl)::value, 0xf, 0xf, false);
+          return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+        };
+        s1 += ror(s1, std::integral_constant<int, 0x128>{}); s2 += ror(s2, std::integral_constant<int, 0x128>{});
+        s1 += ror(s1, std::integral_constant<int, 0x124>{}); s2 += ror(s2, std::integral_constant<int, 0x124>{});
+        s1 += ror(s1, std::integral_constant<int, 0x122>{}); s2 += ror(s2, std::integral_constant<int, 0x122>{});
+        s1 += ror(s1, std::integral_constant<int, 0x121>{}); s2 += ror(s2, std::integral_constant<int, 0x121>{});
+#else
         ADM_UNROLL
         for (int m = 8; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+#endif
         if (l15 == 0) {
           const int tiles = p.tiles_x * p.tiles_y;
           double* dst = p.stats + (((long)t.n * p.Cout + co) * tiles + t.ty * p.tiles_x + t.tx) * 2;
@@ -2254,12 +2283,19 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
       // the row after next is fetched here, not piece by piece above: the statistics' shuffles find these 16 registers free
       if (p.residual != nullptr && r + 2 < 4) {
         ADM_UNROLL
-        for (int a = 0; a < 4; ++a) res[r & 1][a] = load_res(r + 2, a);
+        for (int a = 0; a < 4; ++a) e.res[r & 1][a] = load_res(r + 2, a);
       }
 #endif
     }
   };
   bool pend = false;                           // a finished tile waits for its inverse transform + stores
+#if defined(W6X_PROF) && !defined(ADM_EMU)     // developer build: cycle accounting of waves 0 / 4 ([1] M [2] B [3] epilogue [4] A [5] C [6] barrier)
+  unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = W3_CLK(), tn;
+  const unsigned long long t_start = tq;
+#define W6_LAP(slot) do { tn = W3_CLK(); pr[slot] += tn - tq; tq = tn; } while (0)
+#else
+#define W6_LAP(slot) ((void)0)
+#endif
   auto tile_switch = [&]() {
     ADM_SCHED_FENCE();
     ci = 0; v += bs;
@@ -2276,38 +2312,58 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     o_vo = 4 * k4 * (int)planeO + oy * p.Wo + ox;
 #endif
   };
-  // ---- staging block P: B(pg + 2, pg + 3), C(pg, pg + 1), [the finished tile's epilogue], A(next pair) ----------------------------------
-  // (B first: the prefetched activations — up to 13 registers + 8 of scale / shift — die before C's 35 temporaries are born.)
+  // ---- staging block P: B(pg + 2, pg + 3), [the finished tile's epilogue], A(next pair), C(pg, pg + 1) ----------------------------------
+  // (A in front of C: vmcnt retires in order, so the MFMA block's first wait for a filter group also waits for every older load and store —
+  // the activations' HBM round trip and the epilogue's stores must be given stage C's time, not the MFMA block's.)
   // The epilogue sits in front of stage A: there the prefetched activations have been consumed and the filter ring
   // (24: not refilled behind a tile's last chunk) is dead, which is what its 32 residual registers need.
   auto staging = [&](bool more) {            // (more: false = nothing but the last tile's epilogue)
-    if (more) {
-#ifndef W6X_NOB
-      stage_b(r0, pg + 2);
-      ADM_SCHED_FENCE();
-#endif
-#ifndef W6X_NOC
-      stage_c(pg);
-      ADM_SCHED_FENCE();
-#endif
-    }
-    if (pend) {
+    W6_LAP(7);
+    if (pend) {                                // (stage B twice in the source: the epilogue's operands live in this branch only)
+      EpiOps e;
 #ifndef W6X_NOEPI
-      epilogue();
+      epilogue_fetch(e);                       // (their HBM / L2 round trips pass under stage B)
 #endif
+      if (more) {
+#ifndef W6X_NOB
+        stage_b(r0, pg + 2);
+        ADM_SCHED_FENCE();
+#endif
+      }
+      W6_LAP(2);
+#ifndef W6X_NOEPI
+      epilogue(e);
+#endif
+      W6_LAP(3);
       pend = false;
       // the next tile's first chunk (see the MFMA block). Unconditional — behind the very last tile the (saturated) cursor re-reads the last
       // chunk — so that the compiler sees the ring dead across the epilogue.
       ADM_UNROLL
       for (int q = 0; q < W6AR; ++q) aR[q] = W6_LOAD_A(d_cur + q * 256);
+    } else {
+      if (more) {
+#ifndef W6X_NOB
+        stage_b(r0, pg + 2);
+        ADM_SCHED_FENCE();
+#endif
+      }
+      W6_LAP(2);
     }
     // (unconditional — behind the last pair the saturated cursor re-reads it — so that the activations and their scale / shift are dead
     // across the epilogue in the compiler's eyes too)
 #ifndef W6X_NOA
     stage_a(r0);
 #endif
+    ADM_SCHED_FENCE();
+    W6_LAP(4);
+    if (more) {
+#ifndef W6X_NOC
+      stage_c(pg);
+#endif
+    }
     pg += 2;
     ADM_SCHED_FENCE();
+    W6_LAP(5);
   };
   // The two halves of the workgroup run an interval in opposite order (inside an interval the staging block and the MFMA block touch disjoint
   // ring slots): waves 4-7 run P(it), M(it), barrier; waves 0-3 run M(it), P(it), barrier — written as ONE loop body [P; M] in which the
@@ -2315,9 +2371,10 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
   // while one wave of a SIMD stages, its partner owns the matrix pipe.
   for (int it = 0; it <= npairs; ++it) {
     if (yrole || it > 0) staging(yrole ? it < npairs : true);
-    if (!yrole && it > 0) ADM_BARRIER_KEEP_VMEM(63);
+    if (!yrole && it > 0) { ADM_BARRIER_KEEP_VMEM(63); W6_LAP(6); }
     if (it == npairs) break;
     if (ci == nch) tile_switch();
+    W6_LAP(7);
     // ---- M: the 144 MFMAs of chunks g, g + 1 -------------------------------------------------------------------------------------------
     const int g = 2 * it;
     float rbw[3][4];                           // B operands: a window of three point groups (read three groups ahead of their MFMAs)
@@ -2356,8 +2413,16 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     }
     ci += 2;
     pend = ci == nch;
-    if (yrole) ADM_BARRIER_KEEP_VMEM(63);
+    W6_LAP(1);
+    if (yrole) { ADM_BARRIER_KEEP_VMEM(63); W6_LAP(6); }
   }
+#if defined(W6X_PROF) && !defined(ADM_EMU)
+  if (p.prof != nullptr && (tid & 255) == 0) {
+    pr[0] = W3_CLK() - t_start;
+    for (int i = 0; i < 8; ++i) atomicAdd(p.prof + (yrole ? 8 : 0) + i, pr[i]);
+  }
+#endif
+#undef W6_LAP
 #undef W6_LOAD_A
 }
 
@@ -2737,6 +2802,11 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
       p.prof = nullptr;
       p.stats = a.stats_out;
       set_last_conv_variant(4000 + 316);
+#if defined(W6X_PROF) && !defined(ADM_EMU)
+      static unsigned long long* dprof6 = [] { void* q = nullptr; (void)hipMalloc(&q, 16 * sizeof(unsigned long long)); return (unsigned long long*)q; }();
+      (void)hipMemsetAsync(dprof6, 0, 16 * sizeof(unsigned long long), st);
+      p.prof = dprof6;
+#endif
       const size_t need6 = sizeof(float) * W6LDS;
       const int grid6 = p.nblk < n_cu ? p.nblk : n_cu;
       if (a.up) {
@@ -2746,6 +2816,17 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
         if (a.act) ADM_LAUNCH((conv_wino6_kernel<false, 1>), dim3(grid6), dim3(512), need6, st, p);
         else ADM_LAUNCH((conv_wino6_kernel<false, 0>), dim3(grid6), dim3(512), need6, st, p);
       }
+#if defined(W6X_PROF) && !defined(ADM_EMU)
+      {
+        unsigned long long h[16];
+        (void)hipMemcpyAsync(h, dprof6, sizeof(h), hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        const double nb = grid6;
+        fprintf(stderr, "[wino6 prof] cycles of wave 0: total %.0f M %.0f B %.0f epilogue %.0f A %.0f C %.0f barrier %.0f other %.0f | wave 4: total %.0f M %.0f B %.0f epilogue %.0f A %.0f C %.0f barrier %.0f other %.0f\n",
+                h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, h[5] / nb, h[6] / nb, h[7] / nb,
+                h[8] / nb, h[9] / nb, h[10] / nb, h[11] / nb, h[12] / nb, h[13] / nb, h[14] / nb, h[15] / nb);
+      }
+#endif
       return ADM_CHECK_LAUNCH();
     }
     // v5: 128-cout workgroup tiles (every patch transformed once per 128 couts), taken when those tiles still fill the chip — with
