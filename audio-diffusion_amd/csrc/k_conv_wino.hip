@@ -1927,7 +1927,11 @@ constexpr int W6AR = 6;                            // filter ring: point groups 
 template <bool UP, int KIND, int ACT>
 __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, float* ldsP, const int tid, const int wave,
                                            const int b0, const int bs) {
+#ifdef W6X_SWAP
+  const bool yrole = wave < 4;
+#else
   const bool yrole = wave >= 4;
+#endif
   constexpr int NS = (KIND == 2) ? 3 : 4;                       // active slots
   constexpr int NF = UP ? 0 : (KIND == 0 ? 3 : 2);              // of which float4 pieces (the first NF)
   const int lane = tid & 63;
@@ -2075,7 +2079,9 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
   auto act1 = [&](float x, float sc, float sh) { const float v0 = x * sc + sh; return act_on ? silu_w(v0) : v0; };
   auto stage_b = [&](const Raw& r, int g) {    // raw -> GroupNorm affine (+ SiLU) -> patch buffers of chunks g, g + 1 (zero padding = zeroed affine)
     float* P = ldsP + (g & 3) * W6PSLAB;       // (a pair never wraps the ring: g is even, so slab g + 1 follows slab g)
-    // one slot at a time, a scheduling fence behind every two values: anything more at once and the activations' temporaries spill
+    // ONE scheduling region: beside a partner wave that keeps the matrix pipe full every dependent step of this block waits ~40 cycles for
+    // its turn (cycle accounting, profiles/r05_wino.md), so the up to thirteen activation chains must run side by side, not one behind the
+    // other (fenced slot by slot — as the registers demanded while the filter ring was alive here — the block took 2-3k cycles per pair).
     ADM_UNROLL
     for (int s = 0; s < NS; ++s) {
       const bool ok = (r.ok >> s) & 1u;
@@ -2083,13 +2089,14 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
       float* dst = P + (it_pk[s] >> 4);
       if (s < NF) {
         dst[0] = act1(r.v[s][0], c, h); dst[1] = act1(r.v[s][1], c, h);
-        ADM_SCHED_FENCE();
         dst[2] = act1(r.v[s][2], c, h); dst[3] = act1(r.v[s][3], c, h);
       } else {
         const float x = (UP && s < 3) ? r.v[s][0] : (s == 3 ? r.h1 : r.h0);
         dst[0] = act1(x, c, h);
       }
+#ifdef W6X_BFENCE
       ADM_SCHED_FENCE();
+#endif
     }
   };
   auto stage_c_half = [&](int g, auto half_c) {  // one copy per half: each a single basic block, its 30 window reads free to run ahead of the math
@@ -2249,7 +2256,9 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
 #endif
         f1 += (y[0] + y[1]) + (y[2] + y[3]);
         f2 += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
-        ADM_SCHED_FENCE();
+#ifdef W6X_EFENCE
+        ADM_SCHED_FENCE();                     // (one cout row = one scheduling region: its four output rows' chains run side by side, see stage B)
+#endif
       }
 #ifndef W6X_NOSTATS
       if (p.stats != nullptr) {                // (sum, sum of squares) of this cout row over the 16x16 tile: 16 values per lane in fp32, lanes in fp64
@@ -2318,6 +2327,13 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
   // The epilogue sits in front of stage A: there the prefetched activations have been consumed and the filter ring
   // (24: not refilled behind a tile's last chunk) is dead, which is what its 32 residual registers need.
   auto staging = [&](bool more) {            // (more: false = nothing but the last tile's epilogue)
+    // Priority: the SIMD's arbiter serves its older wave first, so the younger one (waves 4-7) staged only in the gaps of its partner's MFMA
+    // stream — 10.5k cycles for a block that takes the older wave 7k (cycle accounting, profiles/r05_wino.md) — and every barrier waited for
+    // it. A staging block is short dependent chains of VALU / LDS / memory instructions: it gets the issue slots first; the partner's MFMAs
+    // need one slot in eight and fill the rest.
+#if !defined(ADM_EMU) && !defined(W6X_NOPRIO)
+    __builtin_amdgcn_s_setprio(2);
+#endif
     W6_LAP(7);
     if (pend) {                                // (stage B twice in the source: the epilogue's operands live in this branch only)
       EpiOps e;
@@ -2336,10 +2352,10 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
 #endif
       W6_LAP(3);
       pend = false;
-      // the next tile's first chunk (see the MFMA block). Unconditional — behind the very last tile the (saturated) cursor re-reads the last
-      // chunk — so that the compiler sees the ring dead across the epilogue.
+#ifndef W6X_RING_IN_P
       ADM_UNROLL
       for (int q = 0; q < W6AR; ++q) aR[q] = W6_LOAD_A(d_cur + q * 256);
+#endif
     } else {
       if (more) {
 #ifndef W6X_NOB
@@ -2354,6 +2370,13 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
 #ifndef W6X_NOA
     stage_a(r0);
 #endif
+    // (W6X_RING_IN_P, measured and not adopted: the filter ring's first six groups of the NEXT MFMA block fetched here instead of behind the
+    // previous block's last groups — the MFMA blocks get 15 % shorter and stage B's waits stop covering these loads, but stage A grows by as
+    // much: 58.5 vs 57.7 ms per forward, profiles/r05_wino.md)
+#ifdef W6X_RING_IN_P
+    ADM_UNROLL
+    for (int q = 0; q < W6AR; ++q) aR[q] = W6_LOAD_A(d_cur + q * 256);
+#endif
     ADM_SCHED_FENCE();
     W6_LAP(4);
     if (more) {
@@ -2364,6 +2387,9 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     pg += 2;
     ADM_SCHED_FENCE();
     W6_LAP(5);
+#if !defined(ADM_EMU) && !defined(W6X_NOPRIO)
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   // The two halves of the workgroup run an interval in opposite order (inside an interval the staging block and the MFMA block touch disjoint
   // ring slots): waves 4-7 run P(it), M(it), barrier; waves 0-3 run M(it), P(it), barrier — written as ONE loop body [P; M] in which the
@@ -2404,7 +2430,11 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
         // first six groups are loaded right behind it — one exposed L2 round trip per tile)
 #ifndef W6X_NOFILT
         if (gi + W6AR < 18) aR[gi % W6AR] = W6_LOAD_A(d_cur + (gi + W6AR) * 256);
+#ifdef W6X_RING_IN_P
+        else if (c2 == 0) aR[gi % W6AR] = W6_LOAD_A(d_nxt + (gi + W6AR - 18) * 256);
+#else
         else if (!(c2 == 1 && ci + 2 == nch)) aR[gi % W6AR] = W6_LOAD_A(d_nxt + (gi + W6AR - 18) * 256);
+#endif
 #endif
         ADM_SCHED_FENCE();
       }
@@ -2417,7 +2447,10 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     if (yrole) { ADM_BARRIER_KEEP_VMEM(63); W6_LAP(6); }
   }
 #if defined(W6X_PROF) && !defined(ADM_EMU)
-  if (p.prof != nullptr && (tid & 255) == 0) {
+#ifndef W6X_PROFW
+#define W6X_PROFW 0
+#endif
+  if (p.prof != nullptr && (tid & 255) == W6X_PROFW) {    // (W6X_PROFW = 64 k: waves k and 4 + k)
     pr[0] = W3_CLK() - t_start;
     for (int i = 0; i < 8; ++i) atomicAdd(p.prof + (yrole ? 8 : 0) + i, pr[i]);
   }
