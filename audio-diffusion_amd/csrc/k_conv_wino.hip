@@ -2670,13 +2670,19 @@ static int wino6_on() {
   if (g_wino6 < 0) { const char* e = getenv("ADM_WINO6"); g_wino6 = e ? atoi(e) : 1; }
   return g_wino6;
 }
-constexpr int W6_MIN_PLANE = 64;
+// The floor, measured (profiles/r05_wino.md; ms per step): B = 32 forward 73.8 without the kernel, 57.7 / 60.1 / 63.5 with floors 64 / 128 / 256;
+// the 256x256 model at B = 1 7.12 without, 8.33 / 7.31 / 6.79; the 64x64 model at B = 1 3.43 without, 4.00 / 3.42 / 3.42. One 16x16x128
+// tile is 2.25x the work of a 64-cout F(2x2) workgroup, so planes whose tiles do not fill the chip at B = 1 pay for it there — and the
+// choice cannot follow the batch. 128 keeps the latency regimes where they were and takes 22 of the 28 % at B = 32 ("wino6" = 64: the rest).
+constexpr int W6_MIN_PLANE = 128;
 static bool wino6_eligible(const adm_conv_args& a) {
   if (!wino6_on()) return false;
   const int C2 = a.x2 ? a.C2 : 0;
   const int Ho = a.up ? 2 * a.H : a.H, Wo = a.up ? 2 * a.W : a.W;
   if (!wino6_layout(a.Cout, a.C1 + C2) || a.C1 % 16 != 0 || Ho % 16 != 0 || Wo % 16 != 0) return false;
-  return wino6_on() >= 2 || (Ho >= W6_MIN_PLANE && Wo >= W6_MIN_PLANE);
+  if (wino6_on() == 2) return true;
+  const int floor_px = wino6_on() >= 16 ? wino6_on() : W6_MIN_PLANE;     // (values >= 16: that plane-size floor — measurements)
+  return Ho >= floor_px && Wo >= floor_px;
 }
 static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 4) on first use
 bool winograd_mode_available(int m) {

@@ -255,7 +255,7 @@ def test_conv_wino6_f4x4_against_torch(backend, case):
     res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
     wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
     assert wu.numel() == Cout * Ct * 52                      # the F(2x2) image and the F(4x4) image behind it
-    _native.check(lib.adm_set_option(b"wino6", 2))           # 2: no plane-size floor (the default asks for planes of >= 64x64 pixels)
+    _native.check(lib.adm_set_option(b"wino6", 2))           # 2: no plane-size floor (the default asks for planes of >= 128x128 pixels)
     try:
         out, st = ops.conv2d(x1, wp, b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb, residual=res, wino=wu, stats=True)
         assert lib.adm_last_conv_variant() == 4316
@@ -277,20 +277,20 @@ def test_conv_wino6_f4x4_against_torch(backend, case):
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_conv_wino6_is_chosen_by_the_layer_alone_and_rows_do_not_depend_on_the_batch(backend):
     """F(4x4) and F(2x2) are different arithmetic, so which of them a layer runs on must not depend on the batch (a random-weight sampler
-    amplifies one bit to another picture): the default rule is the plane size (>= 64x64) and the channel counts. Row r of a batch is
-    bit-identical to the sample convolved alone; a 32x32 plane of the same layer stays on the F(2x2) kernels at every batch size."""
+    amplifies one bit to another picture): the default rule is the plane size (>= 128x128) and the channel counts. Row r of a batch is
+    bit-identical to the sample convolved alone; a 64x64 plane of the same layer stays on the F(2x2) kernels at every batch size."""
     dev = select(backend)
     from audiodiffusion import _native, ops
     lib = _native.lib()
     w = _rand((128, 32, 3, 3), 3, dev, scale=(32 * 9) ** -0.5)
     b = _rand((128,), 4, dev)
     wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
-    x = _rand((3, 32, 64, 64), 1, dev)
+    x = _rand((3, 32, 128, 128), 1, dev)
     out = ops.conv2d(x, wp, b, 3, wino=wu)
     assert lib.adm_last_conv_variant() == 4316
     for r in (0, 2):
         alone = ops.conv2d(x[r:r + 1].contiguous(), wp, b, 3, wino=wu)
         assert lib.adm_last_conv_variant() == 4316 and torch.equal(alone[0], out[r])
     for n in (1, 3):
-        ops.conv2d(_rand((n, 32, 32, 32), 2, dev), wp, b, 3, wino=wu)
+        ops.conv2d(_rand((n, 32, 64, 64), 2, dev), wp, b, 3, wino=wu)
         assert lib.adm_last_conv_variant() in (4314, 4315)
