@@ -37,7 +37,8 @@ out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) ov
                    "FETCH_SIZE doubled (gfx950 reports 1/2 of 16 B/lane streaming reads; check: gn_stats_kernel reads exactly its inputs — 21.2 GB per forward "
                    "when every GroupNorm runs the read pass (ADM_GN_FOLD=0), the inputs of the remaining read passes otherwise). "
                    "Infinity-Cache hits are counted by this counter.",
-       "by_variant": {"4314": group(lambda k: "conv_wino4" in k), "4313": group(lambda k: "conv_wino3" in k)},
+       "by_variant": {"4316": group(lambda k: "conv_wino6" in k), "4315": group(lambda k: "conv_wino5" in k),
+                      "4314": group(lambda k: "conv_wino4" in k), "4313": group(lambda k: "conv_wino3" in k)},
        "gn_stats_check_GB": group(lambda k: "gn_stats" in k)["fetch_bytes_per_forward"] / 1e9,
        "per_kernel": per}
 out["by_variant"] = {k: v for k, v in out["by_variant"].items() if v["launches_per_forward"]}

@@ -33,7 +33,10 @@ for (C1, C2, H, Co) in shapes:
     torch.cuda.synchronize()
     ms = a.elapsed_time(e) / 5
     var = _native.lib().adm_last_conv_variant()
-    tiles = 32 * (H // 8) * (H // 16) * (Co // (128 if var == 4315 else 64))
+    if var == 4316:      # F(4x4): 16x16-pixel x 128-cout workgroup tiles, 72 MFMAs (32 cycles each) per wave and chunk of 8 input channels
+        tiles, mfma = 32 * (H // 16) * (H // 16) * (Co // 128), 2 * 72 * 32
+    else:
+        tiles, mfma = 32 * (H // 8) * (H // 16) * (Co // (128 if var == 4315 else 64)), (4096 if var == 4315 else 2048)
     chunks = tiles / 256 * (C // 8)
     print(f"W5={os.environ.get('ADM_WINO5', '1')} ABL={os.environ.get('ADM_WINO5_ABL', '0')} variant {var} {C}->{Co}@{H}: {ms:.3f} ms  "
-          f"= {ms * 1e3 / chunks:.3f} us per chunk and CU ({ms * 1e3 / chunks * 2.1e3:.0f} cycles at 2.1 GHz; MFMA {4096 if var == 4315 else 2048})", flush=True)
+          f"= {ms * 1e3 / chunks:.3f} us per chunk and CU ({ms * 1e3 / chunks * 2.1e3:.0f} cycles at 2.1 GHz; MFMA {mfma} per SIMD)", flush=True)
