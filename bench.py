@@ -9,10 +9,10 @@ region. N > 1: one process per GPU (torchrun), the global noise batch is generat
 no collective inside the loop, one all_gather of the uint8 images at the end of each step ("scaling": "weak").
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     — dominant kernel (the Winograd F(2x2,3x3) fp32-MFMA convolution) measured LIVE with HIP events around
-                 every launch of one extra eager forward on the same stream. `achieved`/`frac` are the EXECUTED matrix-pipe
-                 FLOP/s against the 157.3 TF fp32 MFMA peak (a real roofline fraction, <= 1); the algorithmic
-                 (direct-convolution) rate, which Winograd makes 2.25x larger, is reported beside it;
+  roofline     — dominant kernel (since round 5 the Winograd F(4x4,3x3) fp32-MFMA convolution) measured LIVE with HIP events
+                 around every launch of one extra eager forward on the same stream. `achieved`/`frac` are the EXECUTED
+                 matrix-pipe FLOP/s against the 157.3 TF fp32 MFMA peak (a real roofline fraction, <= 1); the algorithmic
+                 (direct-convolution) rate, which Winograd makes 4x (F(2x2): 2.25x) larger, is reported beside it;
   cpu_baseline — the CPU oracle (oracle/, a port: the reference cannot be imported without diffusers/librosa) timed on
                  the host cores on a bounded sample of the same workload;
   train        — BASELINE.json config 5 beside it: 10 optimizer steps of scripts/train_unet.py's step at 256x256,
