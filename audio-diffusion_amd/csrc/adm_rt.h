@@ -141,7 +141,12 @@ template <class T> __device__ __forceinline__ void adm_st_nt(T* p, const T& v) {
     __builtin_amdgcn_sched_barrier(0);     \
   } while (0)
 // v_rcp_f32 (1 ulp) instead of the ~12-instruction IEEE division sequence that `/` and __fdividef expand to
+#if defined(ADM_PRECISE_MATH)   // measurement build (tools/accuracy_probe.py): IEEE division and libm's expf where the product uses v_rcp_f32 / v_exp_f32
+#define ADM_RCP(x) (1.0f / (x))
+#define __expf(x) expf(x)
+#else
 #define ADM_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
 // a value known to be wave-uniform, moved to an SGPR so that tests on it become scalar branches
 #define ADM_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define ADM_BARRIER_KEEP_VMEM(N)                                            \
