@@ -1884,7 +1884,7 @@ __global__ void __launch_bounds__(512) conv_wino5_kernel(const WinoParams p) {
 // MFMA cycles, vector instructions add to them one for one, and three different schedules of the same arithmetic land within 2 % of each
 // other — what is left to cut is the MFMA count itself. F(4x4,3x3) multiplies 36 Winograd points per 16 outputs instead of 16 per 4:
 // 1.78x fewer MFMAs than F(2x2,3x3), 4x fewer than the direct convolution; its fp32 error is 0.6-1.7e-5 of max|out| (rms 1-4e-6; `profiles/r05_accuracy.md`) on this network's layer
-// shapes (F(2x2): 4-5e-7; the per-layer bar is 1e-4; tools/... measured before the kernel was written).
+// shapes (F(2x2): 0.7-1.5e-6; the per-layer bar is 1e-4; tools/... measured before the kernel was written).
 //   Y = A^T [ (G g G^T) . (B^T d B) ] A,  d = 6x6 input window, Y = 4x4 outputs, the standard matrices of Lavin & Gray.
 // Workgroup tile = 128 couts x 16x16 pixels = 16 Winograd tiles; 8 waves, wave w owns couts 16 w .. 16 w + 15 x all 16 tiles x all 36 points
 // (144 accumulators on v_mfma_f32_16x16x4_f32; the inverse transform is lane-local). Per 8-channel chunk and wave: 72 MFMAs (v5: 64 for HALF

@@ -37,7 +37,7 @@ int adm_has_experiments(void);
  *   however few tiles (tests) | bit 3 (8): the two halves of the workgroup run MFMA block and staging block in antiphase instead (the first
  *   schedule built; same results, same speed) | -1 (ADM_WINO5);
  * "wino6" = 1 (default, round 5) 3x3 stride-1 convolutions with 128 | Cout, 32 | Cin on planes of at least 128x128 pixels (16 | H, 16 | W) run
- *   on conv_wino6_kernel: Winograd F(4x4,3x3), 1.78x fewer MFMAs than F(2x2,3x3) at 0.6-1.7e-5 of max|out| (rms 1-4e-6; `profiles/r05_accuracy.md`) (F(2x2): 5e-7; the per-layer bar is
+ *   on conv_wino6_kernel: Winograd F(4x4,3x3), 1.78x fewer MFMAs than F(2x2,3x3) at 0.6-1.7e-5 of max|out| (rms 1-4e-6; `profiles/r05_accuracy.md`) (F(2x2): 0.7-1.5e-6; the per-layer bar is
  *   1e-4). The choice depends on the layer only (the two transforms are not bit-identical) | 0 F(2x2,3x3) kernels everywhere | 2 no plane-size
  *   floor (tests) | n >= 16: planes of at least n x n pixels (64: the throughput setting — B = 32 forward 57.7 instead of 60.1 ms, at 17 % on the
  *   B = 1 step of the 256x256 model; 256: the latency setting) | -1 (ADM_WINO6);
