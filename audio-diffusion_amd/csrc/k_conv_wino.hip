@@ -2604,7 +2604,12 @@ static int wino_pair();
 // alone, so that the packing (done once per layer) and every later launch agree: mode 4 and 64 | couts, 32 | cins -> the
 // conv_wino4_kernel image (such a layer then runs on conv_wino4_kernel or, for arguments that kernel cannot take, on the
 // direct kernel — never on v1-v3, which could not read it). The option must be set before the weights are packed.
-static bool wino4_layout(int couts, int cins) { return wino_mode() == 4 && couts % W3BM == 0 && cins % (4 * WCK) == 0; }
+// (mode 0 — no Winograd kernel runs — packs the mode-4 image as well: an image packed under "conv_wino" = 0 and convolved under the default
+// would otherwise be read in the wrong layout and past its 16 floats per filter; only the experiments builds' modes 1-3 keep the v3 layout)
+static bool wino4_layout(int couts, int cins) {
+  const int m = wino_mode();
+  return (m == 4 || m == 0) && couts % W3BM == 0 && cins % (4 * WCK) == 0;
+}
 
 // The F(4x4,3x3) image of conv_wino6_kernel FOLLOWS the F(2x2,3x3) image in the same buffer (16 + 36 transformed values per filter) whenever
 // the packed channel counts allow the kernel (128 | couts on top of the v4 rule) — whatever the "wino6" option says at packing time, so that

@@ -294,3 +294,33 @@ def test_conv_wino6_is_chosen_by_the_layer_alone_and_rows_do_not_depend_on_the_b
     for n in (1, 3):
         ops.conv2d(_rand((n, 32, 64, 64), 2, dev), wp, b, 3, wino=wu)
         assert lib.adm_last_conv_variant() in (4314, 4315)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_a_winograd_image_packed_while_the_kernels_are_switched_off_is_the_image_they_read(backend):
+    """`adm_pack_winograd_weight` under "conv_wino" = 0 used to write the 16-float layout of the experiments builds' older kernels: a
+    convolution launched under the default afterwards read it in the wrong layout — and, for layers with an F(4x4) image, past its end
+    (found by tools/accuracy_probe.py as a memory fault on the MI355X). The layout is now the same under 0 and 4."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    lib = _native.lib()
+    x1, x2 = _rand((1, 32, 16, 16), 1, dev), _rand((1, 32, 16, 16), 2, dev)
+    w = _rand((128, 64, 3, 3), 3, dev, scale=(64 * 9) ** -0.5)
+    b = _rand((128,), 4, dev)
+    gamma, beta = _rand((64,), 5, dev), _rand((64,), 6, dev)
+    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2)
+    c = lambda t: t.cpu()  # noqa: E731
+    ref = _conv_ref(c(x1), c(x2), c(w), c(b), 3, 1, 0, (c(gamma), c(beta)), 1, None, None)
+    try:
+        _native.check(lib.adm_set_option(b"conv_wino", 0))
+        wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
+        assert wu.numel() == 128 * 64 * 52
+        _native.check(lib.adm_set_option(b"conv_wino", 4))
+        for v6, want in ((2, 4316), (0, 4314)):
+            _native.check(lib.adm_set_option(b"wino6", v6))
+            out = ops.conv2d(x1, wp, b, 3, x2=x2, gn=gn, act=True, wino=wu)
+            assert lib.adm_last_conv_variant() in (want, 4315)
+            assert _relerr(out, ref) < 1e-4
+    finally:
+        _native.check(lib.adm_set_option(b"conv_wino", -1))
+        _native.check(lib.adm_set_option(b"wino6", -1))
