@@ -1927,7 +1927,11 @@ constexpr int W6AR = 6;                            // filter ring: point groups 
 template <bool UP, int KIND, int ACT>
 __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, float* ldsP, const int tid, const int wave,
                                            const int b0, const int bs) {
-#ifdef W6X_SWAP
+#if defined(W6X_ALLX)
+  const bool yrole = false;
+#elif defined(W6X_ALLY)
+  const bool yrole = true;
+#elif defined(W6X_SWAP)
   const bool yrole = wave < 4;
 #else
   const bool yrole = wave >= 4;
