@@ -324,3 +324,23 @@ def test_a_winograd_image_packed_while_the_kernels_are_switched_off_is_the_image
     finally:
         _native.check(lib.adm_set_option(b"conv_wino", -1))
         _native.check(lib.adm_set_option(b"wino6", -1))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_the_f4x4_plane_floor_is_an_option(backend):
+    """"wino6" = n >= 16 moves the plane-size floor of conv_wino6_kernel (64: the throughput setting, 256: the latency setting):
+    still a function of the layer only."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    lib = _native.lib()
+    w = _rand((128, 32, 3, 3), 3, dev, scale=(32 * 9) ** -0.5)
+    b = _rand((128,), 4, dev)
+    wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
+    try:
+        for floor_px, plane, f4 in ((64, 64, True), (64, 32, False), (256, 128, False), (-1, 128, True), (-1, 64, False)):
+            _native.check(lib.adm_set_option(b"wino6", floor_px))
+            for n in (1, 2):
+                ops.conv2d(_rand((n, 32, plane, plane), 1, dev), wp, b, 3, wino=wu)
+                assert (lib.adm_last_conv_variant() == 4316) == f4, (floor_px, plane, n, lib.adm_last_conv_variant())
+    finally:
+        _native.check(lib.adm_set_option(b"wino6", -1))
