@@ -1884,7 +1884,7 @@ __global__ void __launch_bounds__(512) conv_wino5_kernel(const WinoParams p) {
 // MFMA cycles, vector instructions add to them one for one, and three different schedules of the same arithmetic land within 2 % of each
 // other — what is left to cut is the MFMA count itself. F(4x4,3x3) multiplies 36 Winograd points per 16 outputs instead of 16 per 4:
 // 1.78x fewer MFMAs than F(2x2,3x3), 4x fewer than the direct convolution; its fp32 error is 0.6-1.7e-5 of max|out| (rms 1-4e-6; `profiles/r05_accuracy.md`) on this network's layer
-// shapes (F(2x2): 0.7-1.5e-6; the per-layer bar is 1e-4; tools/... measured before the kernel was written).
+// shapes (F(2x2): 0.7-1.5e-6; the per-layer bar is 1e-4).
 //   Y = A^T [ (G g G^T) . (B^T d B) ] A,  d = 6x6 input window, Y = 4x4 outputs, the standard matrices of Lavin & Gray.
 // Workgroup tile = 128 couts x 16x16 pixels = 16 Winograd tiles; 8 waves, wave w owns couts 16 w .. 16 w + 15 x all 16 tiles x all 36 points
 // (144 accumulators on v_mfma_f32_16x16x4_f32; the inverse transform is lane-local). Per 8-channel chunk and wave: 72 MFMAs (v5: 64 for HALF
@@ -1893,6 +1893,12 @@ __global__ void __launch_bounds__(512) conv_wino5_kernel(const WinoParams p) {
 // chunks, shared by all 512 threads: 1152 float4 row pieces + 576 halo elements (raw buffer loads one interval ahead -> GroupNorm affine +
 // SiLU -> 18x18 patch per channel), 256 (channel, tile) windows transformed by two threads each (V rows 0-2 / 3-5: 72 VALU per thread).
 // Rings of four V slabs / patch buffers, one workgroup barrier per pair of chunks — v5's protocol.
+// Schedule (measured step by step, profiles/r05_wino.md §3): the two waves of a SIMD run an interval in antiphase ([MFMA block][staging] /
+// [staging][MFMA block], one loop body); a staging block is B (the activations fetched an interval ago -> patch slab), the epilogue of a
+// finished tile (its residual rows and bias fetched one stage B ahead), A (the next pair's loads), C (window transform): A in front of C
+// because vmcnt retires in order — the MFMA block's first counted wait for a filter group also waits for every older load.
+// Developer macros (timing / accounting builds, never the product): W6X_PROF (s_memtime accounting of waves W6X_PROFW / 64 and + 4),
+// W6X_NO{A,B,C,EPI,RES,STATS,FILT,LDS,PRIO} (stage ablations), W6X_SWAP / W6X_ALLX / W6X_ALLY (roles), W6X_RING_IN_P, W6X_BFENCE / W6X_EFENCE.
 constexpr int W6PP = 20;                           // patch row pitch (18 columns: left halo, 16 pixels, right halo)
 constexpr int W6CS = 18 * W6PP;                    // 360 floats per channel
 constexpr int W6PSLAB = WCK * W6CS + 512;          // + one dummy word per thread
