@@ -77,7 +77,7 @@ void bump_dispatch_epoch();        // net_exec.hip: a process-wide option change
 unsigned dispatch_epoch();
 void set_blk_direct_dy(int v);     // net_exec.hip: option "blk_direct_dy" (read when a training plan is made)
 long winograd_packed_floats(int Cout, int Cin, int transposed);   // size of a wu / wuT buffer: the F(2x2) image (+ the F(4x4) image where conv_wino6_kernel may run)
-void set_winograd_v6(int v);    // conv_wino6_kernel (F(4x4,3x3)): 1 (default) planes >= 128x128 | 0 off | 2 every plane the kernel tiles | n >= 16: planes >= n x n
+void set_winograd_v6(int v);    // conv_wino6_kernel (F(4x4,3x3)): 1 (default) planes >= 64x64 with >= 32 workgroups per sample | 0 off | 2 every plane the kernel tiles | n >= 16: planes >= n x n
 void set_winograd_v5(int v);    // conv_wino5_kernel (128-cout tiles) where eligible: 1 (default) / 0 = conv_wino4_kernel everywhere (bit-identical)
 void set_winograd_pair(int v);  // conv_wino4_kernel: 1 (default) = one workgroup barrier per two chunks, 0 = one per chunk (bit-identical)
 void set_winograd_mode(int m);  // 0 off, 1 v1, 2 wave-specialised v2, 3 persistent v3 (default), -1 = default

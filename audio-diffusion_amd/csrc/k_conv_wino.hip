@@ -2676,28 +2676,35 @@ static int wino5_on() {
   if (g_wino5 < 0) { const char* e = getenv("ADM_WINO5"); g_wino5 = e ? atoi(e) : 1; }
   return g_wino5;
 }
-// conv_wino6_kernel (F(4x4,3x3)): 1 (default) = every layer the kernel tiles (128 | Cout, 32 | Cin, 16 | H, 16 | W) whose plane is at
-// least W6_MIN_PLANE pixels a side — a function of the LAYER only: F(4x4) is not bit-identical to F(2x2), so the choice must not depend on
-// the batch (a sample's bits must not depend on the batch it is sampled in); 0 = F(2x2,3x3) kernels everywhere; 2 = no plane-size floor (tests).
+// conv_wino6_kernel (F(4x4,3x3)): 1 (default) = every layer the kernel tiles (128 | Cout, 32 | Cin, 16 | H, 16 | W) on a plane of at least
+// 64x64 pixels whose tiles give ONE SAMPLE at least W6_MIN_WGS workgroups — a function of the LAYER only: F(4x4) is not bit-identical to
+// F(2x2), so the choice must not depend on the batch (a sample's bits must not depend on the batch it is sampled in); 0 = F(2x2,3x3) kernels
+// everywhere; 2 = every layer the kernel tiles (tests); n >= 16 = planes of at least n x n pixels, whatever their workgroup count.
 static int g_wino6 = -1;
 void set_winograd_v6(int v) { g_wino6 = v; }
 static int wino6_on() {
   if (g_wino6 < 0) { const char* e = getenv("ADM_WINO6"); g_wino6 = e ? atoi(e) : 1; }
   return g_wino6;
 }
-// The floor, measured (profiles/r05_wino.md; ms per step): B = 32 forward 73.8 without the kernel, 57.7 / 60.1 / 63.5 with floors 64 / 128 / 256;
-// the 256x256 model at B = 1 7.12 without, 8.33 / 7.31 / 6.79; the 64x64 model at B = 1 3.43 without, 4.00 / 3.42 / 3.42. One 16x16x128
-// tile is 2.25x the work of a 64-cout F(2x2) workgroup, so planes whose tiles do not fill the chip at B = 1 pay for it there — and the
-// choice cannot follow the batch. 128 keeps the latency regimes where they were and takes 22 of the 28 % at B = 32 ("wino6" = 64: the rest).
-constexpr int W6_MIN_PLANE = 128;
+// The rule, measured (profiles/r05_wino.md §5; captured loop, ms per step). One 16x16x128 tile is 2.25x the work of a 64-cout F(2x2)
+// workgroup, so a plane whose tiles do not fill the chip pays for it at small batches — and the choice cannot follow the batch:
+//                         B = 32 forward   256x256 B = 16   256x256 B = 4   256x256 B = 1   64x64 model B = 1
+//   F(2x2) only                73.8             —                —              7.12             3.43
+//   planes >= 256              63.5             —                —              6.79             3.42        ("wino6" = 256: the latency setting)
+//   planes >= 128              59.7            30.8             11.3            7.29             3.41
+//   default (below)            57.4            29.8             11.7            8.30             3.41
+//   planes >= 64               57.7             —                —              8.33             4.00
+// The default takes the 64x64 level of the 256x256 model (Cout = 256: 32 workgroups per sample) and leaves the 64x64 model's own top level
+// (Cout = 128: 16) on F(2x2): the batched configurations gain 3.6 - 3.8 % over the 128 floor, single-sample sampling at 256x256 loses 14 %.
+constexpr int W6_MIN_PLANE = 64, W6_MIN_WGS = 32;
 static bool wino6_eligible(const adm_conv_args& a) {
   if (!wino6_on()) return false;
   const int C2 = a.x2 ? a.C2 : 0;
   const int Ho = a.up ? 2 * a.H : a.H, Wo = a.up ? 2 * a.W : a.W;
   if (!wino6_layout(a.Cout, a.C1 + C2) || a.C1 % 16 != 0 || Ho % 16 != 0 || Wo % 16 != 0) return false;
   if (wino6_on() == 2) return true;
-  const int floor_px = wino6_on() >= 16 ? wino6_on() : W6_MIN_PLANE;     // (values >= 16: that plane-size floor — measurements)
-  return Ho >= floor_px && Wo >= floor_px;
+  if (wino6_on() >= 16) return Ho >= wino6_on() && Wo >= wino6_on();
+  return Ho >= W6_MIN_PLANE && Wo >= W6_MIN_PLANE && (Ho / 16) * (Wo / 16) * (a.Cout / W5BM) >= W6_MIN_WGS;
 }
 static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 4) on first use
 bool winograd_mode_available(int m) {

@@ -36,11 +36,12 @@ int adm_has_experiments(void);
  *   0 conv_wino4_kernel everywhere (same filter image, bit-identical results) | bit 1 (2): conv_wino5_kernel for every layer with 128 | Cout,
  *   however few tiles (tests) | bit 3 (8): the two halves of the workgroup run MFMA block and staging block in antiphase instead (the first
  *   schedule built; same results, same speed) | -1 (ADM_WINO5);
- * "wino6" = 1 (default, round 5) 3x3 stride-1 convolutions with 128 | Cout, 32 | Cin on planes of at least 128x128 pixels (16 | H, 16 | W) run
- *   on conv_wino6_kernel: Winograd F(4x4,3x3), 1.78x fewer MFMAs than F(2x2,3x3) at 0.6-1.7e-5 of max|out| (rms 1-4e-6; `profiles/r05_accuracy.md`) (F(2x2): 0.7-1.5e-6; the per-layer bar is
- *   1e-4). The choice depends on the layer only (the two transforms are not bit-identical) | 0 F(2x2,3x3) kernels everywhere | 2 no plane-size
- *   floor (tests) | n >= 16: planes of at least n x n pixels (64: the throughput setting — B = 32 forward 57.7 instead of 60.1 ms, at 17 % on the
- *   B = 1 step of the 256x256 model; 256: the latency setting) | -1 (ADM_WINO6);
+ * "wino6" = 1 (default, round 5) 3x3 stride-1 convolutions with 128 | Cout, 32 | Cin, 16 | H, 16 | W on planes of at least 64x64 pixels whose
+ *   16x16x128 tiles give one sample at least 32 workgroups run on conv_wino6_kernel: Winograd F(4x4,3x3), 1.78x fewer MFMAs than F(2x2,3x3) at
+ *   0.6-1.7e-5 of max|out| per layer (F(2x2): 0.7-1.5e-6; the per-layer bar is 1e-4; profiles/r05_accuracy.md). The choice depends on the layer
+ *   only (the two transforms are not bit-identical) | 0 F(2x2,3x3) kernels everywhere | 2 every layer the kernel tiles (tests) | n >= 16: planes
+ *   of at least n x n pixels (256: the latency setting — single-sample sampling at 256x256 is 18 % faster with it than with the default, a B = 32
+ *   forward 10 % slower; 128: in between) | -1 (ADM_WINO6);
  * "wino_pair" = 1 (default) one workgroup barrier per two chunks in conv_wino4_kernel | 0 one per chunk (bit-identical) | -1 (ADM_WINO_PAIR);
  * "wgrad_max_split" = n caps the split-K factor of adm_conv2d_wgrad (0 = heuristic; tests use it to put several pixel tiles on
  *   one workgroup);

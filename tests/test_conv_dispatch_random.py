@@ -74,7 +74,8 @@ def test_conv2d_random_dispatch(backend, case):
     if eligible:      # filters L2 -> registers (v4 / v5 / v6) whenever 32 | input channels, else the LDS-DMA kernel (v3)
         if Ct % 32 != 0:
             assert variant == 4313, (variant, Ct)
-        elif Cout % 128 == 0 and C1 % 16 == 0 and Hi % 16 == 0 and Wi % 16 == 0 and min(Hi, Wi) >= 128:
+        elif (Cout % 128 == 0 and C1 % 16 == 0 and Hi % 16 == 0 and Wi % 16 == 0 and min(Hi, Wi) >= 64
+              and (Hi // 16) * (Wi // 16) * (Cout // 128) >= 32):
             assert variant == 4316, (variant, Hi, Wi)          # F(4x4,3x3): by the layer alone
         elif Cout % 128 != 0:
             assert variant == 4314, (variant, Cout)

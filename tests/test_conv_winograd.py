@@ -255,7 +255,7 @@ def test_conv_wino6_f4x4_against_torch(backend, case):
     res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
     wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
     assert wu.numel() == Cout * Ct * 52                      # the F(2x2) image and the F(4x4) image behind it
-    _native.check(lib.adm_set_option(b"wino6", 2))           # 2: no plane-size floor (the default asks for planes of >= 128x128 pixels)
+    _native.check(lib.adm_set_option(b"wino6", 2))           # 2: no plane-size floor (the default asks for planes of >= 64x64 pixels with >= 32 workgroups per sample)
     try:
         out, st = ops.conv2d(x1, wp, b, 3, x2=x2, up=bool(up), gn=gn, act=bool(act), chan_add=temb, residual=res, wino=wu, stats=True)
         assert lib.adm_last_conv_variant() == 4316
@@ -277,7 +277,7 @@ def test_conv_wino6_f4x4_against_torch(backend, case):
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_conv_wino6_is_chosen_by_the_layer_alone_and_rows_do_not_depend_on_the_batch(backend):
     """F(4x4) and F(2x2) are different arithmetic, so which of them a layer runs on must not depend on the batch (a random-weight sampler
-    amplifies one bit to another picture): the default rule is the plane size (>= 128x128) and the channel counts. Row r of a batch is
+    amplifies one bit to another picture): the default rule reads the plane size and the channel counts (>= 64x64 pixels, >= 32 tiles per sample). Row r of a batch is
     bit-identical to the sample convolved alone; a 64x64 plane of the same layer stays on the F(2x2) kernels at every batch size."""
     dev = select(backend)
     from audiodiffusion import _native, ops

@@ -23,7 +23,7 @@ L=$R/audio-diffusion_amd/audiodiffusion/libadm_hip_exp.so
 for a in 1000 999 7 55; do ADM_WINO6=0 ADM_WINO5_ABL=$a ADM_LIB=$L PROBE_ONE=1 timeout 120 python tools/wino5_abl_probe.py 2>&1 | grep -v amdgpu.ids | tail -2; done > $O/wino5_cycles.txt 2>&1
 # the three Winograd generations on the same box, twice: F(4x4) v6, F(2x2) v5, F(2x2) v4
 for v in "1 1" "0 1" "0 0" "1 1" "0 1" "0 0"; do set -- $v; ADM_WINO6=$1 ADM_WINO5=$2 timeout 120 python tools/wino5_abl_probe.py 2>&1 | grep -v amdgpu.ids | sed "s/^/WINO6=$1 /"; done > $O/wino_ab.txt 2>&1
-for f in 0 128 64; do ADM_WINO6=$f timeout 200 python tools/forward_probe.py 2>&1 | grep forward; done > $O/forward_by_floor.txt 2>&1
+for f in 0 1 128 256; do ADM_WINO6=$f timeout 200 python tools/forward_probe.py 2>&1 | grep forward; done > $O/forward_by_floor.txt 2>&1
 PROBE_CHECK=1 bash tools/r05_cond_trace.sh $T/cond > $O/cond.txt 2>&1
 PROBE_MP=bf16 bash tools/profile_train_trace.sh $T/train > $O/train_trace.txt 2>&1
 PROBE="32,16;64,1;256,1" timeout 400 python tools/small_regime_probe.py > $O/small_regime.txt 2>&1
