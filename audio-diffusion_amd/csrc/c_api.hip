@@ -30,6 +30,9 @@ int adm_set_option(const char* name, int value) {
   if (nm == "conv_wino")   // validate BEFORE the value is recorded: a rejected value must neither move the epoch nor be remembered
     ADM_REQUIRE(adm::winograd_mode_available(value), "set_option: conv_wino modes 1-3 are earlier kernel generations, built only with "
                 "-DADM_EXPERIMENTS (audio-diffusion_amd/csrc/build.sh hip exp); this library has 0 (direct MFMA kernel) and 4");
+  if (nm == "wino6")
+    ADM_REQUIRE(value == -1 || value == 0 || value == 1 || value == 2 || (value >= 16 && value <= 65536),
+                "set_option: wino6 takes -1 (environment), 0 (off), 1 (default layer rule), 2 (every layer the kernel tiles) or a plane-size floor n >= 16");
   static std::mutex mu;
   static std::map<std::string, int> last;
   {

@@ -336,6 +336,7 @@ def test_the_f4x4_plane_floor_is_an_option(backend):
     w = _rand((128, 32, 3, 3), 3, dev, scale=(32 * 9) ** -0.5)
     b = _rand((128,), 4, dev)
     wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
+    assert lib.adm_set_option(b"wino6", 7) != 0 and b"wino6" in lib.adm_last_error()      # neither a mode nor a floor
     try:
         for floor_px, plane, f4 in ((64, 64, True), (64, 32, False), (256, 128, False), (-1, 128, True), (-1, 64, False)):
             _native.check(lib.adm_set_option(b"wino6", floor_px))
