@@ -25,6 +25,15 @@ from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: E402,F401
 from .unet import UNet2DConditionModel, UNet2DModel  # noqa: E402,F401
 from .vae import AutoencoderKL  # noqa: E402,F401
 
+
+
+def set_option(name: str, value: int) -> None:
+    """Process-wide runtime option of the native library (`adm_set_option`, include/adm.h). Not part of the reference's API; the one a user of the
+    drop-in is likely to want: `set_option("wino6", 256)` — the single-sample latency setting of the Winograd F(4x4,3x3) kernel (DESIGN.md §4a:
+    one 256x256 sample at a time is 18 % faster with it, a batch of 32 10 % slower than with the default), `set_option("wino6", -1)` to go back."""
+    _native.check(_native.lib().adm_set_option(name.encode(), int(value)))
+
+
 try:  # progress bars are optional plumbing
     from tqdm.auto import tqdm  # noqa: E402
 except Exception:  # pragma: no cover

@@ -345,3 +345,18 @@ def test_the_f4x4_plane_floor_is_an_option(backend):
                 assert (lib.adm_last_conv_variant() == 4316) == f4, (floor_px, plane, n, lib.adm_last_conv_variant())
     finally:
         _native.check(lib.adm_set_option(b"wino6", -1))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_the_package_level_option_setter(backend):
+    select(backend)
+    import audiodiffusion
+    from audiodiffusion import _native
+    audiodiffusion.set_option("wino6", 256)
+    try:
+        with pytest.raises(_native.NativeError):
+            audiodiffusion.set_option("wino6", 5)
+        with pytest.raises(_native.NativeError):
+            audiodiffusion.set_option("no_such_option", 1)
+    finally:
+        audiodiffusion.set_option("wino6", -1)
