@@ -462,3 +462,43 @@ def test_mel_default_config_forward_and_inverse_vs_oracle(dev):
     ref = om.image_to_audio(img0, init_phase=phase)
     assert mine.shape == ref.shape
     assert float(np.abs(mine - ref).max()) <= 1e-3 * max(1e-6, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("shape", [(256, 128, 128, 128, 0, 0), (128, 0, 128, 128, 1, 0), (256, 256, 64, 256, 0, 1)],
+                         ids=["concat-128px", "upsample-to-256px", "concat-64px-residual"])
+def test_f4x4_layers_at_size_against_float64(dev, shape):
+    """The reduced-accuracy path that ships: full-size layers of the 256x256 model through conv_wino6_kernel (Winograd
+    F(4x4,3x3)) against a float64 reference on the host — GroupNorm(32) -> SiLU -> [nearest x2] -> 3x3 convolution + bias [+ residual].
+    Measured 1.2-1.7e-5 of max|ref| on these three (profiles/r05_accuracy.md: the three largest of the table); the bar here is 4e-5 — a
+    regression guard well inside the suite's per-layer 1e-4 — and the F(2x2) kernels on the same tensors stay below 3e-6."""
+    from audiodiffusion import _native, ops
+    lib = _native.lib()
+    C1, C2, H, Co, up, has_res = shape
+    C = C1 + C2
+    g = torch.Generator().manual_seed(C1 + 7 * C2 + H + 3 * up)
+    x = torch.randn(1, C, H, H, generator=g) * 1.5 + 0.3
+    w = torch.randn(Co, C, 3, 3, generator=g) * (C * 9) ** -0.5
+    b = torch.randn(Co, generator=g) * 0.1
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    Ho = 2 * H if up else H
+    res = torch.randn(1, Co, Ho, Ho, generator=g) if has_res else None
+    h = torch.nn.functional.silu(torch.nn.functional.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5))
+    if up:
+        h = torch.nn.functional.interpolate(h, scale_factor=2.0, mode="nearest")
+    ref = torch.nn.functional.conv2d(h, w.double(), b.double(), padding=1)
+    if has_res:
+        ref = ref + res.double()
+    x1 = x[:, :C1].contiguous().to(dev)
+    x2 = x[:, C1:].contiguous().to(dev) if C2 else None
+    wd = w.to(dev)
+    wp, wu = ops.pack_conv_weight(wd), ops.pack_winograd_weight(wd)
+    gn = ops.groupnorm_stats(x1, gamma.to(dev), beta.to(dev), 32, 1e-5, x2=x2)
+    try:
+        for v6, bar in ((1, 4e-5), (0, 3e-6)):
+            _native.check(lib.adm_set_option(b"wino6", v6))
+            out = ops.conv2d(x1, wp, b.to(dev), 3, x2=x2, up=bool(up), gn=gn, act=True, wino=wu, residual=None if res is None else res.to(dev))
+            assert (lib.adm_last_conv_variant() == 4316) == bool(v6)          # the default layer rule takes all three shapes
+            err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+            assert err <= bar, (v6, err)
+    finally:
+        _native.check(lib.adm_set_option(b"wino6", -1))
