@@ -58,6 +58,7 @@ _SIGS = {
     "adm_last_error": (C.c_char_p, []),
     "adm_is_device_build": (C.c_int, []),
     "adm_last_conv_variant": (C.c_int, []),
+    "adm_release_stream": (C.c_int, [C.c_void_p]),
     "adm_has_experiments": (C.c_int, []),
     "adm_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "adm_sched_step": (C.c_int, [C.c_void_p] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),

@@ -43,6 +43,7 @@ int launch_pack_winograd_batch(const PackItem* items_dev, int n, hipStream_t st)
 int winograd_pack_flag(int Cout, int Cin, int transposed);                                // PackItem::flag of a Winograd image
 int launch_pack_bf16_batch(const PackItem* items_dev, int n, hipStream_t st);            // k_conv_bf16.hip: wb / wbT
 int launch_copy_batch(const PackItem* items_dev, int n, hipStream_t st);                 // k_conv_mfma.hip: dst[0..Cout) = src[0..Cout)
+void conv_ksplit_release(hipStream_t st);                    // give the stream's slab buffer back (before the stream is destroyed)
 float* conv_ksplit_scratch(size_t floats, hipStream_t st);   // per-(device, stream) split-K slab buffer; nullptr: take the unsplit path
 int launch_ksplit_finish(const float* part, int S, long total, const float* bias, const float* chan_add, int chan_add_stride,
                          const float* residual, float* out, int Cout, int HW, hipStream_t st);   // out = bias + ... + sum of S slabs

@@ -54,6 +54,7 @@ int adm_set_option(const char* name, int value) {
   return 0;
 }
 int adm_last_conv_variant(void) { return adm::last_conv_variant(); }
+int adm_release_stream(void* stream) { adm::conv_ksplit_release((hipStream_t)stream); return 0; }
 int adm_has_experiments(void) {
 #if defined(ADM_EXPERIMENTS)
   return 1;

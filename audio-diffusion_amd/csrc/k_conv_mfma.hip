@@ -713,12 +713,32 @@ __global__ void __launch_bounds__(256) ksplit_finish1_kernel(const float* __rest
 // 257th fails loudly instead of stealing a live stream's scratch.
 // nullptr = it cannot be provided (capture in progress and the buffer too small, table full, out of memory):
 // the callers FAIL the launch — the unsplit kernel sums in another fp32 order, and a row's bits must not depend on such things.
+// A stream's owner gives the slot back with conv_ksplit_release (adm_release_stream) before destroying the stream: a server with a stream
+// per request would otherwise keep >= 32 MiB per stream it ever used and hit the 256-slot limit.
+namespace {
+struct KsplitSlot { float* buf = nullptr; size_t cap = 0; };
+std::map<std::pair<int, hipStream_t>, KsplitSlot>& ksplit_slots() { static std::map<std::pair<int, hipStream_t>, KsplitSlot> m; return m; }
+int g_ksplit_per_dev[16] = {};
+std::mutex g_ksplit_mu;
+}  // namespace
+void conv_ksplit_release(hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_ksplit_mu);
+  const int d = conv_dev_slot();
+  auto& slots = ksplit_slots();
+  auto it = slots.find(std::make_pair(d, st));
+  if (it == slots.end()) return;
+  if (it->second.buf != nullptr) {       // launches (or a graph replay) queued on the stream may still use the slabs: drain, then free
+    (void)stream_sync(st);
+    dfree(it->second.buf);
+  }
+  slots.erase(it);
+  --g_ksplit_per_dev[d & 15];
+}
 static float* ksplit_scratch(size_t floats, hipStream_t st) {
-  struct Slot { float* buf = nullptr; size_t cap = 0; };
-  static std::map<std::pair<int, hipStream_t>, Slot> slots;
-  static int per_dev[16] = {};
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
+  typedef KsplitSlot Slot;
+  auto& slots = ksplit_slots();
+  int* per_dev = g_ksplit_per_dev;
+  std::lock_guard<std::mutex> lock(g_ksplit_mu);
   const int d = conv_dev_slot();
   bool capturing = false;
 #if !defined(ADM_EMU)
@@ -731,7 +751,7 @@ static float* ksplit_scratch(size_t floats, hipStream_t st) {
   if (it == slots.end()) {
     if (per_dev[d & 15] >= 256) {
       set_error("split-K scratch: more than 256 streams have run split-K convolutions on this device; a stream's scratch is never "
-                "taken over (captured graphs hold its address) — reuse streams");
+                "taken over (captured graphs hold its address) — reuse streams, or give a stream's slot back with adm_release_stream before destroying it");
       return nullptr;
     }
     ++per_dev[d & 15];

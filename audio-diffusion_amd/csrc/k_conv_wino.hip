@@ -2625,8 +2625,12 @@ static bool wino4_layout(int couts, int cins) {
 // the packed channel counts allow the kernel (128 | couts on top of the v4 rule) — whatever the "wino6" option says at packing time, so that
 // the option may change between packing and launch.
 static bool wino6_layout(int couts, int cins) { return wino4_layout(couts, cins) && couts % W5BM == 0; }
+// (the SIZE follows the channel counts alone — not the "conv_wino" mode at the time of the call: a buffer sized under one mode and re-packed
+//  under another must hold whichever images that mode writes)
 long winograd_packed_floats(int Cout, int Cin, int transposed) {
-  return (long)Cout * Cin * (wino6_layout(transposed ? Cin : Cout, transposed ? Cout : Cin) ? 52 : 16);
+  const int couts = transposed ? Cin : Cout, cins = transposed ? Cout : Cin;
+  const bool room6 = couts % W3BM == 0 && cins % (4 * WCK) == 0 && couts % W5BM == 0;
+  return (long)Cout * Cin * (room6 ? 52 : 16);
 }
 static int pack_winograd(const float* w, float* wu, int Cout, int Cin, int transposed, hipStream_t st) {
   long g = ((long)Cout * Cin + 255) / 256;
@@ -2845,6 +2849,7 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     if (v4 && wino6_eligible(a)) {                               // F(4x4,3x3): chosen by the layer alone (see wino6_on)
 #if !defined(ADM_EMU)
       static bool attr6[16] = {};
+      std::lock_guard<std::mutex> lk6(info_mu);
       if (!attr6[dslot]) {
         const int by6 = (int)(sizeof(float) * W6LDS);
         bool ok6 = true;

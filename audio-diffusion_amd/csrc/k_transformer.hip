@@ -6,6 +6,8 @@
 // kernel (k_conv_mfma.hip) with its bias / residual epilogue; only the four operations here are new. All HBM-bound
 // elementwise / small-GEMM work: lanes run along T (coalesced), no MFMA.
 #include <cstdint>
+#include <mutex>
+
 #include "adm_kernels.h"
 
 namespace adm {
@@ -332,14 +334,40 @@ __global__ void __launch_bounds__(512) attention_mfma_kernel(const float* __rest
     for (int r = 0; r < 4; ++r) ob[(long)(16 * dt + 4 * k4 + r) * T] = o[dt][r] * inv;
 }
 
+// 68 - 70 KiB of dynamic LDS at head_dim 32 / 64: permission asked ONCE per device, under a lock, with the answer kept (the call is not legal
+// inside a stream capture, and an ignored refusal would only show up as a generic launch error — ADVICE r5). Where the runtime refuses,
+// attention_mfma_eligible says no and the caller takes launch_attention_blocked.
+static bool attention_mfma_lds_ok(int head_dim) {
+#if !defined(ADM_EMU)
+  if (head_dim < 32) return true;                              // 34 KiB: no attribute needed
+  static int state[16][2] = {};                                // per device slot x {32, 64}: 0 unknown, 1 granted, -1 refused
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  int& s = state[conv_dev_slot() & 15][head_dim == 64];
+  if (s == 0) {
+    const int KB = head_dim <= 32 ? 256 : 128;
+    const int by = (int)(sizeof(float) * (size_t)head_dim * (KB + 16 + KB + 4));
+    const hipError_t e = head_dim == 32
+        ? hipFuncSetAttribute((const void*)attention_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, by)
+        : hipFuncSetAttribute((const void*)attention_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, by);
+    if (e != hipSuccess) (void)hipGetLastError();
+    s = e == hipSuccess ? 1 : -1;
+  }
+  return s > 0;
+#else
+  (void)head_dim;
+  return true;
+#endif
+}
+
 bool attention_mfma_eligible(int C, int T, int head_dim) {
   if (head_dim != 16 && head_dim != 32 && head_dim != 64) return false;
   const int KB = head_dim <= 32 ? 256 : 128;
-  return C % head_dim == 0 && T % 128 == 0 && T % KB == 0;
+  return C % head_dim == 0 && T % 128 == 0 && T % KB == 0 && attention_mfma_lds_ok(head_dim);
 }
 
 int launch_attention_mfma(const float* qkv, float* out, int N, int C, int T, int head_dim, hipStream_t st) {
-  ADM_REQUIRE(attention_mfma_eligible(C, T, head_dim), "attention_mfma: head_dim 16 / 32 / 64 and T % 128 == 0 (T % 256 for head_dim <= 32)");
+  ADM_REQUIRE(attention_mfma_eligible(C, T, head_dim), "attention_mfma: head_dim 16 / 32 / 64 and T % 128 == 0 (T % 256 for head_dim <= 32), and the device grants the kernel's dynamic LDS");
   ADM_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "attention_mfma: qkv must be 16-byte aligned");
   const int heads = C / head_dim;
   const int KB = head_dim <= 32 ? 256 : 128;
@@ -348,18 +376,11 @@ int launch_attention_mfma(const float* qkv, float* out, int N, int C, int T, int
   const float scale = 1.0f / sqrtf((float)head_dim);
 #define ADM_ATTM_CASE(DD)                                                                                        \
   if (head_dim == DD) {                                                                                          \
-    ADM_ATTM_ATTR(DD);                                                                                           \
     ADM_LAUNCH((attention_mfma_kernel<DD>), grid, block, smem, st, qkv, out, C, T, scale);                       \
     return ADM_CHECK_LAUNCH();                                                                                   \
   }
-#if !defined(ADM_EMU)
-#define ADM_ATTM_ATTR(DD) (void)hipFuncSetAttribute((const void*)attention_mfma_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
-#else
-#define ADM_ATTM_ATTR(DD) ((void)0)
-#endif
   ADM_ATTM_CASE(16) ADM_ATTM_CASE(32) ADM_ATTM_CASE(64)
 #undef ADM_ATTM_CASE
-#undef ADM_ATTM_ATTR
   ADM_FAIL("attention_mfma: unsupported head_dim");
 }
 

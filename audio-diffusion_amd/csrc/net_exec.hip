@@ -497,8 +497,12 @@ void Net::destroy() {
   owned.clear();
 }
 // Assign activation buffers for batch B: exact-size free lists driven by liveness.
+bool Net::plan_current(int B) const { return planned_B == B && plan_epoch == dispatch_epoch(); }
 int Net::plan(int B) {
-  if (planned_B == B) return 0;
+  // (an option set since the plan was made may have moved a layer to another kernel: the per-tensor statistic-tile counts and
+  //  partial-sum buffers below follow the kernels, so the plan is rebuilt — ADVICE r5)
+  if (plan_current(B)) return 0;
+  planned_B = 0;
   use_known = false;                       // another batch size may dispatch other kernels: re-learn which packings are read
   learned_B.clear();
   pk_valid = false;
@@ -714,6 +718,7 @@ int Net::plan(int B) {
     ADM_TRY(arena_alloc((void**)&s12, sizeof(float) * (size_t)B * groups * 2));
   }
   planned_B = B;
+  plan_epoch = dispatch_epoch();
   return 0;
 }
 

@@ -251,6 +251,7 @@ static void free_plan(adm_unet* h) {
   for (void* p : h->extra) dfree(p);
   h->extra.clear();
   h->planned_B = 0;
+  h->warm_B = 0;       // the next capture is preceded by an uncaptured forward again (another kernel's one-time set-up)
 #if !defined(ADM_EMU)
   if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
   h->gkey.clear();
@@ -264,7 +265,9 @@ static int extra_alloc(adm_unet* h, void** p, size_t bytes) {
 }
 
 static int plan(adm_unet* h, int B) {
-  if (h->planned_B == B) return 0;
+  // (re-planned as well when adm_set_option has moved since: a layer may have changed kernel, and the partial-sum buffers of the
+  //  GroupNorm statistics follow the kernels — free_plan also drops the captured graph, which holds the old kernels)
+  if (h->planned_B == B && h->net.plan_current(B)) return 0;
   free_plan(h);
   ADM_TRY(h->net.plan(B));
   ADM_TRY(extra_alloc(h, (void**)&h->emb, sizeof(float) * (size_t)B * h->temb_dim));
@@ -425,7 +428,7 @@ void adm_unet_destroy(adm_unet_t* h) {
   h->ps.free_all();
   for (void* p : h->owned) dfree(p);
 #if !defined(ADM_EMU)
-  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  if (h->own_stream) { conv_ksplit_release(h->own_stream); (void)hipStreamDestroy(h->own_stream); }
 #endif
   delete h;
 }

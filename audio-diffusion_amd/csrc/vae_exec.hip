@@ -192,7 +192,7 @@ int adm_vae_encode(adm_vae_t* h, const float* x, const float* noise, float out_s
   ADM_TRY(vae_finalize(h));
   const int Cz = h->cfg.latent_channels;
   const long hw = (long)h->lat_h * h->lat_w;
-  if (h->planned_B_enc != B) {
+  if (h->planned_B_enc != B || !h->enc.plan_current(B)) {
     ADM_TRY(stream_sync(st));
     ADM_TRY(h->enc.plan(B));
     if (h->moments) dfree(h->moments);
@@ -209,7 +209,7 @@ int adm_vae_decode(adm_vae_t* h, const float* z, float in_scale, float* out, int
   hipStream_t st = (hipStream_t)stream;
   ADM_TRY(vae_finalize(h));
   const long n = (long)B * h->cfg.latent_channels * h->lat_h * h->lat_w;
-  if (h->planned_B_dec != B) {
+  if (h->planned_B_dec != B || !h->dec.plan_current(B)) {
     ADM_TRY(stream_sync(st));
     ADM_TRY(h->dec.plan(B));
     if (h->zq) dfree(h->zq);

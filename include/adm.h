@@ -59,6 +59,10 @@ int adm_has_experiments(void);
  * The dispatch epoch moves only when a value really changes; set options BEFORE adm_unet_refresh_weights / the next train step.
  * adm_version() = 102 since round 5 (Winograd filter buffers hold two images: adm_winograd_packed_floats); 101 since round 4 (adm_slerp_grid takes DOUBLE weights since round 3; blocked-image entry points). */
 int adm_set_option(const char* name, int value);
+/* Per-(device, stream) scratch the library keeps for a stream (the split-K slab buffer of the small-plane convolutions, >= 32 MiB, at most
+ * 256 streams per device): give it back BEFORE destroying a stream that has run library calls. Drains the stream first (a captured graph of
+ * that stream holds the buffer's address: destroy or stop replaying such graphs before). No-op for a stream the library holds nothing for. */
+int adm_release_stream(void* stream);
 /* Kernel variant the last adm_conv2d on this thread dispatched to (see adm_op_profile.variant; 4311 = Winograd). */
 int adm_last_conv_variant(void);
 

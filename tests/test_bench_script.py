@@ -100,5 +100,6 @@ def test_bench_py_one_rank_training_leg_runs_the_overlapped_all_reduce_in_its_ow
     d = _run(1, ["--no-mel-leg"])
     tr = d["train"]
     assert "error" not in tr, tr
-    assert tr["one_rank_group"] is True and tr["allreduce_buckets_overlapped"] == tr["allreduce_buckets"] >= 1
-    assert tr["allreduce_overlapped_on_every_rank"] is True
+    own = tr["one_rank_group"]          # the headline of the leg is measured WITHOUT the group, the one-rank run is reported beside it
+    assert "error" not in own and own["allreduce_buckets_overlapped"] == own["allreduce_buckets"] >= 1 and own["ms_per_step"] > 0
+    assert tr["allreduce_overlapped_on_every_rank"] is None and tr["ms_per_step"] > 0

@@ -17,6 +17,17 @@ CFG256 = dict(sample_size=(256, 256), in_channels=1, out_channels=1, layers_per_
               up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4)
 
 
+def _record(what, **figures):
+    """ADM_ACCURACY_LOG=<file>: every end-to-end figure these tests measure is appended there as one JSON line (with the `wino6` setting the
+    library runs under) — `tools/r06_accuracy.sh` runs the file with the F(4x4) kernel on and off and formats profiles/r06_accuracy.md from it."""
+    import json
+    import os
+    path = os.environ.get("ADM_ACCURACY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(what=what, wino6=os.environ.get("ADM_WINO6", "default"), **figures)) + "\n")
+
+
 @pytest.fixture(scope="module")
 def dev():
     return select("hip")
@@ -37,6 +48,7 @@ def test_unet_256_matches_the_oracle_at_batch_1(dev, unet):
         with torch.no_grad():
             r = ref(x, torch.tensor(t))["sample"]
         o = unet(x.to(dev), torch.tensor(t))["sample"].cpu()
+        _record(f"whole UNet 256x256, B = 1, t = {t}: max|d| / max|ref|", value=float((o - r).abs().max()) / float(r.abs().max()), bar=1e-4)
         assert float((o - r).abs().max()) <= 1e-4 * float(r.abs().max()), (t, float((o - r).abs().max()))
 
 
@@ -133,6 +145,8 @@ def _loop_parity(dev, cfg, sched_name, steps, start_step, B, seed, vae_cfg=None,
     a = np.stack([np.asarray(i).astype(int) for i in mi])
     b = np.stack([np.asarray(i).astype(int) for i in ri])
     assert a.shape == b.shape
+    _record(f"loop {sched_name.upper()} {hw[0]}x{hw[1]}{' latent + VAE decode' if vae_cfg else ''}, steps {start_step}..{steps}, B = {B}, eta {eta}",
+            float_err=err, bar=1e-3, max_lsb=int(np.abs(a - b).max()), identical_pixels=float((a == b).mean()))
     assert err <= 1e-3, err
     assert np.abs(a - b).max() <= 1 and (a == b).mean() >= 0.995, (np.abs(a - b).max(), (a == b).mean())
     return err
@@ -215,6 +229,8 @@ def test_config3_complete_ddim50_sampling_matches_the_oracle_on_a_briefly_traine
     ri, rf = ref(batch_size=1, noise=noise.clone(), audio=False, return_float=True)                        # 50 oracle steps
     err = float((mf[0:1].cpu() - rf).abs().max())
     a, b = np.asarray(mi[0]).astype(int), np.asarray(ri[0]).astype(int)
+    _record("complete DDIM-50 256x256, checkpoint 1 (120 optimizer steps), noise seed 1234", float_err=err, bar=1e-3,
+            max_lsb=int(np.abs(a - b).max()), identical_pixels=float((a == b).mean()), perturbation_growth=calm)
     assert err <= 1e-3, err
     assert np.abs(a - b).max() <= 1 and (a == b).mean() >= 0.995, (np.abs(a - b).max(), (a == b).mean())
     assert float(rf.std()) > 0.02, "degenerate sample: the comparison would be vacuous"
@@ -232,6 +248,8 @@ def test_config3_complete_ddim50_sampling_matches_the_oracle_on_a_briefly_traine
     ri2, rf2 = ref(batch_size=1, noise=noise2.clone(), audio=False, return_float=True)
     err2 = float((mf2.cpu() - rf2).abs().max())
     a2, b2 = np.asarray(mi2[0]).astype(int), np.asarray(ri2[0]).astype(int)
+    _record("complete DDIM-50 256x256, checkpoint 2 (+40 optimizer steps), noise seed 777", float_err=err2, bar=1e-3,
+            max_lsb=int(np.abs(a2 - b2).max()), identical_pixels=float((a2 == b2).mean()))
     assert err2 <= 1e-3, err2
     assert np.abs(a2 - b2).max() <= 1 and (a2 == b2).mean() >= 0.995, (np.abs(a2 - b2).max(), (a2 == b2).mean())
     assert float(rf2.std()) > 0.02 and float((rf2 - rf).abs().max()) > 0.05, "the second sample must be another picture"

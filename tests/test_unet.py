@@ -125,3 +125,38 @@ def test_groupnorm_from_the_split_k_finish_pass(backend, cfg):
     for o in outs.values():
         assert float((o - r).abs().max()) < 1e-3 * max(1.0, float(r.abs().max()))
     assert float((outs[0] - outs[1]).abs().max()) < 1e-5 * max(1.0, float(r.abs().max()))
+
+
+W6NET = dict(sample_size=32, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(128, 128),
+             down_block_types=("DownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "UpBlock2D"))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_an_option_set_between_two_forwards_re_plans_the_net(backend):
+    """`set_option("wino6", ...)` moves layers between the F(4x4) and the F(2x2) kernel, whose GroupNorm partial-sum tiles differ
+    (16x16 / 8x16 pixels); a net planned before the change kept the old tile counts and failed (`stats_tiles does not match`) — and a captured
+    loop kept the old kernels. Forward, change the option, forward, change it back, forward: every pass matches the oracle, and the loop too."""
+    import audiodiffusion
+    from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, Mel, _native
+    dev = select(backend)
+    ref, mine = _pair(W6NET)
+    x = torch.randn(2, 1, 32, 32, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        r = ref(x, 500)["sample"]
+    variants = []
+    try:
+        for v in (2, 0, 2, -1):                    # every layer the kernel tiles -> F(2x2) only -> back -> the environment's default
+            audiodiffusion.set_option("wino6", v)
+            o = mine(x.to(dev), 500)["sample"].cpu()
+            assert float((o - r).abs().max()) < 1e-3 * max(1.0, float(r.abs().max())), v
+            variants.append(_native.lib().adm_last_conv_variant())
+        pipe = AudioDiffusionPipeline(None, mine, Mel(x_res=32, y_res=32, hop_length=256, n_fft=1024, n_iter=2), DDIMScheduler()).to(dev)
+        pipe.set_progress_bar_config(disable=True)
+        outs = []
+        for v in (2, 0, 2):                        # the captured loop: same noise, the option changed between samplings
+            audiodiffusion.set_option("wino6", v)
+            outs.append(pipe(batch_size=2, steps=3, noise=x.clone().to(dev), audio=False, return_float=True)[1].cpu())
+        assert torch.equal(outs[0], outs[2])       # back under the first setting: the same kernels, the same bits
+        assert float((outs[0] - outs[1]).abs().max()) < 1e-3
+    finally:
+        audiodiffusion.set_option("wino6", -1)
