@@ -69,7 +69,7 @@ int launch_ksplit_finish_gn(const float* part, int S, long part_stride, const fl
 const float* conv_zero_bias(int n);  // shared all-zero device buffer of >= n floats (k_conv_mfma.hip)
 const float* conv_const_ones(int n); // shared all-ones device buffer of >= n floats
 int conv_dev_slot();                 // current HIP device as an index 0..15 (per-device static state: constant buffers, LDS attributes)
-bool winograd_mode_available(int m); // k_conv_wino.hip: modes 1-3 (earlier kernel generations) exist only in -DADM_EXPERIMENTS builds
+bool winograd_mode_available(int m); // k_conv_wino.hip: 0 and 4 (modes 1-3 were the kernel generations retired in round 6)
 int launch_pack_winograd_weight(const float* w, float* wu, int Cout, int Cin, hipStream_t st);
 int launch_pack_winograd_weight_T(const float* w, float* wu, int Cout, int Cin, hipStream_t st);  // data-gradient filters
 bool winograd_enabled();

@@ -28,8 +28,8 @@ int adm_set_option(const char* name, int value) {
   // the dispatch epoch (training nets re-learn which weight images they read: a full re-pack) moves only when a value really
   // changes — a model that sets the options it already runs under (every enable_training does) leaves other nets alone
   if (nm == "conv_wino")   // validate BEFORE the value is recorded: a rejected value must neither move the epoch nor be remembered
-    ADM_REQUIRE(adm::winograd_mode_available(value), "set_option: conv_wino modes 1-3 are earlier kernel generations, built only with "
-                "-DADM_EXPERIMENTS (audio-diffusion_amd/csrc/build.sh hip exp); this library has 0 (direct MFMA kernel) and 4");
+    ADM_REQUIRE(adm::winograd_mode_available(value), "set_option: conv_wino takes -1 (environment), 0 (direct MFMA kernel only) or 4 (Winograd kernels: "
+                "the default); modes 1-3 were earlier kernel generations, retired in round 6");
   if (nm == "wino6")
     ADM_REQUIRE(value == -1 || value == 0 || value == 1 || value == 2 || (value >= 16 && value <= 65536),
                 "set_option: wino6 takes -1 (environment), 0 (off), 1 (default layer rule), 2 (every layer the kernel tiles) or a plane-size floor n >= 16");
@@ -55,13 +55,7 @@ int adm_set_option(const char* name, int value) {
 }
 int adm_last_conv_variant(void) { return adm::last_conv_variant(); }
 int adm_release_stream(void* stream) { adm::conv_ksplit_release((hipStream_t)stream); return 0; }
-int adm_has_experiments(void) {
-#if defined(ADM_EXPERIMENTS)
-  return 1;
-#else
-  return 0;
-#endif
-}
+int adm_has_experiments(void) { return 0; }   // (kept for ABI stability: the experiments builds were retired in round 6)
 int adm_is_device_build(void) {
 #if defined(ADM_EMU)
   return 0;

@@ -24,13 +24,13 @@ int adm_version(void);
 const char* adm_last_error(void);
 /* 1 if built for the device (hipcc, gfx950), 0 for the CPU-emulation test build. */
 int adm_is_device_build(void);
-/* 1 if built with -DADM_EXPERIMENTS: the superseded Winograd kernel generations ("conv_wino" = 1 / 2 / 3) and the developer-aid
- * ablation / profiling instantiations of conv_wino4_kernel are present; 0 (the product build) otherwise. */
+/* Always 0 since round 6 (kept for ABI stability): rounds 1-5 had -DADM_EXPERIMENTS builds carrying superseded Winograd kernel generations
+ * ("conv_wino" = 1 / 2 / 3) and ablation / cycle-accounting instantiations; they were retired with that code. */
 int adm_has_experiments(void);
 /* Runtime options (process-wide; a training net re-learns which weight images it reads after any change):
- * "conv_wino" = 0 (direct MFMA kernel only) | 4 (default: conv_wino4_kernel, filters L2 -> registers; it has its own filter image,
- *   so set the mode BEFORE weights are packed) | -1 (back to the default / ADM_CONV_WINO environment variable) | 1 / 2 / 3 (earlier
- *   Winograd kernel generations: only in a library built with -DADM_EXPERIMENTS, see adm_has_experiments; an error otherwise);
+ * "conv_wino" = 0 (direct MFMA kernel only) | 4 (default: the Winograd kernels wherever they tile the layer; they have their own filter image,
+ *   so set the mode BEFORE weights are packed) | -1 (back to the default / ADM_CONV_WINO environment variable); 1 / 2 / 3 (earlier kernel
+ *   generations, retired in round 6) are an error;
  * "wino5" = 1 (default, round 5) layers with 128 | Cout whose 128-cout workgroup tiles fill the chip run on conv_wino5_kernel (every input patch
  *   transformed once per 128 output channels; all eight waves are MFMA waves and share the staging work, placed between their MFMA groups) |
  *   0 conv_wino4_kernel everywhere (same filter image, bit-identical results) | bit 1 (2): conv_wino5_kernel for every layer with 128 | Cout,
@@ -42,7 +42,7 @@ int adm_has_experiments(void);
  *   only (the two transforms are not bit-identical) | 0 F(2x2,3x3) kernels everywhere | 2 every layer the kernel tiles (tests) | n >= 16: planes
  *   of at least n x n pixels (256: the latency setting — single-sample sampling at 256x256 is 18 % faster with it than with the default, a B = 32
  *   forward 10 % slower; 128: in between) | -1 (ADM_WINO6);
- * "wino_pair" = 1 (default) one workgroup barrier per two chunks in conv_wino4_kernel | 0 one per chunk (bit-identical) | -1 (ADM_WINO_PAIR);
+ * "wino_pair": accepted and ignored since round 6 (conv_wino4_kernel keeps one cadence: one workgroup barrier per two chunks);
  * "wgrad_max_split" = n caps the split-K factor of adm_conv2d_wgrad (0 = heuristic; tests use it to put several pixel tiles on
  *   one workgroup);
  * "conv_bf16" = 1 runs eligible 3x3 stride-1 convolutions (forward, data gradient and weight gradient) on 16-bit MFMA operands

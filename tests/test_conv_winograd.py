@@ -20,19 +20,13 @@ CASES = [
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("mode", [1, 2, 3, 4], ids=["v1", "v2wavespec", "v3persistent", "v4regfilters"])
-@pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
+@pytest.mark.parametrize("mode", [4], ids=["v4regfilters"])       # (modes 1-3 were the kernel generations retired in round 6)
+@pytest.mark.parametrize("case", [c for c in CASES if c[5] % 64 == 0 and (c[1] + c[2]) % 32 == 0 and not (c[8] and not c[7])],
+                         ids=lambda c: "-".join(str(v) for v in c))
 def test_conv_winograd(backend, case, mode):
+    """conv_wino4_kernel tiles 64 output and 32 input channels (four chunks in flight) and needs GroupNorm whenever SiLU is requested."""
     dev = select(backend)
     from audiodiffusion import _native, ops
-    if mode < 4 and not _native.lib().adm_has_experiments():
-        pytest.skip("modes 1-3 are superseded kernel generations: built only with -DADM_EXPERIMENTS (build.sh ... exp)")
-    if mode >= 2 and case[5] % 64 != 0:
-        pytest.skip("v2/v3 tile 64 output channels")
-    if mode >= 3 and ((case[8] and not case[7]) or (case[1] + case[2]) % 16 != 0):
-        pytest.skip("v3/v4 need an even number of 8-channel chunks (and GroupNorm whenever SiLU is requested)")
-    if mode == 4 and (case[1] + case[2]) % 32 != 0:
-        pytest.skip("v4 tiles 32 input channels (four chunks in flight)")
     _native.check(_native.lib().adm_set_option(b"conv_wino", mode))
     _native.check(_native.lib().adm_set_option(b"wino5", 0))            # this test pins conv_wino4_kernel (v5 has its own below)
     try:
@@ -65,15 +59,12 @@ def _run_case(dev, case, want_variant):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("mode,Cin,Cout,variant", [(3, 64, 32, 4313), (4, 64, 32, 4314), (4, 128, 64, 4315)],
-                         ids=["v3", "v4", "v5-128-couts"])
+@pytest.mark.parametrize("mode,Cin,Cout,variant", [(4, 64, 32, 4314), (4, 128, 64, 4315)], ids=["v4", "v5-128-couts"])
 def test_conv_winograd_data_gradient(backend, mode, Cin, Cout, variant):
     """3x3 stride-1 backward-data pass as a Winograd convolution with transposed/flipped filters vs torch autograd
     (the data-gradient convolution maps Cout -> Cin channels, so ITS output-channel count is the forward's Cin)."""
     dev = select(backend)
     from audiodiffusion import _native, ops
-    if mode < 4 and not _native.lib().adm_has_experiments():
-        pytest.skip("mode 3 is a superseded kernel generation: built only with -DADM_EXPERIMENTS")
     Nn, H, W = 2, 16, 32
     w = _rand((Cout, Cin, 3, 3), 11, dev, scale=(Cin * 9) ** -0.5)
     dy = _rand((Nn, Cout, H, W), 12, dev)
@@ -126,44 +117,6 @@ def test_groupnorm_statistics_from_the_conv_epilogue(backend):
     # a kernel without the epilogue reports 0 tiles
     _, none = ops.conv2d(x, ops.pack_conv_weight(w1[:, :, :1, :1].contiguous()), b1, 1, pad_lo=0, stats=True)
     assert none is None
-
-
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("shape", [(2, 64, 0, 16, 32, 64, 0), (3, 32, 32, 8, 16, 128, 0), (1, 96, 0, 8, 16, 64, 1), (5, 128, 0, 8, 16, 64, 0)],
-                         ids=["64to64", "concat-two-cout-tiles", "upsample-fold", "several-tiles-per-block"])
-def test_conv_wino4_barrier_cadence_does_not_change_a_bit(backend, shape):
-    """conv_wino4_kernel with one workgroup barrier per TWO chunks (round 3's default: rings of four V slabs / patch buffers) against one
-    barrier per chunk (`wino_pair` 0): the same arithmetic in the same order — outputs must be bit-identical, on the emulator and on
-    the MI355X, where a hand-over that came too early would show (GroupNorm + SiLU on the load path, per-sample term, residual, statistics
-    epilogue, persistent blocks walking several tiles so that the rings roll over tile boundaries)."""
-    dev = select(backend)
-    from audiodiffusion import _native, ops
-    Nn, C1, C2, H, W, Cout, up = shape
-    lib = _native.lib()
-    _native.check(lib.adm_set_option(b"conv_wino", 4))
-    x1 = _rand((Nn, C1, H, W), 1, dev)
-    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
-    w = _rand((Cout, C1 + C2, 3, 3), 3, dev, scale=((C1 + C2) * 9) ** -0.5)
-    b, temb = _rand((Cout,), 4, dev), _rand((Nn, Cout), 7, dev)
-    gamma, beta = _rand((C1 + C2,), 5, dev), _rand((C1 + C2,), 6, dev)
-    gn = ops.groupnorm_stats(x1, gamma, beta, 32, 1e-5, x2=x2)
-    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
-    res = _rand((Nn, Cout, Ho, Wo), 8, dev)
-    wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
-    outs = []
-    try:
-        _native.check(lib.adm_set_option(b"wino5", 0))
-        for pair in (0, 1):
-            _native.check(lib.adm_set_option(b"wino_pair", pair))
-            o, st = ops.conv2d(x1, wp, b, 3, x2=x2, up=bool(up), gn=gn, act=True, chan_add=temb, residual=res, wino=wu, stats=True)
-            assert lib.adm_last_conv_variant() == 4314
-            outs.append((o.clone(), None if st is None else st.clone()))
-    finally:
-        _native.check(lib.adm_set_option(b"wino_pair", -1))
-        _native.check(lib.adm_set_option(b"conv_wino", -1))
-        _native.check(lib.adm_set_option(b"wino5", -1))
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert (outs[0][1] is None) == (outs[1][1] is None) and (outs[0][1] is None or torch.equal(outs[0][1], outs[1][1]))
 
 
 # ---- round 5: conv_wino5_kernel (128-cout workgroup tiles; every wave MFMA + staging, the two halves in antiphase) -------------------

@@ -14,8 +14,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 def _usage(src):
-    # (the flags of csrc/build.sh: k_conv_wino.hip is built without SLP vectorisation)
-    extra = ["-fno-slp-vectorize"] if src == "k_conv_wino.hip" else []
+    # (the flags of csrc/build.sh: k_conv_wino*.hip are built without SLP vectorisation)
+    extra = ["-fno-slp-vectorize"] if src.startswith("k_conv_wino") else []
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", src, "-o", os.devnull,
                         "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -33,7 +33,9 @@ def _usage(src):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("src,max_scratch", [
-    ("k_conv_wino.hip", 0),              # the headline kernel (persistent wave-specialised Winograd) and its predecessors
+    ("k_conv_wino_f4.hip", 0),           # the headline kernel: conv_wino6_kernel, Winograd F(4x4,3x3)
+    ("k_conv_wino_f2.hip", 0),           # F(2x2,3x3): conv_wino5_kernel, conv_wino4_kernel
+    ("k_conv_wino.hip", 0),              # the filter packers
     ("k_conv_wgrad.hip:sp8|sp_kernel|pf_kernelILi3ELb1|pf_kernelILi1ELb1", 0),   # fp32 weight gradients on the fast paths (the
                                          # generic 1x1 fallback `pf_kernel<1, false>` is known to spill; it serves odd chunkings only)
     ("k_conv_bf16.hip", 0),              # measured defaults: forward / data gradient, weight gradient, packing

@@ -1,6 +1,6 @@
-"""Timing of conv_wino5_kernel on 128->128 @256x256, B = 32 (and 256+128 -> 128 @128x128) under the ADM_WINO5_ABL stage / role ablations and
-the ADM_WINO5_PROF cycle accounting (experiments build):
-  for a in 0 7 56 32 16 48 55 64 1 2 4 128 8 119; do ADM_WINO5_ABL=$a ADM_LIB=.../libadm_hip_exp.so python tools/wino5_abl_probe.py; done"""
+"""Event timing of the Winograd convolution on two layers of the bench workload (128 -> 128 @256x256 and 256 + 128 -> 128 @128x128, B = 32; GroupNorm +
+SiLU on load, residual), with the cycles per 8-channel chunk and CU beside the MFMA cycles they contain. ADM_LIB=<tools/variants/libadm_X.so>,
+ADM_WINO6 / ADM_WINO5 select the build / kernel; PROBE_ONE=1: the first layer only."""
 import os
 import sys
 
@@ -38,5 +38,5 @@ for (C1, C2, H, Co) in shapes:
     else:
         tiles, mfma = 32 * (H // 8) * (H // 16) * (Co // (128 if var == 4315 else 64)), (4096 if var == 4315 else 2048)
     chunks = tiles / 256 * (C // 8)
-    print(f"W5={os.environ.get('ADM_WINO5', '1')} ABL={os.environ.get('ADM_WINO5_ABL', '0')} variant {var} {C}->{Co}@{H}: {ms:.3f} ms  "
+    print(f"W5={os.environ.get('ADM_WINO5', '1')} variant {var} {C}->{Co}@{H}: {ms:.3f} ms  "
           f"= {ms * 1e3 / chunks:.3f} us per chunk and CU ({ms * 1e3 / chunks * 2.1e3:.0f} cycles at 2.1 GHz; MFMA {mfma} per SIMD)", flush=True)
