@@ -526,25 +526,49 @@ def roofline(unet, x, B):
            "traffic": None, "launches_per_forward": cnt, "avg_launch_us": round(ms / cnt * 1e3, 2),
            "avg_algorithmic_flops_per_launch": fl / cnt, "share_of_forward_time": round(ms / total_ms, 3),
            "forward_ms": round(total_ms, 3), "forward_breakdown": breakdown}
-    # HBM bytes per launch of the dominant kernel: bench.py cannot collect PMC counters itself, so it reports the newest committed
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass over one forward of this workload (tools/pmc_forward.py), if present.
-    pmc, src = None, None
+    # HBM bytes per launch of the dominant kernel: bench.py cannot collect PMC counters itself, so it reports the committed rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE pass over one forward of this workload (tools/pmc_forward.sh) — but ONLY a pass that was made of THIS build:
+    # the file carries the library's adm_version() and a hash of the Winograd kernel sources (kernel_stamp), and a pass whose stamp differs
+    # from the sources in the tree is refused (a kernel change that keeps the launch count would otherwise print stale traffic — VERDICT r5).
+    stamp = kernel_stamp()
+    pmc, src, stale = None, None, []
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_forward.json")), reverse=True):
         try:
-            pmc, src = json.load(open(f))["by_variant"].get(str(var)), os.path.relpath(f, ROOT)
+            doc = json.load(open(f))
+            cand = doc["by_variant"].get(str(var))
         except (OSError, ValueError, KeyError):
-            pmc = None
-        if pmc and pmc.get("launches_per_forward") == cnt:
-            break
-        pmc = None
+            continue
+        if not cand or cand.get("launches_per_forward") != cnt:
+            continue
+        if doc.get("stamp") != stamp:
+            stale.append(os.path.relpath(f, ROOT))
+            continue
+        pmc, src = cand, os.path.relpath(f, ROOT)
+        break
     if pmc:
         by = sum(r[4] for r in rows if r[0] == 1 and r[1] == var)
         out["traffic"] = round(pmc["hbm_bytes_per_launch"])
         out["traffic_unit"] = "B/launch"
         out["algorithmic_bytes_per_launch"] = round(by / cnt)
-        out["traffic_source"] = (f"{src}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes over one B=32 "
-                                 "forward of this workload; includes Infinity-Cache hits")
+        out["traffic_source"] = (f"{src} (stamp {stamp['kernel_sources_sha16']}, adm_version {stamp['adm_version']} = this build): rocprofv3 --pmc "
+                                 "FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes over one B=32 forward of this workload; includes Infinity-Cache hits")
+    else:
+        out["traffic_source"] = ("no PMC pass of THIS build under profiles/ (tools/pmc_forward.sh writes one; passes of other builds are refused" +
+                                 (": " + ", ".join(stale[:3]) if stale else "") + ")")
     return out
+
+
+def kernel_stamp():
+    """What a PMC pass must have been made of to be quoted beside this build's timings: the library's ABI version and a hash of the Winograd
+    kernel sources (the dominant kernel's translation units)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "audio-diffusion_amd", "csrc")
+    for name in ("k_conv_wino.h", "k_conv_wino.hip", "k_conv_wino_f2.hip", "k_conv_wino_f4.hip"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    from audiodiffusion import _native as N
+    return {"adm_version": int(N.lib().adm_version()), "kernel_sources_sha16": h.hexdigest()[:16]}
 
 
 def configs_leg(job):

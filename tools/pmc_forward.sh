@@ -7,8 +7,12 @@ cd /tmp && export TMPDIR=/tmp
 for CTR in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $O/$CTR -- python $R/tools/pmc_forward.py > $O/$CTR.log 2>&1
 done
-python - <<PY
-import csv, glob, json, collections
+cd $R && python - <<PY
+import csv, glob, json, collections, sys
+sys.path.insert(0, "$R"); sys.path.insert(0, "$R/audio-diffusion_amd")
+from audiodiffusion import _native
+_native.load()
+from bench import kernel_stamp          # the stamp bench.py checks before it quotes this pass
 O = "$O"
 tot = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 cnt = collections.Counter()
@@ -33,7 +37,7 @@ def group(pred):
     w = sum(tot["WRITE_SIZE"][k] for k in ks) / 2 * 1024
     return {"kernel": " | ".join(sorted({k[:40] for k in ks})), "launches_per_forward": int(n), "fetch_bytes_per_forward": f,
             "write_bytes_per_forward": w, "hbm_bytes_per_launch": (f + w) / max(n, 1)}
-out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over two eager UNet forwards, B=32, 256x256 (tools/pmc_forward.sh), halved; "
+out = {"stamp": kernel_stamp(), "_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over two eager UNet forwards, B=32, 256x256 (tools/pmc_forward.sh), halved; "
                    "FETCH_SIZE doubled (gfx950 reports 1/2 of 16 B/lane streaming reads; check: gn_stats_kernel reads exactly its inputs — 21.2 GB per forward "
                    "when every GroupNorm runs the read pass (ADM_GN_FOLD=0), the inputs of the remaining read passes otherwise). "
                    "Infinity-Cache hits are counted by this counter.",
