@@ -43,8 +43,11 @@ def sample_sharded(pipe, global_batch, steps=None, seed=42, eta=0.0, gather=True
     if n_noise:
         it = iter(sn)
         step_noise = [next(it)[lo:hi].to(dev) if r["k_noise"] != 0.0 else None for r in rows]
-    _, u8 = pipe._denoise(x[lo:hi].contiguous().to(dev), 0, eta, None, None, 0, 0, step_noise=step_noise)
-    u8 = u8.reshape(hi - lo, H, W)
+    if hi > lo:
+        _, u8 = pipe._denoise(x[lo:hi].contiguous().to(dev), 0, eta, None, None, 0, 0, step_noise=step_noise)
+        u8 = u8.reshape(hi - lo, H, W)
+    else:      # more ranks than rows (global_batch < world * per): this rank owns nothing, and still takes part in the gather
+        u8 = torch.zeros((0, H, W), dtype=torch.uint8, device=dev)
     if not gather or not dist.is_initialized():      # a 1-rank group still goes through the collective (RCCL shake-out)
         return u8, (lo, hi)
     per = (global_batch + world - 1) // world

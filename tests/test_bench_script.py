@@ -63,6 +63,16 @@ def test_bench_py_result_is_independent_of_the_rank_count_and_a_bare_gpus_2_laun
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["global_batch"] == 4 and two["value"] > 0
     assert one["gathered_checksum"] is None
     assert one_pg["gathered_checksum"] == two["gathered_checksum"] and two["gathered_checksum"] > 0
+    # an UNEVEN global batch: 3 rows on 2 ranks = shards of 2 and 1, the short one padded for the gather; the first
+    # three rows of the same seed on one rank give the same images (rows never interact, and the noise of row r does not depend on the batch)
+    os.environ["ADM_BENCH_FORCE_PG"] = "1"
+    try:
+        three = _run(1, ["--batch-per-gpu", "3", "--no-train-leg", "--no-mel-leg"])
+    finally:
+        del os.environ["ADM_BENCH_FORCE_PG"]
+    uneven = _run(2, ["--no-train-leg", "--no-mel-leg", "--scaling", "strong", "--global-batch", "3"])
+    assert uneven["config"]["global_batch"] == 3 and uneven["value"] > 0
+    assert uneven["gathered_checksum"] == three["gathered_checksum"] > 0
 
 
 def test_bench_py_reports_a_hung_training_leg_beside_the_measured_headline():

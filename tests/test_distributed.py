@@ -27,14 +27,14 @@ def _pipe(kind):
     return pipe
 
 
-def _worker(rank, world, port, kind, q):
+def _worker(rank, world, port, kind, q, global_batch=3):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       ADM_EMU_THREADS="2")
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from audiodiffusion.distributed import sample_sharded
     pipe = _pipe(kind)
-    out, (lo, hi) = sample_sharded(pipe, global_batch=3, steps=2, seed=5)
+    out, (lo, hi) = sample_sharded(pipe, global_batch=global_batch, steps=2, seed=5)
     if rank == 0:
         q.put((out.cpu().numpy().copy(), (lo, hi)))  # by value: the producer may exit before the parent reads
     dist.barrier()
@@ -60,3 +60,32 @@ def test_sharded_sampling_matches_single_process(kind):
     assert (lo, hi) == (0, 2)
     assert out.shape == single.shape == (3, 16, 16)
     assert torch.equal(out, single.cpu())
+
+
+def test_shard_bounds_of_an_uneven_global_batch():
+    """config 3 with a batch the GPU count does not divide: ceil-sized shards, the last one short, ranks beyond the rows empty —
+    contiguous, disjoint, covering [0, global_batch)."""
+    from audiodiffusion.distributed import shard_bounds
+    b = [shard_bounds(250, 8, r) for r in range(8)]
+    assert b == [(32 * r, 32 * r + 32) for r in range(7)] + [(224, 250)]
+    assert [shard_bounds(10, 8, r) for r in range(8)] == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 10), (10, 10), (10, 10)]
+    for gb, w in ((250, 8), (10, 8), (1, 2), (256, 8), (7, 3)):
+        bs = [shard_bounds(gb, w, r) for r in range(w)]
+        assert bs[0][0] == 0 and bs[-1][1] == gb and all(bs[i][1] == bs[i + 1][0] for i in range(w - 1)) and all(lo <= hi for lo, hi in bs)
+
+
+def test_a_rank_without_rows_still_takes_part_in_the_gather():
+    """global_batch 1 on two ranks: rank 1 owns no row, samples nothing, and the padded all_gather still returns the single-process image."""
+    from audiodiffusion.distributed import sample_sharded
+    single, _ = sample_sharded(_pipe("ddim"), global_batch=1, steps=2, seed=5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, "ddim", q, 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out, (lo, hi) = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert (lo, hi) == (0, 1) and torch.equal(torch.from_numpy(out), single.cpu())
