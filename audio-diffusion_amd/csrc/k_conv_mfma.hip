@@ -385,8 +385,12 @@ __global__ void __launch_bounds__(256, STRIDE == 2 ? 2 : 1) conv_mfma_kernel(con
 // order together with bias / per-sample term / residual. Deterministic, and the tile can be 64 couts wide: at 8x8 pixels and B = 32
 // the 32-cout tiles that fill the chip without it move 20.7 KB per 2304 MFMA cycles — two co-resident workgroups sit at the
 // ~10 B/clk a CU is served with (109 us per 512->512 layer whatever the split).
+// 1x1 (round 6): THREE workgroups per CU. A 1x1 tile is short (K = Cin in 8 chunks of 32 channels: 32.8 k cycles of MFMA in an 89 k-cycle
+// workgroup lifetime, profiles/r03_pmc_conv1x1.md) and its two ends — the first chunk's HBM round trip, the epilogue's stores — are covered
+// only by the co-resident workgroups; its LDS (48 KiB) allows a third, the registers do once the allocation is capped at 168 (four
+// epilogue-only values go to scratch outside the loop). Bit-identical; 27 launches of a B = 32 forward 7.14 -> 6.87 ms (r06).
 template <int KS, int WM, int TM, bool KSP = false>
-__global__ void __launch_bounds__(256, 2) conv_mfma_pf_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(256, (KS == 1 && !KSP) ? 3 : 2) conv_mfma_pf_kernel(const ConvParams p) {
   constexpr int WN = 4 / WM;
   constexpr int TN = 4 / WN;
   constexpr int BM = 32 * WM * TM;
