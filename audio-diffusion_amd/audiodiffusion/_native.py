@@ -36,6 +36,7 @@ class ConvArgs(C.Structure):
         ("wino_packed", C.c_void_p),
         ("bf16_packed", C.c_void_p),
         ("stats_out", C.c_void_p), ("stats_tiles", C.c_int),
+        ("wino6_rule", C.c_int),
     ]
 
 
@@ -94,6 +95,7 @@ _SIGS = {
     "adm_dense_act": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "adm_unet_create": (C.c_int, [C.POINTER(UNetConfig), C.POINTER(C.c_void_p)]),
     "adm_unet_destroy": (None, [C.c_void_p]),
+    "adm_unet_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "adm_unet_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "adm_unet_set_encoding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "adm_unet_missing_params": (C.c_int, [C.c_void_p]),

@@ -189,7 +189,20 @@ class UNet2DModel:
         N.check(N.lib().adm_unet_create(C.byref(nc), C.byref(h)))
         self._handle, self._handle_hw = h, hw
         self._loss_scale = 1.0          # a fresh native handle starts at loss scale 1 (train_step caches the value it set)
+        for name, value in getattr(self, "_options", {}).items():       # per-model options survive a re-created handle
+            N.check(N.lib().adm_unet_set_option(h, name.encode(), int(value)))
         return h
+
+    def set_option(self, name: str, value: int):
+        """Per-MODEL runtime option of the native executor (`adm_unet_set_option`, include/adm.h; not part of the reference's API).
+        "wino6": this model's Winograd F(4x4) layer rule — 0 follows the process-wide option, 256 is the single-sample latency rule that
+        `AudioDiffusion` selects for its own model."""
+        if not hasattr(self, "_options"):
+            self._options = {}
+        self._options[name] = int(value)
+        if self._handle is not None:
+            N.check(N.lib().adm_unet_set_option(self._handle, name.encode(), int(value)))
+        return self
 
     def _upload(self, key, t):
         t = t.detach().to(torch.float32).cpu().contiguous()

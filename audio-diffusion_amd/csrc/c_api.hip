@@ -15,7 +15,8 @@ using namespace adm;
 
 extern "C" {
 
-int adm_version(void) { return 102; }   // 102 (round 5): Winograd buffers hold two images (adm_winograd_packed_floats)
+int adm_version(void) { return 103; }   // 103 (round 6): adm_conv_args.wino6_rule, adm_unet_set_option, adm_release_stream
+//   // 102 (round 5): Winograd buffers hold two images (adm_winograd_packed_floats)
 //   // 101 (round 4): adm_slerp_grid takes double weights (round 3), blocked-image entry points
 const char* adm_last_error(void) { return adm::last_error(); }
 int adm_set_option(const char* name, int value) {

@@ -214,12 +214,13 @@ static int wino6_on() {
 // (Cout = 128: 16) on F(2x2): the batched configurations gain 3.6 - 3.8 % over the 128 floor, single-sample sampling at 256x256 loses 14 %.
 constexpr int W6_MIN_PLANE = 64, W6_MIN_WGS = 32;
 static bool wino6_eligible(const adm_conv_args& a) {
-  if (!wino6_on()) return false;
+  const int rule = a.wino6_rule != 0 ? a.wino6_rule : wino6_on();       // the call's (= its model's) own rule, else the process-wide option
+  if (!rule) return false;
   const int C2 = a.x2 ? a.C2 : 0;
   const int Ho = a.up ? 2 * a.H : a.H, Wo = a.up ? 2 * a.W : a.W;
   if (!wino6_layout(a.Cout, a.C1 + C2) || a.C1 % 16 != 0 || Ho % 16 != 0 || Wo % 16 != 0) return false;
-  if (wino6_on() == 2) return true;
-  if (wino6_on() >= 16) return Ho >= wino6_on() && Wo >= wino6_on();
+  if (rule == 2) return true;
+  if (rule >= 16) return Ho >= rule && Wo >= rule;
   return Ho >= W6_MIN_PLANE && Wo >= W6_MIN_PLANE && (Ho / 16) * (Wo / 16) * (a.Cout / W5BM) >= W6_MIN_WGS;
 }
 static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 4) on first use

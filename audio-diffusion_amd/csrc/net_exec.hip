@@ -756,6 +756,7 @@ void Net::fill_conv_args(const Op& o, int B, const float* temb_all, int temb_str
   if (o.temb_off >= 0 && temb_all) { a.chan_add = temb_all + o.temb_off; a.chan_add_stride = temb_stride; }
   if (o.res >= 0) a.residual = tensors[o.res].ptr;
   a.out = tensors[o.out].ptr;
+  a.wino6_rule = wino6_rule;
 }
 
 int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_stride, hipStream_t st, OpTimer* tm) {

@@ -433,6 +433,18 @@ void adm_unet_destroy(adm_unet_t* h) {
   delete h;
 }
 
+int adm_unet_set_option(adm_unet_t* h, const char* name, int value) {
+  ADM_REQUIRE(h && name, "unet_set_option: null argument");
+  ADM_REQUIRE(std::string(name) == "wino6", "unet_set_option: the per-model options are: wino6");
+  ADM_REQUIRE(value == 0 || value == 1 || value == 2 || (value >= 16 && value <= 65536),
+              "unet_set_option: wino6 takes 0 (follow the process-wide option), 1 (default layer rule), 2 (every layer the kernel tiles) or a plane-size floor n >= 16");
+  if (h->net.wino6_rule != value) {
+    h->net.wino6_rule = value;
+    free_plan(h);                     // the statistic-tile counts and a captured loop follow the kernels: plan again on the next call
+  }
+  return 0;
+}
+
 int adm_unet_set_param(adm_unet_t* h, const char* key, const float* host_data, size_t numel) {
   ADM_REQUIRE(h && key && host_data, "unet_set_param: null argument");
   ADM_REQUIRE(!h->finalized, "unet_set_param: model already finalized (first forward ran)");

@@ -57,7 +57,7 @@ int adm_has_experiments(void);
  *   that GroupNorm's scale / shift from its finish pass (one launch instead of finish + statistics; the tensor is bit-identical) |
  *   0 separate launches | -1 ADM_GN_FUSE_FINISH.
  * The dispatch epoch moves only when a value really changes; set options BEFORE adm_unet_refresh_weights / the next train step.
- * adm_version() = 102 since round 5 (Winograd filter buffers hold two images: adm_winograd_packed_floats); 101 since round 4 (adm_slerp_grid takes DOUBLE weights since round 3; blocked-image entry points). */
+ * adm_version() = 103 since round 6 (adm_conv_args.wino6_rule, adm_unet_set_option, adm_release_stream); 102 since round 5 (Winograd filter buffers hold two images: adm_winograd_packed_floats); 101 since round 4 (adm_slerp_grid takes DOUBLE weights since round 3; blocked-image entry points). */
 int adm_set_option(const char* name, int value);
 /* Per-(device, stream) scratch the library keeps for a stream (the split-K slab buffer of the small-plane convolutions, >= 32 MiB, at most
  * 256 streams per device): give it back BEFORE destroying a stream that has run library calls. Drains the stream first (a captured graph of
@@ -139,6 +139,10 @@ typedef struct adm_conv_args {
    * only for the kernels that can do it: the Winograd v4 kernel and the conv_in class kernel (Cin <= 4, W % 4 == 0));
    * adm_groupnorm_finalize turns them into scale / shift. */
   double* stats_out; int stats_tiles;
+  /* optional (0 = the process-wide "wino6" option decides): this call's own F(4x4) layer rule, same values as the option (1 default rule,
+   * 2 every layer the kernel tiles, n >= 16 planes of at least n x n pixels). A model handle carries one (adm_unet_set_option), so that a
+   * single-sample front end can run the latency rule on ITS model without touching other models in the process. Since adm_version() 103. */
+  int wino6_rule;
 } adm_conv_args;
 /* number of statistic tiles per (sample, channel) the kernel chosen for these arguments would emit, 0 = it cannot. */
 int adm_conv_stats_tiles(const adm_conv_args* a);
@@ -241,6 +245,13 @@ typedef struct adm_unet_config {
 } adm_unet_config;
 
 int adm_unet_create(const adm_unet_config* cfg, adm_unet_t** out);
+/* Per-MODEL option (adm_version() >= 103). "wino6": this model's F(4x4) layer rule — 0 = follow the process-wide option (default), 1 / 2 /
+ * n >= 16 as adm_set_option("wino6", .). `audiodiffusion.AudioDiffusion` (the reference's single-sample facade, audiodiffusion/__init__.py:58-68:
+ * batch_size is forced to 1) sets 256 on its own model: planes whose 16x16x128 tiles fill the chip with ONE sample keep F(4x4), the
+ * levels below run the 64-cout F(2x2) kernel, whose smaller tiles are 4x as many workgroups (256x256, one sample: 6.8 instead of 8.3 ms per
+ * step). The rule stays a function of the layer and the model — never of the batch — so rows of one model's batches remain bit-identical to
+ * single-sample runs of THAT model. Re-plans the model (drops a captured loop). */
+int adm_unet_set_option(adm_unet_t* h, const char* name, int value);
 void adm_unet_destroy(adm_unet_t* h);
 /* Upload one parameter by its diffusers state-dict key (host pointer, fp32, `numel` elements).
  * Deprecated attention names (query/key/value/proj_attn, audiodiffusion/utils.py:41-54) are accepted. */

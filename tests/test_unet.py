@@ -160,3 +160,36 @@ def test_an_option_set_between_two_forwards_re_plans_the_net(backend):
         assert float((outs[0] - outs[1]).abs().max()) < 1e-3
     finally:
         audiodiffusion.set_option("wino6", -1)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_the_f4x4_layer_rule_is_a_per_model_setting(backend):
+    """`UNet2DModel.set_option("wino6", rule)` (adm_unet_set_option): one model runs its own rule — here F(4x4) on every layer the kernel
+    tiles — while a second model in the same process keeps the process-wide default (F(2x2) on these 32x32 planes); both match the oracle,
+    each model's batch rows stay bit-identical to its single-sample runs, and rule 0 hands the model back to the process-wide option."""
+    from audiodiffusion import _native
+    dev = select(backend)
+    ref, mine = _pair(W6NET)
+    _, other = _pair(W6NET)
+    x = torch.randn(3, 1, 32, 32, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        r = ref(x, 500)["sample"]
+    import ctypes as C
+
+    def variants(m):                                               # the kernel variant of every launch of one eager forward
+        recs, n = (_native.OpProfile * 512)(), C.c_int(0)
+        xd, out = x.to(dev), torch.empty_like(x.to(dev))
+        _native.check(_native.lib().adm_unet_profile(m._ensure_handle(), _native.ptr(xd), 500.0, _native.ptr(out), x.shape[0], recs, 512,
+                                                     C.byref(n), _native.stream_for(xd)))
+        return {r.variant for r in recs[: n.value]}
+    mine.set_option("wino6", 2)
+    a = mine(x.to(dev), 500)["sample"].cpu()
+    b = other(x.to(dev), 500)["sample"].cpu()
+    va, vb = variants(mine), variants(other)
+    assert 4316 in va and 4316 not in vb and (vb & {4314, 4315}), (va, vb)
+    for o in (a, b):
+        assert float((o - r).abs().max()) < 1e-3 * max(1.0, float(r.abs().max()))
+    assert not torch.equal(a, b)                                   # two roundings of the same network
+    assert torch.equal(mine(x[1:2].to(dev), 500)["sample"].cpu(), a[1:2])      # a row alone = the row in its batch, under the model's rule
+    mine.set_option("wino6", 0)
+    assert torch.equal(mine(x.to(dev), 500)["sample"].cpu(), b)

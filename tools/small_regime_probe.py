@@ -20,6 +20,8 @@ for spec in os.environ.get("PROBE", "32,16;64,1;256,1").split(";"):
     res, B = (int(v) for v in spec.split(","))
     cfg = dict(CFG256, sample_size=res)
     unet = UNet2DModel(**cfg).init_random(0)
+    if os.environ.get("PROBE_RULE"):             # the model's own F(4x4) layer rule (UNet2DModel.set_option; AudioDiffusion sets 256)
+        unet.set_option("wino6", int(os.environ["PROBE_RULE"]))
     x = torch.randn(B, 1, res, res, device=dev)
     out = torch.empty_like(x)
     cap = 1024
