@@ -411,7 +411,6 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     }
   };
   bool pend = false;                           // a finished tile waits for its inverse transform + stores
-#define W6_LAP(slot) ((void)0)
   auto tile_switch = [&]() {
     ADM_SCHED_FENCE();
     ci = 0; v += bs;
@@ -441,7 +440,7 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
 #if !defined(ADM_EMU)
     __builtin_amdgcn_s_setprio(2);
 #endif
-    W6_LAP(7);
+
     if (pend) {                                // (stage B twice in the source: the epilogue's operands live in this branch only)
       EpiOps e;
       epilogue_fetch(e);                       // (their HBM / L2 round trips pass under stage B)
@@ -449,9 +448,9 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
         stage_b(r0, pg + 2);
         ADM_SCHED_FENCE();
       }
-      W6_LAP(2);
+
       epilogue(e);
-      W6_LAP(3);
+
       pend = false;
       ADM_UNROLL
       for (int q = 0; q < W6AR; ++q) aR[q] = W6_LOAD_A(d_cur + q * 256);
@@ -460,7 +459,7 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
         stage_b(r0, pg + 2);
         ADM_SCHED_FENCE();
       }
-      W6_LAP(2);
+
     }
     // (unconditional — behind the last pair the saturated cursor re-reads it — so that the activations and their scale / shift are dead
     // across the epilogue in the compiler's eyes too)
@@ -469,13 +468,13 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     // previous block's last groups — the MFMA blocks get 15 % shorter and stage B's waits stop covering these loads, but stage A grows by as
     // much: 58.5 vs 57.7 ms per forward, profiles/r05_wino.md)
     ADM_SCHED_FENCE();
-    W6_LAP(4);
+
     if (more) {
       stage_c(pg);
     }
     pg += 2;
     ADM_SCHED_FENCE();
-    W6_LAP(5);
+
 #if !defined(ADM_EMU)
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -486,10 +485,10 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
   // while one wave of a SIMD stages, its partner owns the matrix pipe.
   for (int it = 0; it <= npairs; ++it) {
     if (yrole || it > 0) staging(yrole ? it < npairs : true);
-    if (!yrole && it > 0) { ADM_BARRIER_KEEP_VMEM(63); W6_LAP(6); }
+    if (!yrole && it > 0) { ADM_BARRIER_KEEP_VMEM(63); }
     if (it == npairs) break;
     if (ci == nch) tile_switch();
-    W6_LAP(7);
+
     // ---- M: the 144 MFMAs of chunks g, g + 1 -------------------------------------------------------------------------------------------
     const int g = 2 * it;
     float rbw[3][4];                           // B operands: a window of three point groups (read three groups ahead of their MFMAs)
@@ -524,10 +523,9 @@ __device__ __forceinline__ void wino6_wave(const WinoParams& p, float* ldsV, flo
     }
     ci += 2;
     pend = ci == nch;
-    W6_LAP(1);
-    if (yrole) { ADM_BARRIER_KEEP_VMEM(63); W6_LAP(6); }
+
+    if (yrole) { ADM_BARRIER_KEEP_VMEM(63); }
   }
-#undef W6_LAP
 #undef W6_LOAD_A
 }
 
