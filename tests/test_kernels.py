@@ -213,6 +213,13 @@ def test_conv3x3_split_k_at_tiny_spatial_sizes(backend, Cin, Cout, H, W, N):
     a.chan_add, a.chan_add_stride = C.c_void_p(temb.data_ptr()), temb.stride(0)
     _native.check(_native.lib().adm_conv2d(C.byref(a), _native.stream_for(x)))
     assert _relerr(acc, ref) < 1e-4
+    # adm_release_stream: the stream's split-K slab buffer is given back (a caller about to destroy the stream does this); the
+    # next split-K launch on that stream takes a fresh one and produces the same bits; a stream the library holds nothing for is a no-op
+    st = _native.stream_for(x)
+    _native.check(_native.lib().adm_release_stream(st))
+    _native.check(_native.lib().adm_release_stream(st))
+    again = ops.conv2d(x, wp, b, 3, gn=gn, act=True, chan_add=temb, residual=res)
+    assert _native.lib().adm_last_conv_variant() == 2316 and torch.equal(again, out)
 
 
 TINY_LEVELS = [  # (N, C1, C2, H, W, Cout, ks, stride, up, use_gn, act, use_temb, use_res, expected variant)
