@@ -156,6 +156,17 @@ struct Net {
   std::vector<int> producer_of;      // tensor -> index of the op that writes it (-1: none), level-3 training plans
   std::vector<int> gn_fuse_of;       // per op: the GroupNorm op whose statistics this convolution's split-K finish may leave (-1: none)
   std::vector<char> gn_skip;         // per op, during a forward walk: this GroupNorm's scale / shift have been written already
+  // Side-stream overlap (inference, round 6): a convolution whose inputs are ready several ops before its place in the list — the resnets'
+  // 1x1 conv_shortcut, which reads the block input — is launched on a second stream at hoist_from[j] and joined at its own position, so that
+  // it runs beside norm1 / conv1 / norm2 instead of between them. Scheduling only (no arithmetic moves): taken where the launches do not
+  // fill the chip (small planes / batches: the latency regimes), planned per batch size, checked against the arena's buffer reuse (plan()).
+  std::vector<int> hoist_from;       // per op j: the op index in front of which it is launched on the side stream, -1 = in place
+  std::vector<std::vector<int>> hoist_at;   // per op i: the ops launched on the side stream in front of it
+  hipStream_t side = nullptr;
+  void* ev_fork = nullptr;           // hipEvent_t (opaque here: the emulator has no events)
+  void* ev_join = nullptr;
+  int plan_side_overlap(int B);
+  int launch_side_conv(const Op& o, int B, const float* temb_all, int temb_stride, hipStream_t st);
   std::vector<char> bias_done;       // per op, during a reverse walk: its bias gradient came with another convolution's channel sums
   float *tmp_da = nullptr, *wgrad_ws = nullptr, *s12 = nullptr, *tmp_w = nullptr;
   size_t tmp_da_floats = 0, wgrad_ws_floats = 0, tmp_w_floats = 0;

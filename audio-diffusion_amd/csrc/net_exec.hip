@@ -493,6 +493,11 @@ void Net::free_plan() {
 }
 void Net::destroy() {
   free_plan();
+#if !defined(ADM_EMU)
+  if (side) { conv_ksplit_release(side); (void)hipStreamDestroy(side); side = nullptr; }
+  if (ev_fork) { (void)hipEventDestroy((hipEvent_t)ev_fork); ev_fork = nullptr; }
+  if (ev_join) { (void)hipEventDestroy((hipEvent_t)ev_join); ev_join = nullptr; }
+#endif
   for (void* p : owned) dfree(p);
   owned.clear();
 }
@@ -717,6 +722,7 @@ int Net::plan(int B) {
     ADM_TRY(arena_alloc((void**)&tmp_w, sizeof(float) * (max_w + 4096))); tmp_w_floats = max_w + 4096;
     ADM_TRY(arena_alloc((void**)&s12, sizeof(float) * (size_t)B * groups * 2));
   }
+  ADM_TRY(plan_side_overlap(B));
   planned_B = B;
   plan_epoch = dispatch_epoch();
   return 0;
@@ -727,6 +733,59 @@ static unsigned packing_of_variant(int var, bool fwd) {
   if (var / 1000 == 5) return fwd ? PK_WB : PK_WBT;         // bf16-operand kernels (3x3: 5316, 1x1: 5116)
   if (var / 1000 == 4) return fwd ? PK_WU : PK_WUT;         // Winograd kernels
   return fwd ? PK_WP : PK_WPT;                              // direct MFMA / small-channel kernels
+}
+
+// Which convolutions run on the side stream (see net_exec.h). Op j qualifies when it is a plain 1x1 convolution (no GroupNorm / activation on
+// its load path, no statistics epilogue, weights of its own), its inputs are produced at least two ops before it, and NO tensor dies between the
+// hoist point and j: the arena hands a dead tensor's buffer to later outputs in op order, and only with no death in the window can neither j's
+// output buffer nor anything j reads be touched by the ops it now runs beside. One side launch in flight at a time (the two events are reused).
+int Net::plan_side_overlap(int B) {
+  const int n = (int)ops.size();
+  hoist_from.assign(n, -1);
+  hoist_at.assign(n, {});
+  static const int on = [] { const char* e = getenv("ADM_SIDE_OVERLAP"); return e ? atoi(e) : 1; }();
+  if (training || !on) return 0;
+  std::vector<int> prod(tensors.size(), -1), deaths(n, 0);
+  for (int i = 0; i < n; ++i) if (ops[i].out >= 0) prod[ops[i].out] = i;
+  for (const Tensor& t : tensors) if (!t.external && t.last_use >= 0 && t.last_use < n) ++deaths[t.last_use];
+  int busy_until = -1;                                          // the previous side launch's own position: windows must not overlap
+  bool any = false;
+  for (int j = 0; j < n; ++j) {
+    const Op& o = ops[j];
+    if (o.kind != Op::CONV || o.ks != 1 || o.stride != 1 || o.up || o.gn >= 0 || o.act || o.wt >= 0 || o.w == nullptr || o.out < 0) continue;
+    const Tensor& to = tensors[o.out];
+    if (to.external || to.stats != nullptr || (size_t)j < gn_fuse_of.size() && gn_fuse_of[j] >= 0) continue;
+    if ((double)B * to.C * to.H * to.W > 4.0 * 1024 * 1024) continue;      // a launch of this size fills the chip by itself
+    int ready = -1;                                             // last producer of an input
+    bool ext_in = false;
+    for (int t : {o.in1, o.in2, o.res}) if (t >= 0) { ready = prod[t] > ready ? prod[t] : ready; ext_in |= tensors[t].external && t != t_in; }
+    if (ext_in) continue;
+    int i = j;                                                  // walk back while nothing dies and the inputs are ready
+    while (i - 1 > ready && i - 1 > busy_until && deaths[i - 1] == 0) --i;
+    if (j - i < 2) continue;
+    hoist_from[j] = i;
+    hoist_at[i].push_back(j);
+    busy_until = j;
+    any = true;
+  }
+#if !defined(ADM_EMU)
+  if (any && side == nullptr) {                                 // (created here, outside any stream capture)
+    ADM_HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    hipEvent_t e1 = nullptr, e2 = nullptr;
+    ADM_HIP_OK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    ADM_HIP_OK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+    ev_fork = e1; ev_join = e2;
+  }
+#endif
+  return 0;
+}
+
+int Net::launch_side_conv(const Op& o, int B, const float* temb_all, int temb_stride, hipStream_t st) {
+  adm_conv_args a;
+  fill_conv_args(o, B, temb_all, temb_stride, &a);
+  ADM_TRY(launch_conv2d(a, st));
+  if (o.w) ADM_TRY(note_packing(*o.w, packing_of_variant(last_conv_variant(), true)));
+  return 0;
 }
 
 void Net::fill_conv_args(const Op& o, int B, const float* temb_all, int temb_stride, adm_conv_args* ap) const {
@@ -766,8 +825,29 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
   tensors[t_in].ptr = const_cast<float*>(x);
   tensors[t_out].ptr = out;
   gn_skip.assign(ops.size(), 0);
+  // side-stream overlap: only on the product path proper (no per-op timers) and only for a plan made for this batch size
+  const bool overlap = tm == &none && !training && hoist_from.size() == ops.size() && planned_B == B;
   for (const Op& o : ops) {
     const Tensor& t1 = tensors[o.in1];
+    const size_t oidx = (size_t)(&o - ops.data());
+    if (overlap) {
+      for (int j : hoist_at[oidx]) {
+#if !defined(ADM_EMU)
+        ADM_HIP_OK(hipEventRecord((hipEvent_t)ev_fork, st));            // everything enqueued so far (the inputs' producers) ...
+        ADM_HIP_OK(hipStreamWaitEvent(side, (hipEvent_t)ev_fork, 0));    // ... precedes the side launch
+        ADM_TRY(launch_side_conv(ops[j], B, temb_all, temb_stride, side));
+        ADM_HIP_OK(hipEventRecord((hipEvent_t)ev_join, side));
+#else
+        ADM_TRY(launch_side_conv(ops[j], B, temb_all, temb_stride, st));  // emulator: the hoisted ORDER, in line (exercises the buffer-reuse rule)
+#endif
+      }
+      if (hoist_from[oidx] >= 0) {                                   // its own position: join
+#if !defined(ADM_EMU)
+        ADM_HIP_OK(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0));
+#endif
+        continue;
+      }
+    }
     tm->begin();
     if (o.kind == Op::GN && gn_skip[(size_t)(&o - ops.data())]) {
       tm->end(0, 2, 0.0, 0.0);           // its scale / shift came with the producing convolution's split-K finish pass
