@@ -754,7 +754,7 @@ int Net::plan_side_overlap(int B) {
     const Op& o = ops[j];
     if (o.kind != Op::CONV || o.ks != 1 || o.stride != 1 || o.up || o.gn >= 0 || o.act || o.wt >= 0 || o.w == nullptr || o.out < 0) continue;
     const Tensor& to = tensors[o.out];
-    if (to.external || to.stats != nullptr || (size_t)j < gn_fuse_of.size() && gn_fuse_of[j] >= 0) continue;
+    if (to.external || to.stats != nullptr || ((size_t)j < gn_fuse_of.size() && gn_fuse_of[j] >= 0)) continue;
     if ((double)B * to.C * to.H * to.W > 4.0 * 1024 * 1024) continue;      // a launch of this size fills the chip by itself
     int ready = -1;                                             // last producer of an input
     bool ext_in = false;
@@ -768,6 +768,7 @@ int Net::plan_side_overlap(int B) {
     busy_until = j;
     any = true;
   }
+  (void)any;
 #if !defined(ADM_EMU)
   if (any && side == nullptr) {                                 // (created here, outside any stream capture)
     ADM_HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
