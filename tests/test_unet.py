@@ -145,7 +145,7 @@ def test_an_option_set_between_two_forwards_re_plans_the_net(backend):
         r = ref(x, 500)["sample"]
     variants = []
     try:
-        for v in (2, 0, 2, -1):                    # every layer the kernel tiles -> F(2x2) only -> back -> the environment's default
+        for v in (2, 0, -1):                       # every layer the kernel tiles -> F(2x2) only -> the environment's default
             audiodiffusion.set_option("wino6", v)
             o = mine(x.to(dev), 500)["sample"].cpu()
             assert float((o - r).abs().max()) < 1e-3 * max(1.0, float(r.abs().max())), v
@@ -155,7 +155,7 @@ def test_an_option_set_between_two_forwards_re_plans_the_net(backend):
         outs = []
         for v in (2, 0, 2):                        # the captured loop: same noise, the option changed between samplings
             audiodiffusion.set_option("wino6", v)
-            outs.append(pipe(batch_size=2, steps=3, noise=x.clone().to(dev), audio=False, return_float=True)[1].cpu())
+            outs.append(pipe(batch_size=2, steps=2, noise=x.clone().to(dev), audio=False, return_float=True)[1].cpu())
         assert torch.equal(outs[0], outs[2])       # back under the first setting: the same kernels, the same bits
         assert float((outs[0] - outs[1]).abs().max()) < 1e-3
     finally:
