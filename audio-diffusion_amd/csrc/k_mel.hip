@@ -213,8 +213,13 @@ __device__ __forceinline__ void fft1024_wave(double2 (&v)[16], double2* buf, con
 }
 
 // MINW = waves per SIMD: 1 = 4 waves per workgroup (8 frames), ~390 registers; 2 = 8 waves per workgroup (16 frames, one shared
-// filterbank copy: 157 KiB of LDS), 212 registers — the loads of a frame are then issued in four batches instead of sixteen
+// filterbank copy: 157 KiB of LDS), <= 256 registers — the loads of a frame are then issued in four batches instead of sixteen
 // at once, which is what keeps the allocation under 256 without spills. ADM_MEL_OCC selects (measured on the MI355X).
+// Round 6: PERSISTENT workgroups with the next frame's samples prefetched. The kernel was latency-bound on its own global loads (ablations,
+// profiles/r06_mel.md: without the FFT it lost 16 % of its time, without the mel projection 14 % — the other 70 % were two waves per SIMD
+// waiting for a frame's 2048 samples, four dependent batches per frame, and 4096 workgroups each staging the filterbank again): a workgroup
+// now walks the groups of 2 NW frames with a stride of gridDim.x, stages the filterbank once, and every wave requests the samples of its
+// NEXT frame (32 registers) before it transforms the current one. Same arithmetic in the same order: bit-identical spectrograms.
 template <typename T, int MINW>
 __global__ void __launch_bounds__(256 * MINW, 1) mel_stft2048_kernel(const T* __restrict__ audio, long slice_stride, int n_samples,
                                                           int hop, const double* __restrict__ window,
@@ -222,12 +227,13 @@ __global__ void __launch_bounds__(256 * MINW, 1) mel_stft2048_kernel(const T* __
                                                           const int* __restrict__ fb_start, const int* __restrict__ fb_count,
                                                           const int* __restrict__ fb_off, const float* __restrict__ fb_w32,
                                                           const double* __restrict__ fb_w64, int n_mels, int n_frames,
-                                                          T* __restrict__ melspec, unsigned long long* __restrict__ spec_max) {
+                                                          T* __restrict__ melspec, unsigned long long* __restrict__ spec_max,
+                                                          int groups_per_clip, int n_groups) {
   // spec_max (nullptr ok): per-spectrogram maximum for power_to_db(ref=np.max), as the bit pattern of the non-negative
   // double (order-preserving), so that the dB pass needs no reduction of its own
   ADM_DYN_SMEM(double2, sm);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  constexpr int NW = 4 * MINW, FR = 2 * NW;                        // waves and frames per workgroup
+  constexpr int NW = 4 * MINW, FR = 2 * NW;                        // waves and frames per group
   double2* buf = sm + wave * 16 * MF_PITCH;
   T* stage = reinterpret_cast<T*>(sm + NW * 16 * MF_PITCH);        // [n_mels][FR]
   // the filterbank, staged once per workgroup: taps as (first bin, count, offset) per filter + the weights in T
@@ -239,23 +245,33 @@ __global__ void __launch_bounds__(256 * MINW, 1) mel_stft2048_kernel(const T* __
   for (int m = tid; m < n_mels; m += blockDim.x) { f_start[m] = fb_start[m]; f_count[m] = fb_count[m]; f_off[m] = fb_off[m]; }
   for (int i = tid; i < nnz; i += blockDim.x) f_w[i] = sizeof(T) == 4 ? (T)fb_w32[i] : (T)fb_w64[i];
   __syncthreads();
-  const int b = blockIdx.y, f0 = blockIdx.x * FR;
-  const T* y = audio + (long)b * slice_stride;
-#pragma unroll 1
-  for (int fi = 0; fi < 2; ++fi) {
-    const int slot = wave + NW * fi, frame = f0 + slot;            // beyond n_frames: computed on zeros, never stored
+  // the 2048 samples of frame `slot` of group g, two per lane and n1 (zero outside the clip: center=True, pad_mode="constant";
+  // frames beyond n_frames: computed on zeros, never stored)
+  auto load_raw = [&](int g, int slot, T (&raw)[32]) {
+    const int b = g / groups_per_clip, frame = (g - b * groups_per_clip) * FR + slot;
+    const T* y = audio + (long)b * slice_stride;
+    const bool live = frame < n_frames && g < n_groups;
+    ADM_UNROLL
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int n = 64 * n1 + lane;
+      const long src = (long)frame * hop + 2 * n - 1024;
+      raw[2 * n1] = (live && src >= 0 && src < n_samples) ? y[src] : (T)0;
+      raw[2 * n1 + 1] = (live && src + 1 >= 0 && src + 1 < n_samples) ? y[src + 1] : (T)0;
+    }
+  };
+  // (the samples are consumed by the windowing below; the SAME registers then take the wave's next frame, requested before the transform)
+  auto process = [&](int slot, T (&raw)[32], int next_g, int next_slot) {
     double2 v[16];
     ADM_UNROLL
     for (int n1 = 0; n1 < 16; ++n1) {
       const int n = 64 * n1 + lane;
-      const long src = (long)frame * hop + 2 * n - 1024;            // center=True, pad_mode="constant"
-      const bool live = frame < n_frames;
-      const double a0 = (live && src >= 0 && src < n_samples) ? (double)y[src] : 0.0;
-      const double a1 = (live && src + 1 >= 0 && src + 1 < n_samples) ? (double)y[src + 1] : 0.0;
       const double2 w = *reinterpret_cast<const double2*>(window + 2 * n);
-      v[n1] = make_double2(w.x * a0, w.y * a1);
-      if (MINW == 2 && (n1 & 3) == 3) ADM_SCHED_FENCE();            // 256-register build: four batches of loads, not sixteen
+      v[n1] = make_double2(w.x * (double)raw[2 * n1], w.y * (double)raw[2 * n1 + 1]);
+      if (MINW == 2 && (n1 & 3) == 3) ADM_SCHED_FENCE();            // 256-register build: four batches of window loads, not sixteen
     }
+    ADM_SCHED_FENCE();
+    load_raw(next_g, next_slot, raw);
+    ADM_SCHED_FENCE();
     fft1024_wave(v, buf, tw, lane);
     // untangle: X[k] = E + (-i) W2048^k O, E = (Z[k] + conj Z[1024-k]) / 2, O = (Z[k] - conj Z[1024-k]) / 2
     ADM_UNROLL
@@ -308,20 +324,30 @@ __global__ void __launch_bounds__(256 * MINW, 1) mel_stft2048_kernel(const T* __
       stage[m * FR + slot] = (T)acc;
     }
     ADM_WAVE_SYNC();
-  }
-  __syncthreads();
-  // [n_mels][FR] -> melspec[b][m][f0 .. f0 + FR): one row segment per thread pass
-  double mx = 0.0;
-  for (int e = tid; e < n_mels * FR; e += blockDim.x) {
-    const int m = e / FR, s = e % FR;
-    if (f0 + s < n_frames) {
-      melspec[((long)b * n_mels + m) * n_frames + f0 + s] = stage[e];
-      mx = fmax(mx, (double)stage[e]);
+  };
+  T raw[32];
+  int g = blockIdx.x;
+  load_raw(g, wave, raw);
+#pragma unroll 1
+  for (; g < n_groups; g += gridDim.x) {
+    const int b = g / groups_per_clip, f0 = (g - b * groups_per_clip) * FR;
+    process(wave, raw, g, wave + NW);                                // ... requests this group's second frame
+    process(wave + NW, raw, g + (int)gridDim.x, wave);               // ... requests the next group's first frame (past the end: zeros, unused)
+    __syncthreads();
+    // [n_mels][FR] -> melspec[b][m][f0 .. f0 + FR): one row segment per thread pass
+    double mx = 0.0;
+    for (int e = tid; e < n_mels * FR; e += blockDim.x) {
+      const int m = e / FR, sl = e % FR;
+      if (f0 + sl < n_frames) {
+        melspec[((long)b * n_mels + m) * n_frames + f0 + sl] = stage[e];
+        mx = fmax(mx, (double)stage[e]);
+      }
     }
-  }
-  if (spec_max != nullptr) {
-    for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
-    if (lane == 0) atomicMax(spec_max + b, (unsigned long long)__double_as_longlong(mx));
+    if (spec_max != nullptr) {
+      for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+      if (lane == 0) atomicMax(spec_max + b, (unsigned long long)__double_as_longlong(mx));
+    }
+    __syncthreads();                                                 // the stage rows are free for the next group
   }
 }
 
@@ -877,6 +903,15 @@ static bool mel_fast_path(const adm_mel* h) {
   return h->cfg.n_fft == 2048 && fast;
 }
 
+static int mel_cu_count() {
+#if !defined(ADM_EMU)
+  static int n = [] { int dev = 0, v = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+  return n;
+#else
+  return 3;                                   // the emulator: several groups per workgroup
+#endif
+}
+
 static int mel_forward_power_impl(adm_mel_t* h, const void* audio, int is_f64, int B, long slice_stride, int n_samples,
                                   void* melspec_out, unsigned long long* spec_max, void* stream) {
   ADM_REQUIRE(h && audio && melspec_out && B > 0 && n_samples > 0, "mel_forward_power: bad argument");
@@ -894,7 +929,8 @@ static int mel_forward_power_impl(adm_mel_t* h, const void* audio, int is_f64, i
     };
     const int occ = (occ_env == 2 && lds_bytes(8) <= 160 * 1024) ? 2 : 1;     // fp64 audio at 256 mels: the 8-wave image exceeds the LDS
     const int nw = occ == 2 ? 8 : 4, fr = 2 * nw;
-    dim3 g2(ceil_div(n_frames, fr), B);
+    const int gpc = ceil_div(n_frames, fr), n_groups = gpc * B;
+    dim3 g2(n_groups < mel_cu_count() ? n_groups : mel_cu_count());      // persistent: one workgroup per CU (its LDS image fills the CU)
     const size_t sm2 = lds_bytes(nw);
     ADM_REQUIRE(sm2 <= 160 * 1024, "mel_forward: too many mel bands for the fast path staging buffer");
 #if !defined(ADM_EMU)
@@ -910,7 +946,7 @@ static int mel_forward_power_impl(adm_mel_t* h, const void* audio, int is_f64, i
 #define ADM_MEL_FAST_LAUNCH(T_, W_)                                                                                          \
   ADM_LAUNCH((mel_stft2048_kernel<T_, W_>), g2, dim3(256 * W_), sm2, st, (const T_*)audio, slice_stride, n_samples, c.hop_length,   \
              h->window, (const double2*)h->twiddle, h->fb_start, h->fb_count, h->fb_off, h->fb_w32, h->fb_w64, h->n_mels,     \
-             n_frames, (T_*)melspec_out, spec_max)
+             n_frames, (T_*)melspec_out, spec_max, gpc, n_groups)
     if (is_f64) { if (occ == 2) ADM_MEL_FAST_LAUNCH(double, 2); else ADM_MEL_FAST_LAUNCH(double, 1); }
     else { if (occ == 2) ADM_MEL_FAST_LAUNCH(float, 2); else ADM_MEL_FAST_LAUNCH(float, 1); }
 #undef ADM_MEL_FAST_LAUNCH

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "audio-diffusion_amd"))
 from audiodiffusion import Mel, _native as N  # noqa: E402
 
-N.load()
+N.load(os.environ.get("ADM_LIB") or None)
 dev = torch.device("cuda:0")
 mel = Mel()
 h = mel._ensure_handle()
