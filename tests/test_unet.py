@@ -127,7 +127,7 @@ def test_groupnorm_from_the_split_k_finish_pass(backend, cfg):
     assert float((outs[0] - outs[1]).abs().max()) < 1e-5 * max(1.0, float(r.abs().max()))
 
 
-W6NET = dict(sample_size=32, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(128, 128),
+W6NET = dict(sample_size=16, in_channels=1, out_channels=1, layers_per_block=1, block_out_channels=(128, 128),
              down_block_types=("DownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "UpBlock2D"))
 
 
@@ -140,7 +140,7 @@ def test_an_option_set_between_two_forwards_re_plans_the_net(backend):
     from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, Mel, _native
     dev = select(backend)
     ref, mine = _pair(W6NET)
-    x = torch.randn(2, 1, 32, 32, generator=torch.Generator().manual_seed(3))
+    x = torch.randn(2, 1, 16, 16, generator=torch.Generator().manual_seed(3))
     with torch.no_grad():
         r = ref(x, 500)["sample"]
     variants = []
@@ -150,7 +150,7 @@ def test_an_option_set_between_two_forwards_re_plans_the_net(backend):
             o = mine(x.to(dev), 500)["sample"].cpu()
             assert float((o - r).abs().max()) < 1e-3 * max(1.0, float(r.abs().max())), v
             variants.append(_native.lib().adm_last_conv_variant())
-        pipe = AudioDiffusionPipeline(None, mine, Mel(x_res=32, y_res=32, hop_length=256, n_fft=1024, n_iter=2), DDIMScheduler()).to(dev)
+        pipe = AudioDiffusionPipeline(None, mine, Mel(x_res=16, y_res=16, hop_length=64, n_fft=256, n_iter=1), DDIMScheduler()).to(dev)
         pipe.set_progress_bar_config(disable=True)
         outs = []
         for v in (2, 0, 2):                        # the captured loop: same noise, the option changed between samplings
@@ -165,13 +165,14 @@ def test_an_option_set_between_two_forwards_re_plans_the_net(backend):
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_the_f4x4_layer_rule_is_a_per_model_setting(backend):
     """`UNet2DModel.set_option("wino6", rule)` (adm_unet_set_option): one model runs its own rule — here F(4x4) on every layer the kernel
-    tiles — while a second model in the same process keeps the process-wide default (F(2x2) on these 32x32 planes); both match the oracle,
-    each model's batch rows stay bit-identical to its single-sample runs, and rule 0 hands the model back to the process-wide option."""
+    tiles — while a second model in the same process keeps the process-wide default (F(2x2) on these 16x16 planes); both match the oracle,
+    each model's batch rows stay bit-identical to its single-sample runs, and rule 0 hands the model back to the process-wide option.
+    (16x16 planes: one F(4x4) tile per sample and cout block — the kernel's smallest case.)"""
     from audiodiffusion import _native
     dev = select(backend)
     ref, mine = _pair(W6NET)
     _, other = _pair(W6NET)
-    x = torch.randn(3, 1, 32, 32, generator=torch.Generator().manual_seed(4))
+    x = torch.randn(3, 1, 16, 16, generator=torch.Generator().manual_seed(4))
     with torch.no_grad():
         r = ref(x, 500)["sample"]
     import ctypes as C
