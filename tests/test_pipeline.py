@@ -162,27 +162,35 @@ def test_complete_ddim50_sampling_matches_the_oracle_on_a_briefly_trained_model(
     from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, Mel, UNet2DModel
     from brief_training import train_oracle
     dev = select(backend)
-    g = torch.Generator().manual_seed(11)
-    noise = torch.randn(1, 1, 16, 16, generator=g)
-    pert = noise + 1e-6 * torch.randn(1, 1, 16, 16, generator=g)
-    torch.manual_seed(0)
-    ref_unet = OracleUNet(**TINY).eval()
-    ref = opipe.AudioDiffusionPipeline(None, ref_unet, omel.Mel(**MEL), osched.DDIMScheduler())
-    kw = dict(batch_size=1, audio=False, return_float=True)
-    chaos = float((ref(noise=noise.clone(), **kw)[1] - ref(noise=pert.clone(), **kw)[1]).abs().max())
-    assert chaos > 1e-3, chaos
-    losses = train_oracle(ref_unet, (16, 16), 80)
-    assert np.mean(losses[-10:]) < 0.5 * np.mean(losses[:3])
-    ri, rf = ref(noise=noise.clone(), **kw)
-    calm = float((rf - ref(noise=pert.clone(), **kw)[1]).abs().max())
-    assert calm <= 1e-4, calm
-    unet = UNet2DModel(**TINY).load_state_dict(ref_unet.state_dict())
-    mine = AudioDiffusionPipeline(None, unet, Mel(**MEL), DDIMScheduler()).to(dev)
-    mine.set_progress_bar_config(disable=True)
-    mi, mf = mine(noise=noise.clone().to(dev), **kw)
-    assert float((mf.cpu() - rf).abs().max()) <= 1e-3
-    _cmp_images(mi, ri)
-    assert float(rf.std()) > 0.02
+    # The oracle side of this test is ~25 000 tiny torch ops (80 training steps and four 50-step samplings of a 16x16 model): with the default
+    # intra-op pool they are all thread hand-overs, and once another test of the same process has started a second pool (scipy / OpenBLAS) the
+    # two spin against each other — 30 s became 510 s inside the full suite. One thread is the fastest setting for a model of this size.
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        g = torch.Generator().manual_seed(11)
+        noise = torch.randn(1, 1, 16, 16, generator=g)
+        pert = noise + 1e-6 * torch.randn(1, 1, 16, 16, generator=g)
+        torch.manual_seed(0)
+        ref_unet = OracleUNet(**TINY).eval()
+        ref = opipe.AudioDiffusionPipeline(None, ref_unet, omel.Mel(**MEL), osched.DDIMScheduler())
+        kw = dict(batch_size=1, audio=False, return_float=True)
+        chaos = float((ref(noise=noise.clone(), **kw)[1] - ref(noise=pert.clone(), **kw)[1]).abs().max())
+        assert chaos > 1e-3, chaos
+        losses = train_oracle(ref_unet, (16, 16), 80)
+        assert np.mean(losses[-10:]) < 0.5 * np.mean(losses[:3])
+        ri, rf = ref(noise=noise.clone(), **kw)
+        calm = float((rf - ref(noise=pert.clone(), **kw)[1]).abs().max())
+        assert calm <= 1e-4, calm
+        unet = UNet2DModel(**TINY).load_state_dict(ref_unet.state_dict())
+        mine = AudioDiffusionPipeline(None, unet, Mel(**MEL), DDIMScheduler()).to(dev)
+        mine.set_progress_bar_config(disable=True)
+        mi, mf = mine(noise=noise.clone().to(dev), **kw)
+        assert float((mf.cpu() - rf).abs().max()) <= 1e-3
+        _cmp_images(mi, ri)
+        assert float(rf.std()) > 0.02
+    finally:
+        torch.set_num_threads(n_threads)
 
 
 def test_save_load_roundtrip_and_facade(tmp_path):
