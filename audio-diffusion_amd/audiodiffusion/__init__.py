@@ -31,7 +31,8 @@ def set_option(name: str, value: int) -> None:
     """Process-wide runtime option of the native library (`adm_set_option`, include/adm.h). Not part of the reference's API; the one a user of the
     drop-in may want: `set_option("wino6", 256)` — the single-sample latency setting of the Winograd F(4x4,3x3) kernel (one
     256x256 sample at a time is 18 % faster with it, a batch of 32 10 % slower than with the default), `set_option("wino6", -1)` to go back.
-    `AudioDiffusion` (the single-sample facade) selects that rule for ITS model by itself (`UNet2DModel.set_option`, per model)."""
+    `AudioDiffusion` (the single-sample facade) selects that rule — and "single_sample" = 1, the split-K rules for layers whose tiles cannot fill the
+    chip with one sample — for ITS model by itself (`UNet2DModel.set_option`, per model)."""
     _native.check(_native.lib().adm_set_option(name.encode(), int(value)))
 
 
@@ -54,11 +55,13 @@ class AudioDiffusion:
         if cuda:
             self.pipe.to("cuda")
         # Every call of this front end samples ONE spectrogram (`batch_size=1` below, as the reference forces it): its model runs the
-        # single-sample layer rule of the Winograd F(4x4) kernel — the planes whose tiles fill the chip with one sample keep it, the levels
-        # below take the F(2x2) kernel's smaller tiles (256x256: 6.8 instead of 8.3 ms per step). A per-MODEL setting
-        # (`adm_unet_set_option`): other pipelines in the process — batched sampling, training — keep the default rule.
+        # single-sample layer rules — the planes whose F(4x4) tiles fill the chip with one sample keep that kernel, the levels below take
+        # the F(2x2) kernel's smaller tiles ("wino6" = 256), and where even those leave most CUs idle the input channels of a tile are
+        # split over several workgroups ("single_sample" = 1). 256x256: 4.6 instead of 8.1 ms per step. Per-MODEL settings
+        # (`adm_unet_set_option`): other pipelines in the process — batched sampling, training — keep the default rules.
         if hasattr(self.pipe.unet, "set_option"):
             self.pipe.unet.set_option("wino6", 256)
+            self.pipe.unet.set_option("single_sample", 1)
         self.progress_bar = progress_bar if progress_bar is not None else (lambda it: it)
 
     def _one(self, **call) -> Tuple[Image.Image, Tuple[int, np.ndarray]]:

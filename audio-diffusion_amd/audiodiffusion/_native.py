@@ -37,6 +37,7 @@ class ConvArgs(C.Structure):
         ("bf16_packed", C.c_void_p),
         ("stats_out", C.c_void_p), ("stats_tiles", C.c_int),
         ("wino6_rule", C.c_int),
+        ("single_sample", C.c_int),
     ]
 
 

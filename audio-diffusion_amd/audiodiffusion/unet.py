@@ -195,13 +195,14 @@ class UNet2DModel:
 
     def set_option(self, name: str, value: int):
         """Per-MODEL runtime option of the native executor (`adm_unet_set_option`, include/adm.h; not part of the reference's API).
-        "wino6": this model's Winograd F(4x4) layer rule — 0 follows the process-wide option, 256 is the single-sample latency rule that
-        `AudioDiffusion` selects for its own model."""
+        "wino6": this model's Winograd F(4x4) layer rule — 0 follows the process-wide option, 256 is the single-sample latency rule;
+        "single_sample": 1 = the partition rules for a model sampled one spectrogram at a time (layers whose tiles cannot fill the chip with one
+        sample split their input channels over more workgroups), 0 follows the process-wide option, -1 off. `AudioDiffusion` selects both for its own model."""
         if not hasattr(self, "_options"):
             self._options = {}
-        self._options[name] = int(value)
-        if self._handle is not None:
+        if self._handle is not None:           # (a rejected value raises here and is not remembered)
             N.check(N.lib().adm_unet_set_option(self._handle, name.encode(), int(value)))
+        self._options[name] = int(value)
         return self
 
     def _upload(self, key, t):

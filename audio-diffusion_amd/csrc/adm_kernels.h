@@ -47,6 +47,8 @@ void conv_ksplit_release(hipStream_t st);                    // give the stream'
 float* conv_ksplit_scratch(size_t floats, hipStream_t st);   // per-(device, stream) split-K slab buffer; nullptr: take the unsplit path
 int launch_ksplit_finish(const float* part, int S, long total, const float* bias, const float* chan_add, int chan_add_stride,
                          const float* residual, float* out, int Cout, int HW, hipStream_t st);   // out = bias + ... + sum of S slabs
+int launch_ksplit_finish_stats(const float* part, int S, long total, const float* bias, const float* chan_add, int chan_add_stride,
+                               const float* residual, float* out, int Cout, int HW, double* stats, hipStream_t st);   // + (sum, sum of squares) per 256-pixel strip
 int launch_pack_conv_weight(const float* w, float* wp, int Cout, int Cin, int ks, hipStream_t st);
 int launch_pack_conv_weight_T(const float* w, float* wpT, int Cout, int Cin, int ks, hipStream_t st);
 void conv_out_dims(int H, int W, int up, int stride, int ks, int pad_lo, int* Ho, int* Wo);
@@ -78,6 +80,8 @@ void bump_dispatch_epoch();        // net_exec.hip: a process-wide option change
 unsigned dispatch_epoch();
 void set_blk_direct_dy(int v);     // net_exec.hip: option "blk_direct_dy" (read when a training plan is made)
 long winograd_packed_floats(int Cout, int Cin, int transposed);   // size of a wu / wuT buffer: the F(2x2) image (+ the F(4x4) image where conv_wino6_kernel may run)
+void set_single_sample(int v);     // "single_sample" (k_conv_mfma.hip): 0 (default) off | 1 the single-sample partition rules (conv_wino4_kernel split K, 16-part 3x3 split on <= 8x8 planes)
+bool conv_single_sample(const adm_conv_args& a);   // the call's (= its model's) rule, else the option
 void set_winograd_v6(int v);    // conv_wino6_kernel (F(4x4,3x3)): 1 (default) planes >= 64x64 with >= 32 workgroups per sample | 0 off | 2 every plane the kernel tiles | n >= 16: planes >= n x n
 void set_winograd_v5(int v);    // conv_wino5_kernel (128-cout tiles) where eligible: 1 (default) / 0 = conv_wino4_kernel everywhere (bit-identical)
 void set_winograd_pair(int v);  // conv_wino4_kernel: 1 (default) = one workgroup barrier per two chunks, 0 = one per chunk (bit-identical)

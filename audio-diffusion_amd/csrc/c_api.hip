@@ -15,14 +15,14 @@ using namespace adm;
 
 extern "C" {
 
-int adm_version(void) { return 103; }   // 103 (round 6): adm_conv_args.wino6_rule, adm_unet_set_option, adm_release_stream
+int adm_version(void) { return 104; }   // 104 (round 6): adm_conv_args.single_sample, option "single_sample"; 103 (round 6): adm_conv_args.wino6_rule, adm_unet_set_option, adm_release_stream
 //   // 102 (round 5): Winograd buffers hold two images (adm_winograd_packed_floats)
 //   // 101 (round 4): adm_slerp_grid takes double weights (round 3), blocked-image entry points
 const char* adm_last_error(void) { return adm::last_error(); }
 int adm_set_option(const char* name, int value) {
   ADM_REQUIRE(name, "set_option: null name");
   const std::string nm(name);
-  static const char* known[] = {"conv_wino", "wino_pair", "wino5", "wino6", "wgrad_max_split", "conv_bf16", "conv_op16_f16", "blk_direct_dy", "gn_fuse_finish"};
+  static const char* known[] = {"conv_wino", "wino_pair", "wino5", "wino6", "single_sample", "wgrad_max_split", "conv_bf16", "conv_op16_f16", "blk_direct_dy", "gn_fuse_finish"};
   bool ok = false;
   for (const char* k : known) ok |= nm == k;
   if (!ok) ADM_FAIL(std::string("set_option: unknown option ") + name);
@@ -34,6 +34,7 @@ int adm_set_option(const char* name, int value) {
   if (nm == "wino6")
     ADM_REQUIRE(value == -1 || value == 0 || value == 1 || value == 2 || (value >= 16 && value <= 65536),
                 "set_option: wino6 takes -1 (environment), 0 (off), 1 (default layer rule), 2 (every layer the kernel tiles) or a plane-size floor n >= 16");
+  if (nm == "single_sample") ADM_REQUIRE(value >= -1 && value <= 1, "set_option: single_sample takes -1 (environment), 0 (off) or 1 (on)");
   static std::mutex mu;
   static std::map<std::string, int> last;
   {
@@ -46,6 +47,7 @@ int adm_set_option(const char* name, int value) {
   if (nm == "conv_wino") { adm::set_winograd_mode(value); return 0; }
   if (nm == "wino5") { adm::set_winograd_v5(value); return 0; }
   if (nm == "wino6") { adm::set_winograd_v6(value); return 0; }
+  if (nm == "single_sample") { adm::set_single_sample(value); return 0; }
   if (nm == "wino_pair") { adm::set_winograd_pair(value); return 0; }
   if (nm == "wgrad_max_split") { adm::set_wgrad_max_split(value); return 0; }
   if (nm == "conv_bf16") { adm::set_conv_bf16(value); return 0; }

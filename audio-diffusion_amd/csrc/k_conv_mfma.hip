@@ -20,6 +20,7 @@
 // (256^2 ... 1x1). Algorithmic bytes per launch: 4*(N*Cin*Hs*Ws + N*Cout*Ho*Wo [+ residual]) + 4*Cout*Cin*ks^2.
 #include <cstdlib>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -42,6 +43,7 @@ struct ConvParams {
   int lTW, lTH, tiles_x, tiles_y, n_ct, IH, IW, CS, nblk;
   long x1_bs, x2_bs, wp_bs;  // batch strides (elements) of x1/x2 (channel-slice views) and of per-sample weights (0: shared)
   int tap_mask;                // split-K instantiations of the generic kernel: bit t set = tap t can meet a pixel inside the image (a 1-pixel-high plane only needs the middle row of taps)
+  int single;                  // the call's single-sample rule (adm_conv_args.single_sample / the option): partition choices only
   int ksplit; long part_stride; // split-K instantiations: S workgroups per tile, each writes its partial sums to out + s * part_stride
 };
 
@@ -709,6 +711,51 @@ __global__ void __launch_bounds__(256) ksplit_finish1_kernel(const float* __rest
   }
 }
 
+// the finish pass of a split convolution whose consumer is a GroupNorm and whose planes are multiples of 256 pixels (the split Winograd
+// launches of the single-sample rule: 16x16 .. 64x64 planes): ksplit_finish_kernel's arithmetic, one wave per (sample, channel, strip of
+// 256 pixels), and the strip's (sum, sum of squares) left in the layout of the convolutions' statistics epilogues (adm_conv_args.stats_out,
+// HW / 256 tiles per channel) — gn_finalize_kernel reads them; no read pass over the tensor, no second launch beyond the finish itself.
+__global__ void __launch_bounds__(256) ksplit_finish_stats_kernel(const float* __restrict__ part, int S, long part_stride,
+                                                                  const float* __restrict__ bias, const float* __restrict__ chan_add,
+                                                                  int chan_add_stride, const float* residual, float* out, int Cout, int HW,
+                                                                  long nstrips, double* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  for (long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6); w < nstrips; w += (long)gridDim.x * 4) {
+    const long e = w * 256 + lane * 4, nc = e / HW;
+    const int co = (int)(nc % Cout), n = (int)(nc / Cout);
+    float b = bias[co];
+    if (chan_add != nullptr) b += chan_add[(long)n * chan_add_stride + co];
+    float4 v = *reinterpret_cast<const float4*>(part + e);
+#pragma unroll 8
+    for (int s2 = 1; s2 < S; ++s2) {
+      const float4 q = *reinterpret_cast<const float4*>(part + (long)s2 * part_stride + e);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    v.x += b; v.y += b; v.z += b; v.w += b;
+    if (residual != nullptr) {
+      const float4 q = *reinterpret_cast<const float4*>(residual + e);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    *reinterpret_cast<float4*>(out + e) = v;
+    // the lane's four values in fp32, everything across lanes in fp64 (as the convolutions' own epilogues do)
+    double s1 = (double)((v.x + v.y) + (v.z + v.w)), s2 = (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+    ADM_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+    if (lane == 0) { stats[w * 2] = s1; stats[w * 2 + 1] = s2; }
+  }
+}
+
+// "single_sample": the partition rules of a model that is sampled one spectrogram at a time (include/adm.h) — process-wide default, overridden
+// per call (= per model) by adm_conv_args.single_sample (1 on, -1 off)
+static std::atomic<int> g_single_sample{-1};
+void set_single_sample(int v) { g_single_sample.store(v); }
+bool conv_single_sample(const adm_conv_args& a) {
+  if (a.single_sample != 0) return a.single_sample > 0;
+  int v = g_single_sample.load();
+  if (v < 0) { const char* e = getenv("ADM_SINGLE_SAMPLE"); v = e ? atoi(e) : 0; g_single_sample.store(v); }
+  return v > 0;
+}
+
 // scratch for the split-K partial slabs, one buffer per (device, stream): launches on one stream are ordered, two streams must
 // not share it. Grown only outside stream capture (the executors run one uncaptured forward before they capture), geometrically,
 // and the superseded buffer is freed once the stream has drained (it used to be leaked on every growth).
@@ -800,6 +847,19 @@ int launch_ksplit_finish(const float* part, int S, long total, const float* bias
   return ADM_CHECK_LAUNCH();
 }
 
+int launch_ksplit_finish_stats(const float* part, int S, long total, const float* bias, const float* chan_add, int chan_add_stride,
+                               const float* residual, float* out, int Cout, int HW, double* stats, hipStream_t st) {
+  if (bias == nullptr) bias = zero_bias(Cout);
+  ADM_REQUIRE(bias != nullptr, "ksplit_finish_stats: zero-bias buffer");
+  ADM_REQUIRE(HW % 256 == 0 && stats != nullptr, "ksplit_finish_stats: planes of a multiple of 256 pixels only");
+  const long nstrips = total / 256;
+  long g = (nstrips + 3) / 4;
+  if (g > 4096) g = 4096;
+  ADM_LAUNCH(ksplit_finish_stats_kernel, dim3((unsigned)g), dim3(256), 0, st, part, S, total, bias, chan_add, chan_add_stride, residual,
+             out, Cout, HW, nstrips, stats);
+  return ADM_CHECK_LAUNCH();
+}
+
 template <int KS>
 static int launch_ksplit(const ConvParams& p, int bm, int S, hipStream_t st) {
   constexpr int CKP = KS == 1 ? 32 : CK;
@@ -847,6 +907,9 @@ static int dispatch_pf(const ConvParams& p, int bm, hipStream_t st) {
     // batches are 1..16 images: 16..128 workgroups with 4 parts): 8 parts, -85 us per config-4 step, -70 us per config-1 step.
     static const int s8_cout = [] { const char* e = getenv("ADM_KSP_PF_S8_COUT"); return e ? atoi(e) : 256; }();     // developer A/B
     int S = (nch <= 48 || p.Cout <= s8_cout) ? 8 : 4;     // (<= 256 couts: the up-path 8x8 layers of those models, 768 -> 256)
+    // the single-sample rule ("single_sample", by model): 16 parts. One 256x256 sample: 14 such layers 61 -> 28 us each (32 workgroups of
+    // 16 chunks -> 128 of 4; 256x256, B = 1: 5.21 -> 4.62 ms per step), where a batch of 32 pays 4x the slab traffic of the default
+    if (p.single) S = 16;
     while (S > 1 && nch / S < 4) --S;
     if (S > 1) {
       const int rc = launch_ksplit<KS>(p, bm2, S, st);
@@ -1003,6 +1066,7 @@ int launch_conv2d(const adm_conv_args& a, hipStream_t st) {
   p.x2_bs = a.x2_bstride ? a.x2_bstride : (long)C2 * a.H * a.W;
   p.wp_bs = a.w_bstride;
   p.ksplit = 1; p.part_stride = 0; p.tap_mask = 0x1ff;
+  p.single = conv_single_sample(a) ? 1 : 0;
   // 3x3: 16 x 8 pixel tiles (small halo); 1x1 has no halo: rows as long as the image allows (<= 128 pixels), so that the
   // pipelined kernel loads and stores whole contiguous row segments
   int TW = p.Wo >= 16 ? 16 : p.Wo, TH = p.Ho >= 8 ? 8 : p.Ho;

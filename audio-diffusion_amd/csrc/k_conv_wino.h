@@ -27,6 +27,10 @@ struct WinoParams {
   int gn_nstride;             // per-sample stride of gn_scale / gn_shift (0: shared identity rows, conv without GroupNorm)
   double* stats;              // optional: GroupNorm partial sums of the output, [n][cout][tile][2] (adm_conv_args.stats_out)
   int tune;                   // conv_wino5_kernel: developer switches (ADM_WINO5_TUNE; bit 0 = s_setprio 1 for waves 4-7)
+  // conv_wino4_kernel, split K (the single-sample rule, "single_sample"): ksplit workgroups share one output tile, each walks cps of the
+  // layer's 8-channel chunks and writes its partial sums (no bias / per-sample term / residual / statistics) to slab kpart of `out`
+  // (slabs part_stride floats apart); nblk counts (tile, part) pairs. ksplit = 1: cps = every chunk, part_stride unused.
+  int ksplit, cps; long part_stride;
 };
 
 __device__ __forceinline__ float silu_w(float v) { return v * ADM_RCP(1.0f + __expf(-v)); }
@@ -47,14 +51,16 @@ constexpr int W5BM = 128;                   // couts of a conv_wino5_kernel / co
 constexpr int W4ABLK = 4 * 2 * 64 * 4;      // floats of one (chunk, 16-cout block) F(2x2) filter image: 8 KiB  (kernels and packers)
 constexpr int W6ABLK = 2 * 9 * 64 * 4;      // ... of the F(4x4) image: 18 KiB
 
-struct Wino3Tile { int n, ty, tx, m0; };
+struct Wino3Tile { int n, ty, tx, m0, kpart; };
 
 __device__ __forceinline__ Wino3Tile wino3_tile(const WinoParams& p, int v) {
   // bijective XCD-aware remap of the virtual block id (v & 7 == XCD of the persistent block that owns it)
   const int q = p.nblk >> 3, r = p.nblk & 7, xcd = v & 7;
-  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
-  const int ct = lid % p.n_ct, pt = lid / p.n_ct;
+  int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
   Wino3Tile t;
+  t.kpart = 0;
+  if (p.ksplit > 1) { t.kpart = lid % p.ksplit; lid /= p.ksplit; }      // the parts of a tile are neighbours (one XCD, one filter slab)
+  const int ct = lid % p.n_ct, pt = lid / p.n_ct;
   t.tx = pt % p.tiles_x; t.ty = (pt / p.tiles_x) % p.tiles_y; t.n = pt / (p.tiles_x * p.tiles_y);
   t.m0 = ct * W3BM;
   return t;
@@ -66,7 +72,7 @@ __device__ __forceinline__ Wino3Tile wino5_tile(const WinoParams& p, int v) {
   const int ct = lid % p.n_ct, pt = lid / p.n_ct;
   Wino3Tile t;
   t.tx = pt % p.tiles_x; t.ty = (pt / p.tiles_x) % p.tiles_y; t.n = pt / (p.tiles_x * p.tiles_y);
-  t.m0 = ct * W5BM;
+  t.m0 = ct * W5BM; t.kpart = 0;
   return t;
 }
 

@@ -223,6 +223,25 @@ static bool wino6_eligible(const adm_conv_args& a) {
   if (rule >= 16) return Ho >= rule && Wo >= rule;
   return Ho >= W6_MIN_PLANE && Wo >= W6_MIN_PLANE && (Ho / 16) * (Wo / 16) * (a.Cout / W5BM) >= W6_MIN_WGS;
 }
+// Split K for conv_wino4_kernel — part (a) of the single-sample rules ("single_sample", adm_conv_args.single_sample; off by default). A 64-cout x 8x16-pixel
+// tile walks every input channel in one workgroup: at one sample per launch a 16x16 .. 64x64 plane gives the chip 8 .. 128 workgroups, each
+// a serial chain of Cin / 8 chunks (40 - 80 us for 0.3 - 0.6 GFLOP; profiles/r06_small_regime.txt). With the rule on, S workgroups share a
+// tile, each walks Cin / (8 S) chunks and writes its partial sums to slab s of the split-K scratch; ksplit_finish_kernel adds the slabs in
+// order with bias / per-sample term / residual (deterministic). S is a function of the LAYER (and of the rule its model carries) only —
+// the partition fixes the fp32 summation order, and a sample's bits must not depend on the batch it is sampled in: a model with the rule on
+// pays the slab traffic at every batch size (which is why it is a per-model opt-in: AudioDiffusion, the single-sample front end, selects it).
+constexpr int WKS_FILL = 256, WKS_MAX = 8;      // split until one sample's workgroups reach WKS_FILL, at most WKS_MAX parts (measured: 512 / 16 no better, 128 worse)
+static int wino_ksplit_parts(const adm_conv_args& a) {
+  if (!conv_single_sample(a) || wino6_eligible(a)) return 1;
+  const int C2 = a.x2 ? a.C2 : 0;
+  const int Ho = a.up ? 2 * a.H : a.H, Wo = a.up ? 2 * a.W : a.W;
+  const int wgs1 = (Wo / 16) * (Ho / 8) * (a.Cout / W3BM), nch = (a.C1 + C2) / WCK;
+  if (wgs1 >= WKS_FILL) return 1;
+  int S = 2;
+  while (S < WKS_MAX && S * wgs1 < WKS_FILL) S *= 2;
+  while (S > 1 && nch % (4 * S) != 0) S >>= 1;      // the kernel's pipeline stages four chunks per round: every part a multiple of four
+  return S;
+}
 static int g_wino_mode = -1;   // -1: take ADM_CONV_WINO from the environment (default 4) on first use
 bool winograd_mode_available(int m) {
   return m == -1 || m == 0 || m == 4;      // (modes 1-3 were the kernel generations retired in round 6)
@@ -266,6 +285,7 @@ int winograd_stats_tiles(const adm_conv_args& a) {
   if (!wino4_layout(a.Cout, a.C1 + C2)) return 0;
   const int Ho = a.up ? 2 * a.H : a.H, Wo = a.up ? 2 * a.W : a.W;
   if (wino6_eligible(a)) return (Wo / 16) * (Ho / 16);          // conv_wino6_kernel: one (sum, sum of squares) per 16x16-pixel tile
+  if (wino_ksplit_parts(a) > 1) return (Ho * Wo) % 256 == 0 ? Ho * Wo / 256 : 0;   // split K: the finish pass's 256-pixel strips (or none)
   return (Wo / 16) * (Ho / 8);
 }
 
@@ -280,6 +300,7 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
   ADM_REQUIRE(wino4_layout(a.Cout, a.C1 + C2), "conv_winograd: shape outside the kernels' tiling (winograd_eligible should have said no)");
   WinoParams p;
   p.tune = 0;
+  p.ksplit = 1; p.cps = (a.C1 + C2) / WCK; p.part_stride = 0;
   p.x1 = a.x1; p.x2 = a.x2; p.C1 = a.C1; p.C2 = C2;
   p.N = a.N; p.Hs = a.H; p.Ws = a.W;
   p.Hi = a.up ? 2 * a.H : a.H; p.Wi = a.up ? 2 * a.W : a.W;
@@ -325,6 +346,26 @@ int launch_conv_winograd(const adm_conv_args& a, hipStream_t st) {
     return launch_wino6(p, a.up != 0, a.act != 0, p.nblk < n_cu ? p.nblk : n_cu, st);
   }
   p.tiles_x = p.Wo / 16; p.tiles_y = p.Ho / 8;
+  if (const int S = wino_ksplit_parts(a); S > 1) {             // the single-sample rule: by layer and model, before any batch-dependent choice
+    const long total = (long)a.N * a.Cout * p.Ho * p.Wo;
+    float* scratch = conv_ksplit_scratch((size_t)S * total, st);
+    if (scratch == nullptr) return -1;
+    WinoParams q = p;
+    q.n_ct = a.Cout / W3BM;
+    q.ksplit = S; q.cps = (a.C1 + C2) / WCK / S; q.part_stride = total;
+    q.nblk = p.tiles_x * p.tiles_y * a.N * q.n_ct * S;
+    q.out = scratch; q.stats = nullptr; q.residual = nullptr;
+    q.bias = conv_zero_bias(a.Cout); q.chan_add = q.bias; q.chan_add_stride = 0;
+    ADM_REQUIRE(q.bias != nullptr, "conv_winograd: zero-bias buffer");
+    ADM_TRY(launch_wino4(q, a.up != 0, a.act != 0, q.nblk < n_cu ? q.nblk : n_cu, st));
+    set_last_conv_variant(4000 + 317);
+    const int HW = p.Ho * p.Wo;
+    if (a.stats_out != nullptr)
+      return launch_ksplit_finish_stats(scratch, S, total, p.bias, a.chan_add, a.chan_add_stride, a.residual, a.out, a.Cout, HW, a.stats_out, st);
+    if (const GnFuse* f = conv_gn_fuse_pending(a.Cout))
+      return launch_ksplit_finish_gn(scratch, S, total, p.bias, a.chan_add, a.chan_add_stride, a.residual, a.out, a.N, a.Cout, HW, *f, st);
+    return launch_ksplit_finish(scratch, S, total, p.bias, a.chan_add, a.chan_add_stride, a.residual, a.out, a.Cout, HW, st);
+  }
   if (wino5_on() && a.Cout % W5BM == 0) {
     const int nblk5 = p.tiles_x * p.tiles_y * a.N * (a.Cout / W5BM);
     if (nblk5 >= n_cu || (wino5_on() & 2)) {                   // ("wino5" bit 1: wherever the shape allows — tests on small tensors)

@@ -37,7 +37,7 @@ __device__ __forceinline__ void wino4_producer(const WinoParams& p, float* ldsV,
   constexpr int RING = 3;                     // buffer index mask: rings of four
   const int Ct = p.C1 + p.C2;
   const int planeS = p.Hs * p.Ws;
-  const int nch = Ct / WCK;
+  const int nch = p.cps;              // chunks per (tile, part): every chunk of the layer unless K is split
   const int ntile = (p.nblk - b0 + bs - 1) / bs;
   const int total = ntile * nch;      // chunks this workgroup stages
   // Non-UP: every thread stages float4 row piece f = tid (item 0); producer wave 0 (WIDE1) also stages pieces 256..319,
@@ -82,6 +82,7 @@ __device__ __forceinline__ void wino4_producer(const WinoParams& p, float* ldsV,
 
   // ---- stage A cursor: (tile, chunk) of the next global load ----------------------------------------------------------------
   int a_v = b0, a_ci = 0, a_left = total;
+  int a_k0 = 0;                       // first chunk of the tile's part (split K; else 0)
   int a_off0 = 0, a_off1 = 0;         // element offset of the items inside the sample: channel plane + row + column
   unsigned a_ok = 0;
   const float *a_x1 = nullptr, *a_x2 = nullptr, *a_gs = nullptr, *a_gh = nullptr;   // per-tile wave-uniform bases
@@ -95,6 +96,7 @@ __device__ __forceinline__ void wino4_producer(const WinoParams& p, float* ldsV,
 #endif
   auto a_geometry = [&]() {
     const Wino3Tile t = wino3_tile(p, a_v);
+    a_k0 = t.kpart * nch;
     a_x1 = p.x1 + (long)t.n * p.x1_bs;
     a_x2 = p.x2 + (long)t.n * p.x2_bs - (long)p.C1 * planeS;     // indexed with the concatenated channel number
     a_gs = p.gn_scale + (long)t.n * p.gn_nstride;
@@ -120,7 +122,7 @@ __device__ __forceinline__ void wino4_producer(const WinoParams& p, float* ldsV,
   };
   a_geometry();
   auto stage_a = [&](Wino3Raw& r) {           // issue the global loads of chunk (a_v, a_ci); then advance the cursor
-    const int c0 = a_ci * WCK;
+    const int c0 = (a_k0 + a_ci) * WCK;
 #if !defined(ADM_EMU)
     const __amdgpu_buffer_rsrc_t rx = c0 < p.C1 ? a_rx1 : a_rx2;
     const int so = c0 * planeS * 4, sg = c0 * 4;            // wave-uniform byte offsets of the chunk (< 2^31: one sample's channels)
@@ -304,7 +306,7 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   constexpr int RING = 3;                   // rings of four V slabs
   const int lane = tid & 63;
   const int li = lane & 15, k4 = lane >> 4;
-  const int nch = (p.C1 + p.C2) / WCK;
+  const int nch = p.cps;                    // chunks per (tile, part)
   const int n_cblk = p.Cout >> 4;
   const int ntile = (p.nblk - b0 + bs - 1) / bs;
   const int total = ntile * nch;
@@ -313,7 +315,11 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
   // (plain global loads: the eight loads of a chunk share one address register pair; raw buffer loads measured 1.5-4 % slower here, r04)
   int d_v = b0, d_ci = 0, d_left = total;
   const long chunk_stride = (long)n_cblk * W4ABLK;
-  const float* d_src = p.wu + ((long)(wino3_tile(p, d_v).m0 >> 4) + wave) * W4ABLK + lane * 4;   // chunk 0 of the tile
+  auto a_origin = [&](int v) {              // first chunk of virtual block v's (tile, part): this wave's 16-cout block, this lane's words
+    const Wino3Tile t = wino3_tile(p, v);
+    return p.wu + (long)t.kpart * nch * chunk_stride + ((long)(t.m0 >> 4) + wave) * W4ABLK + lane * 4;
+  };
+  const float* d_src = a_origin(d_v);
   f32x4 a[4][2];                            // [point group][k step]: component e = Winograd point 4 q + e
 #define W4_LOAD_A(q)                                                                   \
   do {                                                                                 \
@@ -327,7 +333,7 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
       if (++d_ci == nch) {
         ADM_SCHED_FENCE();
         d_ci = 0; d_v += bs;
-        d_src = p.wu + ((long)(wino3_tile(p, d_v).m0 >> 4) + wave) * W4ABLK + lane * 4;
+        d_src = a_origin(d_v);
       }
     }
   };
@@ -361,7 +367,8 @@ __device__ __forceinline__ void wino4_consumer(const WinoParams& p, const float*
         ADM_UNROLL
         for (int r = 0; r < 4; ++r) acc[xi][c][r] = 0.f;
     const int oy = t.ty * 8 + 2 * (li >> 2), ox = t.tx * 16 + 4 * (li & 3);
-    const long obase = ((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4) * planeO + (long)oy * p.Wo + ox;   // cout row r: + r * planeO
+    const long obase = (long)t.kpart * p.part_stride +      // (split K: slab kpart of the partial-sum buffer; the caller passes zero bias rows)
+                       ((long)t.n * p.Cout + t.m0 + 16 * wave + 4 * k4) * planeO + (long)oy * p.Wo + ox;   // cout row r: + r * planeO
     // Bias, per-sample term and residual enter in the WINOGRAD domain: Y = A^T M A has Y00 / Y01 / Y10 / Y11 depend on the corner
     // entries M00 / M03 / M30 / M33 alone with weights +1 / -1 / -1 / +1, so adding (b + res) there is adding it to the output.
     // One cout row per chunk over the first four chunks: the loads are issued when the chunk starts and consumed when it ends

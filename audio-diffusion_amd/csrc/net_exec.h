@@ -112,6 +112,7 @@ struct Net {
   std::vector<std::pair<std::string, int>> temb_rows;  // (time_emb_proj prefix, Cout) in op order (UNet only)
   int t_in = -1, t_out = -1;
   int planned_B = 0;
+  int single_sample = 0;             // this model's single-sample partition rules (adm_unet_set_option; 0 = the process-wide option, 1 on, -1 off)
   int wino6_rule = 0;                // this model's F(4x4) layer rule (adm_unet_set_option; 0 = the process-wide option): copied into every adm_conv_args
   unsigned plan_epoch = 0;           // dispatch_epoch() the plan was made under: adm_set_option moves kernel choices, and with them the statistic-tile counts
   bool plan_current(int B) const;    // planned for exactly B under the current options

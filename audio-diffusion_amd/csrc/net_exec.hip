@@ -817,6 +817,7 @@ void Net::fill_conv_args(const Op& o, int B, const float* temb_all, int temb_str
   if (o.res >= 0) a.residual = tensors[o.res].ptr;
   a.out = tensors[o.out].ptr;
   a.wino6_rule = wino6_rule;
+  a.single_sample = single_sample;
 }
 
 int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_stride, hipStream_t st, OpTimer* tm) {

@@ -435,7 +435,16 @@ void adm_unet_destroy(adm_unet_t* h) {
 
 int adm_unet_set_option(adm_unet_t* h, const char* name, int value) {
   ADM_REQUIRE(h && name, "unet_set_option: null argument");
-  ADM_REQUIRE(std::string(name) == "wino6", "unet_set_option: the per-model options are: wino6");
+  const std::string nm(name);
+  ADM_REQUIRE(nm == "wino6" || nm == "single_sample", "unet_set_option: the per-model options are: wino6, single_sample");
+  if (nm == "single_sample") {
+    ADM_REQUIRE(value >= -1 && value <= 1, "unet_set_option: single_sample takes 0 (follow the process-wide option), 1 (on) or -1 (off)");
+    if (h->net.single_sample != value) {
+      h->net.single_sample = value;
+      free_plan(h);
+    }
+    return 0;
+  }
   ADM_REQUIRE(value == 0 || value == 1 || value == 2 || (value >= 16 && value <= 65536),
               "unet_set_option: wino6 takes 0 (follow the process-wide option), 1 (default layer rule), 2 (every layer the kernel tiles) or a plane-size floor n >= 16");
   if (h->net.wino6_rule != value) {

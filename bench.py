@@ -487,6 +487,8 @@ def roofline(unet, x, B):
         4314: "adm::conv_wino4_kernel (Winograd F(2x2,3x3) 3x3 stride-1 conv, v_mfma_f32_16x16x4_f32, persistent wave-specialised: "
               "4 producer waves (patch -> GroupNorm/SiLU -> B^T d B into LDS) + 4 consumer waves (16 couts x 32 tiles each, filters "
               "L2 -> registers, lane-local A^T M A), 64-cout x 8x16-pixel tile)",
+        4317: "adm::conv_wino4_kernel, split K (the single-sample rule \"single_sample\": several workgroups per tile, each a part of the input "
+              "channels) + ksplit_finish(_stats)_kernel",
         4315: "adm::conv_wino5_kernel (Winograd F(2x2,3x3) 3x3 stride-1 conv, v_mfma_f32_16x16x4_f32, persistent: 128-cout x 8x16-pixel "
               "workgroup tile, every input patch transformed once per 128 couts; all 8 waves are MFMA waves (16 couts x 32 tiles x 16 "
               "points each, filters L2 -> registers, lane-local A^T M A) and share the staging (patch -> GroupNorm/SiLU -> B^T d B into "
@@ -615,6 +617,7 @@ def configs_leg(job):
     # config 1 (the reference's own CPU-runnable case): 64x64, DDPM, ONE sample, the complete 10-step sampling
     p1 = AudioDiffusionPipeline(None, UNet2DModel(**cfg(64)).init_random(0), Mel(x_res=64, y_res=64, hop_length=1024), DDPMScheduler()).to(dev)
     p1.set_progress_bar_config(disable=True)
+    p1.unet.set_option("single_sample", 1)      # ONE sample per call: the model's single-sample rule, as AudioDiffusion selects it (include/adm.h)
     n1 = torch.randn(1, 1, 64, 64, generator=torch.Generator().manual_seed(6)).to(dev)
     p1(batch_size=1, steps=10, noise=n1.clone(), audio=False)
     torch.cuda.synchronize(dev)
@@ -623,7 +626,8 @@ def configs_leg(job):
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter() - t0
     out["config_1"] = {"workload": "audio-diffusion-64 architecture, 64x64 DDPM, 1 sample, 10 steps (complete sampling through the public "
-                                   "__call__, noise -> PIL image)", "ms_per_sample": round(t1 * 1e3, 2), "ms_per_step": round(t1 * 1e2, 3)}
+                                   "__call__, noise -> PIL image; the model carries the single-sample rule UNet2DModel.set_option("
+                                   "'single_sample', 1), as the AudioDiffusion front end sets it)", "ms_per_sample": round(t1 * 1e3, 2), "ms_per_step": round(t1 * 1e2, 3)}
     del p1
     t, _ = run(AudioDiffusionPipeline(None, UNet2DModel(**cfg(256)).init_random(0), Mel(), DDPMScheduler()).to(dev), 256, False)
     out["config_2"] = {"workload": "teticio/audio-diffusion-256 architecture, pixel-space DDPM on the 1000-step schedule, 256x256, "

@@ -42,6 +42,14 @@ int adm_has_experiments(void);
  *   only (the two transforms are not bit-identical) | 0 F(2x2,3x3) kernels everywhere | 2 every layer the kernel tiles (tests) | n >= 16: planes
  *   of at least n x n pixels (256: the latency setting — single-sample sampling at 256x256 is 18 % faster with it than with the default, a B = 32
  *   forward 10 % slower; 128: in between) | -1 (ADM_WINO6);
+ * "single_sample" = 0 (default) | 1: the partition rules for models that are sampled ONE spectrogram at a time (where a layer's tiles cannot
+ *   fill 256 CUs and its time is a serial chain per workgroup). (a) conv_wino4_kernel: layers whose 64-cout x 8x16-pixel tiles give one sample
+ *   fewer than 256 workgroups (planes of 16x16 .. 64x64 pixels) and that conv_wino6_kernel does not take split their input channels over
+ *   2 / 4 / 8 workgroups per tile (every part a multiple of 32 channels); the partial sums are added in order by a finish launch (which also
+ *   leaves the GroupNorm partial sums the unsplit kernel's epilogue would). (b) the split-K 3x3 kernel of the <= 8x8-pixel planes takes 16
+ *   parts instead of 4 / 8. The partitions depend on the LAYER only, never on the batch — a sample's bits do not depend on its batch — so with
+ *   the rule on a model pays the slab traffic at every batch size: it is a per-model opt-in (adm_unet_set_option; AudioDiffusion selects it).
+ *   Results differ from the default rules' in the last bits (another fp32 summation order) | -1 (ADM_SINGLE_SAMPLE);
  * "wino_pair": accepted and ignored since round 6 (conv_wino4_kernel keeps one cadence: one workgroup barrier per two chunks);
  * "wgrad_max_split" = n caps the split-K factor of adm_conv2d_wgrad (0 = heuristic; tests use it to put several pixel tiles on
  *   one workgroup);
@@ -57,7 +65,7 @@ int adm_has_experiments(void);
  *   that GroupNorm's scale / shift from its finish pass (one launch instead of finish + statistics; the tensor is bit-identical) |
  *   0 separate launches | -1 ADM_GN_FUSE_FINISH.
  * The dispatch epoch moves only when a value really changes; set options BEFORE adm_unet_refresh_weights / the next train step.
- * adm_version() = 103 since round 6 (adm_conv_args.wino6_rule, adm_unet_set_option, adm_release_stream); 102 since round 5 (Winograd filter buffers hold two images: adm_winograd_packed_floats); 101 since round 4 (adm_slerp_grid takes DOUBLE weights since round 3; blocked-image entry points). */
+ * adm_version() = 104 since round 6 (adm_conv_args.single_sample, option "single_sample"; 103: adm_conv_args.wino6_rule, adm_unet_set_option, adm_release_stream); 102 since round 5 (Winograd filter buffers hold two images: adm_winograd_packed_floats); 101 since round 4 (adm_slerp_grid takes DOUBLE weights since round 3; blocked-image entry points). */
 int adm_set_option(const char* name, int value);
 /* Per-(device, stream) scratch the library keeps for a stream (the split-K slab buffer of the small-plane convolutions, >= 32 MiB, at most
  * 256 streams per device): give it back BEFORE destroying a stream that has run library calls. Drains the stream first (a captured graph of
@@ -143,6 +151,9 @@ typedef struct adm_conv_args {
    * 2 every layer the kernel tiles, n >= 16 planes of at least n x n pixels). A model handle carries one (adm_unet_set_option), so that a
    * single-sample front end can run the latency rule on ITS model without touching other models in the process. Since adm_version() 103. */
   int wino6_rule;
+  /* optional (0 = the process-wide "single_sample" option decides; 1 on; -1 off): this call's (its model's) single-sample partition rules —
+   * see the option. Since adm_version() 104. */
+  int single_sample;
 } adm_conv_args;
 /* number of statistic tiles per (sample, channel) the kernel chosen for these arguments would emit, 0 = it cannot. */
 int adm_conv_stats_tiles(const adm_conv_args* a);
@@ -245,7 +256,8 @@ typedef struct adm_unet_config {
 } adm_unet_config;
 
 int adm_unet_create(const adm_unet_config* cfg, adm_unet_t** out);
-/* Per-MODEL option (adm_version() >= 103). "wino6": this model's F(4x4) layer rule — 0 = follow the process-wide option (default), 1 / 2 /
+/* Per-MODEL options (adm_version() >= 103; "single_sample" >= 104: 0 = follow the process-wide option, 1 = on, -1 = off for this model —
+ * AudioDiffusion sets 1: one 256x256 sample per call 6.65 -> 4.6 ms per step, profiles/r06_single_sample.md). "wino6": this model's F(4x4) layer rule — 0 = follow the process-wide option (default), 1 / 2 /
  * n >= 16 as adm_set_option("wino6", .). `audiodiffusion.AudioDiffusion` (the reference's single-sample facade, audiodiffusion/__init__.py:58-68:
  * batch_size is forced to 1) sets 256 on its own model: planes whose 16x16x128 tiles fill the chip with ONE sample keep F(4x4), the
  * levels below run the 64-cout F(2x2) kernel, whose smaller tiles are 4x as many workgroups (256x256, one sample: 6.8 instead of 8.3 ms per

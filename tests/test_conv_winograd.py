@@ -313,3 +313,120 @@ def test_the_package_level_option_setter(backend):
             audiodiffusion.set_option("no_such_option", 1)
     finally:
         audiodiffusion.set_option("wino6", -1)
+
+
+KSPLIT_CASES = [
+    # ((N, C1, C2, H, W, Cout, up, gn, act, temb, res), parts): parts = what the layer rule gives (a function of the layer alone)
+    ((1, 64, 0, 16, 16, 64, 0, 1, 1, 1, 1), 2),        # 8 chunks: two parts of four
+    ((2, 128, 128, 16, 32, 128, 0, 1, 1, 0, 1), 8),    # virtual concat: parts 0-3 read x1, 4-7 x2; two cout tiles; residual
+    ((1, 128, 0, 8, 8, 64, 1, 0, 0, 1, 0), 4),         # nearest-x2 upsample folded into the load path
+    ((3, 256, 0, 32, 32, 128, 0, 1, 1, 1, 0), 8),      # 16 pixel tiles x 2 cout tiles x 8 parts x 3 samples on the emulator's 3-block grid
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case,parts", KSPLIT_CASES, ids=lambda c: "-".join(str(v) for v in c) if isinstance(c, tuple) else str(c))
+def test_conv_winograd_split_k(backend, case, parts):
+    """"single_sample" = 1 (the single-sample rule): conv_wino4_kernel splits the input channels of a layer whose tiles cannot fill the chip with one
+    sample over `parts` workgroups per tile + one finish launch. Against torch fp32 at the usual bar, against the unsplit kernel to
+    rounding, and — what the rule exists for — rows of a batch bit-identical to the same samples convolved alone."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    lib = _native.lib()
+    Nn, C1, C2, H, W, Cout, up, use_gn, act, use_temb, use_res = case
+    x1 = _rand((Nn, C1, H, W), 1, dev)
+    x2 = _rand((Nn, C2, H, W), 2, dev) if C2 else None
+    Ct = C1 + C2
+    w = _rand((Cout, Ct, 3, 3), 3, dev, scale=(Ct * 9) ** -0.5)
+    b = _rand((Cout,), 4, dev)
+    gamma, beta = _rand((Ct,), 5, dev), _rand((Ct,), 6, dev)
+    temb = _rand((Nn, Cout), 7, dev) if use_temb else None
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res = _rand((Nn, Cout, Ho, Wo), 8, dev) if use_res else None
+    wp, wu = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
+
+    def conv(rows, stats=False):
+        sl = lambda t: None if t is None else t[rows].contiguous()  # noqa: E731
+        gn = ops.groupnorm_stats(sl(x1), gamma, beta, 32, 1e-5, x2=sl(x2)) if use_gn else None
+        return ops.conv2d(sl(x1), wp, b, 3, x2=sl(x2), up=bool(up), gn=gn, act=bool(act), chan_add=sl(temb), residual=sl(res), wino=wu,
+                          stats=stats)
+    everything = slice(0, Nn)
+    _native.check(lib.adm_set_option(b"wino6", 0))
+    try:
+        unsplit = conv(everything)
+        assert lib.adm_last_conv_variant() in (4314, 4315)
+        _native.check(lib.adm_set_option(b"single_sample", 1))
+        out, st = conv(everything, stats=True)
+        assert lib.adm_last_conv_variant() == 4317, "the split-K launch was not selected"
+        alone = [conv(slice(i, i + 1)) for i in range(Nn)]
+    finally:
+        _native.check(lib.adm_set_option(b"single_sample", -1))
+        _native.check(lib.adm_set_option(b"wino6", -1))
+    c = lambda t: None if t is None else t.cpu()  # noqa: E731
+    ref = _conv_ref(c(x1), c(x2), c(w), c(b), 3, 1, up, (c(gamma), c(beta)) if use_gn else None, act, c(temb), c(res))
+    assert _relerr(out, ref) < 1e-4, _relerr(out, ref)
+    assert _relerr(out, unsplit) < 3e-6 and (parts == 1) == bool(torch.equal(out.cpu(), unsplit.cpu()))
+    for i in range(Nn):
+        assert torch.equal(out[i:i + 1].cpu(), alone[i].cpu()), "a sample's bits depend on its batch"
+    # the finish pass leaves the GroupNorm partial sums the unsplit kernel's epilogue would: one pair per 256-pixel strip
+    HW = Ho * Wo
+    assert st is not None and tuple(st.shape) == (Nn, Cout, HW // 256, 2)
+    y = out.double().reshape(Nn, Cout, HW // 256, 256).cpu()
+    want = torch.stack([y.sum(-1), (y * y).sum(-1)], -1)
+    assert torch.allclose(st.cpu(), want, rtol=2e-6, atol=2e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_split_k_rule_is_a_function_of_the_layer(backend):
+    """Which layers split, and into how many parts: planes whose 64-cout x 8x16-pixel tiles give one sample >= 256 workgroups do not; the F(4x4)
+    kernel's layers do not; a channel count whose chunks do not divide into parts of four keeps fewer parts (or none); the batch never enters."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    lib = _native.lib()
+
+    def variant(N, Cin, Cout, H, W):
+        x = _rand((N, Cin, H, W), 1, dev)
+        w = _rand((Cout, Cin, 3, 3), 2, dev, scale=(Cin * 9) ** -0.5)
+        ops.conv2d(x, ops.pack_conv_weight(w), None, 3, wino=ops.pack_winograd_weight(w))
+        return lib.adm_last_conv_variant()
+    _native.check(lib.adm_set_option(b"single_sample", 1))
+    try:
+        assert variant(1, 32, 64, 16, 16) in (4314, 4315)      # four chunks: nothing to split
+        assert variant(1, 96, 64, 16, 16) in (4314, 4315)      # twelve chunks: no power-of-two partition into multiples of four
+        assert variant(1, 64, 64, 16, 16) == 4317 and variant(5, 64, 64, 16, 16) == 4317      # the batch does not enter
+        if backend == "hip":                                   # (too large for the emulator's fibers)
+            assert variant(1, 64, 128, 128, 128) == 4316       # a layer the F(4x4) kernel takes is never split
+            _native.check(lib.adm_set_option(b"wino6", 0))
+            assert variant(1, 64, 128, 128, 128) in (4314, 4315)   # 8 x 16 x 2 = 256 workgroups for one sample: filled, not split
+            assert variant(1, 64, 128, 64, 64) == 4317
+    finally:
+        _native.check(lib.adm_set_option(b"single_sample", -1))
+        _native.check(lib.adm_set_option(b"wino6", -1))
+    assert variant(1, 64, 64, 16, 16) in (4314, 4315)          # off by default
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_single_sample_rule_of_the_small_plane_split(backend):
+    """Part (b) of "single_sample": the split-K 3x3 kernel of the <= 8x8-pixel planes takes 16 parts (512 -> 64 channels: 64 chunks, four per part)
+    instead of 8 / 4. Same kernel variant, another summation order: matches torch, agrees with the default partition to rounding, and a sample
+    convolved alone has the bits of its row in a batch."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    lib = _native.lib()
+    x = _rand((3, 512, 8, 8), 1, dev)
+    w = _rand((64, 512, 3, 3), 2, dev, scale=(512 * 9) ** -0.5)
+    b = _rand((64,), 3, dev)
+    wp = ops.pack_conv_weight(w)
+    base = ops.conv2d(x, wp, b, 3)
+    assert lib.adm_last_conv_variant() == 2316
+    _native.check(lib.adm_set_option(b"single_sample", 1))
+    try:
+        out = ops.conv2d(x, wp, b, 3)
+        assert lib.adm_last_conv_variant() == 2316
+        alone = ops.conv2d(x[1:2].contiguous(), wp, b, 3)
+    finally:
+        _native.check(lib.adm_set_option(b"single_sample", -1))
+    ref = torch.nn.functional.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1)
+    assert _relerr(out, ref) < 1e-4 and _relerr(out, base) < 3e-6
+    assert not torch.equal(out.cpu(), base.cpu()) and torch.equal(out[1:2].cpu(), alone.cpu())
+    assert lib.adm_set_option(b"single_sample", 2) != 0 and b"single_sample" in lib.adm_last_error()

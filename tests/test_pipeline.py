@@ -213,7 +213,7 @@ def test_save_load_roundtrip_and_facade(tmp_path):
     img, (sr, audio) = ad.generate_spectrogram_and_audio(steps=2, noise=noise.clone())
     assert img.size == (16, 16) and sr == 4000 and audio.ndim == 1
     # the single-sample front end runs ITS model under the single-sample layer rule of the F(4x4) kernel (adm_unet_set_option), and only its model
-    assert ad.pipe.unet._options == {"wino6": 256} and not getattr(again.unet, "_options", {})
+    assert ad.pipe.unet._options == {"wino6": 256, "single_sample": 1} and not getattr(again.unet, "_options", {})
     looped = AudioDiffusion.loop_it(audio, sr)          # a quarter of a second of model output rarely holds a full bar
     assert looped is None or (looped.ndim == 1 and len(looped) % 12 == 0)
 

@@ -194,3 +194,41 @@ def test_the_f4x4_layer_rule_is_a_per_model_setting(backend):
     assert torch.equal(mine(x[1:2].to(dev), 500)["sample"].cpu(), a[1:2])      # a row alone = the row in its batch, under the model's rule
     mine.set_option("wino6", 0)
     assert torch.equal(mine(x.to(dev), 500)["sample"].cpu(), b)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_the_split_k_rule_is_a_per_model_setting(backend):
+    """`UNet2DModel.set_option("single_sample", 1)` — the single-sample rule of the 64-cout F(2x2) kernel (include/adm.h): this model's 3x3
+    layers split their input channels over several workgroups per tile (variant 4317) and its statistics come from the finish pass; a second
+    model in the process keeps the unsplit kernels. Both match the oracle; the partition is a function of the layer, so the model's batch
+    rows stay bit-identical to its single-sample runs; the captured loop runs under the rule as well; 0 hands the model back."""
+    import ctypes as C
+    from audiodiffusion import _native
+    dev = select(backend)
+    ref, mine = _pair(W6NET)
+    _, other = _pair(W6NET)
+    x = torch.randn(3, 1, 16, 16, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        r = ref(x, 500)["sample"]
+
+    def variants(m):
+        recs, n = (_native.OpProfile * 512)(), C.c_int(0)
+        xd, out = x.to(dev), torch.empty_like(x.to(dev))
+        _native.check(_native.lib().adm_unet_profile(m._ensure_handle(), _native.ptr(xd), 500.0, _native.ptr(out), x.shape[0], recs, 512,
+                                                     C.byref(n), _native.stream_for(xd)))
+        return {r.variant for r in recs[: n.value]}
+    mine.set_option("single_sample", 1)
+    a = mine(x.to(dev), 500)["sample"].cpu()
+    b = other(x.to(dev), 500)["sample"].cpu()
+    va, vb = variants(mine), variants(other)
+    assert 4317 in va and 4317 not in vb and not (va & {4314, 4315}) and (vb & {4314, 4315}), (va, vb)
+    for o in (a, b):
+        assert float((o - r).abs().max()) < 1e-3 * max(1.0, float(r.abs().max()))
+    assert not torch.equal(a, b)                                   # two summation orders of the same network
+    for i in range(3):
+        assert torch.equal(mine(x[i:i + 1].to(dev), 500)["sample"].cpu(), a[i:i + 1])
+    with pytest.raises(RuntimeError, match="single_sample"):
+        mine.set_option("single_sample", 7)
+    assert mine._options == {"single_sample": 1}                     # the rejected value was not remembered
+    mine.set_option("single_sample", 0)
+    assert torch.equal(mine(x.to(dev), 500)["sample"].cpu(), b)

@@ -22,6 +22,8 @@ for spec in os.environ.get("PROBE", "32,16;64,1;256,1").split(";"):
     unet = UNet2DModel(**cfg).init_random(0)
     if os.environ.get("PROBE_RULE"):             # the model's own F(4x4) layer rule (UNet2DModel.set_option; AudioDiffusion sets 256)
         unet.set_option("wino6", int(os.environ["PROBE_RULE"]))
+    if os.environ.get("PROBE_KSPLIT"):           # the model's own split-K rule of the 64-cout F(2x2) kernel (AudioDiffusion sets 1)
+        unet.set_option("single_sample", int(os.environ["PROBE_KSPLIT"]))
     x = torch.randn(B, 1, res, res, device=dev)
     out = torch.empty_like(x)
     cap = 1024
