@@ -942,11 +942,20 @@ static int launch_ksplit_generic(const ConvParams& p, hipStream_t st) {
   // Whether and how K is split depends on the LAYER only (output plane, channel counts), never on the batch size: the partition
   // fixes the fp32 summation order, and a sample's result must not depend on how many samples share its launch (rows sampled
   // alone, in another batch or on another number of GPUs are bit-identical; tests/test_full_size.py, tests/test_distributed.py).
-  if (!use_ksp || p.wp_bs != 0 || nch < 8 || HWo > 64) return 1;
+  // The single-sample rule ("single_sample", by model) lifts the plane bound for whatever reaches this kernel on larger planes — the stride-2
+  // Downsample2D convolutions: one sample gives a 256 -> 256 layer with a 16x16 output 16 workgroups of 32 chunks each (106 us for 0.3 GFLOP).
+  const bool big = HWo > 64;
+  if (!use_ksp || p.wp_bs != 0 || nch < 8 || (big && !(p.single && KS == 3))) return 1;
   // (64-cout tiles = twice the workgroups, two per CU: measured SLOWER in the latency regime, 3.85 vs 3.50 ms per config-4 step —
   // every workgroup of a tile row stages the same patch)
   const int bm = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
   int S = HWo <= 4 ? 64 : (HWo <= 16 ? 32 : 8);
+  if (big) {                            // parts until ONE sample's workgroups reach 256 (the batch never enters), at most 16
+    const int wg1 = p.tiles_x * p.tiles_y * (p.Cout / bm);
+    if (wg1 >= 128) return 1;
+    S = 2;
+    while (S < 16 && S * wg1 < 256) S *= 2;
+  }
   if (S > nch / 2) S = nch / 2;
   if (S < 2) return 1;
   const long total = (long)p.N * p.Cout * p.Ho * p.Wo;
@@ -991,7 +1000,7 @@ static int launch_ksplit_generic(const ConvParams& p, hipStream_t st) {
   }
   const int HW = p.Ho * p.Wo;
   g_last_variant = KS * 100 + STRIDE * 10 + bm / 32 + 5;      // x16 / x26 + ...: 3x3 stride 1 -> 316 / 317 / 319 (bm 32 / 64 / 128)
-  if (const GnFuse* f = conv_gn_fuse_pending(p.Cout))
+  if (const GnFuse* f = big ? nullptr : conv_gn_fuse_pending(p.Cout))      // (one workgroup per (group, sample) is a small-plane design)
     return launch_ksplit_finish_gn(scratch, S, total, p.bias, p.chan_add, p.chan_add_stride, p.residual, p.out, p.N, p.Cout, HW, *f, st);
   if (HW % 4 == 0) {
     long g = (total / 4 + 255) / 256;

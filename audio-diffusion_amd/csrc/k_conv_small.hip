@@ -395,7 +395,10 @@ int launch_conv_small(const adm_conv_args& a, hipStream_t st) {
     ADM_FAIL("conv_small(cin): unsupported (Cin, ks)");
   }
   ADM_REQUIRE(a.Cout <= 4 && a.ks == 3 && a.pad_lo == 1, "conv_small: unsupported shape (need Cin<=4 or Cout<=4, 3x3)");
-  if (a.W % 64 == 0 && a.H % 16 == 0 && use_wide_cout()) {   // whole 64 x 16 tiles: the wide kernel (16-byte aligned rows)
+  // the single-sample rule ("single_sample", by model): the channel split below on planes of any size — one 256x256 sample is 64 wide tiles,
+  // each a serial walk over all input channels (93 us; 64x64: 4 tiles, 97 us)
+  const bool single_split = conv_single_sample(a) && a.C1 >= 64;
+  if (a.W % 64 == 0 && a.H % 16 == 0 && use_wide_cout() && !single_split) {   // whole 64 x 16 tiles: the wide kernel (16-byte aligned rows)
     const int wx = a.W / 64, wy = a.H / 16;
 #define ADM_COUTW_CASE(CO)                                                                                              \
   if (a.Cout == CO) {                                                                                                   \
@@ -413,7 +416,7 @@ int launch_conv_small(const adm_conv_args& a, hipStream_t st) {
   float* part = nullptr;
   const long total = (long)a.N * a.Cout * a.H * a.W;
   static const int use_ksp = [] { const char* e = getenv("ADM_CONV_KSPLIT"); return e ? atoi(e) : 1; }();
-  if (use_ksp && (long)a.H * a.W <= 1024 && a.C1 >= 64) {
+  if (use_ksp && ((long)a.H * a.W <= 1024 || single_split) && a.C1 >= 64) {
     part = conv_ksplit_scratch((size_t)8 * total, st);
     if (part == nullptr) return -1;       // (error recorded) the unsplit kernel sums in another order
     S = 8;

@@ -430,3 +430,45 @@ def test_single_sample_rule_of_the_small_plane_split(backend):
     assert _relerr(out, ref) < 1e-4 and _relerr(out, base) < 3e-6
     assert not torch.equal(out.cpu(), base.cpu()) and torch.equal(out[1:2].cpu(), alone.cpu())
     assert lib.adm_set_option(b"single_sample", 2) != 0 and b"single_sample" in lib.adm_last_error()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_single_sample_rule_of_the_stride_2_and_conv_out_layers(backend):
+    """Parts (c) / (d) of "single_sample": a stride-2 3x3 convolution (Downsample2D) with a plane above 8x8 pixels splits its channels in the
+    generic MFMA kernel (variant + 5), and the conv_out class kernel (Cout <= 4) splits them on planes of any size instead of walking them
+    in one wide tile. Both: torch parity, agreement with the default path to rounding, a sample alone = its row in a batch."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    lib = _native.lib()
+    x = _rand((3, 64, 32, 32), 1, dev)
+    w = _rand((64, 64, 3, 3), 2, dev, scale=(64 * 9) ** -0.5)
+    b = _rand((64,), 3, dev)
+    wp = ops.pack_conv_weight(w)
+    xo = _rand((2, 64, 16, 64), 4, dev)
+    wo = _rand((1, 64, 3, 3), 5, dev, scale=(64 * 9) ** -0.5)
+    bo = _rand((1,), 6, dev)
+    gamma, beta = _rand((64,), 7, dev), _rand((64,), 8, dev)
+    wop = ops.pack_conv_weight(wo)
+
+    def run(xs, xos):
+        down = ops.conv2d(xs, wp, b, 3, stride=2, pad_lo=1)
+        vd = lib.adm_last_conv_variant()
+        gn = ops.groupnorm_stats(xos, gamma, beta, 32, 1e-5)
+        out = ops.conv2d(xos, wop, bo, 3, gn=gn, act=True)
+        return down, vd, out, lib.adm_last_conv_variant()
+    d0, vd0, o0, vo0 = run(x, xo)
+    _native.check(lib.adm_set_option(b"single_sample", 1))
+    try:
+        d1, vd1, o1, vo1 = run(x, xo)
+        d1a, _, o1a, _ = run(x[2:3].contiguous(), xo[1:2].contiguous())
+    finally:
+        _native.check(lib.adm_set_option(b"single_sample", -1))
+    assert vd0 in (321, 322, 324) and vd1 in (326, 327, 329), (vd0, vd1)      # 3x3 stride 2, cout tile 32 / 64 / 128: unsplit, split (+ 5)
+    assert vo0 == 1002 and vo1 == 1002
+    refd = torch.nn.functional.conv2d(x.cpu(), w.cpu(), b.cpu(), stride=2, padding=1)
+    h = torch.nn.functional.silu(torch.nn.functional.group_norm(xo.cpu(), 32, gamma.cpu(), beta.cpu(), 1e-5))
+    refo = torch.nn.functional.conv2d(h, wo.cpu(), bo.cpu(), padding=1)
+    assert _relerr(d1, refd) < 1e-4 and _relerr(o1, refo) < 1e-4
+    assert _relerr(d1, d0) < 3e-6 and _relerr(o1, o0) < 3e-6
+    assert not torch.equal(d1.cpu(), d0.cpu()) and not torch.equal(o1.cpu(), o0.cpu())      # the rule did change the partition
+    assert torch.equal(d1[2:3].cpu(), d1a.cpu()) and torch.equal(o1[1:2].cpu(), o1a.cpu())
