@@ -82,6 +82,7 @@ void set_blk_direct_dy(int v);     // net_exec.hip: option "blk_direct_dy" (read
 long winograd_packed_floats(int Cout, int Cin, int transposed);   // size of a wu / wuT buffer: the F(2x2) image (+ the F(4x4) image where conv_wino6_kernel may run)
 void set_single_sample(int v);     // "single_sample" (k_conv_mfma.hip): 0 (default) off | 1 the single-sample partition rules (conv_wino4_kernel split K, 16-part 3x3 split on <= 8x8 planes)
 bool conv_single_sample(const adm_conv_args& a);   // the call's (= its model's) rule, else the option
+bool single_sample_rule(int model_value);          // the same for a bare model value (1 on, -1 off, 0 = the process-wide option)
 void set_winograd_v6(int v);    // conv_wino6_kernel (F(4x4,3x3)): 1 (default) planes >= 64x64 with >= 32 workgroups per sample | 0 off | 2 every plane the kernel tiles | n >= 16: planes >= n x n
 void set_winograd_v5(int v);    // conv_wino5_kernel (128-cout tiles) where eligible: 1 (default) / 0 = conv_wino4_kernel everywhere (bit-identical)
 void set_winograd_pair(int v);  // conv_wino4_kernel: 1 (default) = one workgroup barrier per two chunks, 0 = one per chunk (bit-identical)
@@ -157,7 +158,7 @@ long conv_wgrad_workspace(const adm_conv_args& a, int* split_out);
 int launch_conv_wgrad(const adm_conv_args& a, const float* dy, float* dW, int accumulate, float* workspace, hipStream_t st);
 
 // k_attention.hip
-int launch_attention(const float* qkv, float* out, int N, int C, int T, int head_dim, hipStream_t st);
+int launch_attention(const float* qkv, float* out, int N, int C, int T, int head_dim, hipStream_t st, int single_sample = 0);   // single_sample: the model's rule (0 = the option)
 
 // k_transformer.hip (UNet2DConditionModel: Transformer2DModel blocks)
 int launch_layernorm_nct(const float* x, const float* gamma, const float* beta, float* y, int N, int C, long T, float eps,

@@ -749,8 +749,9 @@ __global__ void __launch_bounds__(256) ksplit_finish_stats_kernel(const float* _
 // per call (= per model) by adm_conv_args.single_sample (1 on, -1 off)
 static std::atomic<int> g_single_sample{-1};
 void set_single_sample(int v) { g_single_sample.store(v); }
-bool conv_single_sample(const adm_conv_args& a) {
-  if (a.single_sample != 0) return a.single_sample > 0;
+bool conv_single_sample(const adm_conv_args& a) { return single_sample_rule(a.single_sample); }
+bool single_sample_rule(int model_value) {
+  if (model_value != 0) return model_value > 0;
   int v = g_single_sample.load();
   if (v < 0) { const char* e = getenv("ADM_SINGLE_SAMPLE"); v = e ? atoi(e) : 0; g_single_sample.store(v); }
   return v > 0;
@@ -767,7 +768,7 @@ bool conv_single_sample(const adm_conv_args& a) {
 // A stream's owner gives the slot back with conv_ksplit_release (adm_release_stream) before destroying the stream: a server with a stream
 // per request would otherwise keep >= 32 MiB per stream it ever used and hit the 256-slot limit.
 namespace {
-struct KsplitSlot { float* buf = nullptr; size_t cap = 0; };
+struct KsplitSlot { float* buf = nullptr; size_t cap = 0; std::vector<float*> retired; };   // retired: outgrown buffers, kept until the slot is released
 std::map<std::pair<int, hipStream_t>, KsplitSlot>& ksplit_slots() { static std::map<std::pair<int, hipStream_t>, KsplitSlot> m; return m; }
 int g_ksplit_per_dev[16] = {};
 std::mutex g_ksplit_mu;
@@ -781,6 +782,7 @@ void conv_ksplit_release(hipStream_t st) {
   if (it->second.buf != nullptr) {       // launches (or a graph replay) queued on the stream may still use the slabs: drain, then free
     (void)stream_sync(st);
     dfree(it->second.buf);
+    for (float* q : it->second.retired) dfree(q);
   }
   slots.erase(it);
   --g_ksplit_per_dev[d & 15];
@@ -818,10 +820,10 @@ static float* ksplit_scratch(size_t floats, hipStream_t st) {
   if (want < 2 * sl->cap) want = 2 * sl->cap;
   void* q = nullptr;
   if (dmalloc(&q, sizeof(float) * want) != 0) { set_error("split-K scratch: out of device memory"); return nullptr; }
-  if (sl->buf != nullptr) {              // launches queued on this stream may still read the old slabs: drain, then free
-    (void)stream_sync(st);
-    dfree(sl->buf);
-  }
+  // An outgrown buffer is NOT freed: hipGraphs captured on this stream (any model's sampling loop) hold its address in their kernel
+  // arguments and may be replayed after this call — they keep working on their old slabs (launches on one stream are ordered, so sharing
+  // them is as safe as before). Buffers double, so the retired ones add up to less than the live one; adm_release_stream frees them all.
+  if (sl->buf != nullptr) sl->retired.push_back(sl->buf);
   sl->buf = (float*)q;
   sl->cap = want;
   return sl->buf;
@@ -949,7 +951,7 @@ static int launch_ksplit_generic(const ConvParams& p, hipStream_t st) {
   // (64-cout tiles = twice the workgroups, two per CU: measured SLOWER in the latency regime, 3.85 vs 3.50 ms per config-4 step —
   // every workgroup of a tile row stages the same patch)
   const int bm = p.Cout % 128 == 0 ? 128 : (p.Cout % 64 == 0 ? 64 : 32);
-  int S = HWo <= 4 ? 64 : (HWo <= 16 ? 32 : 8);
+  int S = HWo <= 4 ? 64 : (HWo <= 16 ? 32 : (p.single ? 32 : 8));      // (single-sample rule: the 8x8 planes as finely as the 4x4 ones)
   if (big) {                            // parts until ONE sample's workgroups reach 256 (the batch never enters), at most 16
     const int wg1 = p.tiles_x * p.tiles_y * (p.Cout / bm);
     if (wg1 >= 128) return 1;

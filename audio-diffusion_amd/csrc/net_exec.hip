@@ -913,7 +913,7 @@ int Net::run(const float* x, float* out, int B, const float* temb_all, int temb_
               4.0 * ((double)B * Cin * t1.H * t1.W + outel * (o.res >= 0 ? 2 : 1) + (double)to.C * Cin * o.ks * o.ks));
     } else if (o.kind == Op::ATTN) {
       const int C = t1.C / 3, T = t1.H * t1.W;
-      ADM_TRY(launch_attention(t1.ptr, tensors[o.out].ptr, B, C, T, o.head_dim, st));
+      ADM_TRY(launch_attention(t1.ptr, tensors[o.out].ptr, B, C, T, o.head_dim, st, single_sample));
       tm->end(2, o.head_dim, 4.0 * B * C * (double)T * T, 16.0 * B * C * T);
     } else if (o.kind == Op::LN) {
       const long T = (long)t1.H * t1.W;

@@ -111,7 +111,7 @@ def test_ddim50_loop_is_deterministic_shardable_and_quantises_as_documented(dev,
 # Loop-level parity AT BASELINE SIZES against the CPU oracle driven through the same procedure
 # (`pipeline_audio_diffusion.py:159-199`): same weights, same start noise, same injected per-step scheduler noise.
 # Bars: final float image <= 1e-3 (north_star), uint8 image <= 1 LSB and >= 99.5 % identical.
-def _loop_parity(dev, cfg, sched_name, steps, start_step, B, seed, vae_cfg=None, eta=0.0):
+def _loop_parity(dev, cfg, sched_name, steps, start_step, B, seed, vae_cfg=None, eta=0.0, options=None):
     import os
     from audiodiffusion import AudioDiffusionPipeline, DDIMScheduler, DDPMScheduler, Mel, UNet2DModel
     from audiodiffusion.vae import AutoencoderKL
@@ -122,6 +122,8 @@ def _loop_parity(dev, cfg, sched_name, steps, start_step, B, seed, vae_cfg=None,
     from oracle.vae import AutoencoderKL as OracleVAE
     torch.set_num_threads(min(32, os.cpu_count() or 8))            # the oracle convolutions do not scale past this
     unet = UNet2DModel(**cfg).init_random(seed)
+    for k, v in (options or {}).items():                           # per-MODEL options (adm_unet_set_option)
+        unet.set_option(k, v)
     ref_unet = OracleUNet(**cfg).eval()
     ref_unet.load_state_dict(unet.state_dict())
     vae = ref_vae = None
@@ -145,7 +147,8 @@ def _loop_parity(dev, cfg, sched_name, steps, start_step, B, seed, vae_cfg=None,
     a = np.stack([np.asarray(i).astype(int) for i in mi])
     b = np.stack([np.asarray(i).astype(int) for i in ri])
     assert a.shape == b.shape
-    _record(f"loop {sched_name.upper()} {hw[0]}x{hw[1]}{' latent + VAE decode' if vae_cfg else ''}, steps {start_step}..{steps}, B = {B}, eta {eta}",
+    _record(f"loop {sched_name.upper()} {hw[0]}x{hw[1]}{' latent + VAE decode' if vae_cfg else ''}, steps {start_step}..{steps}, B = {B}, eta {eta}"
+            + (f", model options {options}" if options else ""),
             float_err=err, bar=1e-3, max_lsb=int(np.abs(a - b).max()), identical_pixels=float((a == b).mean()))
     assert err <= 1e-3, err
     assert np.abs(a - b).max() <= 1 and (a == b).mean() >= 0.995, (np.abs(a - b).max(), (a == b).mean())
@@ -295,6 +298,38 @@ def test_config1_64x64_ddpm_10_steps_loop_matches_the_oracle(dev):
     the noise term of every DDPM step is injected so both sides consume identical draws."""
     cfg = dict(CFG256, sample_size=(64, 64))
     _loop_parity(dev, cfg, "ddpm", 10, 0, 1, seed=0)
+
+
+def test_config1_64x64_ddpm_10_steps_under_the_single_sample_rules(dev):
+    """configs[0] as bench.py times it: the model carries `set_option("single_sample", 1)` (split-K partitions for layers whose tiles cannot
+    fill the chip with one sample — what the AudioDiffusion front end selects). Same bar as under the default rules."""
+    cfg = dict(CFG256, sample_size=(64, 64))
+    _loop_parity(dev, cfg, "ddpm", 10, 0, 1, seed=0, options={"single_sample": 1})
+
+
+def test_unet_256_under_the_single_sample_front_end_rules(dev, unet):
+    """The 256x256 model under the two per-model rules `AudioDiffusion` sets ("wino6" = 256, "single_sample" = 1): one forward against the
+    oracle at the whole-network bar, and — the partitions are functions of the layer, not of the batch — rows of a batch bit-identical to
+    the same samples alone. (The default-rule model of this module is untouched: the options live on the model handle.)"""
+    from audiodiffusion import UNet2DModel
+    from oracle.unet import UNet2DModel as OracleUNet
+    mine = UNet2DModel(**CFG256)
+    mine.load_state_dict(unet.state_dict())
+    mine.set_option("wino6", 256).set_option("single_sample", 1)
+    ref = OracleUNet(**CFG256).eval()
+    ref.load_state_dict(unet.state_dict())
+    x = torch.randn(3, 1, 256, 256, generator=torch.Generator().manual_seed(43))
+    ts = torch.tensor([980, 500, 20])
+    with torch.no_grad():
+        r = ref(x[:1], ts[0])["sample"]
+    full = mine(x.to(dev), ts)["sample"]
+    err = float((full[:1].cpu() - r).abs().max()) / float(r.abs().max())
+    _record("whole UNet 256x256, B = 1, t = 980, model options wino6 = 256 + single_sample = 1: max|d| / max|ref|", value=err, bar=1e-4)
+    assert err <= 1e-4, err
+    for i in range(3):
+        one = mine(x[i:i + 1].to(dev), ts[i:i + 1])["sample"]
+        assert torch.equal(one[0], full[i]), (i, float((one[0] - full[i]).abs().max()))
+    assert not torch.equal(unet(x[:1].to(dev), ts[:1])["sample"], full[:1])      # the default-rule model rounds differently (and was not touched)
 
 
 def test_config2_256_ddpm_1000_schedule_last_steps_match_the_oracle(dev):

@@ -372,3 +372,27 @@ def test_attention_core(backend, C, T, d):
     s = torch.einsum("nhdt,nhdj->nhtj", q, k) * d ** -0.5
     ref = torch.einsum("nhtj,nhdj->nhdt", s.softmax(-1), v).reshape(2, C, h, T // h)
     assert _relerr(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("C,T,d", [(64, 256, 8), (32, 64, 8), (16, 100, 4)], ids=["16x16", "8x8", "10x10-ragged-block"])
+def test_attention_under_the_single_sample_rule(backend, C, T, d):
+    """"single_sample" = 1: attention_split4_kernel — four lanes per query, each a quarter of the keys (a sample of the 256x256 model gives the
+    one-lane-per-query kernel 64 workgroups with one wave per SIMD). Same softmax; the sums are combined as (p0 + p1) + (p2 + p3): torch
+    parity at the kernel's bar, agreement with the default kernel to rounding, and a sample alone = its row in a batch."""
+    dev = select(backend)
+    from audiodiffusion import _native, ops
+    h = int(round(T ** 0.5))
+    qkv = _rand((3, 3 * C, h, T // h), 1, dev)
+    base = ops.attention(qkv, d)
+    _native.check(_native.lib().adm_set_option(b"single_sample", 1))
+    try:
+        out = ops.attention(qkv, d)
+        alone = ops.attention(qkv[2:3].contiguous(), d)
+    finally:
+        _native.check(_native.lib().adm_set_option(b"single_sample", -1))
+    q, k, v = qkv.cpu().view(3, 3, C // d, d, T).unbind(1)
+    s = torch.einsum("nhdt,nhdj->nhtj", q, k) * d ** -0.5
+    ref = torch.einsum("nhtj,nhdj->nhdt", s.softmax(-1), v).reshape(3, C, h, T // h)
+    assert _relerr(out, ref) < 1e-5 and _relerr(out, base) < 1e-6
+    assert not torch.equal(out.cpu(), base.cpu()) and torch.equal(out[2:3].cpu(), alone.cpu())

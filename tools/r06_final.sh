@@ -21,5 +21,6 @@ bash tools/pmc_conv.sh $T/pmc_1x1 1x1 conv_mfma > $O/pmc_1x1.txt 2>&1
 timeout 300 python tools/layer_table_probe.py 2>&1 | grep -v amdgpu.ids > $O/layers_b32.txt
 PROBE="32,16;64,1;256,1" timeout 400 python tools/small_regime_probe.py > $O/small_regime.txt 2>&1
 PROBE_RULE=256 PROBE="256,1" timeout 300 python tools/small_regime_probe.py 2>&1 | grep "^==" > $O/single_sample_rule.txt
+( PROBE_KSPLIT=1 PROBE_RULE=256 PROBE="256,1" timeout 300 python tools/small_regime_probe.py; PROBE_KSPLIT=1 PROBE="64,1;32,1;32,16" timeout 300 python tools/small_regime_probe.py ) 2>&1 | grep -v amdgpu.ids > $O/single_sample_on.txt
 PROBE_MP=bf16 bash tools/profile_train_trace.sh $T/train > $O/train_trace.txt 2>&1
-cat $O/pytest_gpu.txt; grep '^==' $O/small_regime.txt; cat $O/single_sample_rule.txt; tail -1 $O/smoke.txt; cut -c1-300 $O/bench_line.json; tail -3 $O/bench_err.txt; tail -3 $O/train_trace.txt; tail -8 $O/pmc_v6.txt
+cat $O/pytest_gpu.txt; grep '^==' $O/small_regime.txt; cat $O/single_sample_rule.txt; grep '^==' $O/single_sample_on.txt; tail -1 $O/smoke.txt; cut -c1-300 $O/bench_line.json; tail -3 $O/bench_err.txt; tail -3 $O/train_trace.txt; tail -8 $O/pmc_v6.txt

@@ -52,6 +52,6 @@ for spec in os.environ.get("PROBE", "32,16;64,1;256,1").split(";"):
         e[0] += 1; e[1] += ms; e[2] += fl
     for (k, v), e in sorted(by.items(), key=lambda kv: -kv[1][1]):
         print(f"   {KIND.get(k, k):10s} var {v:5d}: {e[0]:3d} launches {e[1] * 1e3:9.1f} us  ({e[1] / tot * 100:5.1f} %)  {e[2] / 1e9:9.2f} GF")
-    for i, k, v, ms, fl, b in sorted(best, key=lambda r: -r[3])[:24]:
+    for i, k, v, ms, fl, b in sorted(best, key=lambda r: -r[3])[:int(os.environ.get("PROBE_TOP", "24"))]:
         print(f"   op {i:3d} {KIND.get(k, k):10s} var {v:5d} {ms * 1e3:8.1f} us {fl / 1e9:9.3f} GF {b / 1e6:9.3f} MB")
     del pipe, unet
