@@ -13,6 +13,31 @@ const char* last_error() { return g_err.c_str(); }
 
 using namespace adm;
 
+// ADM_SEGV_BACKTRACE=1: a SIGSEGV / SIGABRT inside the process prints the NATIVE stack (backtrace_symbols_fd) before the default action — Python's
+// faulthandler stops at the ctypes call. Diagnostic only; nothing is installed without the variable.
+#if !defined(ADM_EMU)
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+void adm_segv_handler(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "\n[adm] fatal signal, native stack:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+struct AdmSegvInstall {
+  AdmSegvInstall() {
+    const char* e = getenv("ADM_SEGV_BACKTRACE");
+    if (e && atoi(e)) { signal(SIGSEGV, adm_segv_handler); signal(SIGABRT, adm_segv_handler); signal(SIGBUS, adm_segv_handler); }
+  }
+} g_adm_segv_install;
+}  // namespace
+#endif
+
 extern "C" {
 
 int adm_version(void) { return 104; }   // 104 (round 6): adm_conv_args.single_sample, option "single_sample"; 103 (round 6): adm_conv_args.wino6_rule, adm_unet_set_option, adm_release_stream

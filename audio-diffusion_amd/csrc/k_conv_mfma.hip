@@ -758,15 +758,16 @@ bool single_sample_rule(int model_value) {
 }
 
 // scratch for the split-K partial slabs, one buffer per (device, stream): launches on one stream are ordered, two streams must
-// not share it. Grown only outside stream capture (the executors run one uncaptured forward before they capture), geometrically,
-// and the superseded buffer is freed once the stream has drained (it used to be leaked on every growth).
-// The table is keyed dynamically (round 5): a slot is NEVER taken away from the stream it belongs to — a captured
-// hipGraph of that stream holds the buffer's address — so a process may use up to 256 streams per device (>= 32 MiB each) and the
-// 257th fails loudly instead of stealing a live stream's scratch.
+// not share it. Grown only outside stream capture (the executors run one uncaptured forward before they capture), geometrically;
+// a superseded buffer is RETIRED, not freed (round 6): a hipGraph captured on the stream — any model's sampling loop — holds its address
+// and may be replayed after the growth; the retired buffers (less than the live one in total) go when the slot is released.
+// The table is keyed dynamically (round 5): a slot is NEVER taken away from the stream it belongs to, so a process may use
+// up to 1024 streams per device (>= 1 MiB each; every model owns one side stream) and the next fails loudly instead of stealing a live
+// stream's scratch.
 // nullptr = it cannot be provided (capture in progress and the buffer too small, table full, out of memory):
 // the callers FAIL the launch — the unsplit kernel sums in another fp32 order, and a row's bits must not depend on such things.
 // A stream's owner gives the slot back with conv_ksplit_release (adm_release_stream) before destroying the stream: a server with a stream
-// per request would otherwise keep >= 32 MiB per stream it ever used and hit the 256-slot limit.
+// per request would otherwise keep a buffer per stream it ever used and hit the slot limit.
 namespace {
 struct KsplitSlot { float* buf = nullptr; size_t cap = 0; std::vector<float*> retired; };   // retired: outgrown buffers, kept until the slot is released
 std::map<std::pair<int, hipStream_t>, KsplitSlot>& ksplit_slots() { static std::map<std::pair<int, hipStream_t>, KsplitSlot> m; return m; }
@@ -802,8 +803,8 @@ static float* ksplit_scratch(size_t floats, hipStream_t st) {
 #endif
   auto it = slots.find(std::make_pair(d, st));
   if (it == slots.end()) {
-    if (per_dev[d & 15] >= 256) {
-      set_error("split-K scratch: more than 256 streams have run split-K convolutions on this device; a stream's scratch is never "
+    if (per_dev[d & 15] >= 1024) {
+      set_error("split-K scratch: more than 1024 streams have run split-K convolutions on this device; a stream's scratch is never "
                 "taken over (captured graphs hold its address) — reuse streams, or give a stream's slot back with adm_release_stream before destroying it");
       return nullptr;
     }
@@ -816,7 +817,9 @@ static float* ksplit_scratch(size_t floats, hipStream_t st) {
     set_error("split-K scratch must grow during stream capture: run one uncaptured pass at this batch size first");
     return nullptr;
   }
-  size_t want = floats < ((size_t)8 << 20) ? ((size_t)8 << 20) : floats;      // >= 32 MiB
+  // first buffer of a stream: what is asked for, at least 1 MiB (a model's side stream — Net::plan_side_overlap — only ever runs small-plane
+  // launches; round 5's 32 MiB floor cost every live model that much). Growth is safe at any time outside a capture: see below.
+  size_t want = floats < ((size_t)256 << 10) ? ((size_t)256 << 10) : floats;
   if (want < 2 * sl->cap) want = 2 * sl->cap;
   void* q = nullptr;
   if (dmalloc(&q, sizeof(float) * want) != 0) { set_error("split-K scratch: out of device memory"); return nullptr; }

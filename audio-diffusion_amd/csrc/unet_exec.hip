@@ -51,6 +51,7 @@ struct adm_unet {
 #if !defined(ADM_EMU)
   hipStream_t own_stream = nullptr;
   hipGraphExec_t gexec = nullptr;
+  hipStream_t gstream = nullptr;     // the stream gexec was captured on and is replayed on
   std::vector<uint64_t> gkey;
 #endif
 };
@@ -253,7 +254,11 @@ static void free_plan(adm_unet* h) {
   h->planned_B = 0;
   h->warm_B = 0;       // the next capture is preceded by an uncaptured forward again (another kernel's one-time set-up)
 #if !defined(ADM_EMU)
-  if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+  if (h->gexec) {                     // (a replay may still be in flight: drain the stream it ran on before the executable graph goes)
+    (void)stream_sync(h->gstream);
+    (void)hipGraphExecDestroy(h->gexec);
+    h->gexec = nullptr;
+  }
   h->gkey.clear();
 #endif
 }
@@ -365,7 +370,15 @@ static int run_loop(adm_unet* h, const LoopArgs& a, const adm_sched_coef* coef_h
                                  (uint64_t)a.encode, (uint64_t)h->coef_dev, (uint64_t)run, (uint64_t)h->net.ctx,
                                  (uint64_t)h->net.ctx_S};
     if (!h->gexec || key != h->gkey) {
-      if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+      if (h->gexec) {
+        // the previous loop's replays may still be running (a caller that samples again without a host synchronisation in between — 50
+        // single-step calls in tests/test_pipeline.py): destroying an executable graph under them crashed the runtime now and then
+        // (SIGSEGV inside this call, 2 of 3 full GPU suites). Re-capture is the rare path; a drain costs nothing there.
+        static const int drain = [] { const char* e = getenv("ADM_GRAPH_DRAIN"); return e ? atoi(e) : 1; }();   // (0: tools/graph_churn_probe.py's A/B)
+        if (drain) (void)stream_sync(h->gstream);
+        (void)hipGraphExecDestroy(h->gexec);
+        h->gexec = nullptr;
+      }
       if (h->warm_B != a.B) {
         // One UNCAPTURED forward (into eps_buf; the sample is not touched) before the first capture at this batch size:
         // the launchers' one-time work — constant buffers (hipMalloc + null-stream copy), hipFuncSetAttribute for the
@@ -382,6 +395,7 @@ static int run_loop(adm_unet* h, const LoopArgs& a, const adm_sched_coef* coef_h
       ADM_HIP_OK(hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0));
       ADM_HIP_OK(hipGraphDestroy(graph));
       h->gkey = key;
+      h->gstream = run;
     }
     for (int s = 0; s < a.n_steps; ++s) ADM_HIP_OK(hipGraphLaunch(h->gexec, run));
   }

@@ -67,8 +67,8 @@ int adm_has_experiments(void);
  * The dispatch epoch moves only when a value really changes; set options BEFORE adm_unet_refresh_weights / the next train step.
  * adm_version() = 104 since round 6 (adm_conv_args.single_sample, option "single_sample"; 103: adm_conv_args.wino6_rule, adm_unet_set_option, adm_release_stream); 102 since round 5 (Winograd filter buffers hold two images: adm_winograd_packed_floats); 101 since round 4 (adm_slerp_grid takes DOUBLE weights since round 3; blocked-image entry points). */
 int adm_set_option(const char* name, int value);
-/* Per-(device, stream) scratch the library keeps for a stream (the split-K slab buffer of the small-plane convolutions, >= 32 MiB, at most
- * 256 streams per device): give it back BEFORE destroying a stream that has run library calls. Drains the stream first (a captured graph of
+/* Per-(device, stream) scratch the library keeps for a stream (the split-K slab buffer of the small-plane convolutions, >= 1 MiB, at most
+ * 1024 streams per device): give it back BEFORE destroying a stream that has run library calls. Drains the stream first (a captured graph of
  * that stream holds the buffer's address: destroy or stop replaying such graphs before). No-op for a stream the library holds nothing for. */
 int adm_release_stream(void* stream);
 /* Kernel variant the last adm_conv2d on this thread dispatched to (see adm_op_profile.variant; 4311 = Winograd). */
@@ -257,7 +257,7 @@ typedef struct adm_unet_config {
 
 int adm_unet_create(const adm_unet_config* cfg, adm_unet_t** out);
 /* Per-MODEL options (adm_version() >= 103; "single_sample" >= 104: 0 = follow the process-wide option, 1 = on, -1 = off for this model —
- * AudioDiffusion sets 1: one 256x256 sample per call 6.65 -> 4.6 ms per step, profiles/r06_single_sample.md). "wino6": this model's F(4x4) layer rule — 0 = follow the process-wide option (default), 1 / 2 /
+ * AudioDiffusion sets 1: one 256x256 sample per call 6.6 -> 4.2 ms per step, profiles/r06_single_sample.md). "wino6": this model's F(4x4) layer rule — 0 = follow the process-wide option (default), 1 / 2 /
  * n >= 16 as adm_set_option("wino6", .). `audiodiffusion.AudioDiffusion` (the reference's single-sample facade, audiodiffusion/__init__.py:58-68:
  * batch_size is forced to 1) sets 256 on its own model: planes whose 16x16x128 tiles fill the chip with ONE sample keep F(4x4), the
  * levels below run the 64-cout F(2x2) kernel, whose smaller tiles are 4x as many workgroups (256x256, one sample: 6.8 instead of 8.3 ms per
